@@ -1,0 +1,16 @@
+import os
+import sys
+
+# The golden vectors were produced with OMP_NUM_THREADS=8 (the reference's float32 column statistics are
+# summed per thread, math_ops.cpp:255-300, so their last bit depends on the thread count).  Pin it before
+# any OpenMP runtime starts.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,0 +1,153 @@
+"""Golden-vector case list + input synthesis, shared by make_golden.py (authoring container) and the tests.
+
+Inputs are synthesised from integer PCG64 draws with exactly-rounded IEEE arithmetic only (no BLAS, no
+libm transcendentals), so that every machine regenerates bit-identical float32 inputs from the seed.
+Each fixture stores a SHA-256 of its inputs; the tests re-check it before trusting the vectors.
+
+The driver below mirrors what the reference's learner layer does before/around the two hot calls
+(gbrl/learners/gbt_learner.py:92-101, 124-128, 139-148; tests/test_gbt_single.py:46-61): set feature
+weights to ones, add the optimizers, set the feature mapping before the first step, then step / predict.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+TOKENS = np.array([f"c{i:02d}" for i in range(32)], dtype="S128")
+
+
+def _u(rng, shape):
+    """uniform [0,1) float32 on a 2^-24 grid (exact)."""
+    return (rng.integers(0, 1 << 24, size=shape, dtype=np.uint32).astype(np.float32)
+            * np.float32(2.0 ** -24))
+
+
+def _normalish(rng, shape):
+    """Irwin-Hall(4) centred: bell-shaped, range (-2,2)*1.73, unit-ish variance; exact float32 ops."""
+    s = _u(rng, shape) + _u(rng, shape) + _u(rng, shape) + _u(rng, shape)
+    return ((s - np.float32(2.0)) * np.float32(1.7320508)).astype(np.float32)
+
+
+def make_inputs(case):
+    rng = np.random.default_rng(case["seed"])
+    N, F, Fc, D = case["N"], case["F"], case.get("Fc", 0), case["D"]
+    X = _normalish(rng, (N, F)) if F > 0 else None
+    if X is not None:
+        for j in case.get("discrete_cols", []):         # heavy duplicates: exercises duplicate thresholds
+            X[:, j] = np.round(X[:, j] * np.float32(2.0)) * np.float32(0.5)
+        for j in case.get("constant_cols", []):
+            X[:, j] = np.float32(0.25)
+    Xc = None
+    if Fc > 0:
+        Xc = TOKENS[rng.integers(0, case.get("n_tokens", 8), size=(N, Fc))]
+    w = _normalish(rng, (D,)) * np.float32(2.0)
+    v = _normalish(rng, (D,))
+    G = np.empty((N, D), np.float32)
+    noise = _normalish(rng, (N, D)) * np.float32(case.get("noise", 0.5))
+    for d in range(D):
+        if F > 0:
+            z = X[:, d % F] * w[d] + X[:, (d + 1) % F] * v[d]
+        else:
+            z = np.zeros(N, np.float32)
+        if Fc > 0:
+            z = z + (Xc[:, d % Fc] == TOKENS[d % 4]).astype(np.float32) * np.float32(1.5)
+        G[:, d] = z / (np.float32(1.0) + np.abs(z)) + noise[:, d] + np.float32(case.get("g_offset", 0.3))
+    y = None
+    if case.get("loop") == "rmse":                       # tests/test_gbt_single.py:46-61 pattern
+        x0 = np.clip(X[:, 0], np.float32(-2), np.float32(2))
+        y = (x0 - x0 * x0 * x0 / np.float32(6.0) + _normalish(rng, (N,)) * np.float32(0.1)).astype(np.float32)
+        if D > 1:
+            y = np.stack([y * np.float32(d + 1) for d in range(D)], axis=1).astype(np.float32)
+    return X, Xc, np.ascontiguousarray(G), y
+
+
+def inputs_digest(X, Xc, G, y):
+    h = hashlib.sha256()
+    for a in (X, Xc, G, y):
+        if a is not None:
+            h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def ctor_kwargs(case, device="cpu"):
+    return dict(input_dim=case["F"] + case.get("Fc", 0), output_dim=case["D"], policy_dim=case["D"],
+                max_depth=case["depth"], min_data_in_leaf=case.get("min_data_in_leaf", 0),
+                n_bins=case.get("n_bins", 256), par_th=case.get("par_th", 10), cv_beta=0.9,
+                split_score_func=case["score"], generator_type=case["gen"], use_control_variates=False,
+                batch_size=5000, grow_policy=case["policy"], verbose=0, device=device,
+                learner_name=case["name"])
+
+
+def optimizers(case):
+    D = case["D"]
+    return case.get("opts", [dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)])
+
+
+def drive(model, case, X, Xc, G, y, to_input=lambda a: a, to_numpy=np.asarray):
+    """Run the case on any object with the gbrl_cpp.GBRL call surface.  Returns final predictions."""
+    F, Fc = case["F"], case.get("Fc", 0)
+    in_dim = F + Fc
+    model.set_feature_weights(np.asarray(case.get("feature_weights", np.ones(in_dim)), np.float32))
+    for o in optimizers(case):
+        model.set_optimizer(**o)
+    model.set_feature_mapping(np.arange(in_dim, dtype=np.int32),
+                              np.array([True] * F + [False] * Fc, dtype=bool))
+    if "bias" in case:
+        model.set_bias(np.asarray(case["bias"], np.float32))
+    xi = None if X is None else to_input(X)
+    for _ in range(case["trees"]):
+        if y is not None:
+            pred = to_numpy(model.predict(xi, Xc, 0, 0)).astype(np.float32)
+            g = (pred - y).astype(np.float32)
+        else:
+            g = G
+        model.step(xi, Xc, to_input(np.ascontiguousarray(g.copy())))
+    return to_numpy(model.predict(xi, Xc, 0, 0))
+
+
+def _c(name, **kw):
+    base = dict(name=name, seed=0, N=2048, F=8, Fc=0, D=3, depth=4, n_bins=256, score="L2", gen="Quantile",
+                policy="oblivious", trees=3)
+    base.update(kw)
+    return base
+
+
+# The matrix {greedy,oblivious} x {L2,Cosine} x {Quantile,Uniform} x {numeric, numeric+categorical} plus the
+# reference's own CPU-runnable configuration (BASELINE.json configs[0]) and edge cases.
+CASES = [
+    _c("obl_l2_q", seed=1),
+    _c("obl_l2_u", seed=2, gen="Uniform"),
+    _c("obl_cos_q", seed=3, score="Cosine"),
+    _c("obl_cos_u", seed=4, score="Cosine", gen="Uniform"),
+    _c("grd_l2_q", seed=5, policy="greedy"),
+    _c("grd_l2_u", seed=6, policy="greedy", gen="Uniform"),
+    _c("grd_cos_q", seed=7, policy="greedy", score="Cosine"),
+    _c("grd_cos_u", seed=8, policy="greedy", score="Cosine", gen="Uniform"),
+    # configs[0]: GradientBoostingTrees single-output MultiRMSE, batch=4096, n_feat=16, depth=4, greedy/L2
+    _c("cfg1_rmse_loop", seed=9, N=4096, F=16, D=1, depth=4, policy="greedy", loop="rmse", trees=12),
+    # shared actor-critic: two SGD optimisers on one ensemble (A14), D=8 = policy[0,7) + value[7,8)
+    _c("grd_cos_q_ac", seed=10, N=2048, F=8, D=8, depth=5, policy="greedy", score="Cosine",
+       opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
+             dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)]),
+    # config-2 shape in miniature: oblivious / L2 / quantile, D=8, depth 6
+    _c("obl_l2_q_d6", seed=11, N=4096, F=16, D=8, depth=6, trees=2),
+    # duplicates / constant column / min_data_in_leaf / feature weights / bias / ragged N
+    _c("obl_l2_q_dups", seed=12, N=1531, F=6, discrete_cols=[1, 4], constant_cols=[2], trees=2),
+    _c("grd_l2_q_mdl", seed=13, N=1000, F=5, D=2, policy="greedy", min_data_in_leaf=40, trees=3,
+       feature_weights=[1.0, 0.5, 2.0, 1.0, 0.25], bias=[0.5, -1.0]),
+    _c("obl_cos_u_mdl", seed=14, N=777, F=4, D=2, score="Cosine", gen="Uniform", min_data_in_leaf=25, n_bins=64),
+    _c("grd_cos_q_small_bins", seed=15, N=600, F=3, D=1, policy="greedy", score="Cosine", n_bins=16, depth=3),
+    # numeric + categorical
+    _c("obl_l2_q_cat", seed=16, N=1024, F=6, Fc=2, D=2, trees=2),
+    _c("grd_cos_u_cat", seed=17, N=1024, F=4, Fc=3, D=2, policy="greedy", score="Cosine", gen="Uniform", trees=2),
+    _c("grd_l2_q_catonly", seed=18, N=512, F=0, Fc=3, D=2, policy="greedy", trees=2, n_tokens=6),
+    _c("obl_cos_q_cat_rmse", seed=19, N=1024, F=5, Fc=2, D=1, score="Cosine", loop="rmse", trees=5),
+]
+
+BY_NAME = {c["name"]: c for c in CASES}
+
+ENSEMBLE_KEYS = ("tree_indices", "depths", "values", "feature_indices", "feature_values", "edge_weights",
+                 "is_numerics", "inequality_directions", "categorical_values")
+# cases whose saved .gbrl_model bytes are committed (file-format parity)
+MODEL_FILE_CASES = ("obl_l2_q", "grd_cos_q_ac", "obl_l2_q_cat")

@@ -1,0 +1,69 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own CPU path (oracle/_ref, built by oracle/Makefile from
+/root/reference).  Runs in the authoring container only; the reference never travels.
+
+    python tests/golden/make_golden.py            # all cases
+    python tests/golden/make_golden.py obl_l2_q   # selected cases
+
+Each fixture holds: the case dict (json), sha256 of the synthesised inputs, every hot-path array of
+get_ensemble_data() (binding.cpp:330-390), get_metadata(), the final predict() output, the split candidates are
+NOT exposed by the reference binding and therefore not stored.  For MODEL_FILE_CASES the bytes written by
+GBRL.save() are stored too.  Both the -march=x86-64-v3 build (shipped) and a -march=native build are run and
+must agree byte for byte (printed), which pins that the portable flags did not change the oracle's rounding.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import cases as K  # noqa: E402
+import oracle  # noqa: E402
+
+
+def run(mod, case):
+    X, Xc, G, y = K.make_inputs(case)
+    m = mod.GBRL(**K.ctor_kwargs(case))
+    pred = K.drive(m, case, X, Xc, G, y)
+    e = m.get_ensemble_data()
+    out = {k: np.array(e[k]) for k in K.ENSEMBLE_KEYS}
+    out["pred"] = np.array(pred, np.float32)
+    out["n_trees"] = np.int32(m.get_num_trees())
+    out["iteration"] = np.int32(m.get_iteration())
+    out["inputs_sha256"] = np.array(K.inputs_digest(X, Xc, G, y))
+    out["case_json"] = np.array(json.dumps(case))
+    out["meta_json"] = np.array(json.dumps({k: (v if not isinstance(v, (np.generic,)) else v.item())
+                                             for k, v in m.get_metadata().items()}))
+    if case["name"] in K.MODEL_FILE_CASES:
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "m.gbrl_model")
+            assert m.save(p) == 0
+            out["model_file"] = np.frombuffer(open(p, "rb").read(), np.uint8)
+    return out
+
+
+def main():
+    ref = oracle.load_ref()
+    assert ref is not None, "build oracle/_ref first: make -C oracle ref"
+    nat = oracle.load_ref(native=True)
+    names = sys.argv[1:] or [c["name"] for c in K.CASES]
+    for name in names:
+        case = K.BY_NAME[name]
+        a = run(ref, case)
+        msg = ""
+        if nat is not None:
+            b = run(nat, case)
+            same = all(np.array_equal(a[k], b[k]) for k in K.ENSEMBLE_KEYS + ("pred",))
+            msg = "native==v3" if same else "NATIVE BUILD DIFFERS"
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **a)
+        sz = os.path.getsize(os.path.join(HERE, name + ".npz"))
+        print(f"{name:28s} trees={int(a['n_trees'])} leaves={a['values'].shape[0]} {sz/1024:.0f} KiB {msg}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""Pins the oracle: the restatement (oracle/oracle.cpp) must reproduce, bit for bit, the golden vectors that the
+reference's own CPU path produced (tests/golden/make_golden.py), and -- when the reference build oracle/_ref is
+present -- the reference itself on fresh seeds."""
+import numpy as np
+import pytest
+
+import cases as K
+import oracle
+from helpers import STRUCTURE_KEYS, VALUE_KEYS, load_golden
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES])
+def test_restatement_matches_golden_bit_exact(name):
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    pred = K.drive(m, case, X, Xc, G, y)
+    e = m.get_ensemble_data()
+    for k in STRUCTURE_KEYS + VALUE_KEYS:
+        assert np.array_equal(e[k], g[k]), k
+    assert np.array_equal(np.asarray(pred).reshape(g["pred"].shape), g["pred"])
+    assert m.get_num_trees() == int(g["n_trees"]) and m.get_iteration() == int(g["iteration"])
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+@pytest.mark.parametrize("policy,score,gen", [("oblivious", "L2", "Quantile"), ("greedy", "Cosine", "Uniform"),
+                                              ("greedy", "L2", "Quantile"), ("oblivious", "Cosine", "Quantile")])
+def test_restatement_matches_reference_build_live(seed, policy, score, gen):
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    case = dict(name="live", seed=seed, N=900, F=5, Fc=1, D=2, depth=3, n_bins=64, score=score, gen=gen,
+                policy=policy, trees=2)
+    X, Xc, G, y = K.make_inputs(case)
+    a = ref.GBRL(**K.ctor_kwargs(case))
+    pa = K.drive(a, case, X, Xc, G, y)
+    b = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    pb = K.drive(b, case, X, Xc, G, y)
+    ea, eb = a.get_ensemble_data(), b.get_ensemble_data()
+    for k in STRUCTURE_KEYS + VALUE_KEYS:
+        assert np.array_equal(np.asarray(ea[k]), eb[k]), k
+    assert np.array_equal(np.asarray(pa), pb)
+
+
+def test_quantile_thresholds_are_order_statistics():
+    """A3: threshold i of feature f is the data value at sorted rank cum(bin_counts)[i]-1, duplicates kept (Q1)."""
+    case = K.BY_NAME["obl_l2_q_dups"]
+    X, Xc, G, y = K.make_inputs(case)
+    m = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    K.drive(m, dict(case, trees=1), X, Xc, G, y)
+    fi, val, is_cat, _ = m.last_candidates()
+    N, F, B = case["N"], case["F"], case["n_bins"]
+    assert len(fi) == F * B and not is_cat.any()
+    counts = np.full(B + 1, N // (B + 1)); counts[: N % (B + 1)] += 1
+    ranks = np.cumsum(counts)[:B] - 1
+    for f in range(F):
+        assert np.array_equal(val[f * B:(f + 1) * B], np.sort(X[:, f])[ranks])
+        assert (fi[f * B:(f + 1) * B] == f).all()
+
+
+def test_uniform_thresholds_are_fused_multiply_add():
+    """A4 / Q5: min + b*step evaluated with ONE rounding (float64 product+sum rounds identically here)."""
+    case = K.BY_NAME["obl_l2_u"]
+    X, Xc, G, y = K.make_inputs(case)
+    m = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    K.drive(m, dict(case, trees=1), X, Xc, G, y)
+    _, val, _, _ = m.last_candidates()
+    B = case["n_bins"]
+    for f in range(case["F"]):
+        mn, mx = X[:, f].min(), X[:, f].max()
+        step = np.float32((mx - mn) / np.float32(B))
+        want = (np.arange(B, dtype=np.float64) * np.float64(step) + np.float64(mn)).astype(np.float32)
+        assert np.array_equal(val[f * B:(f + 1) * B], want)
