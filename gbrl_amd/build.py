@@ -1,0 +1,59 @@
+"""In-tree build of the HIP library and its Python binding (no cmake: two compiler invocations).
+
+    python gbrl_amd/build.py [--force]   (run as a script: importing the package needs the built extension)
+
+Outputs (git-ignored, but they travel with the gpurun snapshot):
+    gbrl_amd/libgbrl_hip.so                      hipcc --offload-arch=gfx950   (kernels + engine + C ABI)
+    gbrl_amd/gbrl_cpp.<abi>.so                   g++ + pybind11, links only against libgbrl_hip.so (C ABI)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgbrl_hip.so")
+EXT = os.path.join(HERE, "gbrl_cpp" + sysconfig.get_config_var("EXT_SUFFIX"))
+ARCH = os.environ.get("PYTORCH_ROCM_ARCH", "gfx950").split(";")[0]
+
+LIB_SRCS = ["kernels.hip", "engine.hip", "c_api.cpp", "model.cpp"]
+LIB_DEPS = LIB_SRCS + ["kernels.h", "engine.h", "model.h", os.path.join("..", "..", "include", "gbrl_hip.h")]
+EXT_SRCS = ["binding.cpp"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+
+
+def _run(cmd):
+    print(" ".join(cmd), flush=True)
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    if out.returncode != 0:
+        sys.stderr.write(out.stdout + out.stderr)
+        raise RuntimeError("build failed: " + cmd[0])
+    if out.stderr.strip():
+        sys.stderr.write(out.stderr)
+
+
+def build(force: bool = False) -> None:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if force or _stale(LIB, LIB_DEPS):
+        _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+              "-Wno-unused-result", *[os.path.join(CSRC, s) for s in LIB_SRCS], "-o", LIB])
+    if force or _stale(EXT, EXT_SRCS + [os.path.join("..", "..", "include", "gbrl_hip.h")]) or \
+            os.path.getmtime(EXT) < os.path.getmtime(LIB):
+        import pybind11
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+              f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+              *[os.path.join(CSRC, s) for s in EXT_SRCS], f"-L{HERE}", "-lgbrl_hip", "-Wl,-rpath,$ORIGIN", "-o", EXT])
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("built:", LIB, EXT)

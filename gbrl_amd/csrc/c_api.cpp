@@ -1,0 +1,238 @@
+// c_api.cpp -- the extern "C" surface declared in include/gbrl_hip.h.  Exceptions never cross the boundary: they are
+// turned into status codes + a thread-local message (the reference throws std::runtime_error at the same places).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/gbrl_hip.h"
+#include "engine.h"
+
+struct gbrl_hip_model {
+    gbrl::Engine engine;
+    std::vector<const char *> phase_names;
+    explicit gbrl_hip_model(const gbrl_hip_config &c) : engine(c) {}
+    gbrl_hip_model(gbrl::Model &&m, int dev) : engine(std::move(m), dev) {}
+    explicit gbrl_hip_model(const gbrl_hip_model &o) : engine(o.engine) {}
+};
+
+namespace {
+thread_local std::string g_err;
+
+template <typename Fn>
+int guarded(Fn &&fn) {
+    try {
+        fn();
+        return GBRL_HIP_OK;
+    } catch (const gbrl::NoDeviceError &e) { g_err = e.what(); return GBRL_HIP_E_NO_DEVICE;
+    } catch (const gbrl::HipError &e) { g_err = e.what(); return GBRL_HIP_E_HIP;
+    } catch (const gbrl::Unsupported &e) { g_err = e.what(); return GBRL_HIP_E_UNSUPPORTED;
+    } catch (const gbrl::InvalidArgument &e) { g_err = e.what(); return GBRL_HIP_E_INVALID;
+    } catch (const std::bad_alloc &) { g_err = "out of host memory"; return GBRL_HIP_E_INVALID;
+    } catch (const std::exception &e) { g_err = e.what(); return GBRL_HIP_E_INVALID; }
+}
+
+int copy_in(void *dst, const void *src, size_t bytes, int on_device) {
+    if (!on_device) { std::memcpy(dst, src, bytes); return 0; }
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+}  // namespace
+
+extern "C" {
+
+int gbrl_hip_abi_version(void) { return GBRL_HIP_ABI_VERSION; }
+
+int gbrl_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *gbrl_hip_last_error(void) { return g_err.c_str(); }
+
+void *gbrl_hip_device_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
+    return p;
+}
+void gbrl_hip_device_free(void *ptr) {
+    if (ptr) (void)hipFree(ptr);
+}
+
+gbrl_hip_model *gbrl_hip_create(const gbrl_hip_config *cfg) {
+    gbrl_hip_model *m = nullptr;
+    guarded([&] {
+        if (!cfg) throw gbrl::InvalidArgument("null config");
+        if (cfg->input_dim <= 0 || cfg->output_dim <= 0 || cfg->max_depth < 0 || cfg->max_depth > 30 || cfg->n_bins <= 0)
+            throw gbrl::InvalidArgument("invalid model dimensions");
+        if (cfg->use_control_variates)
+            throw gbrl::Unsupported("control variates are CPU-only in the reference (gbrl.cpp:204-207) and not part of this build");
+        if (cfg->split_score_func != GBRL_HIP_SCORE_L2 && cfg->split_score_func != GBRL_HIP_SCORE_COSINE)
+            throw gbrl::InvalidArgument("Invalid score function! Options are: Cosine/L2");
+        if (cfg->generator_type != GBRL_HIP_GEN_UNIFORM && cfg->generator_type != GBRL_HIP_GEN_QUANTILE)
+            throw gbrl::InvalidArgument("Invalid generator function! Options are: Uniform/Quantile");
+        if (cfg->grow_policy != GBRL_HIP_GROW_GREEDY && cfg->grow_policy != GBRL_HIP_GROW_OBLIVIOUS)
+            throw gbrl::InvalidArgument("Invalid generator function! Options are: Greedy/Oblivious");
+        m = new gbrl_hip_model(*cfg);
+    });
+    return m;
+}
+
+gbrl_hip_model *gbrl_hip_clone(const gbrl_hip_model *other) {
+    gbrl_hip_model *m = nullptr;
+    guarded([&] {
+        if (!other) throw gbrl::InvalidArgument("null model");
+        m = new gbrl_hip_model(*other);
+    });
+    return m;
+}
+
+gbrl_hip_model *gbrl_hip_load(const char *filename) {
+    gbrl_hip_model *m = nullptr;
+    int rc = guarded([&] {
+        if (!filename) throw gbrl::InvalidArgument("null filename");
+        m = new gbrl_hip_model(gbrl::Model::load(filename), -1);
+    });
+    if (rc != 0 && g_err.find("file") != std::string::npos) { /* message already set */ }
+    return m;
+}
+
+int gbrl_hip_save(gbrl_hip_model *m, const char *filename) {
+    int rc = guarded([&] {
+        if (!m || !filename) throw gbrl::InvalidArgument("null argument");
+        m->engine.model.save(filename);
+    });
+    return rc == GBRL_HIP_OK ? rc : GBRL_HIP_E_IO;
+}
+
+void gbrl_hip_destroy(gbrl_hip_model *m) { delete m; }
+
+int gbrl_hip_set_bias(gbrl_hip_model *m, const float *bias, int n, int on_device) {
+    return guarded([&] {
+        if (!m || !bias) throw gbrl::InvalidArgument("null argument");
+        if (n != m->engine.model.meta.output_dim) throw gbrl::InvalidArgument("Incompatible dimensions");
+        if (copy_in(m->engine.model.bias.data(), bias, sizeof(float) * n, on_device)) throw gbrl::HipError("hipMemcpy failed");
+        ++m->engine.model.version;
+    });
+}
+
+int gbrl_hip_set_feature_weights(gbrl_hip_model *m, const float *w, int n, int on_device) {
+    return guarded([&] {
+        if (!m || !w) throw gbrl::InvalidArgument("null argument");
+        if (n != m->engine.model.meta.input_dim) throw gbrl::InvalidArgument("Incompatible dimensions");
+        if (copy_in(m->engine.model.feature_weights.data(), w, sizeof(float) * n, on_device)) throw gbrl::HipError("hipMemcpy failed");
+        ++m->engine.model.version;
+    });
+}
+
+int gbrl_hip_set_feature_mapping(gbrl_hip_model *m, const int32_t *feature_mapping, const uint8_t *mapping_numerics, int n) {
+    return guarded([&] {
+        if (!m || !feature_mapping || !mapping_numerics) throw gbrl::InvalidArgument("null argument");
+        if (n != m->engine.model.meta.input_dim) throw gbrl::InvalidArgument("Incompatible dimensions");
+        m->engine.model.set_feature_mapping(feature_mapping, mapping_numerics);
+    });
+}
+
+int gbrl_hip_set_optimizer(gbrl_hip_model *m, const gbrl_hip_optimizer *opt) {
+    return guarded([&] {
+        if (!m || !opt) throw gbrl::InvalidArgument("null argument");
+        m->engine.model.add_optimizer(*opt);
+    });
+}
+
+int gbrl_hip_get_metadata(const gbrl_hip_model *m, gbrl_hip_metadata *out) {
+    if (!m || !out) return GBRL_HIP_E_INVALID;
+    *out = m->engine.model.meta;
+    return GBRL_HIP_OK;
+}
+int gbrl_hip_get_bias(const gbrl_hip_model *m, float *out) {
+    if (!m || !out) return GBRL_HIP_E_INVALID;
+    std::memcpy(out, m->engine.model.bias.data(), sizeof(float) * m->engine.model.bias.size());
+    return GBRL_HIP_OK;
+}
+int gbrl_hip_get_feature_weights(const gbrl_hip_model *m, float *out) {
+    if (!m || !out) return GBRL_HIP_E_INVALID;
+    std::memcpy(out, m->engine.model.feature_weights.data(), sizeof(float) * m->engine.model.feature_weights.size());
+    return GBRL_HIP_OK;
+}
+int gbrl_hip_get_feature_mapping(const gbrl_hip_model *m, int32_t *fm, uint8_t *mn) {
+    if (!m) return GBRL_HIP_E_INVALID;
+    const auto &md = m->engine.model;
+    if (fm) std::memcpy(fm, md.feature_mapping.data(), sizeof(int32_t) * md.feature_mapping.size());
+    if (mn) std::memcpy(mn, md.mapping_numerics.data(), md.mapping_numerics.size());
+    return GBRL_HIP_OK;
+}
+int gbrl_hip_num_optimizers(const gbrl_hip_model *m) { return m ? static_cast<int>(m->engine.model.opts.size()) : 0; }
+int gbrl_hip_get_optimizer(const gbrl_hip_model *m, int idx, gbrl_hip_optimizer *out) {
+    if (!m || !out || idx < 0 || idx >= static_cast<int>(m->engine.model.opts.size())) return GBRL_HIP_E_INVALID;
+    *out = m->engine.model.opts[idx];
+    return GBRL_HIP_OK;
+}
+const char *gbrl_hip_learner_name(const gbrl_hip_model *m) { return m ? m->engine.model.learner_name.c_str() : ""; }
+
+int gbrl_hip_get_ensemble(const gbrl_hip_model *m, int32_t *tree_indices, int32_t *depths, float *values,
+                          int32_t *feature_indices, float *feature_values, float *edge_weights, uint8_t *is_numerics,
+                          uint8_t *inequality_directions, char *categorical_values, int32_t *rev_num, int32_t *rev_cat) {
+    if (!m) return GBRL_HIP_E_INVALID;
+    const gbrl::Model &md = m->engine.model;
+    const size_t T = md.meta.n_trees, L = md.meta.n_leaves, S = md.split_rows(), MD = md.meta.max_depth, D = md.meta.output_dim;
+    auto cp = [](void *dst, const void *src, size_t bytes) { if (dst && bytes) std::memcpy(dst, src, bytes); };
+    cp(tree_indices, md.tree_indices.data(), T * 4);
+    cp(depths, md.depths.data(), S * 4);
+    cp(values, md.values.data(), L * D * 4);
+    cp(feature_indices, md.feature_indices.data(), S * MD * 4);
+    cp(feature_values, md.feature_values.data(), S * MD * 4);
+    cp(edge_weights, md.edge_weights.data(), L * MD * 4);
+    cp(is_numerics, md.is_numerics.data(), S * MD);
+    cp(inequality_directions, md.inequality_directions.data(), L * MD);
+    cp(categorical_values, md.categorical_values.data(), S * MD * gbrl::kCat);
+    cp(rev_num, md.reverse_num.data(), md.reverse_num.size() * 4);
+    cp(rev_cat, md.reverse_cat.data(), md.reverse_cat.size() * 4);
+    return GBRL_HIP_OK;
+}
+
+int gbrl_hip_step(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs, int cat_on_device,
+                  const float *grads, int grads_on_device, int n_samples, int n_num_features, int n_cat_features) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.step(obs, obs_on_device != 0, cat_obs, cat_on_device != 0, grads, grads_on_device != 0, n_samples,
+                       n_num_features, n_cat_features);
+    });
+}
+
+int gbrl_hip_predict(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs, int cat_on_device,
+                     int n_samples, int n_num_features, int n_cat_features, int start_tree, int stop_tree, float *out,
+                     int out_on_device) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.predict(obs, obs_on_device != 0, cat_obs, cat_on_device != 0, n_samples, n_num_features, n_cat_features,
+                          start_tree, stop_tree, out, out_on_device != 0);
+    });
+}
+
+int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.set_collective(hooks);
+    });
+}
+
+int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float *ms, int cap) {
+    if (!m) return 0;
+    const auto &ph = m->engine.phase_times();
+    const int n = static_cast<int>(ph.size());
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = ph[i].first.c_str();
+        if (ms) ms[i] = ph[i].second;
+    }
+    return n;
+}
+
+int gbrl_hip_set_profiling(gbrl_hip_model *m, int enabled) {
+    if (!m) return GBRL_HIP_E_INVALID;
+    m->engine.set_profiling(enabled != 0);
+    return GBRL_HIP_OK;
+}
+
+}  // extern "C"

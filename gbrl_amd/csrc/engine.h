@@ -1,0 +1,96 @@
+// engine.h -- device engine: owns the host model, its device mirror, the per-step workspace and the HIP stream, and
+// drives the kernels of kernels.hip for GBRL::step / GBRL::predict.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "model.h"
+
+namespace gbrl {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct NoDeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct InvalidArgument : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
+void hip_check(hipError_t e, const char *what);
+
+// grow-only device buffer
+class DevBuf {
+   public:
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf();
+    void *ensure(size_t bytes);  // contents are NOT preserved when it grows
+    void *ensure_keep(size_t bytes, size_t keep_bytes, hipStream_t s);  // preserves the first keep_bytes
+    template <typename T>
+    T *as() const { return static_cast<T *>(ptr_); }
+    size_t capacity() const { return cap_; }
+    void release();
+
+   private:
+    void *ptr_ = nullptr;
+    size_t cap_ = 0;
+};
+
+class Engine {
+   public:
+    explicit Engine(const gbrl_hip_config &cfg);
+    explicit Engine(Model &&loaded, int device_ordinal);
+    Engine(const Engine &other);  // deep copy of the model (GBRL::GBRL(GBRL&)); fresh device state
+    ~Engine();
+
+    Model model;
+
+    void step(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *grads, bool grads_dev, int n,
+              int n_num, int n_cat);
+    void predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
+                 int stop_tree, float *out, bool out_dev);
+
+    void set_collective(const gbrl_hip_collective *hooks);
+    void set_profiling(bool on) { profiling_ = on; }
+    const std::vector<std::pair<std::string, float>> &phase_times() const { return phases_; }
+
+   private:
+    void ensure_device();
+    void sync_model_to_device();
+    void phase_begin();
+    void phase_end(const char *name);
+
+    int device_ordinal_ = -1;
+    bool device_ready_ = false;
+    hipStream_t stream_ = nullptr;
+    gbrl_hip_collective coll_{};
+    bool has_coll_ = false;
+
+    // measurement
+    bool profiling_ = false;
+    std::vector<std::pair<std::string, float>> phases_;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+
+    // ---- per-step workspace (grow-only, reused across steps) ----
+    DevBuf d_obs_, d_grads_, d_qg_, d_stat_, d_partials_f64_, d_meanden_, d_maxbits_;
+    DevBuf d_thr_, d_thrkeys_, d_prefix_, d_trial_, d_counts_, d_cum_, d_minmax_;
+    DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
+    DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
+    DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
+    DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_;
+    // ---- predict workspace + device mirror of the ensemble ----
+    DevBuf d_pobs_, d_pcat_, d_pout_;
+    DevBuf m_tree_indices_, m_depths_, m_feature_indices_, m_feature_values_, m_values_, m_is_numerics_, m_ineq_,
+        m_cat_ids_, m_bias_, m_opt_start_, m_opt_stop_, m_opt_lr_;
+    size_t up_trees_ = 0, up_leaves_ = 0, up_splits_ = 0;  // how much of the append-only arrays is already on the device
+    uint64_t mirror_version_ = ~0ull;
+    // dictionary of the categorical strings that occur in the model's conditions: (cat feature, string) -> id >= 1
+    std::vector<int32_t> cat_ids_host_;
+    std::vector<std::pair<int, std::string>> cat_dict_;
+};
+
+}  // namespace gbrl

@@ -1,0 +1,882 @@
+// engine.hip -- host orchestration of the HIP kernels for GBRL::step / GBRL::predict (see engine.h).
+//
+// step() restates Fitter::step_cpu (gbrl/src/cpp/fitter.cpp:50-115) as a histogram algorithm:
+//   1. gradient statistics + fixed-point quantisation of the build gradients           (A2)
+//   2. split candidates: uniform (min/max) or quantile (exact order statistics)          (A3, A4); categorical on the host (A5)
+//   3. observations -> per-feature class codes (once per step)
+//   4. level-synchronous growth: for every frontier node build (count, sum g[D]) per (feature, class) in LDS, reduce to
+//      exact int64 histograms, score every candidate from suffix sums, pick the split, partition the row list   (A6-A10)
+//   5. leaf values = exact mean of the raw gradients per leaf                              (A11)
+// The reference grows greedy trees depth-first; the split chosen for a node depends only on that node's rows, so growing
+// level by level and emitting the leaves in depth-first (left first) order afterwards gives the identical tree.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+
+namespace gbrl {
+
+using kern::Chunk;
+using kern::FeatureSlot;
+using kern::NodeSplit;
+
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw HipError(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+DevBuf::~DevBuf() { release(); }
+void DevBuf::release() {
+    if (ptr_) (void)hipFree(ptr_);
+    ptr_ = nullptr;
+    cap_ = 0;
+}
+void *DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap_ && ptr_) return ptr_;
+    release();
+    const size_t want = std::max<size_t>(256, bytes + bytes / 8);
+    hip_check(hipMalloc(&ptr_, want), "hipMalloc");
+    cap_ = want;
+    return ptr_;
+}
+void *DevBuf::ensure_keep(size_t bytes, size_t keep_bytes, hipStream_t s) {
+    if (bytes <= cap_ && ptr_) return ptr_;
+    void *np = nullptr;
+    const size_t want = std::max<size_t>(4096, bytes * 2);
+    hip_check(hipMalloc(&np, want), "hipMalloc");
+    if (ptr_ && keep_bytes) {
+        hip_check(hipMemcpyAsync(np, ptr_, keep_bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync(grow)");
+        hip_check(hipStreamSynchronize(s), "hipStreamSynchronize(grow)");
+    }
+    if (ptr_) (void)hipFree(ptr_);
+    ptr_ = np;
+    cap_ = want;
+    return ptr_;
+}
+
+Engine::Engine(const gbrl_hip_config &cfg) : model(cfg), device_ordinal_(cfg.device_ordinal) {}
+Engine::Engine(Model &&loaded, int device_ordinal) : model(std::move(loaded)), device_ordinal_(device_ordinal) {}
+Engine::Engine(const Engine &o) : model(o.model), device_ordinal_(o.device_ordinal_) {}
+
+Engine::~Engine() {
+    if (device_ready_) {
+        (void)hipSetDevice(device_ordinal_);
+        if (ev0_) (void)hipEventDestroy(ev0_);
+        if (ev1_) (void)hipEventDestroy(ev1_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+}
+
+void Engine::ensure_device() {
+    if (device_ready_) {
+        hip_check(hipSetDevice(device_ordinal_), "hipSetDevice");
+        return;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw NoDeviceError("no HIP device available: this library has no CPU path (the reference's CPU path lives in oracle/)");
+    if (device_ordinal_ < 0) {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+        device_ordinal_ = cur;
+    }
+    if (device_ordinal_ >= count) throw InvalidArgument("device ordinal out of range");
+    hip_check(hipSetDevice(device_ordinal_), "hipSetDevice");
+    hip_check(hipStreamCreate(&stream_), "hipStreamCreate");  // blocking stream: ordered with the null stream torch uses by default
+    hip_check(hipEventCreate(&ev0_), "hipEventCreate");
+    hip_check(hipEventCreate(&ev1_), "hipEventCreate");
+    device_ready_ = true;
+}
+
+void Engine::set_collective(const gbrl_hip_collective *hooks) {
+    if (hooks == nullptr || hooks->world_size <= 1) {
+        has_coll_ = false;
+        return;
+    }
+    if (!hooks->allreduce_sum_i64 || !hooks->allreduce_sum_f64 || !hooks->allreduce_max_f32 || !hooks->allreduce_min_f32)
+        throw InvalidArgument("collective hooks incomplete");
+    coll_ = *hooks;
+    has_coll_ = true;
+}
+
+void Engine::phase_begin() {
+    if (profiling_) hip_check(hipEventRecord(ev0_, stream_), "hipEventRecord");
+}
+void Engine::phase_end(const char *name) {
+    if (!profiling_) return;
+    hip_check(hipEventRecord(ev1_, stream_), "hipEventRecord");
+    hip_check(hipEventSynchronize(ev1_), "hipEventSynchronize");
+    float ms = 0.f;
+    hip_check(hipEventElapsedTime(&ms, ev0_, ev1_), "hipEventElapsedTime");
+    for (auto &p : phases_)
+        if (p.first == name) { p.second += ms; return; }
+    phases_.emplace_back(name, ms);
+}
+
+namespace {
+
+struct HCond {       // splitCondition (types.h:64-70) + what the kernels need
+    int fslot;       // feature slot (numeric f, or F + categorical c)
+    int feat_idx;    // feature index as stored in the model (within its numeric / categorical block)
+    float value;     // numeric threshold, +inf for categorical (split_candidate_generator.cpp:155)
+    int bin;         // numeric: threshold index; categorical: class id
+    bool is_cat;
+    bool dir;
+    float edge_w;
+    int cat_cand;    // index into cat candidate strings, -1 for numeric
+};
+
+struct HNode {
+    int depth = 0;
+    int seg_start = 0;
+    int n_local = 0;        // rows of this rank in the node
+    long long n_global = 0;  // rows over all ranks
+    std::vector<HCond> path;
+    int left = -1, right = -1;
+    bool leaf = false;
+};
+
+struct CatCandidate { int feat; std::string name; int cls; };
+
+inline int ilog2_floor(double x) { int e; std::frexp(x, &e); return e - 1; }
+
+}  // namespace
+
+// ======================================================================================================== step
+void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *grads, bool grads_dev, int n,
+                  int n_num, int n_cat) {
+    gbrl_hip_metadata &md = model.meta;
+    // GBRL::step, gbrl.cpp:946-958
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n_num + n_cat != md.input_dim) throw InvalidArgument("Total number of features != correct input dim");
+    if (n <= 0 || grads == nullptr) throw InvalidArgument("Cannot call step without grads!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call step without obs!");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call step without cat_obs!");
+    if (md.max_depth > kern::kMaxPath) throw Unsupported("max_depth > 32 is not supported");
+    if (md.n_bins < 1 || md.n_bins > 65534) throw Unsupported("n_bins must be in [1, 65534]");
+    ensure_device();
+    phases_.clear();
+    hipStream_t s = stream_;
+    const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
+    const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
+    const bool oblivious = model.oblivious();
+    const int world = has_coll_ ? coll_.world_size : 1;
+
+    // global row count (rows are sharded over ranks)
+    long long n_global = N;
+    if (has_coll_) {
+        int64_t *tmp = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t)));
+        int64_t hv = N;
+        hip_check(hipMemcpyAsync(tmp, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D n");
+        hip_check(hipStreamSynchronize(s), "sync");
+        if (coll_.allreduce_sum_i64(coll_.ctx, tmp, 1) != 0) throw HipError("allreduce failed");
+        hip_check(hipMemcpy(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost), "D2H n");
+        n_global = hv;
+    }
+
+    // ---- inputs on the device -------------------------------------------------------------------------------------
+    phase_begin();
+    const float *dobs = obs;
+    if (F > 0 && !obs_dev) {
+        dobs = static_cast<float *>(d_obs_.ensure(sizeof(float) * N * F));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * N * F, hipMemcpyHostToDevice, s), "H2D obs");
+    }
+    const float *dgrads = grads;
+    if (!grads_dev) {
+        dgrads = static_cast<float *>(d_grads_.ensure(sizeof(float) * N * D));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dgrads), grads, sizeof(float) * N * D, hipMemcpyHostToDevice, s), "H2D grads");
+    }
+    // categorical features are pre-processed on the host (strings); bring them and the raw grads there if needed
+    std::vector<char> cat_host_buf;
+    const char *hcat = cat;
+    std::vector<float> grads_host_buf;
+    const float *hgrads = grads;
+    if (Fc > 0) {
+        if (cat_dev) {
+            cat_host_buf.resize(static_cast<size_t>(N) * Fc * kCat);
+            hip_check(hipMemcpy(cat_host_buf.data(), cat, cat_host_buf.size(), hipMemcpyDeviceToHost), "D2H cat");
+            hcat = cat_host_buf.data();
+        }
+        if (grads_dev) {
+            grads_host_buf.resize(static_cast<size_t>(N) * D);
+            hip_check(hipMemcpy(grads_host_buf.data(), grads, grads_host_buf.size() * 4, hipMemcpyDeviceToHost), "D2H grads");
+            hgrads = grads_host_buf.data();
+        }
+    }
+    phase_end("inputs");
+
+    // ---- 1. gradient statistics and quantisation (A2) -----------------------------------------------------------------
+    phase_begin();
+    const size_t n_el = static_cast<size_t>(N) * D;
+    float *d_meanden = static_cast<float *>(d_meanden_.ensure(sizeof(float) * 2 * D));
+    const float *d_mean = nullptr, *d_den = nullptr;
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * D));
+    const int nblk = kern::column_sums_blocks(N, D);
+    double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * D));
+    if (D > 1024) throw Unsupported("output_dim > 1024");
+    if (!cosine) {
+        // fitter.cpp:58-63: mean, centre, unbiased std, divide by (std + 1e-8)
+        std::vector<double> hs(D);
+        std::vector<float> hmd(2 * D);
+        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
+        if (has_coll_) {
+            hip_check(hipStreamSynchronize(s), "sync");
+            if (coll_.allreduce_sum_f64(coll_.ctx, d_stat, D) != 0) throw HipError("allreduce failed");
+        }
+        hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * D, hipMemcpyDeviceToHost, s), "D2H mean");
+        hip_check(hipStreamSynchronize(s), "sync");
+        for (int d = 0; d < D; ++d) hmd[d] = static_cast<float>(hs[d] / static_cast<double>(n_global));
+        hip_check(hipMemcpyAsync(d_meanden, hmd.data(), sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D mean");
+        kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat, s);
+        if (has_coll_) {
+            hip_check(hipStreamSynchronize(s), "sync");
+            if (coll_.allreduce_sum_f64(coll_.ctx, d_stat, D) != 0) throw HipError("allreduce failed");
+        }
+        hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * D, hipMemcpyDeviceToHost, s), "D2H var");
+        hip_check(hipStreamSynchronize(s), "sync");
+        const float recip = 1.0f / (static_cast<float>(n_global) - 1.0f);  // math_ops.cpp:464
+        for (int d = 0; d < D; ++d) {
+            const float sd = sqrtf(static_cast<float>(hs[d]) * recip);     // math_ops.cpp:510
+            hmd[D + d] = sd + 1e-8f;                                        // math_ops.cpp:94
+        }
+        hip_check(hipMemcpyAsync(d_meanden + D, hmd.data() + D, sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D std");
+        d_mean = d_meanden;
+        d_den = d_meanden + D;
+    }
+    uint32_t *d_maxbits = static_cast<uint32_t *>(d_maxbits_.ensure(sizeof(uint32_t) * 2));
+    hip_check(hipMemsetAsync(d_maxbits, 0, sizeof(uint32_t) * 2, s), "memset");
+    kern::max_abs(dgrads, n_el, D, d_mean, d_den, d_maxbits, s);       // max |build grad|
+    kern::max_abs(dgrads, n_el, D, nullptr, nullptr, d_maxbits + 1, s);  // max |raw grad| (leaf fixed point)
+    if (has_coll_) {
+        hip_check(hipStreamSynchronize(s), "sync");
+        if (coll_.allreduce_max_f32(coll_.ctx, reinterpret_cast<float *>(d_maxbits), 2) != 0) throw HipError("allreduce failed");
+    }
+    float hmax[2];
+    hip_check(hipMemcpyAsync(hmax, d_maxbits, sizeof(hmax), hipMemcpyDeviceToHost, s), "D2H max");
+    hip_check(hipStreamSynchronize(s), "sync");
+    if (!std::isfinite(hmax[0]) || !std::isfinite(hmax[1])) throw InvalidArgument("non-finite gradients");
+    // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: pick the power-of-two scale
+    // with chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build)
+    const int chunk_rows = std::max(4096, (N + 63) / 64);
+    int sbits = 20;
+    if (hmax[0] > 0.f) sbits = std::min(100, ilog2_floor(2147483647.0 / (static_cast<double>(chunk_rows) * hmax[0])) - 1);
+    const double scale = std::ldexp(1.0, sbits);
+    int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
+    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, static_cast<float>(scale), d_qg, s);
+    // leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62
+    int lbits = 40;
+    if (hmax[1] > 0.f) lbits = std::min(60, ilog2_floor(4.0e18 / (static_cast<double>(n_global) * hmax[1])) - 1);
+    const double leaf_scale = std::ldexp(1.0, lbits);
+    phase_end("grad_stats");
+
+    // ---- 2. split candidates ----------------------------------------------------------------------------------------
+    phase_begin();
+    std::vector<float> h_thr(static_cast<size_t>(F) * B);
+    float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, h_thr.size())));
+    uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, h_thr.size())));
+    if (F > 0) {
+        if (md.generator_type == GBRL_HIP_GEN_UNIFORM) {
+            uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
+            hip_check(hipMemsetAsync(d_mm, 0xff, sizeof(uint32_t) * F, s), "memset");
+            hip_check(hipMemsetAsync(d_mm + F, 0x00, sizeof(uint32_t) * F, s), "memset");
+            kern::column_minmax(dobs, N, F, d_mm, d_mm + F, s);
+            if (has_coll_) {
+                // exchange as floats (max / min are exact)
+                float *tmp = static_cast<float *>(d_trial_.ensure(sizeof(float) * 2 * F));
+                kern::keys_to_floats(d_mm, tmp, 2 * static_cast<size_t>(F), s);
+                hip_check(hipStreamSynchronize(s), "sync");
+                if (coll_.allreduce_min_f32(coll_.ctx, tmp, F) != 0 || coll_.allreduce_max_f32(coll_.ctx, tmp + F, F) != 0)
+                    throw HipError("allreduce failed");
+                kern::floats_to_keys(tmp, d_mm, 2 * static_cast<size_t>(F), s);
+            }
+            kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s);
+            kern::floats_to_keys(d_thr, d_thrkeys, static_cast<size_t>(F) * B, s);
+        } else {
+            // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1
+            if (n_global < B + 1) throw InvalidArgument("quantile candidates need n_samples >= n_bins + 1");
+            std::vector<int64_t> cum(B);
+            const long long per = n_global / (B + 1), rem = n_global % (B + 1);
+            long long run = 0;
+            for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
+            int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+            hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+            uint32_t *d_prefix = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * F * B));
+            uint32_t *d_trial = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * F * B));
+            int64_t *d_counts = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * F * (B + 1)));
+            kern::qsel_init(d_prefix, d_trial, F, B, s);
+            for (int bit = 31; bit >= 0; --bit) {
+                hip_check(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * F * (B + 1), s), "memset");
+                kern::bin_rows(dobs, N, F, d_trial, B, /*strict=*/false, d_counts, nullptr, 0, 0, s);
+                if (has_coll_) {
+                    hip_check(hipStreamSynchronize(s), "sync");
+                    if (coll_.allreduce_sum_i64(coll_.ctx, d_counts, static_cast<size_t>(F) * (B + 1)) != 0)
+                        throw HipError("allreduce failed");
+                }
+                kern::qsel_update(d_prefix, d_trial, d_counts, d_cum, F, B, bit, bit - 1, s);
+            }
+            hip_check(hipMemcpyAsync(d_thrkeys, d_trial, sizeof(uint32_t) * F * B, hipMemcpyDeviceToDevice, s), "D2D keys");
+            kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
+        }
+        hip_check(hipMemcpyAsync(h_thr.data(), d_thr, sizeof(float) * F * B, hipMemcpyDeviceToHost, s), "D2H thr");
+    }
+    phase_end("candidates");
+
+    // categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
+    // same container, same insertion order => same candidate order (Q8)
+    std::vector<CatCandidate> cat_cands;
+    std::vector<uint16_t> h_catcodes;
+    std::vector<int> cat_classes(Fc, 0);
+    if (Fc > 0) {
+        if (has_coll_) throw Unsupported("categorical features with row-sharded multi-GPU are not supported yet");
+        struct Info { float total = 0.f; int count = 0; int feat = 0; std::string name; };
+        std::vector<float> norms(N, 0.0f);
+        for (int i = 0; i < N; ++i) {  // calculate_squared_norm (math_ops.cpp:726-749), contracted like the reference build
+            float acc = 0.0f;
+            for (int d = 0; d < D; ++d) { const float g = hgrads[static_cast<size_t>(i) * D + d]; acc = fmaf(g, g, acc); }
+            norms[i] = acc;
+        }
+        std::unordered_map<std::string, Info> uniq;
+        for (int f = 0; f < Fc; ++f)
+            for (int i = 0; i < N; ++i) {
+                std::string name(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+                Info &ci = uniq[name + "_" + std::to_string(f)];
+                ci.total += norms[i];
+                ci.count += 1;
+                ci.feat = f;
+                ci.name = name;
+            }
+        std::vector<std::pair<std::string, float>> vec;
+        for (const auto &kv : uniq) vec.emplace_back(kv.first, kv.second.total / kv.second.count);
+        int n_unique = static_cast<int>(vec.size());
+        if (n_unique > Fc * B) {
+            std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, float> &a, const std::pair<std::string, float> &b) {
+                return a.second > b.second;
+            });
+            n_unique = Fc * B;
+        }
+        std::unordered_map<std::string, int> cls_of;  // key -> class id within its feature
+        for (int i = 0; i < n_unique; ++i) {
+            const Info &ci = uniq[vec[i].first];
+            const int cls = ++cat_classes[ci.feat];
+            if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+            cat_cands.push_back({ci.feat, ci.name, cls});
+            cls_of[vec[i].first] = cls;
+        }
+        h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
+        for (int i = 0; i < N; ++i)
+            for (int f = 0; f < Fc; ++f) {
+                std::string key(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+                key += "_" + std::to_string(f);
+                auto it = cls_of.find(key);
+                if (it != cls_of.end()) h_catcodes[static_cast<size_t>(i) * Fc + f] = static_cast<uint16_t>(it->second);
+            }
+    }
+
+    // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
+    const int n_slots = F + Fc;
+    int NB = F > 0 ? B + 1 : 1;
+    for (int c = 0; c < Fc; ++c) NB = std::max(NB, cat_classes[c] + 1);
+    int FG = 16;
+    while (FG > 1 && kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512) FG >>= 1;
+    if (kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512)
+        throw Unsupported("(classes per feature) x (output_dim + 1) does not fit the 160 KiB LDS");
+    if (static_cast<size_t>(NB + 1) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");
+    const int Fp = ((n_slots + FG - 1) / FG) * FG;
+    const int n_groups = Fp / FG;
+    // internal candidate order = slot-grouped; cand_ref maps to the reference's candidate index (numeric f-major, then the
+    // categorical candidates in the hash-map order) which decides ties (lowest reference index wins)
+    std::vector<FeatureSlot> slots(n_slots);
+    int n_cand = 0;
+    for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
+    for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
+    std::vector<int32_t> cand_ref(n_cand);
+    std::vector<float> cand_w(n_cand);
+    std::vector<int> ref_to_internal(n_cand);
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < B; ++k) {
+            const int j = slots[f].cand_base + k;
+            cand_ref[j] = f * B + k;
+            // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
+            const int wi = oblivious ? model.reverse_num[f] : f;
+            cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+        }
+    for (size_t q = 0; q < cat_cands.size(); ++q) {
+        const CatCandidate &cc = cat_cands[q];
+        const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
+        cand_ref[j] = F * B + static_cast<int>(q);
+        const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
+        cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+    }
+    for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
+
+    // ---- 3. class codes ----------------------------------------------------------------------------------------------
+    phase_begin();
+    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * static_cast<size_t>(N) * Fp));
+    if (Fp != F) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * static_cast<size_t>(N) * Fp, s), "memset codes");
+    if (F > 0) kern::bin_rows(dobs, N, F, d_thrkeys, B, /*strict=*/true, nullptr, d_codes, Fp, 0, s);
+    if (Fc > 0) {
+        uint16_t *d_cc = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
+        hip_check(hipMemcpyAsync(d_cc, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
+        kern::scatter_cat_codes(d_cc, N, Fc, d_codes, Fp, F, s);
+    }
+    phase_end("binning");
+
+    // ---- 4. growth ---------------------------------------------------------------------------------------------------
+    const int max_front = 1 << std::max(0, MD - 1);
+    const int max_chunks = std::max((N + chunk_rows - 1) / chunk_rows, (N + 8191) / 8192) + 2 * (1 << MD) + 2;
+    const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
+    int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
+                          static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
+    Chunk *d_chunks = static_cast<Chunk *>(d_chunks_.ensure(sizeof(Chunk) * max_chunks));
+    int32_t *d_chunk_begin = static_cast<int32_t *>(d_chunk_begin_.ensure(sizeof(int32_t) * (max_front * 2 + 2)));
+    int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * max_chunks * n_groups * n_acc));
+    const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
+    int64_t *d_hist = static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems));
+    int64_t *d_hist_local = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * hist_node_elems)) : d_hist;
+    FeatureSlot *d_slots = static_cast<FeatureSlot *>(d_slots_.ensure(sizeof(FeatureSlot) * std::max(1, n_slots)));
+    float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
+    float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
+    float *d_cand_w = static_cast<float *>(d_cand_w_.ensure(sizeof(float) * std::max(1, n_cand)));
+    int32_t *d_cand_ref = static_cast<int32_t *>(d_cand_ref_.ensure(sizeof(int32_t) * std::max(1, n_cand)));
+    int32_t *d_path_len = static_cast<int32_t *>(d_path_len_.ensure(sizeof(int32_t) * max_front));
+    int32_t *d_path_slot = static_cast<int32_t *>(d_path_slot_.ensure(sizeof(int32_t) * max_front * kern::kMaxPath));
+    float *d_path_val = static_cast<float *>(d_path_val_.ensure(sizeof(float) * max_front * kern::kMaxPath));
+    int32_t *d_path_bin = static_cast<int32_t *>(d_path_bin_.ensure(sizeof(int32_t) * max_front * kern::kMaxPath));
+    int32_t *d_isroot = static_cast<int32_t *>(d_isroot_.ensure(sizeof(int32_t) * max_front));
+    int32_t *d_best_idx = static_cast<int32_t *>(d_best_idx_.ensure(sizeof(int32_t) * max_front));
+    float *d_best_score = static_cast<float *>(d_best_score_.ensure(sizeof(float) * max_front));
+    NodeSplit *d_splits = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
+    int64_t *d_ntotal = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t) * max_front * 2));
+    int64_t *d_nright = static_cast<int64_t *>(d_nright_.ensure(sizeof(int64_t) * max_front * 2));
+    int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
+    const int max_nodes = 2 * (1 << MD);
+    int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
+    hip_check(hipMemsetAsync(d_leafacc, 0, sizeof(int64_t) * max_nodes * (D + 1), s), "memset leaf acc");
+    if (n_slots > 0) hip_check(hipMemcpyAsync(d_slots, slots.data(), sizeof(FeatureSlot) * n_slots, hipMemcpyHostToDevice, s), "H2D slots");
+    if (n_cand > 0) {
+        hip_check(hipMemcpyAsync(d_cand_w, cand_w.data(), sizeof(float) * n_cand, hipMemcpyHostToDevice, s), "H2D w");
+        hip_check(hipMemcpyAsync(d_cand_ref, cand_ref.data(), sizeof(int32_t) * n_cand, hipMemcpyHostToDevice, s), "H2D ref");
+    }
+    kern::iota_rows(d_rows[0], N, s);
+    hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr is needed on the host from here on
+
+    std::vector<HNode> nodes;
+    nodes.reserve(max_nodes);
+    nodes.push_back(HNode{});
+    nodes[0].n_local = N;
+    nodes[0].n_global = n_global;
+    std::vector<int> frontier{0};
+    int cur = 0;  // which row list is current
+    std::vector<Chunk> h_chunks;
+    std::vector<int32_t> h_chunk_begin;
+    auto build_chunks = [&](const std::vector<int> &ids, int rows_per_chunk) {
+        h_chunks.clear();
+        h_chunk_begin.assign(1, 0);
+        for (size_t k = 0; k < ids.size(); ++k) {
+            const HNode &nd = nodes[ids[k]];
+            for (int off = 0; off < nd.n_local; off += rows_per_chunk)
+                h_chunks.push_back({static_cast<int32_t>(k), nd.seg_start + off, std::min(rows_per_chunk, nd.n_local - off), 0});
+            h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size()));
+        }
+        if (h_chunks.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: chunk table overflow");
+        if (!h_chunks.empty())
+            hip_check(hipMemcpyAsync(d_chunks, h_chunks.data(), sizeof(Chunk) * h_chunks.size(), hipMemcpyHostToDevice, s), "H2D chunks");
+    };
+    auto leaf_sums_for = [&](const std::vector<int> &ids) {  // slot = node id
+        std::vector<Chunk> lc;
+        for (int id : ids) {
+            const HNode &nd = nodes[id];
+            if (nd.depth == 0) continue;  // a depth-0 leaf never "passes": value stays 0 (fitter.cpp:559-565, Q7)
+            for (int off = 0; off < nd.n_local; off += 8192)
+                lc.push_back({id, nd.seg_start + off, std::min(8192, nd.n_local - off), 0});
+        }
+        if (lc.empty()) return;
+        hip_check(hipStreamSynchronize(s), "sync");  // previous users of the chunk table are done
+        if (lc.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: leaf chunk table overflow");
+        hip_check(hipMemcpyAsync(d_chunks, lc.data(), sizeof(Chunk) * lc.size(), hipMemcpyHostToDevice, s), "H2D leaf chunks");
+        kern::leaf_sums(dgrads, D, d_rows[cur], d_chunks, static_cast<int>(lc.size()), leaf_scale, d_leafacc, s);
+        hip_check(hipStreamSynchronize(s), "sync");  // lc goes out of scope
+    };
+
+    int tree_depth = 0;
+    phase_begin();
+    for (int depth = 0; depth < MD && n_cand > 0; ++depth) {
+        // nodes that take part at this level: oblivious -> the whole level; greedy -> nodes with rows (fitter.cpp:300)
+        std::vector<int> active;
+        for (int id : frontier)
+            if (oblivious || nodes[id].n_global > 0) active.push_back(id);
+        if (active.empty()) break;
+        const int n_act = static_cast<int>(active.size());
+        // -- histograms
+        build_chunks(active, chunk_rows);
+        hip_check(hipMemcpyAsync(d_chunk_begin, h_chunk_begin.data(), sizeof(int32_t) * h_chunk_begin.size(), hipMemcpyHostToDevice, s), "H2D chunk begin");
+        if (!h_chunks.empty())
+            kern::hist_build(d_codes, Fp, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
+        kern::hist_reduce(d_partials, d_chunk_begin, n_act, n_groups, FG, NB, D, Fp, d_hist_local, s);
+        if (has_coll_) {
+            hip_check(hipMemcpyAsync(d_hist, d_hist_local, sizeof(int64_t) * n_act * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist");
+            hip_check(hipStreamSynchronize(s), "sync");
+            if (coll_.allreduce_sum_i64(coll_.ctx, d_hist, static_cast<size_t>(n_act) * hist_node_elems) != 0) throw HipError("allreduce failed");
+        }
+        // -- paths (duplicate-on-path rejection, node.cpp:154-166)
+        std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
+        std::vector<float> pv(static_cast<size_t>(n_act) * kern::kMaxPath, 0.f);
+        for (int k = 0; k < n_act; ++k) {
+            const HNode &nd = nodes[active[k]];
+            pl[k] = static_cast<int32_t>(nd.path.size());
+            root[k] = nd.depth == 0;
+            for (size_t p = 0; p < nd.path.size(); ++p) {
+                ps[k * kern::kMaxPath + p] = nd.path[p].fslot;
+                pv[k * kern::kMaxPath + p] = nd.path[p].value;
+                pb[k * kern::kMaxPath + p] = nd.path[p].bin;
+            }
+        }
+        hip_check(hipMemcpyAsync(d_path_len, pl.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipMemcpyAsync(d_path_slot, ps.data(), sizeof(int32_t) * ps.size(), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipMemcpyAsync(d_path_val, pv.data(), sizeof(float) * pv.size(), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipMemcpyAsync(d_path_bin, pb.data(), sizeof(int32_t) * pb.size(), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipMemcpyAsync(d_isroot, root.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s), "H2D");
+        // -- scores and selection
+        kern::score_candidates(d_hist, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
+                               1.0 / scale, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
+        std::vector<int32_t> best_idx(n_act, 0);
+        std::vector<float> best_score(n_act, -INFINITY);
+        if (oblivious) {
+            kern::argmax_oblivious(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_best_idx, d_best_score, s);
+            hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H");
+            hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float), hipMemcpyDeviceToHost, s), "D2H");
+        } else {
+            kern::argmax_greedy(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, d_best_idx, d_best_score, s);
+            hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
+            hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float) * n_act, hipMemcpyDeviceToHost, s), "D2H");
+        }
+        hip_check(hipStreamSynchronize(s), "sync");
+        if (oblivious) {
+            if (best_score[0] == -INFINITY) break;  // fitter.cpp:458
+            for (int k = 1; k < n_act; ++k) { best_idx[k] = best_idx[0]; best_score[k] = best_score[0]; }
+        }
+        // -- decisions (best_idx are REFERENCE candidate indices)
+        std::vector<NodeSplit> sp(n_act);
+        std::vector<int> splitting, new_leaves;
+        for (int k = 0; k < n_act; ++k) {
+            HNode &nd = nodes[active[k]];
+            const bool do_split = oblivious || best_score[k] >= 0.0f;  // fitter.cpp:357
+            NodeSplit q{};
+            q.seg_start = nd.seg_start;
+            if (do_split) {
+                const int j = ref_to_internal[best_idx[k]];
+                int fs = 0;
+                while (fs + 1 < n_slots && slots[fs + 1].cand_base <= j) ++fs;
+                q.do_split = 1;
+                q.fslot = fs;
+                q.is_cat = slots[fs].is_cat;
+                q.bin = slots[fs].is_cat ? (j - slots[fs].cand_base + 1) : (j - slots[fs].cand_base);
+                splitting.push_back(k);
+            } else {
+                nd.leaf = true;
+                new_leaves.push_back(active[k]);
+            }
+            sp[k] = q;
+        }
+        if (!oblivious)
+            for (int id : frontier)
+                if (nodes[id].n_global == 0 && !nodes[id].leaf) { nodes[id].leaf = true; new_leaves.push_back(id); }
+        // child sizes from the histograms: local (for the row lists) and global (edge weights)
+        std::vector<int64_t> tot_l(n_act), right_l(n_act), tot_g(n_act), right_g(n_act);
+        hip_check(hipMemcpyAsync(d_splits, sp.data(), sizeof(NodeSplit) * n_act, hipMemcpyHostToDevice, s), "H2D splits");
+        kern::child_counts(d_hist_local, n_act, Fp, NB, D, d_splits, d_ntotal, d_nright, s);
+        hip_check(hipMemcpyAsync(tot_l.data(), d_ntotal, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(right_l.data(), d_nright, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
+        if (has_coll_) {
+            kern::child_counts(d_hist, n_act, Fp, NB, D, d_splits, d_ntotal + max_front, d_nright + max_front, s);
+            hip_check(hipMemcpyAsync(tot_g.data(), d_ntotal + max_front, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
+            hip_check(hipMemcpyAsync(right_g.data(), d_nright + max_front, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
+        }
+        hip_check(hipStreamSynchronize(s), "sync");
+        if (!has_coll_) { tot_g = tot_l; right_g = right_l; }
+        // leaves finalised at this level: sum their raw gradients while their segment is intact in the current list
+        if (!new_leaves.empty()) leaf_sums_for(new_leaves);
+        if (splitting.empty()) { frontier.clear(); break; }
+        std::vector<int> next;
+        for (int k : splitting) {
+            const int id = active[k];
+            if (tot_l[k] != nodes[id].n_local) throw HipError("internal: histogram row count mismatch");
+            const NodeSplit &q = sp[k];
+            HCond c{};
+            c.fslot = q.fslot;
+            c.is_cat = q.is_cat != 0;
+            c.bin = q.bin;
+            if (c.is_cat) {
+                c.feat_idx = q.fslot - F;
+                c.value = INFINITY;
+                c.cat_cand = -1;
+                for (size_t z = 0; z < cat_cands.size(); ++z)
+                    if (cat_cands[z].feat == c.feat_idx && cat_cands[z].cls == q.bin) c.cat_cand = static_cast<int>(z);
+            } else {
+                c.feat_idx = q.fslot;
+                c.value = h_thr[static_cast<size_t>(q.fslot) * B + q.bin];
+                c.cat_cand = -1;
+            }
+            const long long npar = nodes[id].n_global, nr = right_g[k], nl = npar - nr;
+            HNode l, r;
+            l.depth = r.depth = nodes[id].depth + 1;
+            l.path = nodes[id].path;
+            r.path = nodes[id].path;
+            HCond cl = c, cr = c;
+            cl.dir = false;
+            cl.edge_w = npar > 0 ? static_cast<float>(nl) / static_cast<float>(npar) : 0.0f;  // node.cpp:131
+            cr.dir = true;
+            cr.edge_w = npar > 0 ? static_cast<float>(nr) / static_cast<float>(npar) : 0.0f;
+            l.path.push_back(cl);
+            r.path.push_back(cr);
+            const int nl_local = static_cast<int>(tot_l[k] - right_l[k]);
+            l.seg_start = nodes[id].seg_start;
+            l.n_local = nl_local;
+            l.n_global = nl;
+            r.seg_start = nodes[id].seg_start + nl_local;
+            r.n_local = static_cast<int>(right_l[k]);
+            r.n_global = nr;
+            sp[k].n_left = nl_local;
+            nodes[id].left = static_cast<int>(nodes.size());
+            nodes.push_back(l);
+            nodes[id].right = static_cast<int>(nodes.size());
+            nodes.push_back(r);
+            next.push_back(nodes[id].left);
+            next.push_back(nodes[id].right);
+        }
+        // -- partition the row list of the splitting nodes
+        {
+            std::vector<int> split_ids;
+            std::vector<NodeSplit> sp2;
+            for (int k : splitting) { split_ids.push_back(active[k]); sp2.push_back(sp[k]); }
+            build_chunks(split_ids, 8192);
+            hip_check(hipMemcpyAsync(d_splits, sp2.data(), sizeof(NodeSplit) * sp2.size(), hipMemcpyHostToDevice, s), "H2D splits");
+            hip_check(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * 2 * sp2.size(), s), "memset cursors");
+            if (!h_chunks.empty())
+                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, Fp, d_chunks, static_cast<int>(h_chunks.size()), d_splits, d_cursors, s);
+            hip_check(hipStreamSynchronize(s), "sync");  // host staging vectors go out of scope
+            cur ^= 1;
+        }
+        frontier = next;
+        tree_depth = depth + 1;
+    }
+    phase_end("growth");
+
+    // ---- 5. leaves ---------------------------------------------------------------------------------------------------
+    phase_begin();
+    {
+        std::vector<int> last;
+        for (int id : frontier)
+            if (!nodes[id].leaf) { nodes[id].leaf = true; last.push_back(id); }
+        if (nodes.size() == 1) nodes[0].leaf = true;
+        if (!last.empty()) leaf_sums_for(last);
+    }
+    if (has_coll_) {
+        hip_check(hipStreamSynchronize(s), "sync");
+        if (coll_.allreduce_sum_i64(coll_.ctx, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1)) != 0) throw HipError("allreduce failed");
+    }
+    std::vector<int64_t> acc(nodes.size() * (D + 1));
+    hip_check(hipMemcpyAsync(acc.data(), d_leafacc, sizeof(int64_t) * acc.size(), hipMemcpyDeviceToHost, s), "D2H leaf acc");
+    hip_check(hipStreamSynchronize(s), "sync");
+    phase_end("leaves");
+
+    // leaf order: oblivious = level order of the last level (child slots 2k, 2k+1, fitter.cpp:469-470); greedy = depth-first,
+    // left first (fitter.cpp:364-365)
+    std::vector<int> leaf_order;
+    if (oblivious) {
+        if (nodes.size() == 1) leaf_order.push_back(0);
+        else leaf_order = frontier;
+    } else {
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            const int id = stack.back();
+            stack.pop_back();
+            if (nodes[id].left < 0) { leaf_order.push_back(id); continue; }
+            stack.push_back(nodes[id].right);
+            stack.push_back(nodes[id].left);
+        }
+    }
+    (void)tree_depth;
+
+    // ---- append to the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) -----------------------------
+    model.begin_tree();
+    const size_t tree = md.n_trees;
+    model.tree_indices.push_back(md.n_leaves);
+    auto write_conditions = [&](const HNode &nd, size_t split_row, size_t leaf_row) {
+        for (size_t i = 0; i < nd.path.size(); ++i) {
+            const HCond &c = nd.path[i];
+            if (c.is_cat && c.cat_cand >= 0)
+                std::memcpy(&model.categorical_values[(split_row * MD + i) * kCat], cat_cands[c.cat_cand].name.data(), kCat);
+            model.is_numerics[split_row * MD + i] = c.is_cat ? 0 : 1;
+            model.feature_indices[split_row * MD + i] = c.feat_idx;
+            model.feature_values[split_row * MD + i] = c.value;
+            model.inequality_directions[leaf_row * MD + i] = c.dir ? 1 : 0;
+            model.edge_weights[leaf_row * MD + i] = c.edge_w;
+        }
+    };
+    const size_t n_new = leaf_order.size();
+    const size_t L0 = md.n_leaves;
+    const size_t S_new = oblivious ? tree + 1 : L0 + n_new;
+    model.depths.resize(S_new, 0);
+    model.feature_indices.resize(S_new * MD, 0);
+    model.feature_values.resize(S_new * MD, 0.0f);
+    model.is_numerics.resize(S_new * MD, 0);
+    model.categorical_values.resize(S_new * MD * kCat, 0);
+    model.values.resize((L0 + n_new) * D, 0.0f);
+    model.edge_weights.resize((L0 + n_new) * MD, 0.0f);
+    model.inequality_directions.resize((L0 + n_new) * MD, 0);
+    for (size_t q = 0; q < n_new; ++q) {
+        const HNode &nd = nodes[leaf_order[q]];
+        const size_t leaf_row = L0 + q;
+        if (oblivious) {
+            model.depths[tree] = nd.depth;
+            write_conditions(nd, tree, leaf_row);
+        } else {
+            model.depths[leaf_row] = nd.depth;
+            write_conditions(nd, leaf_row, leaf_row);
+        }
+        const int64_t *a = &acc[static_cast<size_t>(leaf_order[q]) * (D + 1)];
+        const int64_t cnt = a[D];
+        for (int d = 0; d < D; ++d) {
+            float v = 0.0f;
+            if (cnt > 0 && nd.depth > 0)  // fitter.cpp:574-578; depth-0 leaf keeps 0 (Q7)
+                v = static_cast<float>((static_cast<double>(a[d]) / leaf_scale) / static_cast<double>(cnt));
+            model.values[leaf_row * D + d] = v;
+        }
+    }
+    md.n_leaves += static_cast<int32_t>(n_new);
+    md.n_trees += 1;
+    md.iteration += 1;  // fitter.cpp:114
+    ++model.version;
+    (void)world;
+}
+
+// ===================================================================================================== predict
+void Engine::sync_model_to_device() {
+    hipStream_t s = stream_;
+    const gbrl_hip_metadata &md = model.meta;
+    const size_t T = md.n_trees, L = md.n_leaves, S = model.split_rows(), MD = md.max_depth, D = md.output_dim;
+    if (mirror_version_ == model.version) return;
+    // dictionary ids for the categorical conditions (strings are compared on the host once; the device compares ids)
+    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); }
+    cat_ids_host_.resize(S * MD, 0);
+    for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
+        if (model.is_numerics[c]) continue;
+        const int f = model.feature_indices[c];
+        std::string name(&model.categorical_values[c * kCat], kCat);
+        int id = 0;
+        for (size_t z = 0; z < cat_dict_.size(); ++z)
+            if (cat_dict_[z].first == f && cat_dict_[z].second == name) { id = static_cast<int>(z) + 1; break; }
+        if (id == 0) { cat_dict_.emplace_back(f, name); id = static_cast<int>(cat_dict_.size()); }
+        cat_ids_host_[c] = id;
+    }
+    auto append = [&](DevBuf &buf, const void *host, size_t elem, size_t old_n, size_t new_n) {
+        char *p = static_cast<char *>(buf.ensure_keep(std::max<size_t>(new_n, 1) * elem, old_n * elem, s));
+        if (new_n > old_n)
+            hip_check(hipMemcpyAsync(p + old_n * elem, static_cast<const char *>(host) + old_n * elem, (new_n - old_n) * elem, hipMemcpyHostToDevice, s), "H2D model");
+    };
+    append(m_tree_indices_, model.tree_indices.data(), 4, up_trees_, T);
+    append(m_depths_, model.depths.data(), 4, up_splits_, S);
+    append(m_feature_indices_, model.feature_indices.data(), 4, up_splits_ * MD, S * MD);
+    append(m_feature_values_, model.feature_values.data(), 4, up_splits_ * MD, S * MD);
+    append(m_is_numerics_, model.is_numerics.data(), 1, up_splits_ * MD, S * MD);
+    append(m_cat_ids_, cat_ids_host_.data(), 4, up_splits_ * MD, S * MD);
+    append(m_values_, model.values.data(), 4, up_leaves_ * D, L * D);
+    append(m_ineq_, model.inequality_directions.data(), 1, up_leaves_ * MD, L * MD);
+    up_trees_ = T; up_leaves_ = L; up_splits_ = S;
+    // small, mutable state: always refreshed
+    append(m_bias_, model.bias.data(), 4, 0, D);
+    std::vector<int32_t> os, oe;
+    std::vector<float> olr;
+    for (const auto &o : model.opts) { os.push_back(o.start_idx); oe.push_back(o.stop_idx); olr.push_back(o.init_lr); }  // ConstScheduler::get_lr
+    append(m_opt_start_, os.data(), 4, 0, os.size());
+    append(m_opt_stop_, oe.data(), 4, 0, oe.size());
+    append(m_opt_lr_, olr.data(), 4, 0, olr.size());
+    hip_check(hipStreamSynchronize(s), "sync model upload");
+    mirror_version_ = model.version;
+}
+
+void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
+                     int stop_tree, float *out, bool out_dev) {
+    gbrl_hip_metadata &md = model.meta;
+    // GBRL::predict, gbrl.cpp:378-390
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
+    if (n_num + n_cat != md.input_dim) throw InvalidArgument("Incompatible dataset");
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n <= 0 || out == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (md.output_dim > 128) throw Unsupported("predict: output_dim > 128");
+    ensure_device();
+    phases_.clear();
+    hipStream_t s = stream_;
+    const int D = md.output_dim;
+    // predict_cpu, predictor.cpp:127-141
+    int stop = stop_tree;
+    if (md.n_trees == 0 || stop > md.n_trees || model.opts.empty()) { start_tree = 0; stop = 0; }
+    else if (stop == 0) stop = md.n_trees;
+    sync_model_to_device();
+    phase_begin();
+    const float *dobs = obs;
+    if (n_num > 0 && !obs_dev) {
+        dobs = static_cast<float *>(d_pobs_.ensure(sizeof(float) * static_cast<size_t>(n) * n_num));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * static_cast<size_t>(n) * n_num, hipMemcpyHostToDevice, s), "H2D obs");
+    }
+    int32_t *dcat = nullptr;
+    if (n_cat > 0) {
+        std::vector<char> buf;
+        const char *hc = cat;
+        if (cat_dev) {
+            buf.resize(static_cast<size_t>(n) * n_cat * kCat);
+            hip_check(hipMemcpy(buf.data(), cat, buf.size(), hipMemcpyDeviceToHost), "D2H cat");
+            hc = buf.data();
+        }
+        std::unordered_map<std::string, int> ids;
+        for (size_t z = 0; z < cat_dict_.size(); ++z) ids[cat_dict_[z].second + "_" + std::to_string(cat_dict_[z].first)] = static_cast<int>(z) + 1;
+        std::vector<int32_t> codes(static_cast<size_t>(n) * n_cat, 0);
+        if (!ids.empty())
+            for (int i = 0; i < n; ++i)
+                for (int f = 0; f < n_cat; ++f) {
+                    std::string key(hc + (static_cast<size_t>(i) * n_cat + f) * kCat, kCat);
+                    // the reference compares with strcmp: only the bytes up to the first NUL matter (node.cpp:75, predictor.cpp:215)
+                    const size_t z = key.find('\0');
+                    if (z != std::string::npos) key.resize(z);
+                    key.resize(kCat, '\0');
+                    auto it = ids.find(key + "_" + std::to_string(f));
+                    if (it != ids.end()) codes[static_cast<size_t>(i) * n_cat + f] = it->second;
+                }
+        dcat = static_cast<int32_t *>(d_pcat_.ensure(sizeof(int32_t) * codes.size()));
+        hip_check(hipMemcpyAsync(dcat, codes.data(), sizeof(int32_t) * codes.size(), hipMemcpyHostToDevice, s), "H2D cat ids");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    float *dout = out;
+    if (!out_dev) dout = static_cast<float *>(d_pout_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+    phase_end("inputs");
+    phase_begin();
+    kern::PredictModel pm{};
+    pm.tree_indices = m_tree_indices_.as<int32_t>();
+    pm.depths = m_depths_.as<int32_t>();
+    pm.feature_indices = m_feature_indices_.as<int32_t>();
+    pm.cat_ids = m_cat_ids_.as<int32_t>();
+    pm.feature_values = m_feature_values_.as<float>();
+    pm.values = m_values_.as<float>();
+    pm.bias = m_bias_.as<float>();
+    pm.is_numerics = m_is_numerics_.as<uint8_t>();
+    pm.inequality_directions = m_ineq_.as<uint8_t>();
+    pm.n_trees = md.n_trees; pm.n_leaves = md.n_leaves; pm.max_depth = md.max_depth; pm.D = D;
+    pm.oblivious = model.oblivious() ? 1 : 0;
+    pm.n_opts = static_cast<int>(model.opts.size());
+    pm.opt_start = m_opt_start_.as<int32_t>();
+    pm.opt_stop = m_opt_stop_.as<int32_t>();
+    pm.opt_lr = m_opt_lr_.as<float>();
+    kern::predict(pm, dobs, n_num, dcat, n_cat, n, start_tree, stop, dout, s);
+    hip_check(hipGetLastError(), "predict launch");
+    phase_end("predict");
+    if (!out_dev) hip_check(hipMemcpyAsync(out, dout, sizeof(float) * static_cast<size_t>(n) * D, hipMemcpyDeviceToHost, s), "D2H preds");
+    hip_check(hipStreamSynchronize(s), "sync");
+}
+
+}  // namespace gbrl

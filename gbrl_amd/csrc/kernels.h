@@ -1,0 +1,109 @@
+// kernels.h -- launch wrappers of the gfx950 kernels behind GBRL::step / GBRL::predict.
+// Each wrapper enqueues on `stream` and returns immediately; errors surface through hipGetLastError in the engine.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gbrl {
+namespace kern {
+
+// A contiguous run of positions [start, start+len) of the row list that belongs to one slot (node or leaf).
+struct Chunk {
+    int32_t slot;
+    int32_t start;
+    int32_t len;
+    int32_t pad;
+};
+
+// Descriptor of one feature slot (numeric feature or categorical feature) for the scoring kernel.
+struct FeatureSlot {
+    int32_t is_cat;     // 0 numeric: candidate k <-> threshold k, right = classes > k; 1 categorical: candidate j <-> class j+1
+    int32_t n_cand;     // number of candidates of this slot
+    int32_t cand_base;  // index of the slot's first candidate in the global candidate order
+    int32_t pad;
+};
+
+// Per-node split decision used by the partition kernel.
+struct NodeSplit {
+    int32_t do_split;   // 0: copy the segment unchanged
+    int32_t fslot;      // feature slot of the chosen candidate
+    int32_t bin;        // numeric: threshold index k (right <=> code > k); categorical: class id (right <=> code == bin)
+    int32_t is_cat;
+    int32_t seg_start;  // first position of the node's segment
+    int32_t n_left;     // rows going left (right child starts at seg_start + n_left)
+    int32_t pad0, pad1;
+};
+
+constexpr int kMaxPath = 32;  // max_depth supported by the duplicate-on-path check
+
+// ---- gradient preprocessing (A2) ----
+void column_sums(const float *g, int n, int D, const float *center /*nullable [D]*/, double *block_partials,
+                 int n_blocks, double *out /*[D]*/, hipStream_t s);
+int column_sums_blocks(int n, int D);
+// max |standardised g| as float bits in out[0]; mean/inv_std nullable (Cosine: raw grads)
+void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s);
+// qg = rint(((g - mean) / denom) * scale) as int32  (mean/denom nullable)
+void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, float scale,
+                    int32_t *qg, hipStream_t s);
+
+// ---- split candidates (A3, A4) ----
+void column_minmax(const float *obs, int n, int F, uint32_t *min_keys, uint32_t *max_keys, hipStream_t s);  // ordered keys
+void uniform_thresholds(const uint32_t *min_keys, const uint32_t *max_keys, int F, int B, float *thr, hipStream_t s);
+// counts[f][j] += #{rows : j == #{k : trial[f][k] (strict ? < : <=) key(x)}}; optionally writes codes[row*code_stride + code_off + f]
+void bin_rows(const float *obs, int n, int F, const uint32_t *trial_keys, int B, bool strict, int64_t *counts,
+              uint16_t *codes, int code_stride, int code_off, hipStream_t s);
+void qsel_init(uint32_t *prefix, uint32_t *trial, int F, int B, hipStream_t s);
+// one bisection step on bit `bit`: uses counts of trial = prefix|bit; then prepares trial for `next_bit` (or final keys if <0)
+void qsel_update(uint32_t *prefix, uint32_t *trial, const int64_t *counts, const int64_t *cum_ranks, int F, int B,
+                 int bit, int next_bit, hipStream_t s);
+void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s);
+void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
+void scatter_cat_codes(const uint16_t *cat_codes, int n, int Fc, uint16_t *codes, int code_stride, int code_off, hipStream_t s);
+void iota_rows(int32_t *rows, int n, hipStream_t s);
+
+// ---- split-score histograms (A6) ----
+size_t hist_lds_bytes(int NB, int D, int FG);
+void hist_build(const uint16_t *codes, int code_stride, const int32_t *qg, int D, const int32_t *rows,
+                const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s);
+void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, int n_slots, int n_groups,
+                 int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);
+
+// ---- scoring / selection (A6, A7, A8) ----
+void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
+                      const float *thr /*[F][B]*/, int B, int n_cand, int min_data, int cosine, double inv_scale,
+                      const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
+                      float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/, hipStream_t s);
+// best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index
+void argmax_oblivious(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref,
+                      int32_t *best_idx, float *best_score, hipStream_t s);
+void argmax_greedy(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref,
+                   const float *parent, const int32_t *is_root, int32_t *best_idx, float *best_score, hipStream_t s);
+void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits,
+                  int64_t *n_total, int64_t *n_right, hipStream_t s);
+
+// ---- partition (A9) ----
+void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int code_stride,
+                    const Chunk *chunks, int n_chunks, const NodeSplit *splits, int32_t *cursors /*[n_nodes*2], zeroed*/,
+                    hipStream_t s);
+
+// ---- leaf values (A11) ----
+void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, double scale,
+               int64_t *acc /*[n_leaves][D+1], zeroed*/, hipStream_t s);
+
+// ---- prediction (A13) ----
+struct PredictModel {
+    const int32_t *tree_indices, *depths, *feature_indices, *cat_ids;
+    const float *feature_values, *values, *bias;
+    const uint8_t *is_numerics, *inequality_directions;
+    int n_trees, n_leaves, max_depth, D, oblivious;
+    int n_opts;
+    const int32_t *opt_start, *opt_stop;
+    const float *opt_lr;
+};
+void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
+             int stop_tree, float *out, hipStream_t s);
+
+}  // namespace kern
+}  // namespace gbrl

@@ -1,0 +1,753 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) kernels behind GBRL::step / GBRL::predict.
+//
+// Arithmetic policy (DESIGN.md "exact sums"): every sum that feeds a split decision or a leaf value is an INTEGER
+// sum of fixed-point values, so results do not depend on the order in which waves, blocks or GPUs add them
+// (deterministic, and bit-identical for 1/2/4/8 row shards).  Scores are evaluated in fp64 from those exact sums and
+// rounded to fp32 once, then compared the way the reference compares them (fitter.cpp:332-341, 435-444).
+#include "kernels.h"
+
+#include <cmath>
+
+namespace gbrl {
+namespace kern {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t float_to_key(float x) {
+    // order-preserving map float -> uint32; -0.0 and +0.0 map to the same key (they compare equal as floats)
+    uint32_t u = __float_as_uint(x);
+    if ((u << 1) == 0) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A2  gradient statistics: out[d] = sum_i (g[i,d] - center[d])^2  (center != null)  or  sum_i g[i,d]
+// Block size is a multiple of D so that every thread owns one column; per-block partials are combined by a single
+// block in a fixed order => deterministic.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_column_sums(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ center,
+                              double *__restrict__ partials) {
+    extern __shared__ double sh[];
+    const int bs = blockDim.x;
+    const int col = threadIdx.x % D;
+    const float c = center ? center[col] : 0.0f;
+    double acc = 0.0;
+    for (size_t e = static_cast<size_t>(blockIdx.x) * bs + threadIdx.x; e < n_el; e += static_cast<size_t>(gridDim.x) * bs) {
+        const float v = g[e];
+        if (center) {
+            const float dv = v - c;  // fp32 subtraction like the reference (math_ops.cpp:498)
+            acc += static_cast<double>(dv) * static_cast<double>(dv);
+        } else {
+            acc += static_cast<double>(v);
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < D) {
+        double s = 0.0;
+        for (int t = threadIdx.x; t < bs; t += D) s += sh[t];
+        partials[static_cast<size_t>(blockIdx.x) * D + threadIdx.x] = s;
+    }
+}
+__global__ void k_column_sums_final(const double *__restrict__ partials, int n_blocks, int D, double *__restrict__ out) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += partials[static_cast<size_t>(b) * D + d];
+    out[d] = s;
+}
+
+__device__ __forceinline__ float standardise(float v, const float *mean, const float *denom, int col) {
+    // (g - mean) / (std + 1e-8f) evaluated in fp32 exactly like fitter.cpp:58-63 -> math_ops.cpp:498,94
+    if (mean == nullptr) return v;
+    return (v - mean[col]) / denom[col];
+}
+
+__global__ void k_max_abs(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ mean,
+                          const float *__restrict__ denom, uint32_t *__restrict__ out_bits) {
+    float m = 0.0f;
+    for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n_el;
+         e += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const float v = fabsf(standardise(g[e], mean, denom, static_cast<int>(e % D)));
+        m = fmaxf(m, v);  // fmaxf drops NaN
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order as uints
+}
+
+__global__ void k_quantize(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ mean,
+                           const float *__restrict__ denom, float scale, int32_t *__restrict__ qg) {
+    for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n_el;
+         e += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const float v = standardise(g[e], mean, denom, static_cast<int>(e % D));
+        qg[e] = __float2int_rn(v * scale);  // scale is a power of two: the product is exact, one rounding to integer
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A4  uniform candidates: per-column min / max (order independent => atomics are deterministic)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_column_minmax(const float *__restrict__ obs, int n, int F, uint32_t *__restrict__ mn,
+                                uint32_t *__restrict__ mx) {
+    // thread <-> feature (coalesced across a row), grid-stride over rows
+    const int f = blockIdx.y * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint32_t k = float_to_key(obs[static_cast<size_t>(r) * F + f]);
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    atomicMin(&mn[f], lo);
+    atomicMax(&mx[f], hi);
+}
+__global__ void k_uniform_thresholds(const uint32_t *__restrict__ mn, const uint32_t *__restrict__ mx, int F, int B,
+                                     float *__restrict__ thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * B) return;
+    const int f = i / B, b = i % B;
+    const float lo = key_to_float(mn[f]), hi = key_to_float(mx[f]);
+    const float step = (hi - lo) / static_cast<float>(B);
+    // split_candidate_generator.cpp:67: min + b*step, contracted to ONE fma by the reference's release build (Q5)
+    thr[i] = fmaf(static_cast<float>(b), step, lo);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A3  binning / counting:  j(row, f) = #{k : trial[f][k] (<|<=) key(obs[row,f])},  counts[f][j] += 1,
+//     optionally codes[row][f] = j.  Used (a) by the exact quantile bisection (non-strict, counts only) and
+//     (b) to turn observations into bin codes once thresholds are known (strict: code = #{k : t_k < x}).
+// One block = FT features x (256/FT) rows per iteration; trial keys staged in LDS transposed ([k][f], f fastest)
+// so that the lanes of a wave, which hold consecutive features, always hit distinct banks.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kBinFT = 64;        // features per block tile (256 B of each row: two full 128-B lines)
+constexpr int kBinThreads = 256;
+
+template <bool STRICT>
+__global__ __launch_bounds__(kBinThreads) void k_bin_rows(const float *__restrict__ obs, int n, int F,
+                                                           const uint32_t *__restrict__ trial, int B,
+                                                           unsigned long long *__restrict__ counts, uint16_t *__restrict__ codes,
+                                                           int code_stride, int code_off) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *t = lds;                    // [B][FT]
+    uint32_t *cnt = lds + B * kBinFT;     // [B+1][FT]
+    const int f0 = blockIdx.y * kBinFT;
+    const int nf = min(kBinFT, F - f0);
+    for (int i = threadIdx.x; i < B * kBinFT; i += kBinThreads) {
+        const int k = i / kBinFT, fl = i % kBinFT;
+        t[i] = fl < nf ? trial[static_cast<size_t>(f0 + fl) * B + k] : 0xffffffffu;
+    }
+    if (counts)
+        for (int i = threadIdx.x; i < (B + 1) * kBinFT; i += kBinThreads) cnt[i] = 0;
+    __syncthreads();
+    const int fl = threadIdx.x % kBinFT;
+    const int rsub = threadIdx.x / kBinFT;
+    constexpr int RPI = kBinThreads / kBinFT;
+    if (fl < nf) {
+        for (int r = blockIdx.x * RPI + rsub; r < n; r += gridDim.x * RPI) {
+            const uint32_t key = float_to_key(obs[static_cast<size_t>(r) * F + f0 + fl]);
+            int lo = 0, hi = B;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t tv = t[mid * kBinFT + fl];
+                const bool below = STRICT ? (tv < key) : (tv <= key);
+                if (below) lo = mid + 1; else hi = mid;
+            }
+            if (counts) atomicAdd(&cnt[lo * kBinFT + fl], 1u);
+            if (codes) codes[static_cast<size_t>(r) * code_stride + code_off + f0 + fl] = static_cast<uint16_t>(lo);
+        }
+    }
+    if (counts) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (B + 1) * kBinFT; i += kBinThreads) {
+            const int j = i / kBinFT, f = i % kBinFT;
+            const uint32_t c = cnt[i];
+            if (c != 0 && f < nf) atomicAdd(&counts[static_cast<size_t>(f0 + f) * (B + 1) + j], static_cast<unsigned long long>(c));
+        }
+    }
+}
+
+// Exact multi-rank selection by bisection on the 32-bit ordered key (A3).  For every (feature, target k) we build the
+// answer v_k = smallest key with #{keys <= v_k} >= cum_k from the most significant bit down: with prefix p_k (decided
+// high bits, low bits zero) and trial t_k = p_k | bit, the bit is set iff #{keys < t_k} < cum_k.  Targets are sorted
+// by rank, so prefixes and trials stay sorted per feature and one binary search per element serves all targets.
+__global__ void k_qsel_init(uint32_t *__restrict__ prefix, uint32_t *__restrict__ trial, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    prefix[i] = 0u;
+    trial[i] = 0x80000000u;
+}
+__global__ void k_qsel_update(uint32_t *__restrict__ prefix, uint32_t *__restrict__ trial,
+                              const int64_t *__restrict__ counts, const int64_t *__restrict__ cum, int B, int bit,
+                              int next_bit) {
+    // one block per feature; thread k owns target k (loop if B > blockDim)
+    extern __shared__ unsigned long long below[];  // [B+1] inclusive prefix of counts
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int j = 0; j <= B; ++j) {
+            run += static_cast<unsigned long long>(counts[static_cast<size_t>(f) * (B + 1) + j]);
+            below[j] = run;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const size_t i = static_cast<size_t>(f) * B + k;
+        uint32_t p = prefix[i];
+        // #{keys < t_k} = sum_{j<=k'} counts[j] where k' = index of the LAST trial equal to t_k ... trials are sorted and
+        // counts[j] holds rows with exactly j trials <= key, so rows with key < t_k are those with j <= (#trials < t_k).
+        // With duplicated trials (equal targets) the rows sit in the bucket of the first duplicate; use that index.
+        int first = k;
+        const uint32_t tk = trial[i];
+        while (first > 0 && trial[i - (k - first) - 1] == tk) --first;
+        const long long c_below = static_cast<long long>(below[first]);
+        if (c_below < cum[k]) p |= (1u << bit);
+        prefix[i] = p;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const size_t i = static_cast<size_t>(f) * B + k;
+        trial[i] = next_bit >= 0 ? (prefix[i] | (1u << next_bit)) : prefix[i];
+    }
+}
+
+__global__ void k_keys_to_floats(const uint32_t *__restrict__ keys, float *__restrict__ out, size_t n) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = key_to_float(keys[i]);
+}
+__global__ void k_floats_to_keys(const float *__restrict__ in, uint32_t *__restrict__ keys, size_t n) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = float_to_key(in[i]);
+}
+__global__ void k_scatter_cat_codes(const uint16_t *__restrict__ cat_codes, int n, int Fc, uint16_t *__restrict__ codes,
+                                    int code_stride, int code_off) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<size_t>(n) * Fc) return;
+    const size_t r = i / Fc, f = i % Fc;
+    codes[r * code_stride + code_off + f] = cat_codes[i];
+}
+__global__ void k_iota(int32_t *__restrict__ rows, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A6  split-score histogram build (THE hot kernel).
+// For one chunk of one node's row list and one group of FG features, accumulate per (class, feature):
+//   count and the D fixed-point gradient sums, in LDS, with ds_add_u32 atomics.
+// LDS layout h[(class*(D+1) + d)*FG + f_local]: the feature index is the fastest dimension, and the 16 lanes that
+// share a row hold 16 different features, so the bank of an access is decided by the lane, not by the (random)
+// class: a wave-wide atomic touches each bank at most twice (two rows per 32-lane group) -- the 2-way case the LDS
+// absorbs for free.  Integer adds wrap mod 2^32; the host picks the fixed-point scale so that every true partial
+// sum fits in int32, which makes the wrapped result exact.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kHistThreads = 1024;
+
+__global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int code_stride,
+                                                              const int32_t *__restrict__ qg, int D,
+                                                              const int32_t *__restrict__ rows,
+                                                              const Chunk *__restrict__ chunks, int FG, int fg_shift,
+                                                              int NB, int32_t *__restrict__ partials) {
+    extern __shared__ int32_t h[];
+    const int n_acc = NB * (D + 1) * FG;
+    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
+    __syncthreads();
+    const Chunk ck = chunks[blockIdx.x];
+    const int g = blockIdx.y;
+    const int fl = threadIdx.x & (FG - 1);
+    const int slot = threadIdx.x >> fg_shift;
+    const int n_slots = kHistThreads >> fg_shift;
+    const int row_stride = (D + 1) * FG;
+    for (int p = slot; p < ck.len; p += n_slots) {
+        const int row = rows[ck.start + p];
+        const int code = codes[static_cast<size_t>(row) * code_stride + g * FG + fl];
+        const int32_t *q = qg + static_cast<size_t>(row) * D;
+        int32_t *dst = h + code * row_stride + fl;
+        for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
+        atomicAdd(dst + D * FG, 1);
+    }
+    __syncthreads();
+    int32_t *out = partials + (static_cast<size_t>(blockIdx.x) * gridDim.y + g) * n_acc;
+    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) out[i] = h[i];
+}
+
+// Sum the int32 chunk partials of every slot (node) into int64, reordering to hist[slot][feature][class][D+1].
+__global__ void k_hist_reduce(const int32_t *__restrict__ partials, const int32_t *__restrict__ slot_chunk_begin,
+                              int n_groups, int FG, int NB, int D, int Fp, int64_t *__restrict__ hist) {
+    const int n_acc = NB * (D + 1) * FG;
+    const int slot = blockIdx.z, g = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_acc) return;
+    const int c0 = slot_chunk_begin[slot], c1 = slot_chunk_begin[slot + 1];
+    int64_t s = 0;
+    for (int c = c0; c < c1; ++c) s += partials[(static_cast<size_t>(c) * n_groups + g) * n_acc + i];
+    const int fl = i % FG, d = (i / FG) % (D + 1), cls = i / (FG * (D + 1));
+    hist[((static_cast<size_t>(slot) * Fp + g * FG + fl) * NB + cls) * (D + 1) + d] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A6/A7  candidate scores from the exact histograms.  One block per (node, feature slot).
+//   numeric candidate k : right = classes > k (suffix sum), left = total - right
+//   categorical cand. j : right = class j+1,                left = total - right
+//   L2     : |S_L|^2/n_L + |S_R|^2/n_R            (== n_L|mean_L|^2 + n_R|mean_R|^2, node.cpp:360-373)
+//   Cosine : sqrt of the same quantity, 0 if it is 0 (== cosine_score, math_ops.h:538-575, since
+//            sum_{i in S} g_i . mean_S = |sum_S g|^2 / n_S)
+// evaluated in fp64 from integer sums and rounded once to fp32.  -inf when the candidate repeats a condition of the
+// node's path (node.cpp:154-166) or a side has fewer than min_data_in_leaf rows (node.cpp:354).
+// Block (slot 0) also emits the node's parent score for greedy growth (split_candidate_generator.cpp:262-320).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double side_term(const int64_t *S, int D, int64_t n, double inv_scale) {
+    if (n <= 0) return 0.0;
+    double ss = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double v = static_cast<double>(S[d]) * inv_scale;
+        ss += v * v;
+    }
+    return ss / static_cast<double>(n);
+}
+
+__global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist, int Fp, int NB, int D,
+                                               const FeatureSlot *__restrict__ slots, const float *__restrict__ thr,
+                                               int B, int n_cand, int min_data, int cosine, double inv_scale,
+                                               const int32_t *__restrict__ path_len, const int32_t *__restrict__ path_slot,
+                                               const float *__restrict__ path_val, const int32_t *__restrict__ path_bin,
+                                               float *__restrict__ scores, float *__restrict__ parent) {
+    extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
+    const int node = blockIdx.y, fs = blockIdx.x;
+    const FeatureSlot sl = slots[fs];
+    const int W = D + 1;
+    const int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
+    for (int i = threadIdx.x; i < NB * W; i += blockDim.x) sh64[i] = src[i];
+    __syncthreads();
+    // totals = sum over all classes; also turn numeric features into suffix sums in place
+    int64_t *total = sh64 + static_cast<size_t>(NB) * W;  // [D+1]
+    if (threadIdx.x < W) {
+        int64_t run = 0;
+        for (int c = NB - 1; c >= 0; --c) {
+            run += sh64[c * W + threadIdx.x];
+            if (!sl.is_cat) sh64[c * W + threadIdx.x] = run;
+        }
+        total[threadIdx.x] = run;
+    }
+    __syncthreads();
+    const int64_t n_tot = total[D];
+    if (fs == 0 && threadIdx.x == 0) {
+        double x = side_term(total, D, n_tot, inv_scale);
+        parent[node] = static_cast<float>(cosine ? sqrt(x) : x);
+    }
+    const int plen = path_len[node];
+    for (int k = threadIdx.x; k < sl.n_cand; k += blockDim.x) {
+        const int64_t *R = sh64 + (k + 1) * W;
+        const int64_t n_r = R[D], n_l = n_tot - n_r;
+        bool reject = (n_l < min_data) || (n_r < min_data);
+        for (int p = 0; p < plen; ++p) {
+            if (path_slot[node * kMaxPath + p] != fs) continue;
+            if (sl.is_cat) reject |= (path_bin[node * kMaxPath + p] == k + 1);
+            else reject |= (path_val[node * kMaxPath + p] == thr[static_cast<size_t>(fs) * B + k]);
+        }
+        float out;
+        if (reject) {
+            out = -INFINITY;
+        } else {
+            double sr = 0.0, sl_ = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double vr = static_cast<double>(R[d]) * inv_scale;
+                const double vl = static_cast<double>(total[d] - R[d]) * inv_scale;
+                sr += vr * vr;
+                sl_ += vl * vl;
+            }
+            double x = 0.0;
+            if (n_l > 0) x += sl_ / static_cast<double>(n_l);
+            if (n_r > 0) x += sr / static_cast<double>(n_r);
+            out = static_cast<float>(cosine ? sqrt(x) : x);
+        }
+        scores[static_cast<size_t>(node) * n_cand + sl.cand_base + k] = out;
+    }
+}
+
+// A8 oblivious: s_j = (sum over nodes, in node order, fp32) * w_j ; lowest index among maxima wins (fitter.cpp:411-457)
+struct Best { float v; int i; };
+__device__ __forceinline__ Best better(Best a, Best b) {
+    // strictly greater wins; on equality the lower reference index wins.  A -inf score never replaces the initial
+    // (-inf, none) state, exactly like "if (score > local_best_score)" with local_best = -inf (fitter.cpp:338, 441).
+    if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
+    return a;
+}
+__device__ Best block_best(Best mine) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    sv[threadIdx.x] = mine.v;
+    si[threadIdx.x] = mine.i;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            Best a{sv[threadIdx.x], si[threadIdx.x]}, b{sv[threadIdx.x + o], si[threadIdx.x + o]};
+            a = better(a, b);
+            sv[threadIdx.x] = a.v;
+            si[threadIdx.x] = a.i;
+        }
+        __syncthreads();
+    }
+    return Best{sv[0], si[0]};
+}
+__global__ __launch_bounds__(1024) void k_argmax_oblivious(const float *__restrict__ scores, int n_nodes, int n_cand,
+                                                           const float *__restrict__ w, const int32_t *__restrict__ ref,
+                                                           int32_t *__restrict__ best_idx, float *__restrict__ best_score) {
+    // `ref[j]` is the candidate's index in the REFERENCE's candidate order; ties go to the lowest reference index
+    Best mine{-INFINITY, 0x7fffffff};
+    for (int j = threadIdx.x; j < n_cand; j += blockDim.x) {
+        float s = 0.0f;
+        for (int nd = 0; nd < n_nodes; ++nd) s += scores[static_cast<size_t>(nd) * n_cand + j];
+        s = s * w[j];
+        mine = better(mine, Best{s, ref[j]});
+    }
+    Best b = block_best(mine);
+    if (threadIdx.x == 0) { best_idx[0] = b.i == 0x7fffffff ? 0 : b.i; best_score[0] = b.v; }
+}
+// A8 greedy: s_j = fma(score_j, w_j, -parent) (the reference's "score*w - parent" is contracted), fitter.cpp:318-354
+__global__ __launch_bounds__(1024) void k_argmax_greedy(const float *__restrict__ scores, int n_cand,
+                                                        const float *__restrict__ w, const int32_t *__restrict__ ref,
+                                                        const float *__restrict__ parent, const int32_t *__restrict__ is_root,
+                                                        int32_t *__restrict__ best_idx, float *__restrict__ best_score) {
+    const int node = blockIdx.x;
+    const float par = is_root[node] ? 0.0f : parent[node];
+    Best mine{-INFINITY, 0x7fffffff};
+    for (int j = threadIdx.x; j < n_cand; j += blockDim.x) {
+        const float s = fmaf(scores[static_cast<size_t>(node) * n_cand + j], w[j], -par);
+        mine = better(mine, Best{s, ref[j]});
+    }
+    Best b = block_best(mine);
+    if (threadIdx.x == 0) { best_idx[node] = b.i == 0x7fffffff ? 0 : b.i; best_score[node] = b.v; }
+}
+
+__global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, int Fp, int NB, int D,
+                               const NodeSplit *__restrict__ splits, int64_t *__restrict__ n_total,
+                               int64_t *__restrict__ n_right) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= n_nodes) return;
+    const NodeSplit sp = splits[node];
+    const int W = D + 1;
+    const int64_t *src = hist + (static_cast<size_t>(node) * Fp + sp.fslot) * NB * W;
+    int64_t tot = 0, right = 0;
+    for (int c = 0; c < NB; ++c) {
+        const int64_t n = src[c * W + D];
+        tot += n;
+        if (sp.is_cat ? (c == sp.bin) : (c > sp.bin)) right += n;
+    }
+    n_total[node] = tot;
+    n_right[node] = right;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A9  partition: every node's segment [seg_start, seg_start+n) of the row list is split into [left | right] in place
+// of the same range of the output list; segments of nodes that do not split are copied.  Destination slots are handed
+// out with one wave-aggregated atomic per side; the order inside a child is not the reference's stable order, which is
+// harmless because everything computed downstream is an order-independent integer sum.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_partition(const int32_t *__restrict__ rows_in, int32_t *__restrict__ rows_out,
+                                                   const uint16_t *__restrict__ codes, int code_stride,
+                                                   const Chunk *__restrict__ chunks, const NodeSplit *__restrict__ splits,
+                                                   int32_t *__restrict__ cursors) {
+    const Chunk ck = chunks[blockIdx.x];
+    const NodeSplit sp = splits[ck.slot];
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int p0 = 0; p0 < ck.len; p0 += blockDim.x) {
+        const int p = p0 + threadIdx.x;
+        const bool active = p < ck.len;
+        int row = 0;
+        bool right = false;
+        if (active) {
+            row = rows_in[ck.start + p];
+            if (sp.do_split) {
+                const int code = codes[static_cast<size_t>(row) * code_stride + sp.fslot];
+                right = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
+            }
+        }
+        if (!sp.do_split) {
+            if (active) rows_out[ck.start + p] = row;
+            continue;
+        }
+        const unsigned long long mr = __ballot(active && right);
+        const unsigned long long ml = __ballot(active && !right);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+        int base_r = 0, base_l = 0;
+        if (lane == 0) {
+            if (mr) base_r = atomicAdd(&cursors[ck.slot * 2 + 1], __popcll(mr));
+            if (ml) base_l = atomicAdd(&cursors[ck.slot * 2 + 0], __popcll(ml));
+        }
+        base_r = __shfl(base_r, 0, kWave);
+        base_l = __shfl(base_l, 0, kWave);
+        if (active) {
+            const int dst = right ? (sp.seg_start + sp.n_left + base_r + __popcll(mr & below))
+                                  : (sp.seg_start + base_l + __popcll(ml & below));
+            rows_out[dst] = row;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A11  leaf sums of RAW gradients (fixed-point int64, exact) + counts.  acc[leaf][0..D) sums, acc[leaf][D] count.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_leaf_sums(const float *__restrict__ grads, int D, const int32_t *__restrict__ rows,
+                                                   const Chunk *__restrict__ chunks, double scale,
+                                                   int64_t *__restrict__ acc) {
+    extern __shared__ unsigned long long shl[];  // [D+1]
+    for (int i = threadIdx.x; i <= D; i += blockDim.x) shl[i] = 0ull;
+    __syncthreads();
+    const Chunk ck = chunks[blockIdx.x];
+    // thread <-> (row, d): consecutive threads read consecutive d of one row
+    const int per = blockDim.x / D > 0 ? blockDim.x / D : 1;
+    const int d = threadIdx.x % D, sub = threadIdx.x / D;
+    long long s = 0;
+    if (sub < per) {
+        for (int p = sub; p < ck.len; p += per) {
+            const int row = rows[ck.start + p];
+            s += __double2ll_rn(static_cast<double>(grads[static_cast<size_t>(row) * D + d]) * scale);
+        }
+        atomicAdd(&shl[d], static_cast<unsigned long long>(s));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += blockDim.x)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[static_cast<size_t>(ck.slot) * (D + 1) + i]), shl[i]);
+    if (threadIdx.x == 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[static_cast<size_t>(ck.slot) * (D + 1) + D]),
+                  static_cast<unsigned long long>(ck.len));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A13  prediction: one thread per row, trees in order (Q14), pred = fma(-lr, value, pred) per optimizer range
+// (optimizer.cpp:110-118, contracted in the reference build).  Oblivious: leaf index from the tree's conditions
+// (predictor.cpp:231-265).  Greedy: walk the leaves in order, including the reference's behaviour of walking past a
+// leaf that can never match (Q7, predictor.cpp:188-229).
+// ------------------------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_predict(PredictModel pm, const float *__restrict__ obs, int F,
+                                                 const int32_t *__restrict__ cat_codes, int Fc, int n, int start_tree,
+                                                 int stop_tree, float *__restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int D = pm.D, md = pm.max_depth;
+    float p[DMAX];
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + pm.bias[j] : 0.0f;
+    const float *x = obs + static_cast<size_t>(row) * F;
+    const int32_t *xc = cat_codes ? cat_codes + static_cast<size_t>(row) * Fc : nullptr;
+    auto test = [&](int c) -> bool {
+        const int f = pm.feature_indices[c];
+        return pm.is_numerics[c] ? (x[f] > pm.feature_values[c]) : (xc != nullptr && xc[f] == pm.cat_ids[c]);
+    };
+    auto apply = [&](const float *v) {
+        for (int o = 0; o < pm.n_opts; ++o) {
+            const float lr = pm.opt_lr[o];
+            const int a = pm.opt_start[o], b = pm.opt_stop[o];
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j)
+                if (j >= a && j < b) p[j] = fmaf(-lr, v[j], p[j]);
+        }
+    };
+    if (stop_tree > start_tree && pm.n_opts > 0) {
+        if (pm.oblivious) {
+            for (int t = start_tree; t < stop_tree; ++t) {
+                const int depth = pm.depths[t], cond = t * md;
+                int leaf = 0;
+                for (int d = 0; d < depth; ++d) leaf |= (test(cond + d) ? 1 : 0) << (depth - 1 - d);
+                apply(pm.values + static_cast<size_t>(pm.tree_indices[t] + leaf) * D);
+            }
+        } else {
+            int t = start_tree;
+            int leaf = pm.tree_indices[t];
+            while (leaf < pm.n_leaves && t < stop_tree) {
+                const int depth = pm.depths[leaf], cond = leaf * md;
+                bool passed = false;
+                for (int d = depth - 1; d >= 0; --d) {
+                    passed = (test(cond + d) == (pm.inequality_directions[cond + d] != 0));
+                    if (!passed) break;
+                }
+                if (passed) {
+                    apply(pm.values + static_cast<size_t>(leaf) * D);
+                    ++t;
+                    if (t < stop_tree) leaf = pm.tree_indices[t];
+                } else {
+                    ++leaf;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j)
+        if (j < D) out[static_cast<size_t>(row) * D + j] = p[j];
+}
+
+inline int grid_for(size_t n, int bs, int cap) {
+    size_t b = (n + bs - 1) / bs;
+    if (b < 1) b = 1;
+    return static_cast<int>(b > static_cast<size_t>(cap) ? cap : b);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- wrappers
+
+int column_sums_blocks(int n, int D) { return grid_for(static_cast<size_t>(n) * D, 256, 1024); }
+
+void column_sums(const float *g, int n, int D, const float *center, double *block_partials, int n_blocks, double *out,
+                 hipStream_t s) {
+    const int bs = D <= 256 ? (256 / D) * D : D;  // multiple of D so a thread owns one column
+    hipLaunchKernelGGL(k_column_sums, dim3(n_blocks), dim3(bs), bs * sizeof(double), s, g, static_cast<size_t>(n) * D, D,
+                       center, block_partials);
+    hipLaunchKernelGGL(k_column_sums_final, dim3((D + 63) / 64), dim3(64), 0, s, block_partials, n_blocks, D, out);
+}
+
+void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s) {
+    hipLaunchKernelGGL(k_max_abs, dim3(grid_for(n_el, 256, 2048)), dim3(256), 0, s, g, n_el, D, mean, denom, out_bits);
+}
+
+void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, float scale, int32_t *qg,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_quantize, dim3(grid_for(n_el, 256, 4096)), dim3(256), 0, s, g, n_el, D, mean, denom, scale, qg);
+}
+
+void column_minmax(const float *obs, int n, int F, uint32_t *mn, uint32_t *mx, hipStream_t s) {
+    const int bs = 128;
+    dim3 grid(grid_for(n, 1, 1024), (F + bs - 1) / bs);
+    hipLaunchKernelGGL(k_column_minmax, grid, dim3(bs), 0, s, obs, n, F, mn, mx);
+}
+
+void uniform_thresholds(const uint32_t *mn, const uint32_t *mx, int F, int B, float *thr, hipStream_t s) {
+    hipLaunchKernelGGL(k_uniform_thresholds, dim3((F * B + 255) / 256), dim3(256), 0, s, mn, mx, F, B, thr);
+}
+
+void bin_rows(const float *obs, int n, int F, const uint32_t *trial_keys, int B, bool strict, int64_t *counts_,
+              uint16_t *codes, int code_stride, int code_off, hipStream_t s) {
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(counts_);
+    const int tiles = (F + kBinFT - 1) / kBinFT;
+    const int rpi = kBinThreads / kBinFT;
+    dim3 grid(grid_for(static_cast<size_t>(n), rpi * 64, 1024), tiles);
+    const size_t lds = (static_cast<size_t>(B) * kBinFT + static_cast<size_t>(B + 1) * kBinFT) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (strict)
+        hipLaunchKernelGGL(k_bin_rows<true>, grid, dim3(kBinThreads), lds, s, obs, n, F, trial_keys, B, counts, codes,
+                           code_stride, code_off);
+    else
+        hipLaunchKernelGGL(k_bin_rows<false>, grid, dim3(kBinThreads), lds, s, obs, n, F, trial_keys, B, counts, codes,
+                           code_stride, code_off);
+}
+
+void qsel_init(uint32_t *prefix, uint32_t *trial, int F, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_qsel_init, dim3((F * B + 255) / 256), dim3(256), 0, s, prefix, trial, F * B);
+}
+void qsel_update(uint32_t *prefix, uint32_t *trial, const int64_t *counts, const int64_t *cum, int F, int B, int bit,
+                 int next_bit, hipStream_t s) {
+    hipLaunchKernelGGL(k_qsel_update, dim3(F), dim3(256), (B + 1) * sizeof(unsigned long long), s, prefix, trial, counts,
+                       cum, B, bit, next_bit);
+}
+void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_keys_to_floats, dim3((n + 255) / 256), dim3(256), 0, s, keys, out, n);
+}
+void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_floats_to_keys, dim3((n + 255) / 256), dim3(256), 0, s, in, keys, n);
+}
+void scatter_cat_codes(const uint16_t *cat_codes, int n, int Fc, uint16_t *codes, int code_stride, int code_off,
+                       hipStream_t s) {
+    const size_t tot = static_cast<size_t>(n) * Fc;
+    hipLaunchKernelGGL(k_scatter_cat_codes, dim3((tot + 255) / 256), dim3(256), 0, s, cat_codes, n, Fc, codes, code_stride,
+                       code_off);
+}
+void iota_rows(int32_t *rows, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, rows, n);
+}
+
+size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * (D + 1) * FG * sizeof(int32_t); }
+
+void hist_build(const uint16_t *codes, int code_stride, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s) {
+    int shift = 0;
+    while ((1 << shift) < FG) ++shift;
+    const size_t lds = hist_lds_bytes(NB, D, FG);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_hist_build, dim3(n_chunks, n_groups), dim3(kHistThreads), lds, s, codes, code_stride, qg, D, rows,
+                       chunks, FG, shift, NB, partials);
+}
+
+void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, int n_slots, int n_groups, int FG, int NB, int D,
+                 int Fp, int64_t *hist, hipStream_t s) {
+    const int n_acc = NB * (D + 1) * FG;
+    dim3 grid((n_acc + 255) / 256, n_groups, n_slots);
+    hipLaunchKernelGGL(k_hist_reduce, grid, dim3(256), 0, s, partials, slot_chunk_begin, n_groups, FG, NB, D, Fp, hist);
+}
+
+void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
+                      const float *thr, int B, int n_cand, int min_data, int cosine, double inv_scale,
+                      const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
+                      float *scores, float *parent, hipStream_t s) {
+    const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, Fp, NB, D, slots, thr, B, n_cand, min_data,
+                       cosine, inv_scale, path_len, path_slot, path_val, path_bin, scores, parent);
+}
+
+void argmax_oblivious(const float *scores, int n_nodes, int n_cand, const float *w, const int32_t *ref, int32_t *best_idx,
+                      float *best_score, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax_oblivious, dim3(1), dim3(1024), 0, s, scores, n_nodes, n_cand, w, ref, best_idx, best_score);
+}
+void argmax_greedy(const float *scores, int n_nodes, int n_cand, const float *w, const int32_t *ref, const float *parent,
+                   const int32_t *is_root, int32_t *best_idx, float *best_score, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax_greedy, dim3(n_nodes), dim3(1024), 0, s, scores, n_cand, w, ref, parent, is_root, best_idx,
+                       best_score);
+}
+void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits, int64_t *n_total,
+                  int64_t *n_right, hipStream_t s) {
+    hipLaunchKernelGGL(k_child_counts, dim3((n_nodes + 63) / 64), dim3(64), 0, s, hist, n_nodes, Fp, NB, D, splits, n_total,
+                       n_right);
+}
+
+void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int code_stride, const Chunk *chunks,
+                    int n_chunks, const NodeSplit *splits, int32_t *cursors, hipStream_t s) {
+    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(256), 0, s, rows_in, rows_out, codes, code_stride, chunks, splits,
+                       cursors);
+}
+
+void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, double scale, int64_t *acc,
+               hipStream_t s) {
+    const int bs = D <= 256 ? 256 : ((D + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_leaf_sums, dim3(n_chunks), dim3(bs), (D + 1) * sizeof(unsigned long long), s, grads, D, rows, chunks,
+                       scale, acc);
+}
+
+void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
+             int stop_tree, float *out, hipStream_t s) {
+    dim3 grid((n + 255) / 256), block(256);
+    if (pm.D <= 8)
+        hipLaunchKernelGGL(k_predict<8>, grid, block, 0, s, pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out);
+    else if (pm.D <= 32)
+        hipLaunchKernelGGL(k_predict<32>, grid, block, 0, s, pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out);
+    else
+        hipLaunchKernelGGL(k_predict<128>, grid, block, 0, s, pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out);
+}
+
+}  // namespace kern
+}  // namespace gbrl

@@ -1,0 +1,167 @@
+/* gbrl_hip.h -- C ABI of the MI355X-native GBRL hot path (libgbrl_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of NVlabs/gbrl: the per-step tree fit (GBRL::step) and the
+ * ensemble prediction (GBRL::predict), plus the model state those two calls read and write (constructor,
+ * setters/getters, .gbrl_model save/load).  Plain pointers and sizes only; no torch / pybind types.
+ * Every entry point names the reference interface it replaces (paths relative to the reference repo).
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md; this repo's own binding
+ * (gbrl_amd/csrc/binding.cpp -> Python module `gbrl_cpp`, class `GBRL`) is written against this header only.
+ *
+ * Conventions
+ *   - every function that can fail returns 0 on success and a negative gbrl_hip_status otherwise; the message
+ *     is available (thread-local) through gbrl_hip_last_error().  The reference throws std::runtime_error at
+ *     the same places; the binding turns a non-zero status back into that exception.
+ *   - `*_on_device` flags say where a caller buffer lives (0 = host memory, 1 = HIP device memory of the
+ *     model's device), mirroring dataHolder<T>{ptr, deviceType} (gbrl/src/cpp/types.h:252-270).
+ *   - all compute runs on the GPU.  There is NO CPU fallback: step/predict fail with GBRL_HIP_E_NO_DEVICE
+ *     when no HIP device is usable.  The `device` string of the reference ("cpu" / "cuda" / "gpu") only
+ *     selects where predict() results are delivered by the Python binding.
+ *   - a model is not thread-safe (like the reference object, binding.cpp:448); one model <-> one device.
+ */
+#ifndef GBRL_HIP_H
+#define GBRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBRL_HIP_ABI_VERSION 1
+#define GBRL_HIP_MAX_CHAR_SIZE 128 /* MAX_CHAR_SIZE, gbrl/src/cpp/types.h:56 */
+
+typedef struct gbrl_hip_model gbrl_hip_model; /* opaque; replaces class GBRL (gbrl/src/cpp/gbrl.h) */
+
+typedef enum {
+    GBRL_HIP_OK = 0,
+    GBRL_HIP_E_INVALID = -1,   /* bad argument / incompatible dimensions  (std::runtime_error in the reference) */
+    GBRL_HIP_E_NO_DEVICE = -2, /* no usable HIP device: the product has no CPU path */
+    GBRL_HIP_E_HIP = -3,       /* a HIP runtime call failed */
+    GBRL_HIP_E_IO = -4,        /* file open / read / write error */
+    GBRL_HIP_E_UNSUPPORTED = -5 /* valid in the reference, outside this build's scope (Adam, control variates, ...) */
+} gbrl_hip_status;
+
+/* enum values follow gbrl/src/cpp/types.h:110-181 so that the serialized metadata is byte-compatible */
+enum { GBRL_HIP_SCORE_L2 = 0, GBRL_HIP_SCORE_COSINE = 1 };
+enum { GBRL_HIP_GEN_UNIFORM = 0, GBRL_HIP_GEN_QUANTILE = 1 };
+enum { GBRL_HIP_GROW_GREEDY = 0, GBRL_HIP_GROW_OBLIVIOUS = 1 };
+enum { GBRL_HIP_ALGO_SGD = 0, GBRL_HIP_ALGO_ADAM = 1 };
+enum { GBRL_HIP_SCHED_CONST = 0, GBRL_HIP_SCHED_LINEAR = 1 };
+
+/* Constructor arguments: GBRL::GBRL(...) gbrl/src/cpp/gbrl.cpp:76-114, Python defaults binding.cpp:423-440 */
+typedef struct {
+    int32_t input_dim, output_dim, policy_dim, max_depth, min_data_in_leaf, n_bins, par_th;
+    float cv_beta;
+    int32_t split_score_func; /* GBRL_HIP_SCORE_*  */
+    int32_t generator_type;   /* GBRL_HIP_GEN_*    */
+    int32_t use_control_variates; /* must be 0: the reference's GPU path force-disables it too (gbrl.cpp:204-207) */
+    int32_t batch_size;
+    int32_t grow_policy;      /* GBRL_HIP_GROW_*   */
+    int32_t verbose;
+    int32_t device_ordinal;   /* HIP device to run on (the reference hard-codes 0, cuda_utils.cu:59); -1 = current */
+    const char *learner_name;
+} gbrl_hip_config;
+
+/* ensembleMetaData, gbrl/src/cpp/types.h:218-242 -- exactly 80 bytes, written raw into .gbrl_model files */
+typedef struct {
+    int32_t n_leaves, n_trees, max_trees, max_leaves, max_trees_batch, max_leaves_batch;
+    int32_t input_dim, output_dim, policy_dim, max_depth, min_data_in_leaf, n_bins, par_th;
+    float cv_beta;
+    int32_t verbose, batch_size;
+    uint8_t use_cv, split_score_func, generator_type, grow_policy;
+    int32_t n_num_features, n_cat_features, iteration;
+} gbrl_hip_metadata;
+
+/* optimizerConfig, gbrl/src/cpp/types.h:186-197 */
+typedef struct {
+    int32_t algo, scheduler;
+    float init_lr, stop_lr;
+    int32_t start_idx, stop_idx, T;
+    float beta_1, beta_2, eps;
+} gbrl_hip_optimizer;
+
+/* ---- library / device --------------------------------------------------------------------------------- */
+int gbrl_hip_abi_version(void);
+/* number of usable HIP devices (0 when none); replaces GBRL::cuda_available (gbrl.cpp:542-548) */
+int gbrl_hip_device_count(void);
+const char *gbrl_hip_last_error(void);
+/* device buffers handed to callers (predict results) -- replaces cudaMalloc/cudaFree in binding.cpp:208-219 */
+void *gbrl_hip_device_alloc(size_t bytes);
+void gbrl_hip_device_free(void *ptr);
+
+/* ---- lifetime ----------------------------------------------------------------------------------------- */
+gbrl_hip_model *gbrl_hip_create(const gbrl_hip_config *cfg);            /* GBRL::GBRL          gbrl.cpp:76-114   */
+gbrl_hip_model *gbrl_hip_clone(const gbrl_hip_model *other);            /* GBRL::GBRL(GBRL&)   gbrl.cpp:125-148  */
+gbrl_hip_model *gbrl_hip_load(const char *filename);                    /* GBRL::loadFromFile  gbrl.cpp:1175-1250 */
+int gbrl_hip_save(gbrl_hip_model *m, const char *filename);             /* GBRL::saveToFile    gbrl.cpp:1130-1173 */
+void gbrl_hip_destroy(gbrl_hip_model *m);                               /* GBRL::~GBRL         gbrl.cpp:150-165  */
+
+/* ---- state the hot path reads ------------------------------------------------------------------------- */
+int gbrl_hip_set_bias(gbrl_hip_model *m, const float *bias, int n, int on_device);               /* gbrl.cpp:213-240 */
+int gbrl_hip_set_feature_weights(gbrl_hip_model *m, const float *w, int n, int on_device);       /* gbrl.cpp:242-269 */
+int gbrl_hip_set_feature_mapping(gbrl_hip_model *m, const int32_t *feature_mapping,
+                                 const uint8_t *mapping_numerics, int n);                        /* gbrl.cpp:271-316 */
+int gbrl_hip_set_optimizer(gbrl_hip_model *m, const gbrl_hip_optimizer *opt);                    /* gbrl.cpp:452-525 */
+int gbrl_hip_get_metadata(const gbrl_hip_model *m, gbrl_hip_metadata *out);                      /* binding.cpp:309-328 */
+int gbrl_hip_get_bias(const gbrl_hip_model *m, float *out);                                      /* gbrl.cpp:318-330 */
+int gbrl_hip_get_feature_weights(const gbrl_hip_model *m, float *out);                           /* gbrl.cpp:332-344 */
+int gbrl_hip_get_feature_mapping(const gbrl_hip_model *m, int32_t *feature_mapping, uint8_t *mapping_numerics);
+int gbrl_hip_num_optimizers(const gbrl_hip_model *m);
+int gbrl_hip_get_optimizer(const gbrl_hip_model *m, int idx, gbrl_hip_optimizer *out);           /* binding.cpp:393-419 */
+const char *gbrl_hip_learner_name(const gbrl_hip_model *m);
+/* GBRL::get_ensemble_data (gbrl.cpp:1344-1356): copies of the ensembleData arrays (types.h:279-304).  Sizes:
+ * T=n_trees, L=n_leaves, S = T (oblivious) or L (greedy), md=max_depth, D=output_dim, in=input_dim.  Any
+ * pointer may be NULL. */
+int gbrl_hip_get_ensemble(const gbrl_hip_model *m,
+                          int32_t *tree_indices /*[T]*/, int32_t *depths /*[S]*/, float *values /*[L*D]*/,
+                          int32_t *feature_indices /*[S*md]*/, float *feature_values /*[S*md]*/,
+                          float *edge_weights /*[L*md]*/, uint8_t *is_numerics /*[S*md]*/,
+                          uint8_t *inequality_directions /*[L*md]*/, char *categorical_values /*[S*md*128]*/,
+                          int32_t *reverse_num_feature_mapping /*[in]*/, int32_t *reverse_cat_feature_mapping /*[in]*/);
+
+/* ---- THE HOT PATH ------------------------------------------------------------------------------------- */
+/* GBRL::step (gbrl.cpp:939-981) == Fitter::step_cpu semantics (fitter.cpp:50-115), computed on the GPU:
+ * fits ONE tree to `grads` and appends it to the ensemble.
+ *   obs      float32 [n_samples, n_num_features] row-major, or NULL when n_num_features == 0
+ *   cat_obs  char    [n_samples, n_cat_features, 128] (NUL-padded strings), or NULL
+ *   grads    float32 [n_samples, output_dim] row-major
+ * Buffers are borrowed for the duration of the call only. */
+int gbrl_hip_step(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs,
+                  int cat_on_device, const float *grads, int grads_on_device, int n_samples,
+                  int n_num_features, int n_cat_features);
+
+/* GBRL::predict (gbrl.cpp:369-422) == Predictor::predict_cpu semantics (predictor.cpp:122-265) + SGDOptimizer::step
+ * (optimizer.cpp:110-118): out[i,:] = bias - sum_t lr_k * leaf_value(i, t) over trees [start_tree, stop_tree)
+ * (stop_tree == 0 means n_trees).  `out` is float32 [n_samples, output_dim], host or device per out_on_device. */
+int gbrl_hip_predict(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs,
+                     int cat_on_device, int n_samples, int n_num_features, int n_cat_features,
+                     int start_tree, int stop_tree, float *out, int out_on_device);
+
+/* ---- row-sharded multi-GPU (new; the reference is single-GPU) ------------------------------------------ */
+/* One process per GPU, each holding a contiguous block of rows.  When hooks are installed, step() calls them at
+ * its exchange points so that every rank grows the identical tree; predict() needs no exchange.  Buffers are
+ * DEVICE pointers; the hook must return only after the reduced result is visible on the HIP null stream
+ * ordering used by the model.  sum hooks are exact (integers), so 1/2/4/8-GPU trees are
+ * bit-identical.  Install NULL hooks to go back to single-GPU. */
+typedef struct {
+    void *ctx;
+    int world_size, rank;
+    int (*allreduce_sum_i64)(void *ctx, int64_t *dev_buf, size_t count);
+    int (*allreduce_sum_f64)(void *ctx, double *dev_buf, size_t count);
+    int (*allreduce_max_f32)(void *ctx, float *dev_buf, size_t count);
+    int (*allreduce_min_f32)(void *ctx, float *dev_buf, size_t count);
+} gbrl_hip_collective;
+int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks);
+
+/* ---- measurement -------------------------------------------------------------------------------------- */
+/* Per-phase GPU time of the LAST step()/predict() call, measured with HIP events on the model's stream.
+ * names/ms hold up to `cap` entries; returns the number of phases. */
+int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float *ms, int cap);
+/* When enabled (default off), step()/predict() bracket every kernel phase with HIP events. */
+int gbrl_hip_set_profiling(gbrl_hip_model *m, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBRL_HIP_H */

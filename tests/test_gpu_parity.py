@@ -1,0 +1,165 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP product, called through the gbrl_cpp binding which
+goes through the C ABI only, against (a) the committed golden vectors produced by the reference's CPU path and (b) the
+oracle restatement on fresh seeds.
+
+Bar (BASELINE.json north_star): tree STRUCTURE bit-identical (split feature indices, threshold bits, directions, leaf
+layout); leaf values and predictions within 1e-5 relative, where "relative" is |a-b| / max(|b|, gradient scale)
+(SURVEY.md hard part 5: the oracle's own float32 sequential sums limit what a relative error of a near-zero mean means).
+"""
+import numpy as np
+import pytest
+
+import cases as K
+from helpers import assert_structure_equal, assert_values_close, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _torch_input(keep):
+    import torch
+
+    def to_input(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        keep.append(t)
+        return (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    return to_input
+
+
+def _from_capsule(c):
+    import torch
+    if isinstance(c, np.ndarray):
+        return c
+    return torch.from_dlpack(c).cpu().numpy()
+
+
+def _run_product(case, X, Xc, G, y, device):
+    import gbrl_amd
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case, device=device))
+    if device == "cpu":      # host buffers in, NumPy out (compute is on the GPU regardless)
+        pred = K.drive(m, case, X, Xc, G, y)
+    else:                    # torch device tensors in as 4-tuples, DLPack (kDLROCM) out
+        keep = []
+        pred = K.drive(m, case, X, Xc, G, y, to_input=_torch_input(keep), to_numpy=_from_capsule)
+    return m, np.asarray(pred)
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES])
+def test_product_matches_reference_golden(name):
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m, pred = _run_product(case, X, Xc, G, y, "cpu")
+    e = m.get_ensemble_data()
+    assert m.get_num_trees() == int(g["n_trees"]) and m.get_iteration() == int(g["iteration"])
+    assert_structure_equal(e, g, what=name + ": ")
+    scale = float(np.abs(G).mean()) if y is None else float(np.abs(y).mean())
+    assert_values_close(e, g, scale, TOL, what=name + ": ")
+    assert rel_err(pred.reshape(g["pred"].shape), g["pred"], scale) <= TOL
+
+
+@pytest.mark.parametrize("name", ["obl_l2_q", "grd_cos_q_ac", "cfg1_rmse_loop"])
+def test_torch_device_tuple_path_equals_host_path(name):
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m1, p1 = _run_product(case, X, Xc, G, y, "cpu")
+    m2, p2 = _run_product(case, X, Xc, G, y, "cuda")
+    e1, e2 = m1.get_ensemble_data(), m2.get_ensemble_data()
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(np.asarray(e1[k]), np.asarray(e2[k])), k   # same bytes, whichever way the data came in
+    assert np.array_equal(p1.reshape(-1), p2.reshape(-1))
+    assert m2.get_device() == "cuda"
+
+
+def test_same_inputs_same_bytes():
+    """Determinism: integer accumulation makes every run produce identical bytes (the reference's CUDA path does not)."""
+    case, g, (X, Xc, G, y) = load_golden("obl_l2_q_d6")
+    runs = [_run_product(case, X, Xc, G, y, "cpu") for _ in range(3)]
+    for m, p in runs[1:]:
+        for k in K.ENSEMBLE_KEYS:
+            assert np.array_equal(np.asarray(m.get_ensemble_data()[k]), np.asarray(runs[0][0].get_ensemble_data()[k])), k
+        assert np.array_equal(p, runs[0][1])
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203, 204])
+@pytest.mark.parametrize("policy,score,gen", [("oblivious", "L2", "Quantile"), ("greedy", "Cosine", "Quantile"),
+                                              ("greedy", "L2", "Uniform"), ("oblivious", "Cosine", "Uniform")])
+def test_product_matches_oracle_on_fresh_seeds(seed, policy, score, gen):
+    import oracle
+    case = dict(name="fresh", seed=seed, N=3000, F=10, Fc=0, D=4, depth=5, n_bins=128, score=score, gen=gen,
+                policy=policy, trees=3)
+    X, Xc, G, y = K.make_inputs(case)
+    m, pred = _run_product(case, X, Xc, G, y, "cpu")
+    ref = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    pref = K.drive(ref, case, X, Xc, G, y)
+    e, r = m.get_ensemble_data(), ref.get_ensemble_data()
+    assert_structure_equal(e, r)
+    scale = float(np.abs(G).mean())
+    assert_values_close(e, r, scale, TOL)
+    assert rel_err(pred, pref, scale) <= TOL
+
+
+def test_quantile_thresholds_bit_exact_at_scale():
+    """A3 at a size where the oracle's sort is still cheap: thresholds chosen by the GPU's exact selection are data
+    values at the reference's ranks -- checked through the tree (every stored threshold must be one of them) and the
+    early-stop/ragged path (N not a multiple of n_bins+1, heavy duplicates, a constant column)."""
+    import gbrl_amd
+    rng = np.random.default_rng(7)
+    N, F, B = 50021, 12, 256
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    X[:, 3] = np.round(X[:, 3])          # ~7 distinct values
+    X[:, 5] = 1.5                        # constant
+    X[::7, 6] = -0.0                     # signed zeros
+    G = (np.sign(X[:, :2]) + 0.1 * rng.standard_normal((N, 2))).astype(np.float32)
+    case = dict(name="q", seed=0, N=N, F=F, D=2, depth=6, n_bins=B, score="L2", gen="Quantile", policy="greedy", trees=1)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, None, G, None)
+    e = m.get_ensemble_data()
+    counts = np.full(B + 1, N // (B + 1)); counts[: N % (B + 1)] += 1
+    ranks = np.cumsum(counts)[:B] - 1
+    allowed = {f: set(np.sort(X[:, f])[ranks].view(np.uint32).tolist()) | {0, 0x80000000} for f in range(F)}
+    fi, fv, dep = np.asarray(e["feature_indices"]), np.asarray(e["feature_values"]), np.asarray(e["depths"])
+    for leaf in range(fi.shape[0]):
+        for d in range(dep[leaf]):
+            assert int(fv[leaf, d].view(np.uint32)) in allowed[int(fi[leaf, d])]
+
+
+def test_full_size_properties_config2_shape():
+    """BASELINE configs[1] shape (oblivious / L2 / quantile, F=128, D=8, depth 6) at N=2^18 through size-independent
+    properties: (1) predict(X) after one tree with lr=1 returns -(leaf mean) so the per-leaf means of G reproduce the
+    stored values; (2) leaf counts from edge weights multiply to the leaf population; (3) the tree is a proper
+    oblivious tree (same condition per level for all leaves); (4) adding a constant to G leaves the structure unchanged
+    (L2 standardisation is shift invariant)."""
+    import gbrl_amd
+    rng = np.random.default_rng(0)
+    N, F, D = 1 << 18, 128, 8
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    W = rng.standard_normal((8, D)).astype(np.float32)
+    G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((N, D))).astype(np.float32)
+    case = dict(name="c2", seed=0, N=N, F=F, D=D, depth=6, n_bins=256, score="L2", gen="Quantile", policy="oblivious",
+                trees=1, opts=[dict(algo="SGD", scheduler="Const", init_lr=1.0, start_idx=0, stop_idx=D)])
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pred = np.asarray(K.drive(m, case, X, None, G, None))
+    e = m.get_ensemble_data()
+    depth = int(e["depths"][0])
+    assert depth == 6 and e["values"].shape == (64, D)
+    fi, fv = np.asarray(e["feature_indices"])[0], np.asarray(e["feature_values"])[0]
+    leaf = np.zeros(N, np.int64)
+    for d in range(depth):
+        leaf |= (X[:, fi[d]] > fv[d]).astype(np.int64) << (depth - 1 - d)
+    vals = np.asarray(e["values"])
+    assert np.array_equal(pred, (np.float32(0) - vals[leaf]).astype(np.float32))          # (1a) routing
+    for l in range(64):                                                                    # (1b) exact leaf means
+        rows = leaf == l
+        if rows.any():
+            want = G[rows].astype(np.float64).mean(axis=0)
+            assert np.max(np.abs(vals[l] - want) / np.maximum(np.abs(want), 0.5)) < 1e-6
+    ew = np.asarray(e["edge_weights"])                                                    # (2)
+    assert np.allclose(np.prod(ew.astype(np.float64), axis=1) * N, np.bincount(leaf, minlength=64), rtol=1e-5, atol=0.5)
+    ineq = np.asarray(e["inequality_directions"])                                         # (3)
+    for l in range(64):
+        assert [int(b) for b in ineq[l]] == [(l >> (depth - 1 - d)) & 1 for d in range(depth)]
+    case2 = dict(case, name="c2s")
+    m2 = gbrl_amd.GBRL(**K.ctor_kwargs(case2))                                            # (4)
+    K.drive(m2, case2, X, None, (G + np.float32(3.0)).astype(np.float32), None)
+    e2 = m2.get_ensemble_data()
+    assert np.array_equal(np.asarray(e2["feature_indices"]), np.asarray(e["feature_indices"]))
+    assert np.array_equal(np.asarray(e2["feature_values"]), np.asarray(e["feature_values"]))

@@ -1,0 +1,167 @@
+"""CPU-side checks of the product: the C ABI exports what include/gbrl_hip.h declares, the .gbrl_model format is byte
+compatible with files written by the reference, argument checking mirrors the reference binding, and the product fails
+loudly (never falls back) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases as K
+import gbrl_amd
+from helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "gbrl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(gbrl_hip_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if n not in ("gbrl_hip_model",)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = ctypes.CDLL(gbrl_amd.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.gbrl_hip_abi_version.restype = ctypes.c_int
+    assert lib.gbrl_hip_abi_version() == 1
+    assert lib.gbrl_hip_device_count() >= 0
+
+
+def test_metadata_struct_is_80_bytes_like_the_reference():
+    class Meta(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("n_leaves", "n_trees", "max_trees", "max_leaves", "max_trees_batch",
+                                                  "max_leaves_batch", "input_dim", "output_dim", "policy_dim", "max_depth",
+                                                  "min_data_in_leaf", "n_bins", "par_th")] + \
+                   [("cv_beta", ctypes.c_float), ("verbose", ctypes.c_int32), ("batch_size", ctypes.c_int32),
+                    ("use_cv", ctypes.c_uint8), ("split_score_func", ctypes.c_uint8), ("generator_type", ctypes.c_uint8),
+                    ("grow_policy", ctypes.c_uint8), ("n_num_features", ctypes.c_int32), ("n_cat_features", ctypes.c_int32),
+                    ("iteration", ctypes.c_int32)]
+    assert ctypes.sizeof(Meta) == 80 and Meta.iteration.offset == 76 and Meta.use_cv.offset == 64
+
+
+def _mask_header_padding(b):
+    b = bytearray(b)
+    b[6:8] = b"\0\0"      # serializationHeader padding after the three u16 (uninitialised in the reference)
+    b[20:24] = b"\0\0\0\0"  # ... and after reserved2
+    return bytes(b)
+
+
+@pytest.mark.parametrize("name", K.MODEL_FILE_CASES)
+def test_model_file_roundtrip_is_byte_compatible(name, tmp_path):
+    case, g, _ = load_golden(name)
+    ref_bytes = g["model_file"].tobytes()
+    p = tmp_path / "ref.gbrl_model"
+    p.write_bytes(ref_bytes)
+    m = gbrl_amd.GBRL.load(str(p))            # a file written by the reference loads ...
+    e = m.get_ensemble_data()
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(np.asarray(e[k]), g[k]), k
+    assert m.get_num_trees() == int(g["n_trees"]) and m.get_iteration() == int(g["iteration"])
+    assert m.get_learner_name() == case["name"]
+    assert len(m.get_optimizers()) == len(K.optimizers(case))
+    q = tmp_path / "ours.gbrl_model"
+    assert m.save(str(q)) == 0                # ... and what we write back is the same file
+    assert _mask_header_padding(q.read_bytes()) == _mask_header_padding(ref_bytes)
+    m2 = gbrl_amd.GBRL(m)                     # copy constructor keeps everything
+    assert np.array_equal(np.asarray(m2.get_ensemble_data()["values"]), g["values"])
+
+
+def test_model_file_written_here_loads_in_the_reference(tmp_path):
+    import oracle
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    case, g, _ = load_golden("grd_cos_q_ac")
+    p = tmp_path / "a.gbrl_model"
+    p.write_bytes(g["model_file"].tobytes())
+    q = tmp_path / "b.gbrl_model"
+    gbrl_amd.GBRL.load(str(p)).save(str(q))
+    r = ref.GBRL.load(str(q))
+    er = r.get_ensemble_data()
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(np.asarray(er[k]), g[k]), k
+
+
+def _model(**kw):
+    base = dict(input_dim=4, output_dim=2, policy_dim=2, max_depth=3, split_score_func="L2", generator_type="Quantile",
+                grow_policy="oblivious", device="cpu")
+    base.update(kw)
+    return gbrl_amd.GBRL(**base)
+
+
+def test_constructor_and_setters_mirror_reference_errors():
+    m = _model()
+    md = m.get_metadata()
+    assert md["grow_policy"] == "Oblivious" and md["split_score_func"] == "L2" and md["n_bins"] == 256
+    with pytest.raises(RuntimeError):
+        _model(split_score_func="l3")
+    with pytest.raises(RuntimeError):
+        _model(use_control_variates=True)
+    with pytest.raises(RuntimeError):
+        m.set_bias(np.zeros(3, np.float32))
+    m.set_bias(np.array([1.0, -2.0], np.float32))
+    assert np.array_equal(m.get_bias(), [1.0, -2.0])
+    m.set_feature_weights(np.arange(4, dtype=np.float32))
+    assert np.array_equal(m.get_feature_weights(), np.arange(4))
+    m.set_feature_mapping(np.array([0, 1, 2, 3], np.int32), np.array([True, False, True, False]))
+    e = m.get_ensemble_data()
+    assert e["reverse_num_feature_mapping"].tolist() == [0, 2, -1, -1]
+    assert e["reverse_cat_feature_mapping"].tolist() == [1, 3, -1, -1]
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=1)
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=1, stop_idx=2)
+    with pytest.raises(RuntimeError):          # limit = output_dim (gbrl.cpp:457)
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=2)
+    with pytest.raises(RuntimeError):
+        _model().set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=1, stop_idx=1)
+    with pytest.raises(RuntimeError):          # Adam / Linear are CPU-only in the reference (gbrl.cpp:477-506)
+        _model().set_optimizer(algo="Adam", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=2)
+    assert np.allclose(m.get_scheduler_lrs(), [0.1, 0.01])
+    assert [o["stop_idx"] for o in m.get_optimizers()] == [1, 2]
+
+
+def test_step_and_predict_shape_checks():
+    m = _model()
+    X = np.zeros((300, 4), np.float32)
+    with pytest.raises(RuntimeError, match="Gradient output dim"):
+        m.step(X, None, np.zeros((300, 3), np.float32))
+    with pytest.raises(RuntimeError, match="Number of observations"):
+        m.step(X, None, np.zeros((200, 2), np.float32))
+    with pytest.raises(RuntimeError, match="Total number of features"):
+        m.step(np.zeros((300, 3), np.float32), None, np.zeros((300, 2), np.float32))
+    with pytest.raises(RuntimeError, match="Expected array of format"):
+        m.step(X, np.zeros((300, 1)), np.zeros((300, 2), np.float32))   # categorical must be S128
+    with pytest.raises(RuntimeError, match="without observations"):
+        m.predict(None, None)
+    with pytest.raises(RuntimeError, match="stop_tree_idx is out of bounds"):
+        m.predict(X, None, 0, 5)
+    for fn in ("fit", "export", "tree_shap", "ensemble_shap", "plot_tree", "print_tree"):
+        with pytest.raises(RuntimeError, match="outside the accelerated"):
+            getattr(m, fn)()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if gbrl_amd.cuda_available():
+        pytest.skip("a HIP device is present")
+    m = _model()
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=2)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        m.step(np.zeros((300, 4), np.float32), None, np.zeros((300, 2), np.float32))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        m.predict(np.zeros((300, 4), np.float32), None)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must not import / link / load anything under oracle/."""
+    for root, _, files in os.walk(os.path.join(ROOT, "gbrl_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "oracle.h" not in txt, f
+    out = os.popen("ldd " + gbrl_amd.LIB_PATH).read()
+    assert "oracle" not in out
