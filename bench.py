@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- trees-fit/sec (+ predict rows/sec) of the MI355X-native GBRL hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): oblivious tree, L2 split score, quantile
+candidates, batch = 2^20 rows PER GPU, 128 features, depth 6, output_dim 8, n_bins 256, one SGD optimiser; synthetic
+inputs X ~ N(0,1), G = tanh(X[:, :8] W) + 0.5 N(0,1) generated on the device before the timed region (inputs resident in
+HBM).  One "step" = one GBRL.step() = one tree fitted on the whole batch.  With N > 1 the rows are sharded over the ranks
+(weak scaling: 2^20 rows per GPU, the SAME tree is grown on every rank from all-reduced integer histograms), and `value`
+counts 2^20-row batches: value = steps * n_gpus / seconds.
+
+Printed JSON (rank 0, one line): the driver contract + "roofline" for the dominant kernel (split-score histogram build,
+HBM-bound, algorithmic bytes from SURVEY.md 8(d)) + "cpu_baseline" (the reference's own CPU path if oracle/_ref is
+loadable, else this repo's restatement) on a bounded sample + predict throughput.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def hist_algorithmic_bytes(n_rows, n_feat, out_dim, depth, n_bins):
+    """per level read N*(F*1 B code + D*4 B grads + 4 B row id) + write 2^l * F*B*(D+1)*4 B."""
+    per_level_read = n_rows * (n_feat * 1 + out_dim * 4 + 4)
+    hist = n_feat * n_bins * (out_dim + 1) * 4
+    return depth * per_level_read + ((1 << depth) - 1) * hist
+
+
+def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows):
+    """Reference CPU path on a bounded sample of the same workload (rows only are reduced).  Cost of the reference's
+    brute-force scan is linear in the row count (depth * N * candidates * (1 + D)), so trees/s at the full batch is
+    the sample's trees/s * sample_rows / full_rows."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((sample_rows, n_feat)).astype(np.float32)
+    W = rng.standard_normal((8, out_dim)).astype(np.float32)
+    G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((sample_rows, out_dim))).astype(np.float32)
+    kind, mod = "reference", oracle.load_ref()
+    kw = dict(input_dim=n_feat, output_dim=out_dim, policy_dim=out_dim, max_depth=depth, min_data_in_leaf=0, n_bins=n_bins,
+              par_th=10, cv_beta=0.9, split_score_func="L2", generator_type="Quantile", use_control_variates=False,
+              batch_size=5000, grow_policy="oblivious", verbose=0, device="cpu", learner_name="cpu_baseline")
+    if mod is not None:
+        m = mod.GBRL(**kw)
+    else:
+        kind = "port"
+        m = oracle.OracleGBRL(**kw)
+    m.set_feature_weights(np.ones(n_feat, np.float32))
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=out_dim)
+    m.set_feature_mapping(np.arange(n_feat, dtype=np.int32), np.ones(n_feat, dtype=bool))
+    t0 = time.perf_counter()
+    m.step(X, None, G)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    m.predict(X, None, 0, 0)
+    dtp = time.perf_counter() - t1
+    cores = os.cpu_count() or 1
+    return {"value": (1.0 / dt) * sample_rows / full_rows, "unit": "trees/s at batch=2^20 (extrapolated linearly in rows)",
+            "cores": cores, "kind": kind,
+            "sample": "1 tree on %d of %d rows (same F=%d, D=%d, depth=%d, n_bins=%d): %.2f s; predict 1 tree %.3f s" % (
+                sample_rows, full_rows, n_feat, out_dim, depth, n_bins, dt, dtp),
+            "sample_seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU (default 2^20 = the metric's batch)")
+    ap.add_argument("--features", type=int, default=128)
+    ap.add_argument("--out-dim", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=8192)
+    ap.add_argument("--predict-trees", type=int, default=0, help="0: predict over the ensemble grown by the bench")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import gbrl_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available() or not gbrl_amd.cuda_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, F, D, depth, B = args.rows, args.features, args.out_dim, args.depth, args.bins
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    X = torch.randn((N, F), device=dev, dtype=torch.float32, generator=gen)
+    wgen = torch.Generator(device=dev)
+    wgen.manual_seed(99)
+    W = torch.randn((8, D), device=dev, dtype=torch.float32, generator=wgen)
+    G = (torch.tanh(X[:, :8] @ W) + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)).contiguous()
+
+    m = gbrl_amd.GBRL(input_dim=F, output_dim=D, policy_dim=D, max_depth=depth, min_data_in_leaf=0, n_bins=B, par_th=10,
+                      cv_beta=0.9, split_score_func="L2", generator_type="Quantile", use_control_variates=False,
+                      batch_size=5000, grow_policy="oblivious", verbose=0, device="cuda", learner_name="bench")
+    m.set_feature_weights(np.ones(F, np.float32))
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
+    m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+    m.set_profiling(True)   # HIP events on the engine's own stream, resolved after each call: no sync inside the step
+    coll = None
+    if world > 1:
+        from gbrl_amd.dist import install_torch_collective
+        coll = install_torch_collective(m, dev)
+
+    def tup(t):
+        return (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+
+    xo, go = tup(X), tup(G)
+    for _ in range(args.warmup):
+        m.step(xo, None, go)
+    phase_acc = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.step(xo, None, go)
+        for k, v in m.last_phase_times().items():
+            phase_acc[k] = phase_acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # predict over the ensemble (rows stay sharded; no exchange)
+    n_trees = m.get_num_trees()
+    torch.cuda.synchronize()
+    reps = 5
+    m.predict(xo, None, 0, 0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        p = m.predict(xo, None, 0, 0)
+        del p
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t1) / reps
+    pk = m.last_phase_times().get("predict", 0.0)
+
+    if rank == 0:
+        steps = args.steps
+        ms_per_step = dt / steps * 1e3
+        hist_ms = (phase_acc.get("hist_build", 0.0) + phase_acc.get("hist_reduce", 0.0)) / steps
+        build_ms = phase_acc.get("hist_build", 0.0) / steps
+        alg = hist_algorithmic_bytes(N, F, D, depth, B)
+        achieved = alg / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
+        out = {
+            "metric": "trees-fit/sec + predict rows/sec at batch=2^20, feat=128, depth=6, out=8",
+            "value": steps * world * (N / float(1 << 20)) / dt,
+            "unit": "trees/s (2^20-row batches fitted per second; one tree per batch per step)",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 fixed-point sums / f32 scores",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: oblivious tree, L2 score, quantile candidates", "rows_per_gpu": N,
+                       "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world},
+            "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
+                        "row_trees_per_s": world * N * n_trees / dtp},
+            "phases_ms_per_step": {k: v / steps for k, v in sorted(phase_acc.items())},
+            "roofline": {"bound": "hbm", "kernel": "k_hist_build (+k_hist_reduce), 6 launches per tree",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_tree": alg, "hist_ms_per_tree": hist_ms,
+                         "hist_build_ms_per_tree": build_ms},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(F, D, depth, B, 1 << 20, args.cpu_sample_rows)
+            except Exception as e:  # the baseline is reporting only; never let it hide the measurement
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

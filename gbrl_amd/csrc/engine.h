@@ -63,6 +63,7 @@ class Engine {
     void sync_model_to_device();
     void phase_begin();
     void phase_end(const char *name);
+    void phases_resolve();
 
     int device_ordinal_ = -1;
     bool device_ready_ = false;
@@ -73,7 +74,9 @@ class Engine {
     // measurement
     bool profiling_ = false;
     std::vector<std::pair<std::string, float>> phases_;
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
+    std::vector<const char *> ev_names_;
+    size_t ev_used_ = 0;
 
     // ---- per-step workspace (grow-only, reused across steps) ----
     DevBuf d_obs_, d_grads_, d_qg_, d_stat_, d_partials_f64_, d_meanden_, d_maxbits_;

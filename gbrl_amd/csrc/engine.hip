@@ -63,8 +63,7 @@ Engine::Engine(const Engine &o) : model(o.model), device_ordinal_(o.device_ordin
 Engine::~Engine() {
     if (device_ready_) {
         (void)hipSetDevice(device_ordinal_);
-        if (ev0_) (void)hipEventDestroy(ev0_);
-        if (ev1_) (void)hipEventDestroy(ev1_);
+        for (auto &e : ev_pool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (stream_) (void)hipStreamDestroy(stream_);
     }
 }
@@ -85,8 +84,6 @@ void Engine::ensure_device() {
     if (device_ordinal_ >= count) throw InvalidArgument("device ordinal out of range");
     hip_check(hipSetDevice(device_ordinal_), "hipSetDevice");
     hip_check(hipStreamCreate(&stream_), "hipStreamCreate");  // blocking stream: ordered with the null stream torch uses by default
-    hip_check(hipEventCreate(&ev0_), "hipEventCreate");
-    hip_check(hipEventCreate(&ev1_), "hipEventCreate");
     device_ready_ = true;
 }
 
@@ -101,18 +98,38 @@ void Engine::set_collective(const gbrl_hip_collective *hooks) {
     has_coll_ = true;
 }
 
+// Phase timing: HIP events recorded on the model's stream WITHOUT synchronising; resolved once at the end of the call
+// (after the call's final stream synchronisation), so enabling it does not perturb the timed region.
 void Engine::phase_begin() {
-    if (profiling_) hip_check(hipEventRecord(ev0_, stream_), "hipEventRecord");
+    if (!profiling_) return;
+    if (ev_used_ == ev_pool_.size()) {
+        hipEvent_t a, b;
+        hip_check(hipEventCreate(&a), "hipEventCreate");
+        hip_check(hipEventCreate(&b), "hipEventCreate");
+        ev_pool_.push_back({a, b});
+    }
+    hip_check(hipEventRecord(ev_pool_[ev_used_].first, stream_), "hipEventRecord");
 }
 void Engine::phase_end(const char *name) {
     if (!profiling_) return;
-    hip_check(hipEventRecord(ev1_, stream_), "hipEventRecord");
-    hip_check(hipEventSynchronize(ev1_), "hipEventSynchronize");
-    float ms = 0.f;
-    hip_check(hipEventElapsedTime(&ms, ev0_, ev1_), "hipEventElapsedTime");
-    for (auto &p : phases_)
-        if (p.first == name) { p.second += ms; return; }
-    phases_.emplace_back(name, ms);
+    hip_check(hipEventRecord(ev_pool_[ev_used_].second, stream_), "hipEventRecord");
+    ev_names_.push_back(name);
+    ++ev_used_;
+}
+void Engine::phases_resolve() {
+    phases_.clear();
+    if (!profiling_) return;
+    for (size_t i = 0; i < ev_used_; ++i) {
+        float ms = 0.f;
+        hip_check(hipEventSynchronize(ev_pool_[i].second), "hipEventSynchronize");
+        hip_check(hipEventElapsedTime(&ms, ev_pool_[i].first, ev_pool_[i].second), "hipEventElapsedTime");
+        bool found = false;
+        for (auto &p : phases_)
+            if (p.first == ev_names_[i]) { p.second += ms; found = true; break; }
+        if (!found) phases_.emplace_back(ev_names_[i], ms);
+    }
+    ev_used_ = 0;
+    ev_names_.clear();
 }
 
 namespace {
@@ -158,7 +175,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     if (md.max_depth > kern::kMaxPath) throw Unsupported("max_depth > 32 is not supported");
     if (md.n_bins < 1 || md.n_bins > 65534) throw Unsupported("n_bins must be in [1, 65534]");
     ensure_device();
-    phases_.clear();
+    ev_used_ = 0;
+    ev_names_.clear();
     hipStream_t s = stream_;
     const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
     const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
@@ -502,7 +520,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     };
 
     int tree_depth = 0;
-    phase_begin();
     for (int depth = 0; depth < MD && n_cand > 0; ++depth) {
         // nodes that take part at this level: oblivious -> the whole level; greedy -> nodes with rows (fitter.cpp:300)
         std::vector<int> active;
@@ -513,9 +530,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // -- histograms
         build_chunks(active, chunk_rows);
         hip_check(hipMemcpyAsync(d_chunk_begin, h_chunk_begin.data(), sizeof(int32_t) * h_chunk_begin.size(), hipMemcpyHostToDevice, s), "H2D chunk begin");
+        phase_begin();
         if (!h_chunks.empty())
             kern::hist_build(d_codes, Fp, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
+        phase_end("hist_build");
+        phase_begin();
         kern::hist_reduce(d_partials, d_chunk_begin, n_act, n_groups, FG, NB, D, Fp, d_hist_local, s);
+        phase_end("hist_reduce");
         if (has_coll_) {
             hip_check(hipMemcpyAsync(d_hist, d_hist_local, sizeof(int64_t) * n_act * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist");
             hip_check(hipStreamSynchronize(s), "sync");
@@ -540,6 +561,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         hip_check(hipMemcpyAsync(d_path_bin, pb.data(), sizeof(int32_t) * pb.size(), hipMemcpyHostToDevice, s), "H2D");
         hip_check(hipMemcpyAsync(d_isroot, root.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s), "H2D");
         // -- scores and selection
+        phase_begin();
         kern::score_candidates(d_hist, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                1.0 / scale, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
         std::vector<int32_t> best_idx(n_act, 0);
@@ -553,7 +575,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
             hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float) * n_act, hipMemcpyDeviceToHost, s), "D2H");
         }
+        phase_end("score_select");
         hip_check(hipStreamSynchronize(s), "sync");
+        hip_check(hipGetLastError(), "growth kernels");
         if (oblivious) {
             if (best_score[0] == -INFINITY) break;  // fitter.cpp:458
             for (int k = 1; k < n_act; ++k) { best_idx[k] = best_idx[0]; best_score[k] = best_score[0]; }
@@ -655,15 +679,16 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             build_chunks(split_ids, 8192);
             hip_check(hipMemcpyAsync(d_splits, sp2.data(), sizeof(NodeSplit) * sp2.size(), hipMemcpyHostToDevice, s), "H2D splits");
             hip_check(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * 2 * sp2.size(), s), "memset cursors");
+            phase_begin();
             if (!h_chunks.empty())
                 kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, Fp, d_chunks, static_cast<int>(h_chunks.size()), d_splits, d_cursors, s);
+            phase_end("partition");
             hip_check(hipStreamSynchronize(s), "sync");  // host staging vectors go out of scope
             cur ^= 1;
         }
         frontier = next;
         tree_depth = depth + 1;
     }
-    phase_end("growth");
 
     // ---- 5. leaves ---------------------------------------------------------------------------------------------------
     phase_begin();
@@ -752,6 +777,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     md.iteration += 1;  // fitter.cpp:114
     ++model.version;
     (void)world;
+    hip_check(hipGetLastError(), "step kernels");
+    phases_resolve();
 }
 
 // ===================================================================================================== predict
@@ -811,7 +838,8 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (md.output_dim > 128) throw Unsupported("predict: output_dim > 128");
     ensure_device();
-    phases_.clear();
+    ev_used_ = 0;
+    ev_names_.clear();
     hipStream_t s = stream_;
     const int D = md.output_dim;
     // predict_cpu, predictor.cpp:127-141
@@ -877,6 +905,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     phase_end("predict");
     if (!out_dev) hip_check(hipMemcpyAsync(out, dout, sizeof(float) * static_cast<size_t>(n) * D, hipMemcpyDeviceToHost, s), "D2H preds");
     hip_check(hipStreamSynchronize(s), "sync");
+    phases_resolve();
 }
 
 }  // namespace gbrl

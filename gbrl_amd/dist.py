@@ -1,0 +1,87 @@
+"""Row-sharded multi-GPU support: torch.distributed (backend "nccl" == RCCL on ROCm) behind the C ABI's collective hooks.
+
+One process per GPU; every rank holds a contiguous block of rows and calls ``GBRL.step`` with its shard.  The engine
+calls the hooks installed here at its exchange points (include/gbrl_hip.h, gbrl_hip_collective): gradient statistics,
+min/max or quantile-selection counts, the per-level integer histograms and the leaf sums.  All sums are integer (or
+max/min), so every rank grows the same tree bit for bit and the result does not depend on the number of GPUs.
+``predict`` needs no exchange: rows are independent.
+
+The hooks receive raw device pointers.  They are wrapped zero-copy as torch tensors through ``__cuda_array_interface__``
+and reduced in place with ``torch.distributed.all_reduce`` on the current torch stream; the hook synchronises before it
+returns, which is the contract the engine expects.  With ``device=None`` the pointers are host pointers (used by the
+world_size-2 gloo tests, which exercise the same hook code on CPU buffers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+
+class _Coll(C.Structure):
+    _I64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+    _fields_ = [("ctx", C.c_void_p), ("world_size", C.c_int), ("rank", C.c_int),
+                ("allreduce_sum_i64", _I64), ("allreduce_sum_f64", _I64),
+                ("allreduce_max_f32", _I64), ("allreduce_min_f32", _I64)]
+
+
+class _DevArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class TorchCollective:
+    """Owns the ctypes callbacks (must outlive the model's use of them)."""
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.device, self.group = torch, dist, device, group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.calls = 0
+        self.bytes = 0
+        mk = lambda typestr, np_dtype, op: _Coll._I64(lambda ctx, ptr, n: self._reduce(ptr, n, typestr, np_dtype, op))  # noqa: E731
+        self._cbs = (mk("<i8", np.int64, dist.ReduceOp.SUM), mk("<f8", np.float64, dist.ReduceOp.SUM),
+                     mk("<f4", np.float32, dist.ReduceOp.MAX), mk("<f4", np.float32, dist.ReduceOp.MIN))
+        self.struct = _Coll(None, self.world_size, self.rank, *self._cbs)
+
+    def _tensor(self, ptr, n, typestr, np_dtype):
+        if self.device is None:
+            buf = (C.c_char * (int(n) * np.dtype(np_dtype).itemsize)).from_address(int(ptr))
+            return self.torch.from_numpy(np.frombuffer(buf, dtype=np_dtype))
+        return self.torch.as_tensor(_DevArray(ptr, n, typestr), device=self.device)
+
+    def _reduce(self, ptr, n, typestr, np_dtype, op):
+        try:
+            t = self._tensor(ptr, n, typestr, np_dtype)
+            self.dist.all_reduce(t, op=op, group=self.group)
+            if self.device is not None:
+                self.torch.cuda.synchronize(self.device)
+            self.calls += 1
+            self.bytes += int(n) * np.dtype(np_dtype).itemsize
+            return 0
+        except Exception as e:  # never let an exception unwind through the C frame
+            print("gbrl_amd.dist: all_reduce failed:", repr(e), flush=True)
+            return -1
+
+    # direct (Python-side) access to the same code path, used by the tests
+    def allreduce_sum_i64(self, arr): return self._cbs[0](None, arr.ctypes.data, arr.size)
+    def allreduce_sum_f64(self, arr): return self._cbs[1](None, arr.ctypes.data, arr.size)
+    def allreduce_max_f32(self, arr): return self._cbs[2](None, arr.ctypes.data, arr.size)
+    def allreduce_min_f32(self, arr): return self._cbs[3](None, arr.ctypes.data, arr.size)
+
+
+def install_torch_collective(model, device, group=None) -> TorchCollective:
+    """Attach torch.distributed hooks to a gbrl_amd.GBRL model.  Keep the returned object alive."""
+    from . import LIB_PATH
+    coll = TorchCollective(device, group)
+    lib = C.CDLL(LIB_PATH)
+    lib.gbrl_hip_set_collective.argtypes = [C.c_void_p, C.POINTER(_Coll)]
+    lib.gbrl_hip_set_collective.restype = C.c_int
+    lib.gbrl_hip_last_error.restype = C.c_char_p
+    rc = lib.gbrl_hip_set_collective(C.c_void_p(model._handle()), C.byref(coll.struct))
+    if rc != 0:
+        raise RuntimeError(lib.gbrl_hip_last_error().decode())
+    model._collective = coll if hasattr(model, "__dict__") else None
+    return coll
