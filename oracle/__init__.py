@@ -8,7 +8,7 @@ Two checkers live here:
 * :class:`OracleGBRL` -- ctypes front-end of ``liboracle.so`` (this repo's own restatement,
   ``oracle/oracle.cpp``), with the call surface of the reference's ``gbrl_cpp.GBRL`` for the hot
   path (``step`` / ``predict`` / ``get_ensemble_data`` / setters; ``binding.cpp:421-960``).
-* :func:`load_ref` -- imports ``oracle/_ref/gbrl_cpp*.so``, i.e. the reference's own CPU path compiled
+* :func:`load_ref` -- imports ``oracle/_ref/gbrl_cpp_ref*.so``, i.e. the reference's own CPU path compiled
   from ``/root/reference`` by ``oracle/Makefile`` (present in the authoring container; travels to the
   GPU box as a prebuilt binary; never committed).
 """
@@ -175,7 +175,7 @@ class OracleGBRL:
 
 
 def ref_path(native: bool = False):
-    pat = os.path.join(_HERE, "_ref", "native" if native else "", "gbrl_cpp*.so")
+    pat = os.path.join(_HERE, "_ref", "native" if native else "", "gbrl_cpp_ref*.so")
     hits = sorted(glob.glob(pat))
     return hits[0] if hits else None
 
@@ -185,7 +185,7 @@ def load_ref(native: bool = False):
     path = ref_path(native)
     if path is None:
         return None
-    spec = importlib.util.spec_from_file_location("gbrl_cpp", path)
+    spec = importlib.util.spec_from_file_location("gbrl_cpp_ref", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
