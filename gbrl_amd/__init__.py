@@ -20,6 +20,12 @@ if not (os.path.exists(_EXT) and os.path.exists(LIB_PATH)):
         "gbrl_amd: the HIP extension is not built (expected %s and %s). Run `python gbrl_amd/build.py` "
         "(or __graft_entry__.build()). There is no pure-Python / CPU fallback." % (LIB_PATH, _EXT))
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if this library were loaded first, the system
+# copy under /opt/rocm would be bound instead and torch would then fail to see the GPU.  Importing torch first (when it
+# is installed) makes both share torch's runtime.  torch is plumbing here (device tensors, DLPack, torch.distributed).
+if importlib.util.find_spec("torch") is not None:
+    import torch  # noqa: F401
+
 _spec = importlib.util.spec_from_file_location("gbrl_cpp", _EXT)
 gbrl_cpp = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(gbrl_cpp)

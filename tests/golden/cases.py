@@ -125,7 +125,10 @@ CASES = [
     _c("grd_cos_q", seed=7, policy="greedy", score="Cosine"),
     _c("grd_cos_u", seed=8, policy="greedy", score="Cosine", gen="Uniform"),
     # configs[0]: GradientBoostingTrees single-output MultiRMSE, batch=4096, n_feat=16, depth=4, greedy/L2
-    _c("cfg1_rmse_loop", seed=9, N=4096, F=16, D=1, depth=4, policy="greedy", loop="rmse", trees=12),
+    # seed 9 was rejected by make_golden.py: the reference disagrees with ITSELF there between OMP_NUM_THREADS=3 and 8
+    # (a 1.6e-7 relative near-tie at a 896-row node of tree 0); it is kept below as `cfg1_rmse_fragile`.
+    _c("cfg1_rmse_loop", seed=21, N=4096, F=16, D=1, depth=4, policy="greedy", loop="rmse", trees=12),
+    _c("cfg1_rmse_fragile", seed=9, N=4096, F=16, D=1, depth=4, policy="greedy", loop="rmse", trees=12, fragile=True),
     # shared actor-critic: two SGD optimisers on one ensemble (A14), D=8 = policy[0,7) + value[7,8)
     _c("grd_cos_q_ac", seed=10, N=2048, F=8, D=8, depth=5, policy="greedy", score="Cosine",
        opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),

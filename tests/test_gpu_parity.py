@@ -45,7 +45,7 @@ def _run_product(case, X, Xc, G, y, device):
     return m, np.asarray(pred)
 
 
-@pytest.mark.parametrize("name", [c["name"] for c in K.CASES])
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES if not c.get("fragile")])
 def test_product_matches_reference_golden(name):
     case, g, (X, Xc, G, y) = load_golden(name)
     m, pred = _run_product(case, X, Xc, G, y, "cpu")
@@ -55,6 +55,33 @@ def test_product_matches_reference_golden(name):
     scale = float(np.abs(G).mean()) if y is None else float(np.abs(y).mean())
     assert_values_close(e, g, scale, TOL, what=name + ": ")
     assert rel_err(pred.reshape(g["pred"].shape), g["pred"], scale) <= TOL
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES if c.get("fragile")])
+def test_fragile_case_is_exact_or_an_explained_near_tie(name):
+    """Inputs on which the reference disagrees with ITSELF between OMP_NUM_THREADS 3 and 8 (make_golden.py flags them):
+    the product must either reproduce the 8-thread fixture exactly or differ first at a split whose two candidates
+    are tied within the reference's own float32 summation noise (neartie.py), with the product holding the true max."""
+    import neartie
+    import oracle
+    case, g, (X, Xc, G, y) = load_golden(name)
+    assert not bool(g["ref_stable_across_threads"])
+    m, pred = _run_product(case, X, Xc, G, y, "cpu")
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    mm = neartie.first_mismatch(g, e, case["policy"])
+    if mm is None:
+        return
+    t = mm[0]
+    if y is not None:   # gradients of tree t in the rmse loop: pred(t trees) - y, reproduced with the bit-exact restatement
+        o = oracle.OracleGBRL(**K.ctor_kwargs(case))
+        K.drive(o, dict(case, trees=t), X, Xc, G, y)
+        G_t = (np.asarray(o.predict(X, Xc, 0, 0)).astype(np.float32).reshape(y.shape) - y) if t else (0 - y)
+    else:
+        G_t = G
+    info = neartie.explain_first_mismatch(case, X, Xc, G_t, g, e)
+    print("near-tie:", info)
+    assert info["explained"], info
+    assert info["product_is_true_max"], info
 
 
 @pytest.mark.parametrize("name", ["obl_l2_q", "grd_cos_q_ac", "cfg1_rmse_loop"])
