@@ -56,6 +56,8 @@ class Engine {
 
     void set_collective(const gbrl_hip_collective *hooks);
     void set_profiling(bool on) { profiling_ = on; }
+    void set_force_bisection(bool on) { force_bisection_ = on; }   // test hook: exercise the slow exact quantile path
+    bool last_quantile_fallback() const { return last_quantile_fallback_; }
     const std::vector<std::pair<std::string, float>> &phase_times() const { return phases_; }
 
    private:
@@ -73,6 +75,7 @@ class Engine {
 
     // measurement
     bool profiling_ = false;
+    bool force_bisection_ = false, last_quantile_fallback_ = false;
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
     std::vector<const char *> ev_names_;
@@ -81,6 +84,7 @@ class Engine {
     // ---- per-step workspace (grow-only, reused across steps) ----
     DevBuf d_obs_, d_grads_, d_qg_, d_stat_, d_partials_f64_, d_meanden_, d_maxbits_;
     DevBuf d_thr_, d_thrkeys_, d_prefix_, d_trial_, d_counts_, d_cum_, d_minmax_;
+    DevBuf d_kt_, d_qflags_, d_splitters_, d_ccounts_, d_c2l_, d_tgt_list_, d_tgt_rank_, d_list_off_, d_qlists_;
     DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
     DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <unordered_map>
@@ -177,6 +178,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ensure_device();
     ev_used_ = 0;
     ev_names_.clear();
+    if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
     hipStream_t s = stream_;
     const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
     const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
@@ -295,6 +297,37 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     std::vector<float> h_thr(static_cast<size_t>(F) * B);
     float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, h_thr.size())));
     uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, h_thr.size())));
+    uint32_t *d_kt = nullptr;
+    uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
+    bool fast_quantile = false;
+    if (F > 0) {
+        // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
+        d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
+        kern::transpose_keys(dobs, N, F, d_kt, s);
+    }
+    phase_end("transpose");
+    phase_begin();
+    auto bisection_quantiles = [&](const std::vector<int64_t> &cum) {
+        // exact but slow: 32 counting passes (also the multi-GPU path: only integer counts cross ranks)
+        int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+        hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+        uint32_t *d_prefix = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * F * B));
+        uint32_t *d_trial = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * F * B));
+        int64_t *d_counts = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * F * (B + 1)));
+        kern::qsel_init(d_prefix, d_trial, F, B, s);
+        for (int bit = 31; bit >= 0; --bit) {
+            hip_check(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * F * (B + 1), s), "memset");
+            kern::bin_rows(dobs, N, F, d_trial, B, /*strict=*/false, d_counts, nullptr, 0, 0, s);
+            if (has_coll_) {
+                hip_check(hipStreamSynchronize(s), "sync");
+                if (coll_.allreduce_sum_i64(coll_.ctx, d_counts, static_cast<size_t>(F) * (B + 1)) != 0)
+                    throw HipError("allreduce failed");
+            }
+            kern::qsel_update(d_prefix, d_trial, d_counts, d_cum, F, B, bit, bit - 1, s);
+        }
+        hip_check(hipMemcpyAsync(d_thrkeys, d_trial, sizeof(uint32_t) * F * B, hipMemcpyDeviceToDevice, s), "D2D keys");
+    };
+    std::vector<int64_t> cum;
     if (F > 0) {
         if (md.generator_type == GBRL_HIP_GEN_UNIFORM) {
             uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
@@ -315,30 +348,54 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         } else {
             // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1
             if (n_global < B + 1) throw InvalidArgument("quantile candidates need n_samples >= n_bins + 1");
-            std::vector<int64_t> cum(B);
+            cum.resize(B);
             const long long per = n_global / (B + 1), rem = n_global % (B + 1);
             long long run = 0;
             for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
-            int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
-            hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
-            uint32_t *d_prefix = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * F * B));
-            uint32_t *d_trial = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * F * B));
-            int64_t *d_counts = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * F * (B + 1)));
-            kern::qsel_init(d_prefix, d_trial, F, B, s);
-            for (int bit = 31; bit >= 0; --bit) {
-                hip_check(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * F * (B + 1), s), "memset");
-                kern::bin_rows(dobs, N, F, d_trial, B, /*strict=*/false, d_counts, nullptr, 0, 0, s);
-                if (has_coll_) {
-                    hip_check(hipStreamSynchronize(s), "sync");
-                    if (coll_.allreduce_sum_i64(coll_.ctx, d_counts, static_cast<size_t>(F) * (B + 1)) != 0)
-                        throw HipError("allreduce failed");
-                }
-                kern::qsel_update(d_prefix, d_trial, d_counts, d_cum, F, B, bit, bit - 1, s);
+            if (has_coll_ || force_bisection_) {
+                bisection_quantiles(cum);
+            } else {
+                fast_quantile = true;
+                const kern::QuantilePlan plan = kern::quantile_plan(N);
+                const uint32_t max_lists = static_cast<uint32_t>(F) * B;
+                const uint32_t max_elems = static_cast<uint32_t>(std::min<size_t>(static_cast<size_t>(N) * F, std::max<size_t>(1u << 20, static_cast<size_t>(N) * F / 4)));
+                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * F * kern::kQuantileMaxSplit));
+                uint32_t *d_cc = static_cast<uint32_t *>(d_ccounts_.ensure(sizeof(uint32_t) * F * kern::kQuantileClasses));
+                int32_t *d_c2l = static_cast<int32_t *>(d_c2l_.ensure(sizeof(int32_t) * F * kern::kQuantileClasses));
+                int32_t *d_tl = static_cast<int32_t *>(d_tgt_list_.ensure(sizeof(int32_t) * F * B));
+                uint32_t *d_tr = static_cast<uint32_t *>(d_tgt_rank_.ensure(sizeof(uint32_t) * F * B));
+                uint32_t *d_loff = static_cast<uint32_t *>(d_list_off_.ensure(sizeof(uint32_t) * max_lists * 3));
+                uint32_t *d_llen = d_loff + max_lists, *d_lcur = d_loff + 2 * static_cast<size_t>(max_lists);
+                uint32_t *d_lists = static_cast<uint32_t *>(d_qlists_.ensure(sizeof(uint32_t) * max_elems));
+                hip_check(hipMemsetAsync(d_cc, 0, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
+                hip_check(hipMemsetAsync(d_c2l, 0xff, sizeof(int32_t) * F * kern::kQuantileClasses, s), "memset");
+                hip_check(hipMemsetAsync(d_qflags, 0, sizeof(uint32_t) * 4, s), "memset");
+                hip_check(hipMemsetAsync(d_lcur, 0, sizeof(uint32_t) * max_lists, s), "memset");
+                kern::sample_splitters(d_kt, N, F, plan, d_split, s);
+                kern::class_count(d_kt, N, F, plan, d_split, d_cc, s);
+                kern::quantile_targets(d_cc, d_split, d_cum, F, B, plan, d_c2l, d_tl, d_tr, d_thrkeys, d_loff, d_llen, d_qflags,
+                                       max_lists, max_elems, d_qflags + 2, s);
+                kern::quantile_extract(d_kt, N, F, plan, d_split, d_c2l, d_loff, d_lcur, d_lists, s);
+                kern::quantile_select(d_lists, d_loff, d_llen, d_tl, d_tr, F * B, d_thrkeys, s);
             }
-            hip_check(hipMemcpyAsync(d_thrkeys, d_trial, sizeof(uint32_t) * F * B, hipMemcpyDeviceToDevice, s), "D2D keys");
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
         }
+        uint32_t qflags[4] = {0, 0, 0, 0};
         hip_check(hipMemcpyAsync(h_thr.data(), d_thr, sizeof(float) * F * B, hipMemcpyDeviceToHost, s), "D2H thr");
+        if (fast_quantile) {
+            hip_check(hipMemcpyAsync(qflags, d_qflags, sizeof(qflags), hipMemcpyDeviceToHost, s), "D2H flags");
+            hip_check(hipStreamSynchronize(s), "sync");
+            if (qflags[2] != 0) {  // a class list outgrew its budget (pathological value distribution): redo exactly, slowly
+                bisection_quantiles(cum);
+                kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
+                hip_check(hipMemcpyAsync(h_thr.data(), d_thr, sizeof(float) * F * B, hipMemcpyDeviceToHost, s), "D2H thr");
+                last_quantile_fallback_ = true;
+            } else {
+                last_quantile_fallback_ = false;
+            }
+        }
     }
     phase_end("candidates");
 
@@ -430,15 +487,17 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     }
     for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
 
-    // ---- 3. class codes ----------------------------------------------------------------------------------------------
+    // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
     phase_begin();
-    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * static_cast<size_t>(N) * Fp));
-    if (Fp != F) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * static_cast<size_t>(N) * Fp, s), "memset codes");
-    if (F > 0) kern::bin_rows(dobs, N, F, d_thrkeys, B, /*strict=*/true, nullptr, d_codes, Fp, 0, s);
+    const int n_code_groups = (n_slots + kern::kCodeGroup - 1) / kern::kCodeGroup;
+    const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
+    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
+    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
+    if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
     if (Fc > 0) {
-        uint16_t *d_cc = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
-        hip_check(hipMemcpyAsync(d_cc, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
-        kern::scatter_cat_codes(d_cc, N, Fc, d_codes, Fp, F, s);
+        uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
+        hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
+        kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
     }
     phase_end("binning");
 
@@ -532,7 +591,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         hip_check(hipMemcpyAsync(d_chunk_begin, h_chunk_begin.data(), sizeof(int32_t) * h_chunk_begin.size(), hipMemcpyHostToDevice, s), "H2D chunk begin");
         phase_begin();
         if (!h_chunks.empty())
-            kern::hist_build(d_codes, Fp, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
+            kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
         phase_end("hist_build");
         phase_begin();
         kern::hist_reduce(d_partials, d_chunk_begin, n_act, n_groups, FG, NB, D, Fp, d_hist_local, s);
@@ -681,7 +740,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             hip_check(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * 2 * sp2.size(), s), "memset cursors");
             phase_begin();
             if (!h_chunks.empty())
-                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, Fp, d_chunks, static_cast<int>(h_chunks.size()), d_splits, d_cursors, s);
+                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_chunks, static_cast<int>(h_chunks.size()), d_splits, d_cursors, s);
             phase_end("partition");
             hip_check(hipStreamSynchronize(s), "sync");  // host staging vectors go out of scope
             cur ^= 1;

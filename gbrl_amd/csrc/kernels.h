@@ -63,9 +63,30 @@ void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
 void scatter_cat_codes(const uint16_t *cat_codes, int n, int Fc, uint16_t *codes, int code_stride, int code_off, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 
+// ---- exact quantile selection and binning on transposed keys (quantile.hip) ----
+struct QuantilePlan { int sample, n_split, n_chunks, chunk; };
+constexpr int kQuantileClasses = 8192;
+constexpr int kQuantileMaxSplit = 4095;
+QuantilePlan quantile_plan(int n);
+void transpose_keys(const float *obs, int n, int F, uint32_t *kt /*[F][n]*/, hipStream_t s);
+void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters /*[F][4095]*/, hipStream_t s);
+void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *counts /*[F][8192], zeroed*/, hipStream_t s);
+void quantile_targets(const uint32_t *counts, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
+                      int32_t *class_to_list /*[F][8192], preset -1*/, int32_t *tgt_list, uint32_t *tgt_rank, uint32_t *thr_keys,
+                      uint32_t *list_off, uint32_t *list_len, uint32_t *alloc /*[2], zeroed*/, uint32_t max_lists, uint32_t max_elems,
+                      uint32_t *overflow /*zeroed*/, hipStream_t s);
+void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const int32_t *class_to_list,
+                      const uint32_t *list_off, uint32_t *cursors /*zeroed*/, uint32_t *out, hipStream_t s);
+void quantile_select(const uint32_t *lists, const uint32_t *list_off, const uint32_t *list_len, const int32_t *tgt_list,
+                     const uint32_t *tgt_rank, int n_targets, uint32_t *thr_keys, hipStream_t s);
+// codes[(slot/16)*n*16 + row*16 + slot%16] (u16) = #{k : thr_key[f][k] < key(row, f)}
+void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s);
+void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s);
+constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [group][row][16]
+
 // ---- split-score histograms (A6) ----
 size_t hist_lds_bytes(int NB, int D, int FG);
-void hist_build(const uint16_t *codes, int code_stride, const int32_t *qg, int D, const int32_t *rows,
+void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
                 const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s);
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, int n_slots, int n_groups,
                  int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);
@@ -84,7 +105,7 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
                   int64_t *n_total, int64_t *n_right, hipStream_t s);
 
 // ---- partition (A9) ----
-void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int code_stride,
+void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows,
                     const Chunk *chunks, int n_chunks, const NodeSplit *splits, int32_t *cursors /*[n_nodes*2], zeroed*/,
                     hipStream_t s);
 

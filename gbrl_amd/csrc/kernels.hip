@@ -26,11 +26,6 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float(u);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // A2  gradient statistics: out[d] = sum_i (g[i,d] - center[d])^2  (center != null)  or  sum_i g[i,d]
 // Block size is a multiple of D so that every thread owns one column; per-block partials are combined by a single
@@ -253,7 +248,12 @@ __global__ void k_iota(int32_t *__restrict__ rows, int n) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kHistThreads = 1024;
 
-__global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int code_stride,
+__device__ __forceinline__ size_t code_index(int slot, int row, int n_rows) {
+    // group-major code layout written by bin_cols: [slot/16][row][slot%16]
+    return (static_cast<size_t>(slot >> 4) * n_rows + row) * kCodeGroup + (slot & (kCodeGroup - 1));
+}
+
+__global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
                                                               const int32_t *__restrict__ qg, int D,
                                                               const int32_t *__restrict__ rows,
                                                               const Chunk *__restrict__ chunks, int FG, int fg_shift,
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const int row_stride = (D + 1) * FG;
     for (int p = slot; p < ck.len; p += n_slots) {
         const int row = rows[ck.start + p];
-        const int code = codes[static_cast<size_t>(row) * code_stride + g * FG + fl];
+        const int code = codes[code_index(g * FG + fl, row, n_rows)];
         const int32_t *q = qg + static_cast<size_t>(row) * D;
         int32_t *dst = h + code * row_stride + fl;
         for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
@@ -455,7 +455,7 @@ __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, in
 // harmless because everything computed downstream is an order-independent integer sum.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_partition(const int32_t *__restrict__ rows_in, int32_t *__restrict__ rows_out,
-                                                   const uint16_t *__restrict__ codes, int code_stride,
+                                                   const uint16_t *__restrict__ codes, int n_rows,
                                                    const Chunk *__restrict__ chunks, const NodeSplit *__restrict__ splits,
                                                    int32_t *__restrict__ cursors) {
     const Chunk ck = chunks[blockIdx.x];
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_partition(const int32_t *__restrict__ r
         if (active) {
             row = rows_in[ck.start + p];
             if (sp.do_split) {
-                const int code = codes[static_cast<size_t>(row) * code_stride + sp.fslot];
+                const int code = codes[code_index(sp.fslot, row, n_rows)];
                 right = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
             }
         }
@@ -674,7 +674,7 @@ void iota_rows(int32_t *rows, int n, hipStream_t s) {
 
 size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * (D + 1) * FG * sizeof(int32_t); }
 
-void hist_build(const uint16_t *codes, int code_stride, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                 int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s) {
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
@@ -685,7 +685,7 @@ void hist_build(const uint16_t *codes, int code_stride, const int32_t *qg, int D
                             160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_hist_build, dim3(n_chunks, n_groups), dim3(kHistThreads), lds, s, codes, code_stride, qg, D, rows,
+    hipLaunchKernelGGL(k_hist_build, dim3(n_chunks, n_groups), dim3(kHistThreads), lds, s, codes, n_rows, qg, D, rows,
                        chunks, FG, shift, NB, partials);
 }
 
@@ -725,9 +725,9 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
                        n_right);
 }
 
-void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int code_stride, const Chunk *chunks,
+void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows, const Chunk *chunks,
                     int n_chunks, const NodeSplit *splits, int32_t *cursors, hipStream_t s) {
-    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(256), 0, s, rows_in, rows_out, codes, code_stride, chunks, splits,
+    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(256), 0, s, rows_in, rows_out, codes, n_rows, chunks, splits,
                        cursors);
 }
 

@@ -1,0 +1,380 @@
+// quantile.hip -- exact multi-rank selection (A3) and binning on gfx950, column-major formulation.
+//
+// Problem: for each of F features, the data values at B given ranks (the reference sorts every column,
+// fitter.cpp:77-90, and reads split_candidate_generator.cpp:216-249's ranks).  A full sort is ~100x more work than
+// needed.  Here:
+//   1. k_transpose_keys   obs [N][F] f32  ->  KT [F][N] u32, order-preserving keys (coalesced both ways through LDS)
+//   2. k_sample_splitters per feature: jittered-stratified sample of <= 16384 keys, bitonic sort in LDS, every
+//                         (S/4096)-th sample becomes a splitter (<= 4095 per feature)
+//   3. k_class_count      class(x) = 2*#{splitters < x} + [x equals the next splitter]; exact class counts per feature.
+//                         Odd ("equality") classes hold copies of ONE value, so heavy duplicates never inflate a list.
+//   4. k_targets          per target rank: its class and rank inside the class; distinct open classes get a list
+//   5. k_extract          second sweep: keys of listed classes are appended to their lists (~6 % of the data)
+//   6. k_select           one wave per target: exact order statistic inside its (small) list by 32-step bisection
+// Everything is exact; the sample only balances the classes.  If a list would overflow its budget the engine falls back
+// to the 32-pass bisection of kernels.hip (same results, slower).
+#include "kernels.h"
+
+namespace gbrl {
+namespace kern {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxSplit = 4095;
+constexpr int kClasses = 2 * (kMaxSplit + 1);  // 8192
+
+__device__ __forceinline__ uint32_t float_to_key(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u << 1) == 0) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---- 1. transpose + key ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_keys(const float *__restrict__ obs, int n, int F, uint32_t *__restrict__ kt) {
+    __shared__ uint32_t tile[64][65];
+    const int r0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, f = f0 + tx;
+        tile[i][tx] = (r < n && f < F) ? float_to_key(obs[static_cast<size_t>(r) * F + f]) : 0xffffffffu;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int f = f0 + i, r = r0 + tx;
+        if (f < F && r < n) kt[static_cast<size_t>(f) * n + r] = tile[tx][i];
+    }
+}
+
+// ---- 2. sample + sort + splitters ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__restrict__ kt, int n, int S, int n_split,
+                                                           uint32_t *__restrict__ splitters) {
+    extern __shared__ uint32_t s[];  // [S], S power of two
+    const int f = blockIdx.x;
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    if (n <= S) {
+        for (int i = threadIdx.x; i < S; i += blockDim.x) s[i] = i < n ? col[i] : 0xffffffffu;
+    } else {
+        const double stride = static_cast<double>(n) / S;
+        for (int i = threadIdx.x; i < S; i += blockDim.x) {
+            const long long lo = static_cast<long long>(i * stride), hi = static_cast<long long>((i + 1) * stride);
+            uint32_t h = (static_cast<uint32_t>(i) * 2654435761u) ^ (static_cast<uint32_t>(f) * 40503u + 0x9e3779b9u);
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const long long span = hi > lo ? hi - lo : 1;
+            long long idx = lo + static_cast<long long>(h % static_cast<uint32_t>(span));
+            if (idx >= n) idx = n - 1;
+            s[i] = col[idx];
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= S; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < S; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // splitter j = sample at position (j+1)*S/(n_split+1) - 1
+    const int step = S / (n_split + 1);
+    for (int j = threadIdx.x; j < n_split; j += blockDim.x) splitters[static_cast<size_t>(f) * kMaxSplit + j] = s[(j + 1) * step - 1];
+}
+
+// class of a key: 2 * #{splitters < key} + (key == splitter[that index])
+__device__ __forceinline__ int classify(const uint32_t *sp, int n_split, uint32_t key) {
+    int lo = 0, hi = n_split;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sp[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return 2 * lo + ((lo < n_split && sp[lo] == key) ? 1 : 0);
+}
+
+// ---- 3. class counts ----------------------------------------------------------------------------------------------
+constexpr int kCountThreads = 512;
+__global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *__restrict__ kt, int n, int n_split,
+                                                               const uint32_t *__restrict__ splitters, int chunk,
+                                                               uint32_t *__restrict__ counts) {
+    __shared__ uint32_t sp[kMaxSplit + 1];
+    __shared__ uint32_t cnt[kClasses];
+    const int f = blockIdx.y;
+    for (int i = threadIdx.x; i < n_split; i += kCountThreads) sp[i] = splitters[static_cast<size_t>(f) * kMaxSplit + i];
+    for (int i = threadIdx.x; i < kClasses; i += kCountThreads) cnt[i] = 0;
+    __syncthreads();
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    int i = lo + threadIdx.x;
+    for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {  // 4 independent searches in flight per thread
+        const uint32_t k0 = col[i], k1 = col[i + kCountThreads], k2 = col[i + 2 * kCountThreads], k3 = col[i + 3 * kCountThreads];
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = n_split, b1 = n_split, b2 = n_split, b3 = n_split;
+        while ((a0 < b0) | (a1 < b1) | (a2 < b2) | (a3 < b3)) {
+            if (a0 < b0) { const int m = (a0 + b0) >> 1; if (sp[m] < k0) a0 = m + 1; else b0 = m; }
+            if (a1 < b1) { const int m = (a1 + b1) >> 1; if (sp[m] < k1) a1 = m + 1; else b1 = m; }
+            if (a2 < b2) { const int m = (a2 + b2) >> 1; if (sp[m] < k2) a2 = m + 1; else b2 = m; }
+            if (a3 < b3) { const int m = (a3 + b3) >> 1; if (sp[m] < k3) a3 = m + 1; else b3 = m; }
+        }
+        atomicAdd(&cnt[2 * a0 + ((a0 < n_split && sp[a0] == k0) ? 1 : 0)], 1u);
+        atomicAdd(&cnt[2 * a1 + ((a1 < n_split && sp[a1] == k1) ? 1 : 0)], 1u);
+        atomicAdd(&cnt[2 * a2 + ((a2 < n_split && sp[a2] == k2) ? 1 : 0)], 1u);
+        atomicAdd(&cnt[2 * a3 + ((a3 < n_split && sp[a3] == k3) ? 1 : 0)], 1u);
+    }
+    for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, n_split, col[i])], 1u);
+    __syncthreads();
+    for (int c = threadIdx.x; c < kClasses; c += kCountThreads)
+        if (cnt[c]) atomicAdd(&counts[static_cast<size_t>(f) * kClasses + c], cnt[c]);
+}
+
+// ---- 4. targets -----------------------------------------------------------------------------------------------------
+// Per feature: inclusive prefix over the 8192 class counts; target k (rank cum_k, 1-based) lies in the first class whose
+// inclusive prefix >= cum_k.  Equality classes answer directly; each distinct open class gets one list.
+__global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ splitters,
+                                                  const int64_t *__restrict__ cum, int B, int n_split,
+                                                  int32_t *__restrict__ class_to_list /*[F][8192]*/,
+                                                  int32_t *__restrict__ tgt_list /*[F][B] list id or -1*/,
+                                                  uint32_t *__restrict__ tgt_rank /*[F][B] rank inside the list (1-based)*/,
+                                                  uint32_t *__restrict__ thr_keys /*[F][B], written for direct answers*/,
+                                                  uint32_t *__restrict__ list_off, uint32_t *__restrict__ list_len,
+                                                  uint32_t *__restrict__ alloc /*[0]=next list id, [1]=next element offset*/,
+                                                  uint32_t max_lists, uint32_t max_elems, uint32_t *__restrict__ overflow) {
+    __shared__ uint32_t pre[kClasses];   // inclusive prefix of the class counts (n < 2^31 rows)
+    const int f = blockIdx.x;
+    int32_t *c2l = class_to_list + static_cast<size_t>(f) * kClasses;   // pre-set to -1 by the caller
+    for (int c = threadIdx.x; c < kClasses; c += blockDim.x) pre[c] = counts[static_cast<size_t>(f) * kClasses + c];
+    __syncthreads();
+    // block-wide inclusive scan of 8192 values: 8 per thread
+    {
+        const int base = threadIdx.x * 8;
+        uint32_t loc[8], run = 0;
+        for (int q = 0; q < 8; ++q) { run += pre[base + q]; loc[q] = run; }
+        __shared__ uint32_t tot[1024];
+        tot[threadIdx.x] = run;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? tot[threadIdx.x - o] : 0;
+            __syncthreads();
+            tot[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t off = threadIdx.x ? tot[threadIdx.x - 1] : 0;
+        for (int q = 0; q < 8; ++q) pre[base + q] = loc[q] + off;
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const uint32_t want = static_cast<uint32_t>(cum[k]);
+        int lo = 0, hi = kClasses - 1;
+        while (lo < hi) {  // first class with inclusive prefix >= want
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        const int c = lo;
+        const uint32_t before = c ? pre[c - 1] : 0;
+        const size_t t = static_cast<size_t>(f) * B + k;
+        tgt_rank[t] = want - before;
+        if (c & 1) {
+            thr_keys[t] = splitters[static_cast<size_t>(f) * kMaxSplit + (c >> 1)];
+            tgt_list[t] = -1;
+        } else {
+            tgt_list[t] = -2 - c;  // resolved below once the class has a list
+        }
+    }
+    __syncthreads();
+    // one list per distinct open target class (targets are sorted, equal classes are adjacent; let the first one allocate)
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const size_t t = static_cast<size_t>(f) * B + k;
+        const int v = tgt_list[t];
+        if (v >= -1) continue;
+        const int c = -2 - v;
+        const bool first = (k == 0) || (tgt_list[t - 1] != v);
+        if (first) {
+            const uint32_t len = static_cast<uint32_t>(pre[c] - (c ? pre[c - 1] : 0));
+            const uint32_t id = atomicAdd(&alloc[0], 1u);
+            const uint32_t off = atomicAdd(&alloc[1], len);
+            if (id >= max_lists || off + len > max_elems) { atomicExch(overflow, 1u); }
+            else { list_off[id] = off; list_len[id] = len; c2l[c] = static_cast<int32_t>(id); }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const size_t t = static_cast<size_t>(f) * B + k;
+        const int v = tgt_list[t];
+        if (v < -1) tgt_list[t] = c2l[-2 - v];
+    }
+}
+
+// ---- 5. extract -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__restrict__ kt, int n, int n_split,
+                                                           const uint32_t *__restrict__ splitters, int chunk,
+                                                           const int32_t *__restrict__ class_to_list,
+                                                           const uint32_t *__restrict__ list_off, uint32_t *__restrict__ cursors,
+                                                           uint32_t *__restrict__ out) {
+    __shared__ uint32_t sp[kMaxSplit + 1];
+    __shared__ int32_t c2l[kClasses];
+    const int f = blockIdx.y;
+    for (int i = threadIdx.x; i < n_split; i += kCountThreads) sp[i] = splitters[static_cast<size_t>(f) * kMaxSplit + i];
+    for (int i = threadIdx.x; i < kClasses; i += kCountThreads) c2l[i] = class_to_list[static_cast<size_t>(f) * kClasses + i];
+    __syncthreads();
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    int i = lo + threadIdx.x;
+    for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {
+        uint32_t k[4] = {col[i], col[i + kCountThreads], col[i + 2 * kCountThreads], col[i + 3 * kCountThreads]};
+        int a[4] = {0, 0, 0, 0}, b[4] = {n_split, n_split, n_split, n_split};
+        while ((a[0] < b[0]) | (a[1] < b[1]) | (a[2] < b[2]) | (a[3] < b[3])) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (a[q] < b[q]) { const int m = (a[q] + b[q]) >> 1; if (sp[m] < k[q]) a[q] = m + 1; else b[q] = m; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cls = 2 * a[q] + ((a[q] < n_split && sp[a[q]] == k[q]) ? 1 : 0);
+            const int id = c2l[cls];
+            if (id >= 0) out[list_off[id] + atomicAdd(&cursors[id], 1u)] = k[q];
+        }
+    }
+    for (; i < hi; i += kCountThreads) {
+        const uint32_t key = col[i];
+        const int id = c2l[classify(sp, n_split, key)];
+        if (id >= 0) out[list_off[id] + atomicAdd(&cursors[id], 1u)] = key;
+    }
+}
+
+// ---- 6. select ------------------------------------------------------------------------------------------------------
+// One wave per target: v = smallest key with #{keys <= v} >= r, built bit by bit (prefix p; trial t = p|bit; set the bit
+// iff #{keys < t} < r).
+__global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ list_off,
+                                                const uint32_t *__restrict__ list_len, const int32_t *__restrict__ tgt_list,
+                                                const uint32_t *__restrict__ tgt_rank, int n_targets,
+                                                uint32_t *__restrict__ thr_keys) {
+    const int t = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    if (t >= n_targets) return;
+    const int id = tgt_list[t];
+    if (id < 0) return;  // answered directly by an equality class
+    const uint32_t *keys = lists + list_off[id];
+    const uint32_t m = list_len[id], r = tgt_rank[t];
+    uint32_t p = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = p | (1u << bit);
+        uint32_t c = 0;
+        for (uint32_t i = lane; i < m; i += kWave) c += keys[i] < trial ? 1u : 0u;
+        for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+        if (c < r) p = trial;
+    }
+    if (lane == 0) thr_keys[t] = p;
+}
+
+// ---- binning from the transposed keys ---------------------------------------------------------------------------------
+// codes[g][row][fl] (u16, fl fastest, 16 features per group) = #{k : thr_key[f][k] < key(row, f)}.  One block = one group x
+// 256 rows: reads 16 column segments of 1 KiB (coalesced), searches the 16 threshold rows staged in LDS, and writes the
+// 8 KiB code tile contiguously.
+constexpr int kGroup = 16;
+__global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ kt, int n, int F, const uint32_t *__restrict__ thr,
+                                                  int B, uint16_t *__restrict__ codes) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *t = lds;                                    // [16][B+1] (+1 pad against bank conflicts)
+    uint16_t *tile = reinterpret_cast<uint16_t *>(lds + kGroup * (B + 1));  // [256][16]
+    const int g = blockIdx.y, r0 = blockIdx.x * 256;
+    for (int i = threadIdx.x; i < kGroup * B; i += 256) {
+        const int fl = i / B, k = i % B, f = g * kGroup + fl;
+        t[fl * (B + 1) + k] = f < F ? thr[static_cast<size_t>(f) * B + k] : 0xffffffffu;
+    }
+    __syncthreads();
+    const int r = r0 + threadIdx.x;
+    for (int fl = 0; fl < kGroup; ++fl) {
+        const int f = g * kGroup + fl;
+        int code = 0;
+        if (f < F && r < n) {
+            const uint32_t key = kt[static_cast<size_t>(f) * n + r];
+            const uint32_t *tf = t + fl * (B + 1);
+            int lo = 0, hi = B;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (tf[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            code = lo;
+        }
+        tile[threadIdx.x * kGroup + fl] = static_cast<uint16_t>(code);
+    }
+    __syncthreads();
+    const int rows = min(256, n - r0);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(codes + (static_cast<size_t>(g) * n + r0) * kGroup);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(tile);
+    for (int i = threadIdx.x; i < rows * kGroup / 2; i += 256) dst[i] = src[i];
+}
+
+__global__ void k_scatter_cat_codes_grouped(const uint16_t *__restrict__ cat_codes, int n, int Fc, int F,
+                                            uint16_t *__restrict__ codes) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<size_t>(n) * Fc) return;
+    const size_t r = i / Fc;
+    const int slot = F + static_cast<int>(i % Fc);
+    codes[(static_cast<size_t>(slot / kGroup) * n + r) * kGroup + (slot % kGroup)] = cat_codes[i];
+}
+
+}  // namespace
+
+void transpose_keys(const float *obs, int n, int F, uint32_t *kt, hipStream_t s) {
+    dim3 grid((n + 63) / 64, (F + 63) / 64);
+    hipLaunchKernelGGL(k_transpose_keys, grid, dim3(256), 0, s, obs, n, F, kt);
+}
+
+QuantilePlan quantile_plan(int n) {
+    QuantilePlan p;
+    int S = 64;
+    while (S < n && S < 16384) S <<= 1;   // whole column when n <= S, else a 16384-key jittered-stratified sample
+    p.sample = S;
+    p.n_split = S - 1 < kMaxSplit ? S - 1 : kMaxSplit;   // (n_split + 1) divides S: both are powers of two
+    p.n_chunks = n >= (1 << 18) ? 8 : (n >= (1 << 15) ? 2 : 1);
+    p.chunk = (n + p.n_chunks - 1) / p.n_chunks;
+    return p;
+}
+
+void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); attr = true; }
+    hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters);
+}
+
+void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, counts);
+}
+
+void quantile_targets(const uint32_t *counts, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
+                      int32_t *class_to_list, int32_t *tgt_list, uint32_t *tgt_rank, uint32_t *thr_keys, uint32_t *list_off,
+                      uint32_t *list_len, uint32_t *alloc, uint32_t max_lists, uint32_t max_elems, uint32_t *overflow, hipStream_t s) {
+    hipLaunchKernelGGL(k_targets, dim3(F), dim3(1024), 0, s, counts, splitters, cum, B, p.n_split, class_to_list, tgt_list, tgt_rank,
+                       thr_keys, list_off, list_len, alloc, max_lists, max_elems, overflow);
+}
+
+void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const int32_t *class_to_list,
+                      const uint32_t *list_off, uint32_t *cursors, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, class_to_list,
+                       list_off, cursors, out);
+}
+
+void quantile_select(const uint32_t *lists, const uint32_t *list_off, const uint32_t *list_len, const int32_t *tgt_list,
+                     const uint32_t *tgt_rank, int n_targets, uint32_t *thr_keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_select, dim3((n_targets + 3) / 4), dim3(256), 0, s, lists, list_off, list_len, tgt_list, tgt_rank, n_targets,
+                       thr_keys);
+}
+
+void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s) {
+    const size_t lds = static_cast<size_t>(kGroup) * (B + 1) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    dim3 grid((n + 255) / 256, (F + kGroup - 1) / kGroup);
+    hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, codes);
+}
+
+void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s) {
+    const size_t tot = static_cast<size_t>(n) * Fc;
+    hipLaunchKernelGGL(k_scatter_cat_codes_grouped, dim3((tot + 255) / 256), dim3(256), 0, s, cat_codes, n, Fc, F, codes);
+}
+
+}  // namespace kern
+}  // namespace gbrl

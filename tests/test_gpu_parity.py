@@ -190,3 +190,25 @@ def test_full_size_properties_config2_shape():
     e2 = m2.get_ensemble_data()
     assert np.array_equal(np.asarray(e2["feature_indices"]), np.asarray(e["feature_indices"]))
     assert np.array_equal(np.asarray(e2["feature_values"]), np.asarray(e["feature_values"]))
+
+
+def test_fast_quantile_path_equals_bisection_path(monkeypatch):
+    """The sample-splitter selection (quantile.hip) and the 32-pass bisection (kernels.hip) are both exact: identical trees."""
+    import gbrl_amd
+    rng = np.random.default_rng(11)
+    N, F = 70001, 20
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    X[:, 1] = np.round(X[:, 1] * 3) / 3          # heavy duplicates -> equality classes
+    X[:, 2] = (rng.random(N) < 0.97) * 1.0       # one value holds 97 % of the column
+    X[:, 4] = np.exp(3 * X[:, 4])                # heavy tail
+    X[:, 7] = 0.0
+    G = (np.tanh(X[:, :3]) + 0.3 * rng.standard_normal((N, 3))).astype(np.float32)
+    case = dict(name="qq", seed=0, N=N, F=F, D=3, depth=6, n_bins=256, score="Cosine", gen="Quantile", policy="greedy", trees=2)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("GBRL_HIP_FORCE_BISECTION", force)
+        m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+        K.drive(m, case, X, None, G, None)
+        outs.append({k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS})
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
