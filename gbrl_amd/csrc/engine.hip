@@ -153,6 +153,8 @@ struct HNode {
     long long n_global = 0;  // rows over all ranks
     std::vector<HCond> path;
     int left = -1, right = -1;
+    int parent = -1;
+    int hist_slot = -1;     // slot of this node's histogram in its level's buffer
     bool leaf = false;
 };
 
@@ -357,28 +359,24 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             } else {
                 fast_quantile = true;
                 const kern::QuantilePlan plan = kern::quantile_plan(N);
-                const uint32_t max_lists = static_cast<uint32_t>(F) * B;
                 const uint32_t max_elems = static_cast<uint32_t>(std::min<size_t>(static_cast<size_t>(N) * F, std::max<size_t>(1u << 20, static_cast<size_t>(N) * F / 4)));
                 int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
                 hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
                 uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * F * kern::kQuantileMaxSplit));
-                uint32_t *d_cc = static_cast<uint32_t *>(d_ccounts_.ensure(sizeof(uint32_t) * F * kern::kQuantileClasses));
-                int32_t *d_c2l = static_cast<int32_t *>(d_c2l_.ensure(sizeof(int32_t) * F * kern::kQuantileClasses));
-                int32_t *d_tl = static_cast<int32_t *>(d_tgt_list_.ensure(sizeof(int32_t) * F * B));
+                uint32_t *d_cc = static_cast<uint32_t *>(d_ccounts_.ensure(sizeof(uint32_t) * static_cast<size_t>(plan.n_chunks) * F * kern::kQuantileClasses));
+                uint32_t *d_coff = static_cast<uint32_t *>(d_c2l_.ensure(sizeof(uint32_t) * F * kern::kQuantileClasses));
+                uint32_t *d_toff = static_cast<uint32_t *>(d_tgt_list_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * B));
+                uint32_t *d_tlen = d_toff + static_cast<size_t>(F) * B;
                 uint32_t *d_tr = static_cast<uint32_t *>(d_tgt_rank_.ensure(sizeof(uint32_t) * F * B));
-                uint32_t *d_loff = static_cast<uint32_t *>(d_list_off_.ensure(sizeof(uint32_t) * max_lists * 3));
-                uint32_t *d_llen = d_loff + max_lists, *d_lcur = d_loff + 2 * static_cast<size_t>(max_lists);
                 uint32_t *d_lists = static_cast<uint32_t *>(d_qlists_.ensure(sizeof(uint32_t) * max_elems));
-                hip_check(hipMemsetAsync(d_cc, 0, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
-                hip_check(hipMemsetAsync(d_c2l, 0xff, sizeof(int32_t) * F * kern::kQuantileClasses, s), "memset");
+                hip_check(hipMemsetAsync(d_coff, 0xff, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
                 hip_check(hipMemsetAsync(d_qflags, 0, sizeof(uint32_t) * 4, s), "memset");
-                hip_check(hipMemsetAsync(d_lcur, 0, sizeof(uint32_t) * max_lists, s), "memset");
                 kern::sample_splitters(d_kt, N, F, plan, d_split, s);
                 kern::class_count(d_kt, N, F, plan, d_split, d_cc, s);
-                kern::quantile_targets(d_cc, d_split, d_cum, F, B, plan, d_c2l, d_tl, d_tr, d_thrkeys, d_loff, d_llen, d_qflags,
-                                       max_lists, max_elems, d_qflags + 2, s);
-                kern::quantile_extract(d_kt, N, F, plan, d_split, d_c2l, d_loff, d_lcur, d_lists, s);
-                kern::quantile_select(d_lists, d_loff, d_llen, d_tl, d_tr, F * B, d_thrkeys, s);
+                kern::quantile_targets(d_cc, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
+                                       d_qflags + 2, s);
+                kern::quantile_extract(d_kt, N, F, plan, d_split, d_coff, d_cc, d_lists, s);
+                kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
             }
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
         }
@@ -503,7 +501,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
 
     // ---- 4. growth ---------------------------------------------------------------------------------------------------
     const int max_front = 1 << std::max(0, MD - 1);
-    const int max_chunks = std::max((N + chunk_rows - 1) / chunk_rows, (N + 8191) / 8192) + 2 * (1 << MD) + 2;
+    const int max_chunks = std::max((N + chunk_rows - 1) / chunk_rows, (N + kern::kPartitionRows - 1) / kern::kPartitionRows) + 2 * (1 << MD) + 2;
     const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
     int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
                           static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
@@ -511,8 +509,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     int32_t *d_chunk_begin = static_cast<int32_t *>(d_chunk_begin_.ensure(sizeof(int32_t) * (max_front * 2 + 2)));
     int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * max_chunks * n_groups * n_acc));
     const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
-    int64_t *d_hist = static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems));
-    int64_t *d_hist_local = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * hist_node_elems)) : d_hist;
+    // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
+    int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems)),
+                              static_cast<int64_t *>(d_hist_prev_.ensure(sizeof(int64_t) * max_front * hist_node_elems))};
+    int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * hist_node_elems)) : nullptr;
+    int32_t *d_slotmap = static_cast<int32_t *>(d_slotmap_.ensure(sizeof(int32_t) * (max_front * 4 + 4)));
+    const int am_parts = kern::argmax_parts(std::max(1, n_cand));
+    float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * static_cast<size_t>(max_front) * am_parts));
+    int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * am_parts));
     FeatureSlot *d_slots = static_cast<FeatureSlot *>(d_slots_.ensure(sizeof(FeatureSlot) * std::max(1, n_slots)));
     float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
     float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
@@ -586,15 +590,53 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             if (oblivious || nodes[id].n_global > 0) active.push_back(id);
         if (active.empty()) break;
         const int n_act = static_cast<int>(active.size());
-        // -- histograms
-        build_chunks(active, chunk_rows);
+        // -- histograms.  Level 0: the root.  Deeper levels: of every sibling pair only the child with fewer rows is
+        //    accumulated from the data; the other one is parent - sibling (exact integers), which halves the LDS-atomic work.
+        //    (Row-sharded runs accumulate every node: the "smaller" child differs per rank.)
+        int64_t *d_hist_local = d_hist_lvl[depth & 1];
+        const int64_t *d_hist_prev = d_hist_lvl[(depth & 1) ^ 1];
+        int64_t *d_hist = has_coll_ ? d_hist_coll : d_hist_local;
+        std::vector<int> compute_ids;
+        std::vector<int32_t> slot_map, sub_entries;
+        if (depth == 0 || has_coll_) {
+            compute_ids = active;
+            for (int k = 0; k < n_act; ++k) slot_map.push_back(k);
+        } else {
+            std::vector<int> slot_of(nodes.size(), -1);
+            for (int k = 0; k < n_act; ++k) slot_of[active[k]] = k;
+            for (int k = 0; k < n_act; ++k) {
+                const int id = active[k], par = nodes[id].parent;
+                const int sib = nodes[par].left == id ? nodes[par].right : nodes[par].left;
+                const bool sib_active = slot_of[sib] >= 0;
+                // the child that is accumulated: fewer local rows; ties -> the left child
+                const bool i_am_small = sib_active && (nodes[id].n_local < nodes[sib].n_local ||
+                                                       (nodes[id].n_local == nodes[sib].n_local && nodes[par].left == id));
+                if (i_am_small) {
+                    compute_ids.push_back(id);
+                    slot_map.push_back(k);
+                } else {
+                    sub_entries.push_back(k);
+                    sub_entries.push_back(nodes[par].hist_slot);
+                    sub_entries.push_back(sib_active ? slot_of[sib] : -1);
+                }
+            }
+        }
+        for (int k = 0; k < n_act; ++k) nodes[active[k]].hist_slot = k;
+        build_chunks(compute_ids, chunk_rows);
         hip_check(hipMemcpyAsync(d_chunk_begin, h_chunk_begin.data(), sizeof(int32_t) * h_chunk_begin.size(), hipMemcpyHostToDevice, s), "H2D chunk begin");
+        if (!slot_map.empty())
+            hip_check(hipMemcpyAsync(d_slotmap, slot_map.data(), sizeof(int32_t) * slot_map.size(), hipMemcpyHostToDevice, s), "H2D slot map");
+        if (!sub_entries.empty())
+            hip_check(hipMemcpyAsync(d_slotmap + max_front, sub_entries.data(), sizeof(int32_t) * sub_entries.size(), hipMemcpyHostToDevice, s), "H2D sub entries");
         phase_begin();
         if (!h_chunks.empty())
             kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
         phase_end("hist_build");
         phase_begin();
-        kern::hist_reduce(d_partials, d_chunk_begin, n_act, n_groups, FG, NB, D, Fp, d_hist_local, s);
+        if (!compute_ids.empty())
+            kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist_local, s);
+        if (!sub_entries.empty())
+            kern::hist_subtract(d_hist_prev, d_hist_local, d_slotmap + max_front, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
         phase_end("hist_reduce");
         if (has_coll_) {
             hip_check(hipMemcpyAsync(d_hist, d_hist_local, sizeof(int64_t) * n_act * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist");
@@ -625,15 +667,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                                1.0 / scale, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
         std::vector<int32_t> best_idx(n_act, 0);
         std::vector<float> best_score(n_act, -INFINITY);
-        if (oblivious) {
-            kern::argmax_oblivious(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_best_idx, d_best_score, s);
-            hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H");
-            hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float), hipMemcpyDeviceToHost, s), "D2H");
-        } else {
-            kern::argmax_greedy(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, d_best_idx, d_best_score, s);
-            hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
-            hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float) * n_act, hipMemcpyDeviceToHost, s), "D2H");
-        }
+        kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
+        const int n_best = oblivious ? 1 : n_act;
+        hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t) * n_best, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float) * n_best, hipMemcpyDeviceToHost, s), "D2H");
         phase_end("score_select");
         hip_check(hipStreamSynchronize(s), "sync");
         hip_check(hipGetLastError(), "growth kernels");
@@ -706,6 +743,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             const long long npar = nodes[id].n_global, nr = right_g[k], nl = npar - nr;
             HNode l, r;
             l.depth = r.depth = nodes[id].depth + 1;
+            l.parent = r.parent = id;
             l.path = nodes[id].path;
             r.path = nodes[id].path;
             HCond cl = c, cr = c;
@@ -735,7 +773,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             std::vector<int> split_ids;
             std::vector<NodeSplit> sp2;
             for (int k : splitting) { split_ids.push_back(active[k]); sp2.push_back(sp[k]); }
-            build_chunks(split_ids, 8192);
+            build_chunks(split_ids, kern::kPartitionRows);
             hip_check(hipMemcpyAsync(d_splits, sp2.data(), sizeof(NodeSplit) * sp2.size(), hipMemcpyHostToDevice, s), "H2D splits");
             hip_check(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * 2 * sp2.size(), s), "memset cursors");
             phase_begin();

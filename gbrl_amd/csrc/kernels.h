@@ -36,7 +36,8 @@ struct NodeSplit {
     int32_t pad0, pad1;
 };
 
-constexpr int kMaxPath = 32;  // max_depth supported by the duplicate-on-path check
+constexpr int kMaxPath = 32;
+constexpr int kPartitionRows = 4096;  // rows per partition block (chunk size the engine must use)  // max_depth supported by the duplicate-on-path check
 
 // ---- gradient preprocessing (A2) ----
 void column_sums(const float *g, int n, int D, const float *center /*nullable [D]*/, double *block_partials,
@@ -70,15 +71,16 @@ constexpr int kQuantileMaxSplit = 4095;
 QuantilePlan quantile_plan(int n);
 void transpose_keys(const float *obs, int n, int F, uint32_t *kt /*[F][n]*/, hipStream_t s);
 void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters /*[F][4095]*/, hipStream_t s);
-void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *counts /*[F][8192], zeroed*/, hipStream_t s);
-void quantile_targets(const uint32_t *counts, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
-                      int32_t *class_to_list /*[F][8192], preset -1*/, int32_t *tgt_list, uint32_t *tgt_rank, uint32_t *thr_keys,
-                      uint32_t *list_off, uint32_t *list_len, uint32_t *alloc /*[2], zeroed*/, uint32_t max_lists, uint32_t max_elems,
-                      uint32_t *overflow /*zeroed*/, hipStream_t s);
-void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const int32_t *class_to_list,
-                      const uint32_t *list_off, uint32_t *cursors /*zeroed*/, uint32_t *out, hipStream_t s);
-void quantile_select(const uint32_t *lists, const uint32_t *list_off, const uint32_t *list_len, const int32_t *tgt_list,
-                     const uint32_t *tgt_rank, int n_targets, uint32_t *thr_keys, hipStream_t s);
+void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters,
+                 uint32_t *partial /*[n_chunks][F][8192]*/, hipStream_t s);
+void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
+                      uint32_t *class_off /*[F][8192], preset 0xff*/, uint32_t *tgt_off, uint32_t *tgt_len, uint32_t *tgt_rank,
+                      uint32_t *thr_keys, uint32_t *alloc /*[1], zeroed*/, uint32_t max_elems, uint32_t *overflow /*zeroed*/,
+                      hipStream_t s);
+void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const uint32_t *class_off,
+                      const uint32_t *partial, uint32_t *out, hipStream_t s);
+void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
+                     uint32_t *thr_keys, hipStream_t s);
 // codes[(slot/16)*n*16 + row*16 + slot%16] (u16) = #{k : thr_key[f][k] < key(row, f)}
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s);
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s);
@@ -88,19 +90,23 @@ constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [gro
 size_t hist_lds_bytes(int NB, int D, int FG);
 void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
                 const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s);
-void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, int n_slots, int n_groups,
-                 int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);
+// hist[slot_map ? slot_map[k] : k] = sum of the partials of chunk-slot k
+void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
+                 int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);
+// cur[dst] = prev[parent] - cur[sibling]  (entries: triples {dst, parent, sibling or -1})
+void hist_subtract(const int64_t *prev, int64_t *cur, const int32_t *entries, int n_entries, size_t node_elems, hipStream_t s);
 
 // ---- scoring / selection (A6, A7, A8) ----
 void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
                       const float *thr /*[F][B]*/, int B, int n_cand, int min_data, int cosine, double inv_scale,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/, hipStream_t s);
-// best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index
-void argmax_oblivious(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref,
-                      int32_t *best_idx, float *best_score, hipStream_t s);
-void argmax_greedy(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref,
-                   const float *parent, const int32_t *is_root, int32_t *best_idx, float *best_score, hipStream_t s);
+// best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
+// result (sum over nodes); greedy: one per node.  part_v/part_i: scratch of n_nodes * argmax_parts(n_cand).
+int argmax_parts(int n_cand);
+void argmax(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref, const float *parent,
+            const int32_t *is_root, bool oblivious, float *part_v, int32_t *part_i, int32_t *best_idx, float *best_score,
+            hipStream_t s);
 void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits,
                   int64_t *n_total, int64_t *n_right, hipStream_t s);
 

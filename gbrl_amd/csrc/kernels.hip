@@ -6,6 +6,7 @@
 // rounded to fp32 once, then compared the way the reference compares them (fitter.cpp:332-341, 435-444).
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace gbrl {
@@ -253,12 +254,17 @@ __device__ __forceinline__ size_t code_index(int slot, int row, int n_rows) {
     return (static_cast<size_t>(slot >> 4) * n_rows + row) * kCodeGroup + (slot & (kCodeGroup - 1));
 }
 
+// DT = compile-time output_dim (vector loads of the quantised gradients) or 0 = run-time D.  Every row-slot keeps U rows
+// in flight: all row-index, code and gradient loads of the U rows are issued before the first atomic, which is what hides
+// the dependent-load latency of the gathered rows (the v1 kernel was latency-bound at ~6x the LDS-atomic time).
+template <int DT, int U>
 __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
-                                                              const int32_t *__restrict__ qg, int D,
+                                                              const int32_t *__restrict__ qg, int D_rt,
                                                               const int32_t *__restrict__ rows,
                                                               const Chunk *__restrict__ chunks, int FG, int fg_shift,
                                                               int NB, int32_t *__restrict__ partials) {
     extern __shared__ int32_t h[];
+    const int D = DT ? DT : D_rt;
     const int n_acc = NB * (D + 1) * FG;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
     __syncthreads();
@@ -268,13 +274,49 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const int slot = threadIdx.x >> fg_shift;
     const int n_slots = kHistThreads >> fg_shift;
     const int row_stride = (D + 1) * FG;
-    for (int p = slot; p < ck.len; p += n_slots) {
-        const int row = rows[ck.start + p];
-        const int code = codes[code_index(g * FG + fl, row, n_rows)];
-        const int32_t *q = qg + static_cast<size_t>(row) * D;
-        int32_t *dst = h + code * row_stride + fl;
-        for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
-        atomicAdd(dst + D * FG, 1);
+    const int fslot = g * FG + fl;
+    const uint16_t *cbase = codes + (static_cast<size_t>(fslot >> 4) * n_rows) * kCodeGroup + (fslot & (kCodeGroup - 1));
+    for (int p0 = slot; p0 < ck.len; p0 += n_slots * U) {
+        int row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * n_slots;
+            row[u] = p < ck.len ? rows[ck.start + p] : -1;
+        }
+        int code[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) code[u] = row[u] >= 0 ? cbase[static_cast<size_t>(row[u]) * kCodeGroup] : 0;
+        if (DT >= 4) {
+            int4 q[U][DT >= 4 ? DT / 4 : 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int4 *src = reinterpret_cast<const int4 *>(qg + static_cast<size_t>(row[u] >= 0 ? row[u] : 0) * DT);
+#pragma unroll
+                for (int v = 0; v < DT / 4; ++v) q[u][v] = src[v];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (row[u] < 0) continue;
+                int32_t *dst = h + code[u] * row_stride + fl;
+#pragma unroll
+                for (int v = 0; v < DT / 4; ++v) {
+                    atomicAdd(dst + (4 * v + 0) * FG, q[u][v].x);
+                    atomicAdd(dst + (4 * v + 1) * FG, q[u][v].y);
+                    atomicAdd(dst + (4 * v + 2) * FG, q[u][v].z);
+                    atomicAdd(dst + (4 * v + 3) * FG, q[u][v].w);
+                }
+                atomicAdd(dst + DT * FG, 1);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (row[u] < 0) continue;
+                const int32_t *q = qg + static_cast<size_t>(row[u]) * D;
+                int32_t *dst = h + code[u] * row_stride + fl;
+                for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
+                atomicAdd(dst + D * FG, 1);
+            }
+        }
     }
     __syncthreads();
     int32_t *out = partials + (static_cast<size_t>(blockIdx.x) * gridDim.y + g) * n_acc;
@@ -283,16 +325,30 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
 
 // Sum the int32 chunk partials of every slot (node) into int64, reordering to hist[slot][feature][class][D+1].
 __global__ void k_hist_reduce(const int32_t *__restrict__ partials, const int32_t *__restrict__ slot_chunk_begin,
-                              int n_groups, int FG, int NB, int D, int Fp, int64_t *__restrict__ hist) {
+                              const int32_t *__restrict__ slot_map, int n_groups, int FG, int NB, int D, int Fp,
+                              int64_t *__restrict__ hist) {
     const int n_acc = NB * (D + 1) * FG;
-    const int slot = blockIdx.z, g = blockIdx.y;
+    const int k = blockIdx.z, g = blockIdx.y;
+    const int slot = slot_map ? slot_map[k] : k;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_acc) return;
-    const int c0 = slot_chunk_begin[slot], c1 = slot_chunk_begin[slot + 1];
+    const int c0 = slot_chunk_begin[k], c1 = slot_chunk_begin[k + 1];
     int64_t s = 0;
     for (int c = c0; c < c1; ++c) s += partials[(static_cast<size_t>(c) * n_groups + g) * n_acc + i];
     const int fl = i % FG, d = (i / FG) % (D + 1), cls = i / (FG * (D + 1));
     hist[((static_cast<size_t>(slot) * Fp + g * FG + fl) * NB + cls) * (D + 1) + d] = s;
+}
+
+// Sibling subtraction: the histogram of the larger child is parent - smaller child (exact: integers).  entry =
+// {dst slot, parent slot in the previous level's buffer, slot of the computed sibling or -1 (sibling has no rows)}.
+__global__ void k_hist_subtract(const int64_t *__restrict__ prev, int64_t *__restrict__ cur, const int32_t *__restrict__ entries,
+                                size_t node_elems) {
+    const int32_t dst = entries[blockIdx.y * 3 + 0], par = entries[blockIdx.y * 3 + 1], sib = entries[blockIdx.y * 3 + 2];
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < node_elems;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int64_t p = prev[static_cast<size_t>(par) * node_elems + i];
+        cur[static_cast<size_t>(dst) * node_elems + i] = sib >= 0 ? p - cur[static_cast<size_t>(sib) * node_elems + i] : p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -383,51 +439,68 @@ __device__ __forceinline__ Best better(Best a, Best b) {
     if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
     return a;
 }
-__device__ Best block_best(Best mine) {
-    __shared__ float sv[1024];
-    __shared__ int si[1024];
+// Two stages: stage 1 (many blocks) reduces a slice of the candidates, stage 2 (one block per node) the per-block bests.
+constexpr int kArgmaxThreads = 256;
+__global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *__restrict__ scores, int n_nodes, int n_cand,
+                                                                  const float *__restrict__ w, const int32_t *__restrict__ ref,
+                                                                  const float *__restrict__ parent, const int32_t *__restrict__ is_root,
+                                                                  int oblivious, float *__restrict__ part_v, int32_t *__restrict__ part_i) {
+    const int j = blockIdx.x * kArgmaxThreads + threadIdx.x;
+    const int node = blockIdx.y;
+    Best mine{-INFINITY, 0x7fffffff};
+    if (j < n_cand) {
+        float sc;
+        if (oblivious) {   // sum over nodes in node order, fp32, then * w (fitter.cpp:426-435)
+            sc = 0.0f;
+            for (int nd = 0; nd < n_nodes; ++nd) sc += scores[static_cast<size_t>(nd) * n_cand + j];
+            sc = sc * w[j];
+        } else {           // fma(score, w, -parent): the reference's "score*w - parent" is contracted (fitter.cpp:332)
+            const float par = is_root[node] ? 0.0f : parent[node];
+            sc = fmaf(scores[static_cast<size_t>(node) * n_cand + j], w[j], -par);
+        }
+        mine = better(mine, Best{sc, ref[j]});
+    }
+    __shared__ float sv[kArgmaxThreads];
+    __shared__ int si[kArgmaxThreads];
     sv[threadIdx.x] = mine.v;
     si[threadIdx.x] = mine.i;
     __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    for (int o = kArgmaxThreads / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
-            Best a{sv[threadIdx.x], si[threadIdx.x]}, b{sv[threadIdx.x + o], si[threadIdx.x + o]};
-            a = better(a, b);
-            sv[threadIdx.x] = a.v;
-            si[threadIdx.x] = a.i;
+            Best a2{sv[threadIdx.x], si[threadIdx.x]}, b2{sv[threadIdx.x + o], si[threadIdx.x + o]};
+            a2 = better(a2, b2);
+            sv[threadIdx.x] = a2.v;
+            si[threadIdx.x] = a2.i;
         }
         __syncthreads();
     }
-    return Best{sv[0], si[0]};
-}
-__global__ __launch_bounds__(1024) void k_argmax_oblivious(const float *__restrict__ scores, int n_nodes, int n_cand,
-                                                           const float *__restrict__ w, const int32_t *__restrict__ ref,
-                                                           int32_t *__restrict__ best_idx, float *__restrict__ best_score) {
-    // `ref[j]` is the candidate's index in the REFERENCE's candidate order; ties go to the lowest reference index
-    Best mine{-INFINITY, 0x7fffffff};
-    for (int j = threadIdx.x; j < n_cand; j += blockDim.x) {
-        float s = 0.0f;
-        for (int nd = 0; nd < n_nodes; ++nd) s += scores[static_cast<size_t>(nd) * n_cand + j];
-        s = s * w[j];
-        mine = better(mine, Best{s, ref[j]});
+    if (threadIdx.x == 0) {
+        part_v[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = sv[0];
+        part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = si[0];
     }
-    Best b = block_best(mine);
-    if (threadIdx.x == 0) { best_idx[0] = b.i == 0x7fffffff ? 0 : b.i; best_score[0] = b.v; }
 }
-// A8 greedy: s_j = fma(score_j, w_j, -parent) (the reference's "score*w - parent" is contracted), fitter.cpp:318-354
-__global__ __launch_bounds__(1024) void k_argmax_greedy(const float *__restrict__ scores, int n_cand,
-                                                        const float *__restrict__ w, const int32_t *__restrict__ ref,
-                                                        const float *__restrict__ parent, const int32_t *__restrict__ is_root,
-                                                        int32_t *__restrict__ best_idx, float *__restrict__ best_score) {
+__global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage2(const float *__restrict__ part_v, const int32_t *__restrict__ part_i,
+                                                                  int n_parts, int32_t *__restrict__ best_idx,
+                                                                  float *__restrict__ best_score) {
     const int node = blockIdx.x;
-    const float par = is_root[node] ? 0.0f : parent[node];
     Best mine{-INFINITY, 0x7fffffff};
-    for (int j = threadIdx.x; j < n_cand; j += blockDim.x) {
-        const float s = fmaf(scores[static_cast<size_t>(node) * n_cand + j], w[j], -par);
-        mine = better(mine, Best{s, ref[j]});
+    for (int q = threadIdx.x; q < n_parts; q += kArgmaxThreads)
+        mine = better(mine, Best{part_v[static_cast<size_t>(node) * n_parts + q], part_i[static_cast<size_t>(node) * n_parts + q]});
+    __shared__ float sv[kArgmaxThreads];
+    __shared__ int si[kArgmaxThreads];
+    sv[threadIdx.x] = mine.v;
+    si[threadIdx.x] = mine.i;
+    __syncthreads();
+    for (int o = kArgmaxThreads / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            Best a2{sv[threadIdx.x], si[threadIdx.x]}, b2{sv[threadIdx.x + o], si[threadIdx.x + o]};
+            a2 = better(a2, b2);
+            sv[threadIdx.x] = a2.v;
+            si[threadIdx.x] = a2.i;
+        }
+        __syncthreads();
     }
-    Best b = block_best(mine);
-    if (threadIdx.x == 0) { best_idx[node] = b.i == 0x7fffffff ? 0 : b.i; best_score[node] = b.v; }
+    if (threadIdx.x == 0) { best_idx[node] = si[0] == 0x7fffffff ? 0 : si[0]; best_score[node] = sv[0]; }
 }
 
 __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, int Fp, int NB, int D,
@@ -449,37 +522,40 @@ __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// A9  partition: every node's segment [seg_start, seg_start+n) of the row list is split into [left | right] in place
-// of the same range of the output list; segments of nodes that do not split are copied.  Destination slots are handed
+// A9  partition: every splitting node's segment [seg_start, seg_start+n) of the row list is split into [left | right] in
+// place of the same range of the output list.  Destination slots are handed
 // out with one wave-aggregated atomic per side; the order inside a child is not the reference's stable order, which is
 // harmless because everything computed downstream is an order-independent integer sum.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_partition(const int32_t *__restrict__ rows_in, int32_t *__restrict__ rows_out,
-                                                   const uint16_t *__restrict__ codes, int n_rows,
-                                                   const Chunk *__restrict__ chunks, const NodeSplit *__restrict__ splits,
-                                                   int32_t *__restrict__ cursors) {
+constexpr int kPartThreads = 1024;
+constexpr int kPartRows = 4096;  // rows per block: 4 per thread, all loads issued before the ballots
+__global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__restrict__ rows_in, int32_t *__restrict__ rows_out,
+                                                            const uint16_t *__restrict__ codes, int n_rows,
+                                                            const Chunk *__restrict__ chunks, const NodeSplit *__restrict__ splits,
+                                                            int32_t *__restrict__ cursors) {
     const Chunk ck = chunks[blockIdx.x];
     const NodeSplit sp = splits[ck.slot];
     const int lane = threadIdx.x & (kWave - 1);
-    for (int p0 = 0; p0 < ck.len; p0 += blockDim.x) {
-        const int p = p0 + threadIdx.x;
-        const bool active = p < ck.len;
-        int row = 0;
-        bool right = false;
-        if (active) {
-            row = rows_in[ck.start + p];
-            if (sp.do_split) {
-                const int code = codes[code_index(sp.fslot, row, n_rows)];
-                right = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
-            }
-        }
-        if (!sp.do_split) {
-            if (active) rows_out[ck.start + p] = row;
-            continue;
-        }
-        const unsigned long long mr = __ballot(active && right);
-        const unsigned long long ml = __ballot(active && !right);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+    constexpr int U = kPartRows / kPartThreads;
+    int row[U];
+    bool right[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = u * kPartThreads + threadIdx.x;
+        row[u] = p < ck.len ? rows_in[ck.start + p] : -1;
+    }
+    const uint16_t *cbase = codes + (static_cast<size_t>(sp.fslot >> 4) * n_rows) * kCodeGroup + (sp.fslot & (kCodeGroup - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int code = row[u] >= 0 ? cbase[static_cast<size_t>(row[u]) * kCodeGroup] : 0;
+        right[u] = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
+    }
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool active = row[u] >= 0;
+        const unsigned long long mr = __ballot(active && right[u]);
+        const unsigned long long ml = __ballot(active && !right[u]);
         int base_r = 0, base_l = 0;
         if (lane == 0) {
             if (mr) base_r = atomicAdd(&cursors[ck.slot * 2 + 1], __popcll(mr));
@@ -488,9 +564,9 @@ __global__ __launch_bounds__(256) void k_partition(const int32_t *__restrict__ r
         base_r = __shfl(base_r, 0, kWave);
         base_l = __shfl(base_l, 0, kWave);
         if (active) {
-            const int dst = right ? (sp.seg_start + sp.n_left + base_r + __popcll(mr & below))
-                                  : (sp.seg_start + base_l + __popcll(ml & below));
-            rows_out[dst] = row;
+            const int dst = right[u] ? (sp.seg_start + sp.n_left + base_r + __popcll(mr & below))
+                                     : (sp.seg_start + base_l + __popcll(ml & below));
+            rows_out[dst] = row[u];
         }
     }
 }
@@ -674,26 +750,40 @@ void iota_rows(int32_t *rows, int n, hipStream_t s) {
 
 size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * (D + 1) * FG * sizeof(int32_t); }
 
+template <int DT, int U>
+static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                        int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_hist_build<DT, U>), dim3(n_chunks, n_groups), dim3(kHistThreads), lds, s, codes, n_rows, qg, D, rows,
+                       chunks, FG, shift, NB, partials);
+}
+
 void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                 int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s) {
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_hist_build, dim3(n_chunks, n_groups), dim3(kHistThreads), lds, s, codes, n_rows, qg, D, rows,
-                       chunks, FG, shift, NB, partials);
+    if (D == 8) launch_hist<8, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
+    else if (D == 4) launch_hist<4, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
+    else if (D == 16) launch_hist<16, 2>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
+    else launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
 }
 
-void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, int n_slots, int n_groups, int FG, int NB, int D,
-                 int Fp, int64_t *hist, hipStream_t s) {
+void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,
+                 int NB, int D, int Fp, int64_t *hist, hipStream_t s) {
     const int n_acc = NB * (D + 1) * FG;
     dim3 grid((n_acc + 255) / 256, n_groups, n_slots);
-    hipLaunchKernelGGL(k_hist_reduce, grid, dim3(256), 0, s, partials, slot_chunk_begin, n_groups, FG, NB, D, Fp, hist);
+    hipLaunchKernelGGL(k_hist_reduce, grid, dim3(256), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
+}
+
+void hist_subtract(const int64_t *prev, int64_t *cur, const int32_t *entries, int n_entries, size_t node_elems, hipStream_t s) {
+    dim3 grid(static_cast<unsigned>(std::min<size_t>(256, (node_elems + 255) / 256)), n_entries);
+    hipLaunchKernelGGL(k_hist_subtract, grid, dim3(256), 0, s, prev, cur, entries, node_elems);
 }
 
 void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
@@ -710,14 +800,15 @@ void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, c
                        cosine, inv_scale, path_len, path_slot, path_val, path_bin, scores, parent);
 }
 
-void argmax_oblivious(const float *scores, int n_nodes, int n_cand, const float *w, const int32_t *ref, int32_t *best_idx,
-                      float *best_score, hipStream_t s) {
-    hipLaunchKernelGGL(k_argmax_oblivious, dim3(1), dim3(1024), 0, s, scores, n_nodes, n_cand, w, ref, best_idx, best_score);
-}
-void argmax_greedy(const float *scores, int n_nodes, int n_cand, const float *w, const int32_t *ref, const float *parent,
-                   const int32_t *is_root, int32_t *best_idx, float *best_score, hipStream_t s) {
-    hipLaunchKernelGGL(k_argmax_greedy, dim3(n_nodes), dim3(1024), 0, s, scores, n_cand, w, ref, parent, is_root, best_idx,
-                       best_score);
+int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }
+void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const int32_t *ref, const float *parent,
+            const int32_t *is_root, bool oblivious, float *part_v, int32_t *part_i, int32_t *best_idx, float *best_score,
+            hipStream_t s) {
+    const int parts = argmax_parts(n_cand);
+    const int out_nodes = oblivious ? 1 : n_nodes;
+    hipLaunchKernelGGL(k_argmax_stage1, dim3(parts, out_nodes), dim3(kArgmaxThreads), 0, s, scores, n_nodes, n_cand, w, ref, parent,
+                       is_root, oblivious ? 1 : 0, part_v, part_i);
+    hipLaunchKernelGGL(k_argmax_stage2, dim3(out_nodes), dim3(kArgmaxThreads), 0, s, part_v, part_i, parts, best_idx, best_score);
 }
 void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits, int64_t *n_total,
                   int64_t *n_right, hipStream_t s) {
@@ -727,7 +818,7 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
 
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows, const Chunk *chunks,
                     int n_chunks, const NodeSplit *splits, int32_t *cursors, hipStream_t s) {
-    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(256), 0, s, rows_in, rows_out, codes, n_rows, chunks, splits,
+    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(kPartThreads), 0, s, rows_in, rows_out, codes, n_rows, chunks, splits,
                        cursors);
 }
 

@@ -99,7 +99,7 @@ __device__ __forceinline__ int classify(const uint32_t *sp, int n_split, uint32_
 constexpr int kCountThreads = 512;
 __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *__restrict__ kt, int n, int n_split,
                                                                const uint32_t *__restrict__ splitters, int chunk,
-                                                               uint32_t *__restrict__ counts) {
+                                                               uint32_t *__restrict__ partial /*[n_chunks][F][8192]*/) {
     __shared__ uint32_t sp[kMaxSplit + 1];
     __shared__ uint32_t cnt[kClasses];
     const int f = blockIdx.y;
@@ -125,29 +125,34 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
     }
     for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, n_split, col[i])], 1u);
     __syncthreads();
-    for (int c = threadIdx.x; c < kClasses; c += kCountThreads)
-        if (cnt[c]) atomicAdd(&counts[static_cast<size_t>(f) * kClasses + c], cnt[c]);
+    // per-chunk partials, plain coalesced stores (no global atomics); k_targets and k_extract sum them
+    uint32_t *dst = partial + (static_cast<size_t>(blockIdx.x) * gridDim.y + f) * kClasses;
+    for (int c = threadIdx.x; c < kClasses; c += kCountThreads) dst[c] = cnt[c];
 }
 
 // ---- 4. targets -----------------------------------------------------------------------------------------------------
-// Per feature: inclusive prefix over the 8192 class counts; target k (rank cum_k, 1-based) lies in the first class whose
-// inclusive prefix >= cum_k.  Equality classes answer directly; each distinct open class gets one list.
-__global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ splitters,
-                                                  const int64_t *__restrict__ cum, int B, int n_split,
-                                                  int32_t *__restrict__ class_to_list /*[F][8192]*/,
-                                                  int32_t *__restrict__ tgt_list /*[F][B] list id or -1*/,
-                                                  uint32_t *__restrict__ tgt_rank /*[F][B] rank inside the list (1-based)*/,
+// Per feature: inclusive prefix over the 8192 class counts (summed over the chunk partials); target k (rank cum_k, 1-based)
+// lies in the first class whose inclusive prefix >= cum_k.  Equality classes answer directly; each distinct open target
+// class gets a contiguous list [off, off+len) in the extraction buffer (class_off[f][class], 0xffffffff = not extracted).
+__global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ partial, int n_chunks, int F,
+                                                  const uint32_t *__restrict__ splitters, const int64_t *__restrict__ cum, int B,
+                                                  uint32_t *__restrict__ class_off /*[F][8192], preset 0xffffffff*/,
+                                                  uint32_t *__restrict__ tgt_off /*[F][B] list offset or 0xffffffff*/,
+                                                  uint32_t *__restrict__ tgt_len, uint32_t *__restrict__ tgt_rank,
                                                   uint32_t *__restrict__ thr_keys /*[F][B], written for direct answers*/,
-                                                  uint32_t *__restrict__ list_off, uint32_t *__restrict__ list_len,
-                                                  uint32_t *__restrict__ alloc /*[0]=next list id, [1]=next element offset*/,
-                                                  uint32_t max_lists, uint32_t max_elems, uint32_t *__restrict__ overflow) {
+                                                  uint32_t *__restrict__ alloc /*[0] next element offset*/, uint32_t max_elems,
+                                                  uint32_t *__restrict__ overflow) {
     __shared__ uint32_t pre[kClasses];   // inclusive prefix of the class counts (n < 2^31 rows)
+    __shared__ int32_t tcls[1024];       // class of each target of the current tile of targets
     const int f = blockIdx.x;
-    int32_t *c2l = class_to_list + static_cast<size_t>(f) * kClasses;   // pre-set to -1 by the caller
-    for (int c = threadIdx.x; c < kClasses; c += blockDim.x) pre[c] = counts[static_cast<size_t>(f) * kClasses + c];
+    uint32_t *coff = class_off + static_cast<size_t>(f) * kClasses;
+    for (int c = threadIdx.x; c < kClasses; c += blockDim.x) {
+        uint32_t v = 0;
+        for (int q = 0; q < n_chunks; ++q) v += partial[(static_cast<size_t>(q) * F + f) * kClasses + c];
+        pre[c] = v;
+    }
     __syncthreads();
-    // block-wide inclusive scan of 8192 values: 8 per thread
-    {
+    {   // block-wide inclusive scan of 8192 values: 8 per thread
         const int base = threadIdx.x * 8;
         uint32_t loc[8], run = 0;
         for (int q = 0; q < 8; ++q) { run += pre[base + q]; loc[q] = run; }
@@ -164,59 +169,66 @@ __global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ c
         for (int q = 0; q < 8; ++q) pre[base + q] = loc[q] + off;
         __syncthreads();
     }
-    for (int k = threadIdx.x; k < B; k += blockDim.x) {
-        const uint32_t want = static_cast<uint32_t>(cum[k]);
-        int lo = 0, hi = kClasses - 1;
-        while (lo < hi) {  // first class with inclusive prefix >= want
-            const int mid = (lo + hi) >> 1;
-            if (pre[mid] < want) lo = mid + 1; else hi = mid;
+    for (int k0 = 0; k0 < B; k0 += 1024) {
+        const int k = k0 + threadIdx.x;
+        int c = -1;
+        uint32_t want = 0, before = 0;
+        if (k < B) {
+            want = static_cast<uint32_t>(cum[k]);
+            int lo = 0, hi = kClasses - 1;
+            while (lo < hi) {  // first class with inclusive prefix >= want
+                const int mid = (lo + hi) >> 1;
+                if (pre[mid] < want) lo = mid + 1; else hi = mid;
+            }
+            c = lo;
+            before = c ? pre[c - 1] : 0;
         }
-        const int c = lo;
-        const uint32_t before = c ? pre[c - 1] : 0;
-        const size_t t = static_cast<size_t>(f) * B + k;
-        tgt_rank[t] = want - before;
-        if (c & 1) {
-            thr_keys[t] = splitters[static_cast<size_t>(f) * kMaxSplit + (c >> 1)];
-            tgt_list[t] = -1;
-        } else {
-            tgt_list[t] = -2 - c;  // resolved below once the class has a list
+        tcls[threadIdx.x] = c;
+        __syncthreads();
+        if (k < B) {
+            const size_t t = static_cast<size_t>(f) * B + k;
+            tgt_rank[t] = want - before;
+            if (c & 1) {
+                thr_keys[t] = splitters[static_cast<size_t>(f) * kMaxSplit + (c >> 1)];
+                tgt_off[t] = 0xffffffffu;
+                tgt_len[t] = 0;
+            } else {
+                // targets are sorted by rank, so equal classes are adjacent: the first target of a class allocates its list
+                // (a class shared with the last target of the previous tile was allocated there: coff is already set)
+                const bool first = (threadIdx.x == 0) ? (coff[c] == 0xffffffffu) : (tcls[threadIdx.x - 1] != c);
+                const uint32_t len = pre[c] - before;
+                if (first) {
+                    const uint32_t off = atomicAdd(&alloc[0], len);
+                    if (off + len > max_elems || off + len < off) { atomicExch(overflow, 1u); coff[c] = 0xfffffffeu; }
+                    else coff[c] = off;
+                }
+                tgt_len[t] = len;
+            }
         }
-    }
-    __syncthreads();
-    // one list per distinct open target class (targets are sorted, equal classes are adjacent; let the first one allocate)
-    for (int k = threadIdx.x; k < B; k += blockDim.x) {
-        const size_t t = static_cast<size_t>(f) * B + k;
-        const int v = tgt_list[t];
-        if (v >= -1) continue;
-        const int c = -2 - v;
-        const bool first = (k == 0) || (tgt_list[t - 1] != v);
-        if (first) {
-            const uint32_t len = static_cast<uint32_t>(pre[c] - (c ? pre[c - 1] : 0));
-            const uint32_t id = atomicAdd(&alloc[0], 1u);
-            const uint32_t off = atomicAdd(&alloc[1], len);
-            if (id >= max_lists || off + len > max_elems) { atomicExch(overflow, 1u); }
-            else { list_off[id] = off; list_len[id] = len; c2l[c] = static_cast<int32_t>(id); }
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < B; k += blockDim.x) {
-        const size_t t = static_cast<size_t>(f) * B + k;
-        const int v = tgt_list[t];
-        if (v < -1) tgt_list[t] = c2l[-2 - v];
+        __syncthreads();
+        if (k < B && !(c & 1)) tgt_off[static_cast<size_t>(f) * B + k] = coff[c];
+        __syncthreads();
     }
 }
 
 // ---- 5. extract -----------------------------------------------------------------------------------------------------
+// Second sweep over the column chunk.  The chunk's write position inside each list is known exactly from the partial
+// counts (list offset + counts of the earlier chunks), so ranks inside the block come from LDS cursors: no global atomics.
 __global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__restrict__ kt, int n, int n_split,
                                                            const uint32_t *__restrict__ splitters, int chunk,
-                                                           const int32_t *__restrict__ class_to_list,
-                                                           const uint32_t *__restrict__ list_off, uint32_t *__restrict__ cursors,
-                                                           uint32_t *__restrict__ out) {
+                                                           const uint32_t *__restrict__ class_off,
+                                                           const uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
     __shared__ uint32_t sp[kMaxSplit + 1];
-    __shared__ int32_t c2l[kClasses];
-    const int f = blockIdx.y;
+    __shared__ uint32_t cur[kClasses];
+    const int f = blockIdx.y, F = gridDim.y;
     for (int i = threadIdx.x; i < n_split; i += kCountThreads) sp[i] = splitters[static_cast<size_t>(f) * kMaxSplit + i];
-    for (int i = threadIdx.x; i < kClasses; i += kCountThreads) c2l[i] = class_to_list[static_cast<size_t>(f) * kClasses + i];
+    for (int c = threadIdx.x; c < kClasses; c += kCountThreads) {
+        uint32_t off = class_off[static_cast<size_t>(f) * kClasses + c];
+        if (off < 0xfffffffeu)
+            for (unsigned q = 0; q < blockIdx.x; ++q) off += partial[(static_cast<size_t>(q) * F + f) * kClasses + c];
+        else off = 0xffffffffu;
+        cur[c] = off;
+    }
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
@@ -232,31 +244,29 @@ __global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__res
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cls = 2 * a[q] + ((a[q] < n_split && sp[a[q]] == k[q]) ? 1 : 0);
-            const int id = c2l[cls];
-            if (id >= 0) out[list_off[id] + atomicAdd(&cursors[id], 1u)] = k[q];
+            if (cur[cls] != 0xffffffffu) out[atomicAdd(&cur[cls], 1u)] = k[q];
         }
     }
     for (; i < hi; i += kCountThreads) {
         const uint32_t key = col[i];
-        const int id = c2l[classify(sp, n_split, key)];
-        if (id >= 0) out[list_off[id] + atomicAdd(&cursors[id], 1u)] = key;
+        const int cls = classify(sp, n_split, key);
+        if (cur[cls] != 0xffffffffu) out[atomicAdd(&cur[cls], 1u)] = key;
     }
 }
 
 // ---- 6. select ------------------------------------------------------------------------------------------------------
 // One wave per target: v = smallest key with #{keys <= v} >= r, built bit by bit (prefix p; trial t = p|bit; set the bit
 // iff #{keys < t} < r).
-__global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ list_off,
-                                                const uint32_t *__restrict__ list_len, const int32_t *__restrict__ tgt_list,
-                                                const uint32_t *__restrict__ tgt_rank, int n_targets,
-                                                uint32_t *__restrict__ thr_keys) {
+__global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ tgt_off,
+                                                const uint32_t *__restrict__ tgt_len, const uint32_t *__restrict__ tgt_rank,
+                                                int n_targets, uint32_t *__restrict__ thr_keys) {
     const int t = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
     if (t >= n_targets) return;
-    const int id = tgt_list[t];
-    if (id < 0) return;  // answered directly by an equality class
-    const uint32_t *keys = lists + list_off[id];
-    const uint32_t m = list_len[id], r = tgt_rank[t];
+    const uint32_t off = tgt_off[t];
+    if (off >= 0xfffffffeu) return;  // answered directly by an equality class (or overflowed: the engine falls back)
+    const uint32_t *keys = lists + off;
+    const uint32_t m = tgt_len[t], r = tgt_rank[t];
     uint32_t p = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t trial = p | (1u << bit);
@@ -340,27 +350,26 @@ void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, u
     hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters);
 }
 
-void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *counts, hipStream_t s) {
-    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, counts);
+void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, hipStream_t s) {
+    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, partial);
 }
 
-void quantile_targets(const uint32_t *counts, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
-                      int32_t *class_to_list, int32_t *tgt_list, uint32_t *tgt_rank, uint32_t *thr_keys, uint32_t *list_off,
-                      uint32_t *list_len, uint32_t *alloc, uint32_t max_lists, uint32_t max_elems, uint32_t *overflow, hipStream_t s) {
-    hipLaunchKernelGGL(k_targets, dim3(F), dim3(1024), 0, s, counts, splitters, cum, B, p.n_split, class_to_list, tgt_list, tgt_rank,
-                       thr_keys, list_off, list_len, alloc, max_lists, max_elems, overflow);
+void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
+                      uint32_t *class_off, uint32_t *tgt_off, uint32_t *tgt_len, uint32_t *tgt_rank, uint32_t *thr_keys,
+                      uint32_t *alloc, uint32_t max_elems, uint32_t *overflow, hipStream_t s) {
+    hipLaunchKernelGGL(k_targets, dim3(F), dim3(1024), 0, s, partial, p.n_chunks, F, splitters, cum, B, class_off, tgt_off, tgt_len,
+                       tgt_rank, thr_keys, alloc, max_elems, overflow);
 }
 
-void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const int32_t *class_to_list,
-                      const uint32_t *list_off, uint32_t *cursors, uint32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, class_to_list,
-                       list_off, cursors, out);
+void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const uint32_t *class_off,
+                      const uint32_t *partial, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, class_off,
+                       partial, out);
 }
 
-void quantile_select(const uint32_t *lists, const uint32_t *list_off, const uint32_t *list_len, const int32_t *tgt_list,
-                     const uint32_t *tgt_rank, int n_targets, uint32_t *thr_keys, hipStream_t s) {
-    hipLaunchKernelGGL(k_select, dim3((n_targets + 3) / 4), dim3(256), 0, s, lists, list_off, list_len, tgt_list, tgt_rank, n_targets,
-                       thr_keys);
+void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
+                     uint32_t *thr_keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_select, dim3((n_targets + 3) / 4), dim3(256), 0, s, lists, tgt_off, tgt_len, tgt_rank, n_targets, thr_keys);
 }
 
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s) {
