@@ -362,7 +362,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 const uint32_t max_elems = static_cast<uint32_t>(std::min<size_t>(static_cast<size_t>(N) * F, std::max<size_t>(1u << 20, static_cast<size_t>(N) * F / 4)));
                 int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
                 hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
-                uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * F * kern::kQuantileMaxSplit));
+                uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * kern::kQuantileMaxSplit));
+                uint32_t *d_split_bfs = d_split + static_cast<size_t>(F) * kern::kQuantileMaxSplit;
                 uint32_t *d_cc = static_cast<uint32_t *>(d_ccounts_.ensure(sizeof(uint32_t) * static_cast<size_t>(plan.n_chunks) * F * kern::kQuantileClasses));
                 uint32_t *d_coff = static_cast<uint32_t *>(d_c2l_.ensure(sizeof(uint32_t) * F * kern::kQuantileClasses));
                 uint32_t *d_toff = static_cast<uint32_t *>(d_tgt_list_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * B));
@@ -371,11 +372,11 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 uint32_t *d_lists = static_cast<uint32_t *>(d_qlists_.ensure(sizeof(uint32_t) * max_elems));
                 hip_check(hipMemsetAsync(d_coff, 0xff, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
                 hip_check(hipMemsetAsync(d_qflags, 0, sizeof(uint32_t) * 4, s), "memset");
-                kern::sample_splitters(d_kt, N, F, plan, d_split, s);
-                kern::class_count(d_kt, N, F, plan, d_split, d_cc, s);
+                kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
+                kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
                 kern::quantile_targets(d_cc, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
                                        d_qflags + 2, s);
-                kern::quantile_extract(d_kt, N, F, plan, d_split, d_coff, d_cc, d_lists, s);
+                kern::quantile_extract(d_kt, N, F, plan, d_split_bfs, d_coff, d_cc, d_lists, s);
                 kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
             }
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);

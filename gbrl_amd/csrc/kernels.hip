@@ -56,12 +56,20 @@ __global__ void k_column_sums(const float *__restrict__ g, size_t n_el, int D, c
         partials[static_cast<size_t>(blockIdx.x) * D + threadIdx.x] = s;
     }
 }
-__global__ void k_column_sums_final(const double *__restrict__ partials, int n_blocks, int D, double *__restrict__ out) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+__global__ __launch_bounds__(256) void k_column_sums_final(const double *__restrict__ partials, int n_blocks, int D,
+                                                           double *__restrict__ out) {
+    // one block per column; fixed-shape tree => deterministic
+    __shared__ double sh[256];
+    const int d = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += partials[static_cast<size_t>(b) * D + d];
-    out[d] = s;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) s += partials[static_cast<size_t>(b) * D + d];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[d] = sh[0];
 }
 
 __device__ __forceinline__ float standardise(float v, const float *mean, const float *denom, int col) {
@@ -506,19 +514,19 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage2(const float *_
 __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, int Fp, int NB, int D,
                                const NodeSplit *__restrict__ splits, int64_t *__restrict__ n_total,
                                int64_t *__restrict__ n_right) {
-    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    const int node = blockIdx.x;   // one wave per node
     if (node >= n_nodes) return;
     const NodeSplit sp = splits[node];
     const int W = D + 1;
     const int64_t *src = hist + (static_cast<size_t>(node) * Fp + sp.fslot) * NB * W;
-    int64_t tot = 0, right = 0;
-    for (int c = 0; c < NB; ++c) {
-        const int64_t n = src[c * W + D];
+    long long tot = 0, right = 0;
+    for (int c = threadIdx.x; c < NB; c += kWave) {
+        const long long n = src[c * W + D];
         tot += n;
         if (sp.is_cat ? (c == sp.bin) : (c > sp.bin)) right += n;
     }
-    n_total[node] = tot;
-    n_right[node] = right;
+    for (int o = kWave / 2; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, kWave); right += __shfl_xor(right, o, kWave); }
+    if (threadIdx.x == 0) { n_total[node] = tot; n_right[node] = right; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -550,24 +558,36 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__res
         const int code = row[u] >= 0 ? cbase[static_cast<size_t>(row[u]) * kCodeGroup] : 0;
         right[u] = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
     }
+    // destination slots: ballots give the rank inside a wave; per-(wave,u) counts are scanned in LDS and the block reserves
+    // its range with ONE global atomic per side (at level 0 every wave of the grid would otherwise hit the same two words).
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+    constexpr int W = kPartThreads / kWave;
+    __shared__ int cnt[W * U][2];
+    __shared__ int base[2];
+    const int wave = threadIdx.x / kWave;
+    unsigned long long mr[U], ml[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const bool active = row[u] >= 0;
-        const unsigned long long mr = __ballot(active && right[u]);
-        const unsigned long long ml = __ballot(active && !right[u]);
-        int base_r = 0, base_l = 0;
-        if (lane == 0) {
-            if (mr) base_r = atomicAdd(&cursors[ck.slot * 2 + 1], __popcll(mr));
-            if (ml) base_l = atomicAdd(&cursors[ck.slot * 2 + 0], __popcll(ml));
-        }
-        base_r = __shfl(base_r, 0, kWave);
-        base_l = __shfl(base_l, 0, kWave);
-        if (active) {
-            const int dst = right[u] ? (sp.seg_start + sp.n_left + base_r + __popcll(mr & below))
-                                     : (sp.seg_start + base_l + __popcll(ml & below));
-            rows_out[dst] = row[u];
-        }
+        mr[u] = __ballot(active && right[u]);
+        ml[u] = __ballot(active && !right[u]);
+        if (lane == 0) { cnt[wave * U + u][1] = __popcll(mr[u]); cnt[wave * U + u][0] = __popcll(ml[u]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int side = threadIdx.x;
+        int run = 0;
+        for (int q = 0; q < W * U; ++q) { const int c = cnt[q][side]; cnt[q][side] = run; run += c; }
+        base[side] = run ? atomicAdd(&cursors[ck.slot * 2 + side], run) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (row[u] < 0) continue;
+        const int off = cnt[wave * U + u][right[u] ? 1 : 0];
+        const int dst = right[u] ? (sp.seg_start + sp.n_left + base[1] + off + __popcll(mr[u] & below))
+                                 : (sp.seg_start + base[0] + off + __popcll(ml[u] & below));
+        rows_out[dst] = row[u];
     }
 }
 
@@ -681,7 +701,7 @@ void column_sums(const float *g, int n, int D, const float *center, double *bloc
     const int bs = D <= 256 ? (256 / D) * D : D;  // multiple of D so a thread owns one column
     hipLaunchKernelGGL(k_column_sums, dim3(n_blocks), dim3(bs), bs * sizeof(double), s, g, static_cast<size_t>(n) * D, D,
                        center, block_partials);
-    hipLaunchKernelGGL(k_column_sums_final, dim3((D + 63) / 64), dim3(64), 0, s, block_partials, n_blocks, D, out);
+    hipLaunchKernelGGL(k_column_sums_final, dim3(D), dim3(256), 0, s, block_partials, n_blocks, D, out);
 }
 
 void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s) {
@@ -812,7 +832,7 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const 
 }
 void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits, int64_t *n_total,
                   int64_t *n_right, hipStream_t s) {
-    hipLaunchKernelGGL(k_child_counts, dim3((n_nodes + 63) / 64), dim3(64), 0, s, hist, n_nodes, Fp, NB, D, splits, n_total,
+    hipLaunchKernelGGL(k_child_counts, dim3(n_nodes), dim3(64), 0, s, hist, n_nodes, Fp, NB, D, splits, n_total,
                        n_right);
 }
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_transpose_keys(const float *__restrict_
 
 // ---- 2. sample + sort + splitters ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__restrict__ kt, int n, int S, int n_split,
-                                                           uint32_t *__restrict__ splitters) {
+                                                           uint32_t *__restrict__ splitters, uint32_t *__restrict__ splitters_bfs) {
     extern __shared__ uint32_t s[];  // [S], S power of two
     const int f = blockIdx.x;
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
@@ -83,16 +83,49 @@ __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__res
     // splitter j = sample at position (j+1)*S/(n_split+1) - 1
     const int step = S / (n_split + 1);
     for (int j = threadIdx.x; j < n_split; j += blockDim.x) splitters[static_cast<size_t>(f) * kMaxSplit + j] = s[(j + 1) * step - 1];
+    // the same splitters in breadth-first (Eytzinger) order: BFS index i at level L, position p holds sorted index
+    // (2p+1) * 2^(levels-1-L) - 1.  A binary search over the SORTED array probes power-of-two strides, i.e. one LDS bank
+    // (up to 32-way conflicts); in BFS order the probes of one level are contiguous.
+    int levels = 0;
+    while ((1 << levels) < n_split + 1) ++levels;
+    for (int i = threadIdx.x; i < n_split; i += blockDim.x) {
+        const int L = 31 - __clz(i + 1), pp = i + 1 - (1 << L);
+        const int q = ((2 * pp + 1) << (levels - 1 - L)) - 1;
+        splitters_bfs[static_cast<size_t>(f) * kMaxSplit + i] = s[(q + 1) * step - 1];
+    }
 }
 
-// class of a key: 2 * #{splitters < key} + (key == splitter[that index])
-__device__ __forceinline__ int classify(const uint32_t *sp, int n_split, uint32_t key) {
-    int lo = 0, hi = n_split;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sp[mid] < key) lo = mid + 1; else hi = mid;
+// class of a key: 2 * #{splitters < key} + (key equals the first splitter >= key).  `e` holds the n_split = 2^levels - 1
+// splitters in BFS order; the first splitter >= key is the node of the last left turn of the descent.
+__device__ __forceinline__ int classify(const uint32_t *e, int levels, uint32_t key) {
+    int i = 0;
+    uint32_t last_ge = 0;
+    bool went_left = false;
+    for (int l = 0; l < levels; ++l) {
+        const uint32_t v = e[i];
+        const bool lt = v < key;
+        if (!lt) { last_ge = v; went_left = true; }
+        i = 2 * i + 1 + (lt ? 1 : 0);
     }
-    return 2 * lo + ((lo < n_split && sp[lo] == key) ? 1 : 0);
+    const int j = i - ((1 << levels) - 1);
+    return 2 * j + ((went_left && last_ge == key) ? 1 : 0);
+}
+// four independent descents in flight per thread (the LDS latency of one dependent chain is ~12 x 64 cycles)
+__device__ __forceinline__ void classify4(const uint32_t *e, int levels, const uint32_t (&key)[4], int (&cls)[4]) {
+    int i[4] = {0, 0, 0, 0};
+    uint32_t ge[4] = {0, 0, 0, 0};
+    bool wl[4] = {false, false, false, false};
+    for (int l = 0; l < levels; ++l) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t v = e[i[q]];
+            const bool lt = v < key[q];
+            if (!lt) { ge[q] = v; wl[q] = true; }
+            i[q] = 2 * i[q] + 1 + (lt ? 1 : 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cls[q] = 2 * (i[q] - ((1 << levels) - 1)) + ((wl[q] && ge[q] == key[q]) ? 1 : 0);
 }
 
 // ---- 3. class counts ----------------------------------------------------------------------------------------------
@@ -108,22 +141,17 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    int levels = 0;
+    while ((1 << levels) < n_split + 1) ++levels;
     int i = lo + threadIdx.x;
-    for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {  // 4 independent searches in flight per thread
-        const uint32_t k0 = col[i], k1 = col[i + kCountThreads], k2 = col[i + 2 * kCountThreads], k3 = col[i + 3 * kCountThreads];
-        int a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = n_split, b1 = n_split, b2 = n_split, b3 = n_split;
-        while ((a0 < b0) | (a1 < b1) | (a2 < b2) | (a3 < b3)) {
-            if (a0 < b0) { const int m = (a0 + b0) >> 1; if (sp[m] < k0) a0 = m + 1; else b0 = m; }
-            if (a1 < b1) { const int m = (a1 + b1) >> 1; if (sp[m] < k1) a1 = m + 1; else b1 = m; }
-            if (a2 < b2) { const int m = (a2 + b2) >> 1; if (sp[m] < k2) a2 = m + 1; else b2 = m; }
-            if (a3 < b3) { const int m = (a3 + b3) >> 1; if (sp[m] < k3) a3 = m + 1; else b3 = m; }
-        }
-        atomicAdd(&cnt[2 * a0 + ((a0 < n_split && sp[a0] == k0) ? 1 : 0)], 1u);
-        atomicAdd(&cnt[2 * a1 + ((a1 < n_split && sp[a1] == k1) ? 1 : 0)], 1u);
-        atomicAdd(&cnt[2 * a2 + ((a2 < n_split && sp[a2] == k2) ? 1 : 0)], 1u);
-        atomicAdd(&cnt[2 * a3 + ((a3 < n_split && sp[a3] == k3) ? 1 : 0)], 1u);
+    for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {
+        const uint32_t k[4] = {col[i], col[i + kCountThreads], col[i + 2 * kCountThreads], col[i + 3 * kCountThreads]};
+        int cls[4];
+        classify4(sp, levels, k, cls);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&cnt[cls[q]], 1u);
     }
-    for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, n_split, col[i])], 1u);
+    for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, levels, col[i])], 1u);
     __syncthreads();
     // per-chunk partials, plain coalesced stores (no global atomics); k_targets and k_extract sum them
     uint32_t *dst = partial + (static_cast<size_t>(blockIdx.x) * gridDim.y + f) * kClasses;
@@ -232,24 +260,20 @@ __global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__res
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    int levels = 0;
+    while ((1 << levels) < n_split + 1) ++levels;
     int i = lo + threadIdx.x;
     for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {
-        uint32_t k[4] = {col[i], col[i + kCountThreads], col[i + 2 * kCountThreads], col[i + 3 * kCountThreads]};
-        int a[4] = {0, 0, 0, 0}, b[4] = {n_split, n_split, n_split, n_split};
-        while ((a[0] < b[0]) | (a[1] < b[1]) | (a[2] < b[2]) | (a[3] < b[3])) {
+        const uint32_t k[4] = {col[i], col[i + kCountThreads], col[i + 2 * kCountThreads], col[i + 3 * kCountThreads]};
+        int cls[4];
+        classify4(sp, levels, k, cls);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (a[q] < b[q]) { const int m = (a[q] + b[q]) >> 1; if (sp[m] < k[q]) a[q] = m + 1; else b[q] = m; }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cls = 2 * a[q] + ((a[q] < n_split && sp[a[q]] == k[q]) ? 1 : 0);
-            if (cur[cls] != 0xffffffffu) out[atomicAdd(&cur[cls], 1u)] = k[q];
-        }
+        for (int q = 0; q < 4; ++q)
+            if (cur[cls[q]] != 0xffffffffu) out[atomicAdd(&cur[cls[q]], 1u)] = k[q];
     }
     for (; i < hi; i += kCountThreads) {
         const uint32_t key = col[i];
-        const int cls = classify(sp, n_split, key);
+        const int cls = classify(sp, levels, key);
         if (cur[cls] != 0xffffffffu) out[atomicAdd(&cur[cls], 1u)] = key;
     }
 }
@@ -284,31 +308,39 @@ __global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lis
 // 8 KiB code tile contiguously.
 constexpr int kGroup = 16;
 __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ kt, int n, int F, const uint32_t *__restrict__ thr,
-                                                  int B, uint16_t *__restrict__ codes) {
+                                                  int B, int levels, uint16_t *__restrict__ codes) {
     extern __shared__ uint32_t lds[];
-    uint32_t *t = lds;                                    // [16][B+1] (+1 pad against bank conflicts)
-    uint16_t *tile = reinterpret_cast<uint16_t *>(lds + kGroup * (B + 1));  // [256][16]
+    const int P = (1 << levels) - 1;                      // thresholds padded with the maximal key to a full tree
+    uint32_t *t = lds;                                    // [16][P] in BFS order
+    uint16_t *tile = reinterpret_cast<uint16_t *>(lds + kGroup * P);  // [256][16]
     const int g = blockIdx.y, r0 = blockIdx.x * 256;
-    for (int i = threadIdx.x; i < kGroup * B; i += 256) {
-        const int fl = i / B, k = i % B, f = g * kGroup + fl;
-        t[fl * (B + 1) + k] = f < F ? thr[static_cast<size_t>(f) * B + k] : 0xffffffffu;
+    for (int i = threadIdx.x; i < kGroup * P; i += 256) {
+        const int fl = i / P, e = i % P, f = g * kGroup + fl;
+        const int L = 31 - __clz(e + 1), pp = e + 1 - (1 << L);
+        const int q = ((2 * pp + 1) << (levels - 1 - L)) - 1;   // sorted index held by BFS node e
+        t[i] = (f < F && q < B) ? thr[static_cast<size_t>(f) * B + q] : 0xffffffffu;
     }
     __syncthreads();
     const int r = r0 + threadIdx.x;
-    for (int fl = 0; fl < kGroup; ++fl) {
-        const int f = g * kGroup + fl;
-        int code = 0;
-        if (f < F && r < n) {
-            const uint32_t key = kt[static_cast<size_t>(f) * n + r];
-            const uint32_t *tf = t + fl * (B + 1);
-            int lo = 0, hi = B;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (tf[mid] < key) lo = mid + 1; else hi = mid;
-            }
-            code = lo;
+    for (int fl0 = 0; fl0 < kGroup; fl0 += 4) {           // 4 independent descents in flight
+        uint32_t key[4];
+        int idx[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = g * kGroup + fl0 + q;
+            key[q] = (f < F && r < n) ? kt[static_cast<size_t>(f) * n + r] : 0u;
         }
-        tile[threadIdx.x * kGroup + fl] = static_cast<uint16_t>(code);
+        for (int l = 0; l < levels; ++l) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) idx[q] = 2 * idx[q] + 1 + ((t[(fl0 + q) * P + idx[q]] < key[q]) ? 1 : 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = g * kGroup + fl0 + q;
+            int code = idx[q] - P;                        // #{padded thresholds < key}; pads are never < key
+            if (code > B) code = B;
+            tile[threadIdx.x * kGroup + fl0 + q] = static_cast<uint16_t>((f < F && r < n) ? code : 0);
+        }
     }
     __syncthreads();
     const int rows = min(256, n - r0);
@@ -344,10 +376,10 @@ QuantilePlan quantile_plan(int n) {
     return p;
 }
 
-void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters, hipStream_t s) {
+void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters, uint32_t *splitters_bfs, hipStream_t s) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); attr = true; }
-    hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters);
+    hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters, splitters_bfs);
 }
 
 void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, hipStream_t s) {
@@ -373,11 +405,13 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 }
 
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s) {
-    const size_t lds = static_cast<size_t>(kGroup) * (B + 1) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
+    int levels = 1;
+    while ((1 << levels) - 1 < B) ++levels;
+    const size_t lds = static_cast<size_t>(kGroup) * ((1 << levels) - 1) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     dim3 grid((n + 255) / 256, (F + kGroup - 1) / kGroup);
-    hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, codes);
+    hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, levels, codes);
 }
 
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s) {
