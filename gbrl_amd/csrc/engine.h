@@ -40,6 +40,20 @@ class DevBuf {
     size_t cap_ = 0;
 };
 
+// grow-only pinned host buffer (async copies from/to it do not stage through pageable memory)
+class PinnedBuf {
+   public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf();
+    void *ensure(size_t bytes);
+
+   private:
+    void *ptr_ = nullptr;
+    size_t cap_ = 0;
+};
+
 class Engine {
    public:
     explicit Engine(const gbrl_hip_config &cfg);
@@ -86,7 +100,8 @@ class Engine {
     DevBuf d_thr_, d_thrkeys_, d_prefix_, d_trial_, d_counts_, d_cum_, d_minmax_;
     DevBuf d_kt_, d_qflags_, d_splitters_, d_ccounts_, d_c2l_, d_tgt_list_, d_tgt_rank_, d_list_off_, d_qlists_;
     DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
-    DevBuf d_hist_prev_, d_slotmap_, d_am_v_, d_am_i_;
+    DevBuf d_hist_prev_, d_slotmap_, d_am_v_, d_am_i_, d_stage_const_, d_stage_a_, d_stage_b_, d_results_;
+    PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_;
     DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
     DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_;

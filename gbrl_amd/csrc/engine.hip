@@ -42,6 +42,18 @@ void *DevBuf::ensure(size_t bytes) {
     cap_ = want;
     return ptr_;
 }
+PinnedBuf::~PinnedBuf() {
+    if (ptr_) (void)hipHostFree(ptr_);
+}
+void *PinnedBuf::ensure(size_t bytes) {
+    if (bytes <= cap_ && ptr_) return ptr_;
+    if (ptr_) (void)hipHostFree(ptr_);
+    ptr_ = nullptr;
+    const size_t want = std::max<size_t>(4096, bytes + bytes / 4);
+    hip_check(hipHostMalloc(&ptr_, want, hipHostMallocDefault), "hipHostMalloc");
+    cap_ = want;
+    return ptr_;
+}
 void *DevBuf::ensure_keep(size_t bytes, size_t keep_bytes, hipStream_t s) {
     if (bytes <= cap_ && ptr_) return ptr_;
     void *np = nullptr;
@@ -160,6 +172,36 @@ struct HNode {
 
 struct CatCandidate { int feat; std::string name; int cls; };
 
+// Packs many small host arrays into one pinned block and uploads them with ONE async copy; put() returns the DEVICE
+// address the array will have.  The pinned block must not be refilled before the copy has executed (the caller's
+// per-level synchronisation guarantees it).
+class Stager {
+   public:
+    Stager(PinnedBuf &pin, DevBuf &dev, size_t cap, hipStream_t s) : s_(s) {
+        host_ = static_cast<char *>(pin.ensure(cap));
+        dev_ = static_cast<char *>(dev.ensure(cap));
+        cap_ = cap;
+    }
+    void reset() { used_ = 0; }
+    template <typename T>
+    T *put(const T *src, size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (used_ + bytes + 256 > cap_) throw HipError("internal: staging buffer overflow");
+        if (bytes) std::memcpy(host_ + used_, src, bytes);
+        T *d = reinterpret_cast<T *>(dev_ + used_);
+        used_ += (bytes + 255) & ~static_cast<size_t>(255);
+        return d;
+    }
+    void flush() {
+        if (used_) hip_check(hipMemcpyAsync(dev_, host_, used_, hipMemcpyHostToDevice, s_), "H2D staged descriptors");
+    }
+
+   private:
+    hipStream_t s_;
+    char *host_ = nullptr, *dev_ = nullptr;
+    size_t cap_ = 0, used_ = 0;
+};
+
 inline int ilog2_floor(double x) { int e; std::frexp(x, &e); return e - 1; }
 
 }  // namespace
@@ -235,50 +277,56 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const size_t n_el = static_cast<size_t>(N) * D;
     float *d_meanden = static_cast<float *>(d_meanden_.ensure(sizeof(float) * 2 * D));
     const float *d_mean = nullptr, *d_den = nullptr;
-    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * D));
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 2 * D));
     const int nblk = kern::column_sums_blocks(N, D);
-    double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * D));
-    if (D > 1024) throw Unsupported("output_dim > 1024");
+    double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
+    if (D > 512) throw Unsupported("output_dim > 512");
+    std::vector<double> hs(2 * D);
+    float hmax[2] = {0.f, 0.f};  // max |build grad|, max |raw grad|
+    auto reduce_stats = [&]() {
+        if (has_coll_) {
+            hip_check(hipStreamSynchronize(s), "sync");
+            float *tmpf = reinterpret_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
+            if (coll_.allreduce_sum_f64(coll_.ctx, d_stat, D) != 0) throw HipError("allreduce failed");
+            // maxima travel as floats (exact)
+            std::vector<double> m(D);
+            hip_check(hipMemcpy(m.data(), d_stat + D, sizeof(double) * D, hipMemcpyDeviceToHost), "D2H");
+            std::vector<float> mf(D);
+            for (int d = 0; d < D; ++d) mf[d] = static_cast<float>(m[d]);
+            hip_check(hipMemcpy(tmpf, mf.data(), sizeof(float) * D, hipMemcpyHostToDevice), "H2D");
+            if (coll_.allreduce_max_f32(coll_.ctx, tmpf, D) != 0) throw HipError("allreduce failed");
+            hip_check(hipMemcpy(mf.data(), tmpf, sizeof(float) * D, hipMemcpyDeviceToHost), "D2H");
+            hip_check(hipMemcpy(hs.data(), d_stat, sizeof(double) * D, hipMemcpyDeviceToHost), "D2H");
+            for (int d = 0; d < D; ++d) hs[D + d] = mf[d];
+        } else {
+            hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * 2 * D, hipMemcpyDeviceToHost, s), "D2H stats");
+            hip_check(hipStreamSynchronize(s), "sync");
+        }
+    };
+    // pass 1: column sums and max |g|
+    kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
+    reduce_stats();
+    for (int d = 0; d < D; ++d) hmax[1] = std::max(hmax[1], static_cast<float>(hs[D + d]));
     if (!cosine) {
         // fitter.cpp:58-63: mean, centre, unbiased std, divide by (std + 1e-8)
-        std::vector<double> hs(D);
         std::vector<float> hmd(2 * D);
-        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
-        if (has_coll_) {
-            hip_check(hipStreamSynchronize(s), "sync");
-            if (coll_.allreduce_sum_f64(coll_.ctx, d_stat, D) != 0) throw HipError("allreduce failed");
-        }
-        hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * D, hipMemcpyDeviceToHost, s), "D2H mean");
-        hip_check(hipStreamSynchronize(s), "sync");
         for (int d = 0; d < D; ++d) hmd[d] = static_cast<float>(hs[d] / static_cast<double>(n_global));
         hip_check(hipMemcpyAsync(d_meanden, hmd.data(), sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D mean");
-        kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat, s);
-        if (has_coll_) {
-            hip_check(hipStreamSynchronize(s), "sync");
-            if (coll_.allreduce_sum_f64(coll_.ctx, d_stat, D) != 0) throw HipError("allreduce failed");
-        }
-        hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * D, hipMemcpyDeviceToHost, s), "D2H var");
-        hip_check(hipStreamSynchronize(s), "sync");
+        kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat, s);   // pass 2: centred squares, max |g - mean|
+        reduce_stats();
         const float recip = 1.0f / (static_cast<float>(n_global) - 1.0f);  // math_ops.cpp:464
         for (int d = 0; d < D; ++d) {
             const float sd = sqrtf(static_cast<float>(hs[d]) * recip);     // math_ops.cpp:510
             hmd[D + d] = sd + 1e-8f;                                        // math_ops.cpp:94
+            hmax[0] = std::max(hmax[0], static_cast<float>(hs[D + d]) / hmd[D + d] * 1.0001f);
         }
         hip_check(hipMemcpyAsync(d_meanden + D, hmd.data() + D, sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D std");
+        hip_check(hipStreamSynchronize(s), "sync");   // hmd goes out of scope
         d_mean = d_meanden;
         d_den = d_meanden + D;
+    } else {
+        hmax[0] = hmax[1];
     }
-    uint32_t *d_maxbits = static_cast<uint32_t *>(d_maxbits_.ensure(sizeof(uint32_t) * 2));
-    hip_check(hipMemsetAsync(d_maxbits, 0, sizeof(uint32_t) * 2, s), "memset");
-    kern::max_abs(dgrads, n_el, D, d_mean, d_den, d_maxbits, s);       // max |build grad|
-    kern::max_abs(dgrads, n_el, D, nullptr, nullptr, d_maxbits + 1, s);  // max |raw grad| (leaf fixed point)
-    if (has_coll_) {
-        hip_check(hipStreamSynchronize(s), "sync");
-        if (coll_.allreduce_max_f32(coll_.ctx, reinterpret_cast<float *>(d_maxbits), 2) != 0) throw HipError("allreduce failed");
-    }
-    float hmax[2];
-    hip_check(hipMemcpyAsync(hmax, d_maxbits, sizeof(hmax), hipMemcpyDeviceToHost, s), "D2H max");
-    hip_check(hipStreamSynchronize(s), "sync");
     if (!std::isfinite(hmax[0]) || !std::isfinite(hmax[1])) throw InvalidArgument("non-finite gradients");
     // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: pick the power-of-two scale
     // with chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build)
@@ -501,47 +549,52 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     phase_end("binning");
 
     // ---- 4. growth ---------------------------------------------------------------------------------------------------
+    // Level-synchronous.  Per level the host (1) uploads ONE packed descriptor block (chunk tables, slot maps, paths) from
+    // pinned memory, (2) enqueues histogram / score / argmax / resolve kernels, (3) reads back ONE small result block (best
+    // candidate, child sizes) -- the only synchronisation of the level -- and (4) uploads the split descriptors and enqueues
+    // leaf sums and the partition without waiting for them.
     const int max_front = 1 << std::max(0, MD - 1);
+    const int max_nodes = 2 * (1 << MD);
     const int max_chunks = std::max((N + chunk_rows - 1) / chunk_rows, (N + kern::kPartitionRows - 1) / kern::kPartitionRows) + 2 * (1 << MD) + 2;
     const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
     int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
                           static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
-    Chunk *d_chunks = static_cast<Chunk *>(d_chunks_.ensure(sizeof(Chunk) * max_chunks));
-    int32_t *d_chunk_begin = static_cast<int32_t *>(d_chunk_begin_.ensure(sizeof(int32_t) * (max_front * 2 + 2)));
     int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * max_chunks * n_groups * n_acc));
     const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
     // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
     int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems)),
                               static_cast<int64_t *>(d_hist_prev_.ensure(sizeof(int64_t) * max_front * hist_node_elems))};
     int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * hist_node_elems)) : nullptr;
-    int32_t *d_slotmap = static_cast<int32_t *>(d_slotmap_.ensure(sizeof(int32_t) * (max_front * 4 + 4)));
+    float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
+    float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
     const int am_parts = kern::argmax_parts(std::max(1, n_cand));
     float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * static_cast<size_t>(max_front) * am_parts));
     int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * am_parts));
-    FeatureSlot *d_slots = static_cast<FeatureSlot *>(d_slots_.ensure(sizeof(FeatureSlot) * std::max(1, n_slots)));
-    float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
-    float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
-    float *d_cand_w = static_cast<float *>(d_cand_w_.ensure(sizeof(float) * std::max(1, n_cand)));
-    int32_t *d_cand_ref = static_cast<int32_t *>(d_cand_ref_.ensure(sizeof(int32_t) * std::max(1, n_cand)));
-    int32_t *d_path_len = static_cast<int32_t *>(d_path_len_.ensure(sizeof(int32_t) * max_front));
-    int32_t *d_path_slot = static_cast<int32_t *>(d_path_slot_.ensure(sizeof(int32_t) * max_front * kern::kMaxPath));
-    float *d_path_val = static_cast<float *>(d_path_val_.ensure(sizeof(float) * max_front * kern::kMaxPath));
-    int32_t *d_path_bin = static_cast<int32_t *>(d_path_bin_.ensure(sizeof(int32_t) * max_front * kern::kMaxPath));
-    int32_t *d_isroot = static_cast<int32_t *>(d_isroot_.ensure(sizeof(int32_t) * max_front));
-    int32_t *d_best_idx = static_cast<int32_t *>(d_best_idx_.ensure(sizeof(int32_t) * max_front));
-    float *d_best_score = static_cast<float *>(d_best_score_.ensure(sizeof(float) * max_front));
-    NodeSplit *d_splits = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
-    int64_t *d_ntotal = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t) * max_front * 2));
-    int64_t *d_nright = static_cast<int64_t *>(d_nright_.ensure(sizeof(int64_t) * max_front * 2));
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
-    const int max_nodes = 2 * (1 << MD);
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
     hip_check(hipMemsetAsync(d_leafacc, 0, sizeof(int64_t) * max_nodes * (D + 1), s), "memset leaf acc");
-    if (n_slots > 0) hip_check(hipMemcpyAsync(d_slots, slots.data(), sizeof(FeatureSlot) * n_slots, hipMemcpyHostToDevice, s), "H2D slots");
-    if (n_cand > 0) {
-        hip_check(hipMemcpyAsync(d_cand_w, cand_w.data(), sizeof(float) * n_cand, hipMemcpyHostToDevice, s), "H2D w");
-        hip_check(hipMemcpyAsync(d_cand_ref, cand_ref.data(), sizeof(int32_t) * n_cand, hipMemcpyHostToDevice, s), "H2D ref");
-    }
+    // per-step constants: slots, candidate weights / reference order / slot lookup
+    std::vector<int32_t> cand_slot(n_cand);
+    for (int fs = 0; fs < n_slots; ++fs)
+        for (int k = 0; k < slots[fs].n_cand; ++k) cand_slot[slots[fs].cand_base + k] = fs;
+    const size_t stage_bytes = 4096 + sizeof(FeatureSlot) * n_slots + static_cast<size_t>(n_cand) * 16 +
+                               sizeof(Chunk) * (static_cast<size_t>(max_chunks) + N / 4096 + 2 * max_nodes + 64) +
+                               static_cast<size_t>(max_front) * (kern::kMaxPath * 12 + 256);
+    Stager stc(pin_const_, d_stage_const_, stage_bytes, s), sta(pin_a_, d_stage_a_, stage_bytes, s), stb(pin_b_, d_stage_b_, stage_bytes, s);
+    FeatureSlot *d_slots = stc.put(slots.data(), slots.size());
+    float *d_cand_w = stc.put(cand_w.data(), cand_w.size());
+    int32_t *d_cand_ref = stc.put(cand_ref.data(), cand_ref.size());
+    int32_t *d_ref_to_internal = stc.put(ref_to_internal.data(), ref_to_internal.size());
+    int32_t *d_cand_slot = stc.put(cand_slot.data(), cand_slot.size());
+    stc.flush();
+    // result block read back once per level: [best_idx i32 x mf][best_score f32 x mf][counts i64 x 4 x mf]
+    const size_t res_bytes = static_cast<size_t>(max_front) * (4 + 4 + 32) + 64;
+    char *d_res = static_cast<char *>(d_results_.ensure(res_bytes));
+    char *h_res = static_cast<char *>(pin_res_.ensure(res_bytes));
+    int32_t *d_best_idx = reinterpret_cast<int32_t *>(d_res);
+    float *d_best_score = reinterpret_cast<float *>(d_res + 4 * static_cast<size_t>(max_front));
+    int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
+    NodeSplit *d_resolved = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
     kern::iota_rows(d_rows[0], N, s);
     hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr is needed on the host from here on
 
@@ -554,36 +607,19 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     int cur = 0;  // which row list is current
     std::vector<Chunk> h_chunks;
     std::vector<int32_t> h_chunk_begin;
-    auto build_chunks = [&](const std::vector<int> &ids, int rows_per_chunk) {
+    auto make_chunks = [&](const std::vector<int> &ids, int rows_per_chunk, bool slot_is_node_id) {
         h_chunks.clear();
         h_chunk_begin.assign(1, 0);
         for (size_t k = 0; k < ids.size(); ++k) {
             const HNode &nd = nodes[ids[k]];
+            if (slot_is_node_id && nd.depth == 0) { h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size())); continue; }  // Q7
             for (int off = 0; off < nd.n_local; off += rows_per_chunk)
-                h_chunks.push_back({static_cast<int32_t>(k), nd.seg_start + off, std::min(rows_per_chunk, nd.n_local - off), 0});
+                h_chunks.push_back({static_cast<int32_t>(slot_is_node_id ? ids[k] : static_cast<int>(k)), nd.seg_start + off,
+                                    std::min(rows_per_chunk, nd.n_local - off), 0});
             h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size()));
         }
-        if (h_chunks.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: chunk table overflow");
-        if (!h_chunks.empty())
-            hip_check(hipMemcpyAsync(d_chunks, h_chunks.data(), sizeof(Chunk) * h_chunks.size(), hipMemcpyHostToDevice, s), "H2D chunks");
-    };
-    auto leaf_sums_for = [&](const std::vector<int> &ids) {  // slot = node id
-        std::vector<Chunk> lc;
-        for (int id : ids) {
-            const HNode &nd = nodes[id];
-            if (nd.depth == 0) continue;  // a depth-0 leaf never "passes": value stays 0 (fitter.cpp:559-565, Q7)
-            for (int off = 0; off < nd.n_local; off += 8192)
-                lc.push_back({id, nd.seg_start + off, std::min(8192, nd.n_local - off), 0});
-        }
-        if (lc.empty()) return;
-        hip_check(hipStreamSynchronize(s), "sync");  // previous users of the chunk table are done
-        if (lc.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: leaf chunk table overflow");
-        hip_check(hipMemcpyAsync(d_chunks, lc.data(), sizeof(Chunk) * lc.size(), hipMemcpyHostToDevice, s), "H2D leaf chunks");
-        kern::leaf_sums(dgrads, D, d_rows[cur], d_chunks, static_cast<int>(lc.size()), leaf_scale, d_leafacc, s);
-        hip_check(hipStreamSynchronize(s), "sync");  // lc goes out of scope
     };
 
-    int tree_depth = 0;
     for (int depth = 0; depth < MD && n_cand > 0; ++depth) {
         // nodes that take part at this level: oblivious -> the whole level; greedy -> nodes with rows (fitter.cpp:300)
         std::vector<int> active;
@@ -623,12 +659,32 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             }
         }
         for (int k = 0; k < n_act; ++k) nodes[active[k]].hist_slot = k;
-        build_chunks(compute_ids, chunk_rows);
-        hip_check(hipMemcpyAsync(d_chunk_begin, h_chunk_begin.data(), sizeof(int32_t) * h_chunk_begin.size(), hipMemcpyHostToDevice, s), "H2D chunk begin");
-        if (!slot_map.empty())
-            hip_check(hipMemcpyAsync(d_slotmap, slot_map.data(), sizeof(int32_t) * slot_map.size(), hipMemcpyHostToDevice, s), "H2D slot map");
-        if (!sub_entries.empty())
-            hip_check(hipMemcpyAsync(d_slotmap + max_front, sub_entries.data(), sizeof(int32_t) * sub_entries.size(), hipMemcpyHostToDevice, s), "H2D sub entries");
+        make_chunks(compute_ids, chunk_rows, false);
+        if (h_chunks.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: chunk table overflow");
+        // paths (duplicate-on-path rejection, node.cpp:154-166)
+        std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
+        std::vector<float> pv(static_cast<size_t>(n_act) * kern::kMaxPath, 0.f);
+        for (int k = 0; k < n_act; ++k) {
+            const HNode &nd = nodes[active[k]];
+            pl[k] = static_cast<int32_t>(nd.path.size());
+            root[k] = nd.depth == 0;
+            for (size_t q = 0; q < nd.path.size(); ++q) {
+                ps[k * kern::kMaxPath + q] = nd.path[q].fslot;
+                pv[k * kern::kMaxPath + q] = nd.path[q].value;
+                pb[k * kern::kMaxPath + q] = nd.path[q].bin;
+            }
+        }
+        sta.reset();
+        Chunk *d_chunks = sta.put(h_chunks.data(), h_chunks.size());
+        int32_t *d_chunk_begin = sta.put(h_chunk_begin.data(), h_chunk_begin.size());
+        int32_t *d_slotmap = sta.put(slot_map.data(), slot_map.size());
+        int32_t *d_subent = sta.put(sub_entries.data(), sub_entries.size());
+        int32_t *d_path_len = sta.put(pl.data(), pl.size());
+        int32_t *d_path_slot = sta.put(ps.data(), ps.size());
+        float *d_path_val = sta.put(pv.data(), pv.size());
+        int32_t *d_path_bin = sta.put(pb.data(), pb.size());
+        int32_t *d_isroot = sta.put(root.data(), root.size());
+        sta.flush();
         phase_begin();
         if (!h_chunks.empty())
             kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
@@ -637,60 +693,42 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         if (!compute_ids.empty())
             kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist_local, s);
         if (!sub_entries.empty())
-            kern::hist_subtract(d_hist_prev, d_hist_local, d_slotmap + max_front, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
+            kern::hist_subtract(d_hist_prev, d_hist_local, d_subent, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
         phase_end("hist_reduce");
         if (has_coll_) {
             hip_check(hipMemcpyAsync(d_hist, d_hist_local, sizeof(int64_t) * n_act * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist");
             hip_check(hipStreamSynchronize(s), "sync");
             if (coll_.allreduce_sum_i64(coll_.ctx, d_hist, static_cast<size_t>(n_act) * hist_node_elems) != 0) throw HipError("allreduce failed");
         }
-        // -- paths (duplicate-on-path rejection, node.cpp:154-166)
-        std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
-        std::vector<float> pv(static_cast<size_t>(n_act) * kern::kMaxPath, 0.f);
-        for (int k = 0; k < n_act; ++k) {
-            const HNode &nd = nodes[active[k]];
-            pl[k] = static_cast<int32_t>(nd.path.size());
-            root[k] = nd.depth == 0;
-            for (size_t p = 0; p < nd.path.size(); ++p) {
-                ps[k * kern::kMaxPath + p] = nd.path[p].fslot;
-                pv[k * kern::kMaxPath + p] = nd.path[p].value;
-                pb[k * kern::kMaxPath + p] = nd.path[p].bin;
-            }
-        }
-        hip_check(hipMemcpyAsync(d_path_len, pl.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s), "H2D");
-        hip_check(hipMemcpyAsync(d_path_slot, ps.data(), sizeof(int32_t) * ps.size(), hipMemcpyHostToDevice, s), "H2D");
-        hip_check(hipMemcpyAsync(d_path_val, pv.data(), sizeof(float) * pv.size(), hipMemcpyHostToDevice, s), "H2D");
-        hip_check(hipMemcpyAsync(d_path_bin, pb.data(), sizeof(int32_t) * pb.size(), hipMemcpyHostToDevice, s), "H2D");
-        hip_check(hipMemcpyAsync(d_isroot, root.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s), "H2D");
-        // -- scores and selection
+        // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
         kern::score_candidates(d_hist, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                1.0 / scale, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
-        std::vector<int32_t> best_idx(n_act, 0);
-        std::vector<float> best_score(n_act, -INFINITY);
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
-        const int n_best = oblivious ? 1 : n_act;
-        hip_check(hipMemcpyAsync(best_idx.data(), d_best_idx, sizeof(int32_t) * n_best, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipMemcpyAsync(best_score.data(), d_best_score, sizeof(float) * n_best, hipMemcpyDeviceToHost, s), "D2H");
+        kern::resolve_splits(d_best_idx, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist_local,
+                             has_coll_ ? d_hist : nullptr, Fp, NB, D, d_resolved, d_counts4, max_front, s);
+        hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
         phase_end("score_select");
         hip_check(hipStreamSynchronize(s), "sync");
         hip_check(hipGetLastError(), "growth kernels");
-        if (oblivious) {
-            if (best_score[0] == -INFINITY) break;  // fitter.cpp:458
-            for (int k = 1; k < n_act; ++k) { best_idx[k] = best_idx[0]; best_score[k] = best_score[0]; }
-        }
+        const int32_t *best_idx_h = reinterpret_cast<const int32_t *>(h_res);
+        const float *best_score_h = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
+        const int64_t *cnt4 = reinterpret_cast<const int64_t *>(h_res + 8 * static_cast<size_t>(max_front));
+        const int64_t *tot_l = cnt4, *right_l = cnt4 + max_front;
+        const int64_t *right_g = has_coll_ ? cnt4 + 3 * static_cast<size_t>(max_front) : right_l;
+        if (oblivious && best_score_h[0] == -INFINITY) break;  // fitter.cpp:458
         // -- decisions (best_idx are REFERENCE candidate indices)
         std::vector<NodeSplit> sp(n_act);
         std::vector<int> splitting, new_leaves;
         for (int k = 0; k < n_act; ++k) {
             HNode &nd = nodes[active[k]];
-            const bool do_split = oblivious || best_score[k] >= 0.0f;  // fitter.cpp:357
+            const int bk = oblivious ? 0 : k;
+            const bool do_split = oblivious || best_score_h[bk] >= 0.0f;  // fitter.cpp:357
             NodeSplit q{};
             q.seg_start = nd.seg_start;
             if (do_split) {
-                const int j = ref_to_internal[best_idx[k]];
-                int fs = 0;
-                while (fs + 1 < n_slots && slots[fs + 1].cand_base <= j) ++fs;
+                const int j = ref_to_internal[best_idx_h[bk]];
+                const int fs = cand_slot[j];
                 q.do_split = 1;
                 q.fslot = fs;
                 q.is_cat = slots[fs].is_cat;
@@ -705,22 +743,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         if (!oblivious)
             for (int id : frontier)
                 if (nodes[id].n_global == 0 && !nodes[id].leaf) { nodes[id].leaf = true; new_leaves.push_back(id); }
-        // child sizes from the histograms: local (for the row lists) and global (edge weights)
-        std::vector<int64_t> tot_l(n_act), right_l(n_act), tot_g(n_act), right_g(n_act);
-        hip_check(hipMemcpyAsync(d_splits, sp.data(), sizeof(NodeSplit) * n_act, hipMemcpyHostToDevice, s), "H2D splits");
-        kern::child_counts(d_hist_local, n_act, Fp, NB, D, d_splits, d_ntotal, d_nright, s);
-        hip_check(hipMemcpyAsync(tot_l.data(), d_ntotal, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipMemcpyAsync(right_l.data(), d_nright, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
-        if (has_coll_) {
-            kern::child_counts(d_hist, n_act, Fp, NB, D, d_splits, d_ntotal + max_front, d_nright + max_front, s);
-            hip_check(hipMemcpyAsync(tot_g.data(), d_ntotal + max_front, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
-            hip_check(hipMemcpyAsync(right_g.data(), d_nright + max_front, sizeof(int64_t) * n_act, hipMemcpyDeviceToHost, s), "D2H");
-        }
-        hip_check(hipStreamSynchronize(s), "sync");
-        if (!has_coll_) { tot_g = tot_l; right_g = right_l; }
-        // leaves finalised at this level: sum their raw gradients while their segment is intact in the current list
-        if (!new_leaves.empty()) leaf_sums_for(new_leaves);
-        if (splitting.empty()) { frontier.clear(); break; }
         std::vector<int> next;
         for (int k : splitting) {
             const int id = active[k];
@@ -769,33 +791,53 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             next.push_back(nodes[id].left);
             next.push_back(nodes[id].right);
         }
-        // -- partition the row list of the splitting nodes
+        // -- leaves finalised at this level (their segment is intact in the current list) and the partition: enqueued, not awaited
+        stb.reset();
+        if (!new_leaves.empty()) {
+            make_chunks(new_leaves, 4096, true);
+            if (!h_chunks.empty()) {
+                Chunk *d_lc = stb.put(h_chunks.data(), h_chunks.size());
+                stb.flush();
+                phase_begin();
+                kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), leaf_scale, d_leafacc, s);
+                phase_end("leaves");
+            }
+        }
+        if (splitting.empty()) { frontier.clear(); break; }
         {
             std::vector<int> split_ids;
             std::vector<NodeSplit> sp2;
             for (int k : splitting) { split_ids.push_back(active[k]); sp2.push_back(sp[k]); }
-            build_chunks(split_ids, kern::kPartitionRows);
-            hip_check(hipMemcpyAsync(d_splits, sp2.data(), sizeof(NodeSplit) * sp2.size(), hipMemcpyHostToDevice, s), "H2D splits");
+            make_chunks(split_ids, kern::kPartitionRows, false);
+            Chunk *d_pc = stb.put(h_chunks.data(), h_chunks.size());
+            NodeSplit *d_sp2 = stb.put(sp2.data(), sp2.size());
+            stb.flush();
             hip_check(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * 2 * sp2.size(), s), "memset cursors");
             phase_begin();
             if (!h_chunks.empty())
-                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_chunks, static_cast<int>(h_chunks.size()), d_splits, d_cursors, s);
+                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_pc, static_cast<int>(h_chunks.size()), d_sp2, d_cursors, s);
             phase_end("partition");
-            hip_check(hipStreamSynchronize(s), "sync");  // host staging vectors go out of scope
             cur ^= 1;
         }
         frontier = next;
-        tree_depth = depth + 1;
     }
 
     // ---- 5. leaves ---------------------------------------------------------------------------------------------------
-    phase_begin();
     {
         std::vector<int> last;
         for (int id : frontier)
             if (!nodes[id].leaf) { nodes[id].leaf = true; last.push_back(id); }
         if (nodes.size() == 1) nodes[0].leaf = true;
-        if (!last.empty()) leaf_sums_for(last);
+        make_chunks(last, 4096, true);
+        if (!h_chunks.empty()) {
+            // stage B may still be in flight for the partition of the last level: stage A is free (its level is complete)
+            sta.reset();
+            Chunk *d_lc = sta.put(h_chunks.data(), h_chunks.size());
+            sta.flush();
+            phase_begin();
+            kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), leaf_scale, d_leafacc, s);
+            phase_end("leaves");
+        }
     }
     if (has_coll_) {
         hip_check(hipStreamSynchronize(s), "sync");
@@ -804,7 +846,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     std::vector<int64_t> acc(nodes.size() * (D + 1));
     hip_check(hipMemcpyAsync(acc.data(), d_leafacc, sizeof(int64_t) * acc.size(), hipMemcpyDeviceToHost, s), "D2H leaf acc");
     hip_check(hipStreamSynchronize(s), "sync");
-    phase_end("leaves");
 
     // leaf order: oblivious = level order of the last level (child slots 2k, 2k+1, fitter.cpp:469-470); greedy = depth-first,
     // left first (fitter.cpp:364-365)
@@ -822,7 +863,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             stack.push_back(nodes[id].left);
         }
     }
-    (void)tree_depth;
 
     // ---- append to the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) -----------------------------
     model.begin_tree();

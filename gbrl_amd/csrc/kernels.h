@@ -40,8 +40,10 @@ constexpr int kMaxPath = 32;
 constexpr int kPartitionRows = 4096;  // rows per partition block (chunk size the engine must use)  // max_depth supported by the duplicate-on-path check
 
 // ---- gradient preprocessing (A2) ----
+// out[0..D) = sum_i g[i,d] (center == null) or sum_i (g[i,d]-center[d])^2 ; out[D..2D) = max_i |g[i,d] (- center[d])|
+// block_partials: n_blocks * 2D doubles.  Deterministic (fixed reduction tree).
 void column_sums(const float *g, int n, int D, const float *center /*nullable [D]*/, double *block_partials,
-                 int n_blocks, double *out /*[D]*/, hipStream_t s);
+                 int n_blocks, double *out /*[2D]*/, hipStream_t s);
 int column_sums_blocks(int n, int D);
 // max |standardised g| as float bits in out[0]; mean/inv_std nullable (Cosine: raw grads)
 void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s);
@@ -110,6 +112,11 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *cand_weig
             hipStream_t s);
 void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits,
                   int64_t *n_total, int64_t *n_right, hipStream_t s);
+
+// winner -> (feature slot, class) and the child sizes it induces, per active node (one read-back per level)
+void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
+                    const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global /*nullable*/, int Fp, int NB, int D,
+                    NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front, hipStream_t s);
 
 // ---- partition (A9) ----
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows,

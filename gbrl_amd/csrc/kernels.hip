@@ -33,40 +33,49 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
 // block in a fixed order => deterministic.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_column_sums(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ center,
-                              double *__restrict__ partials) {
-    extern __shared__ double sh[];
+                              double *__restrict__ partials /*[blocks][2D]: sums then maxima*/) {
+    extern __shared__ double sh[];  // [2*bs]
     const int bs = blockDim.x;
     const int col = threadIdx.x % D;
     const float c = center ? center[col] : 0.0f;
     double acc = 0.0;
+    float mx = 0.0f;
     for (size_t e = static_cast<size_t>(blockIdx.x) * bs + threadIdx.x; e < n_el; e += static_cast<size_t>(gridDim.x) * bs) {
         const float v = g[e];
         if (center) {
             const float dv = v - c;  // fp32 subtraction like the reference (math_ops.cpp:498)
             acc += static_cast<double>(dv) * static_cast<double>(dv);
+            mx = fmaxf(mx, fabsf(dv));
         } else {
             acc += static_cast<double>(v);
+            mx = fmaxf(mx, fabsf(v));
         }
     }
     sh[threadIdx.x] = acc;
+    sh[bs + threadIdx.x] = static_cast<double>(mx);
     __syncthreads();
     if (threadIdx.x < D) {
-        double s = 0.0;
-        for (int t = threadIdx.x; t < bs; t += D) s += sh[t];
-        partials[static_cast<size_t>(blockIdx.x) * D + threadIdx.x] = s;
+        double s = 0.0, m = 0.0;
+        for (int t = threadIdx.x; t < bs; t += D) { s += sh[t]; m = fmax(m, sh[bs + t]); }
+        partials[static_cast<size_t>(blockIdx.x) * 2 * D + threadIdx.x] = s;
+        partials[static_cast<size_t>(blockIdx.x) * 2 * D + D + threadIdx.x] = m;
     }
 }
 __global__ __launch_bounds__(256) void k_column_sums_final(const double *__restrict__ partials, int n_blocks, int D,
-                                                           double *__restrict__ out) {
-    // one block per column; fixed-shape tree => deterministic
+                                                           double *__restrict__ out /*[2D]*/) {
+    // one block per output (D sums, then D maxima); fixed-shape tree => deterministic
     __shared__ double sh[256];
     const int d = blockIdx.x;
+    const bool is_max = d >= D;
     double s = 0.0;
-    for (int b = threadIdx.x; b < n_blocks; b += 256) s += partials[static_cast<size_t>(b) * D + d];
+    for (int b = threadIdx.x; b < n_blocks; b += 256) {
+        const double v = partials[static_cast<size_t>(b) * 2 * D + d];
+        s = is_max ? fmax(s, v) : s + v;
+    }
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        if (threadIdx.x < o) sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + o]) : sh[threadIdx.x] + sh[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[d] = sh[0];
@@ -262,9 +271,28 @@ __device__ __forceinline__ size_t code_index(int slot, int row, int n_rows) {
     return (static_cast<size_t>(slot >> 4) * n_rows + row) * kCodeGroup + (slot & (kCodeGroup - 1));
 }
 
-// DT = compile-time output_dim (vector loads of the quantised gradients) or 0 = run-time D.  Every row-slot keeps U rows
-// in flight: all row-index, code and gradient loads of the U rows are issued before the first atomic, which is what hides
-// the dependent-load latency of the gathered rows (the v1 kernel was latency-bound at ~6x the LDS-atomic time).
+// Broadcast lane `SRC` of every 16-lane row to the whole row (v_mov_b32_dpp row_newbcast: a VALU move, no LDS traffic).
+template <int SRC>
+__device__ __forceinline__ int row_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, false);
+}
+template <int DT, int K>
+struct RowAtomics {   // adds q[K..DT) of this lane's row into dst, one LDS atomic per output dim
+    static __device__ __forceinline__ void run(int32_t *dst, int FG, int myq) {
+        atomicAdd(dst + K * FG, row_bcast<K>(myq));
+        RowAtomics<DT, K + 1>::run(dst, FG, myq);
+    }
+};
+template <int DT>
+struct RowAtomics<DT, DT> {
+    static __device__ __forceinline__ void run(int32_t *, int, int) {}
+};
+
+// k_hist_build<DT, U>.  DT = compile-time output_dim (1..16) for the FG == 16 layout, or 0 = generic (run-time D, any FG).
+// Fast path: the 16 lanes that share a row are one DPP row.  Lane fl < DT loads ONE dword, q[fl], of the row's quantised
+// gradients (32 contiguous bytes per row for D = 8) and the D values are handed to all 16 lanes with row_newbcast moves,
+// instead of every lane loading all D values (which made the vector-memory path, not the LDS atomics, the bottleneck).
+// Every row-slot keeps U rows in flight: all loads of the U rows are issued before the first atomic.
 template <int DT, int U>
 __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
                                                               const int32_t *__restrict__ qg, int D_rt,
@@ -273,6 +301,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
                                                               int NB, int32_t *__restrict__ partials) {
     extern __shared__ int32_t h[];
     const int D = DT ? DT : D_rt;
+    if (DT) { FG = 16; fg_shift = 4; }
     const int n_acc = NB * (D + 1) * FG;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
     __syncthreads();
@@ -284,46 +313,49 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const int row_stride = (D + 1) * FG;
     const int fslot = g * FG + fl;
     const uint16_t *cbase = codes + (static_cast<size_t>(fslot >> 4) * n_rows) * kCodeGroup + (fslot & (kCodeGroup - 1));
-    for (int p0 = slot; p0 < ck.len; p0 += n_slots * U) {
-        int row[U];
+    const int32_t *rlist = rows + ck.start;
+    const int qlane = fl < (DT ? DT : 1) ? fl : (DT ? DT - 1 : 0);   // lanes >= D re-load the last value (never used)
+    int p0 = slot;
+    // main loop: U rows per slot, no bounds checks inside => straight-line code: 3U independent loads, then 9U atomics
+    for (; p0 + (U - 1) * n_slots < ck.len; p0 += n_slots * U) {
+        int row[U], code[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * n_slots;
-            row[u] = p < ck.len ? rows[ck.start + p] : -1;
-        }
-        int code[U];
+        for (int u = 0; u < U; ++u) row[u] = rlist[p0 + u * n_slots];
 #pragma unroll
-        for (int u = 0; u < U; ++u) code[u] = row[u] >= 0 ? cbase[static_cast<size_t>(row[u]) * kCodeGroup] : 0;
-        if (DT >= 4) {
-            int4 q[U][DT >= 4 ? DT / 4 : 1];
+        for (int u = 0; u < U; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * kCodeGroup];
+        if (DT) {
+            int myq[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int4 *src = reinterpret_cast<const int4 *>(qg + static_cast<size_t>(row[u] >= 0 ? row[u] : 0) * DT);
-#pragma unroll
-                for (int v = 0; v < DT / 4; ++v) q[u][v] = src[v];
-            }
+            for (int u = 0; u < U; ++u) myq[u] = qg[static_cast<size_t>(row[u]) * DT + qlane];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (row[u] < 0) continue;
                 int32_t *dst = h + code[u] * row_stride + fl;
-#pragma unroll
-                for (int v = 0; v < DT / 4; ++v) {
-                    atomicAdd(dst + (4 * v + 0) * FG, q[u][v].x);
-                    atomicAdd(dst + (4 * v + 1) * FG, q[u][v].y);
-                    atomicAdd(dst + (4 * v + 2) * FG, q[u][v].z);
-                    atomicAdd(dst + (4 * v + 3) * FG, q[u][v].w);
-                }
-                atomicAdd(dst + DT * FG, 1);
+                RowAtomics<DT, 0>::run(dst, 16, myq[u]);
+                atomicAdd(dst + DT * 16, 1);
             }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (row[u] < 0) continue;
                 const int32_t *q = qg + static_cast<size_t>(row[u]) * D;
                 int32_t *dst = h + code[u] * row_stride + fl;
                 for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
                 atomicAdd(dst + D * FG, 1);
             }
+        }
+    }
+    // tail: one row per slot (p0 is uniform across the 16 lanes of a DPP row, so whole rows take the branch)
+    for (; p0 < ck.len; p0 += n_slots) {
+        const int row = rlist[p0];
+        const int code = cbase[static_cast<size_t>(row) * kCodeGroup];
+        int32_t *dst = h + code * row_stride + fl;
+        if (DT) {
+            const int myq = qg[static_cast<size_t>(row) * DT + qlane];
+            RowAtomics<DT, 0>::run(dst, 16, myq);
+            atomicAdd(dst + DT * 16, 1);
+        } else {
+            const int32_t *q = qg + static_cast<size_t>(row) * D;
+            for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
+            atomicAdd(dst + D * FG, 1);
         }
     }
     __syncthreads();
@@ -529,6 +561,41 @@ __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, in
     if (threadIdx.x == 0) { n_total[node] = tot; n_right[node] = right; }
 }
 
+// Child sizes of the selected split of every active node, straight from the histograms (one wave per node), so that the
+// host learns the winner AND the sizes of its children with a single read-back.  counts4 = [total_local | right_local |
+// total_global | right_global], each max_front wide.
+__global__ __launch_bounds__(64) void k_resolve_splits(const int32_t *__restrict__ best_idx, int oblivious,
+                                                       const int32_t *__restrict__ ref_to_internal, const int32_t *__restrict__ cand_slot,
+                                                       const FeatureSlot *__restrict__ slots, const int64_t *__restrict__ hist_local,
+                                                       const int64_t *__restrict__ hist_global, int Fp, int NB, int D,
+                                                       NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front) {
+    const int node = blockIdx.x;
+    const int j = ref_to_internal[best_idx[oblivious ? 0 : node]];
+    const int fs = cand_slot[j];
+    const FeatureSlot sl = slots[fs];
+    const int bin = sl.is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
+    const int W = D + 1;
+    for (int pass = 0; pass < (hist_global ? 2 : 1); ++pass) {
+        const int64_t *src = (pass ? hist_global : hist_local) + (static_cast<size_t>(node) * Fp + fs) * NB * W;
+        long long tot = 0, right = 0;
+        for (int c = threadIdx.x; c < NB; c += kWave) {
+            const long long n = src[c * W + D];
+            tot += n;
+            if (sl.is_cat ? (c == bin) : (c > bin)) right += n;
+        }
+        for (int o = kWave / 2; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, kWave); right += __shfl_xor(right, o, kWave); }
+        if (threadIdx.x == 0) {
+            counts4[(2 * pass + 0) * static_cast<size_t>(max_front) + node] = tot;
+            counts4[(2 * pass + 1) * static_cast<size_t>(max_front) + node] = right;
+        }
+    }
+    if (threadIdx.x == 0) {
+        NodeSplit q{};
+        q.fslot = fs; q.bin = bin; q.is_cat = sl.is_cat;
+        out[node] = q;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // A9  partition: every splitting node's segment [seg_start, seg_start+n) of the row list is split into [left | right] in
 // place of the same range of the output list.  Destination slots are handed
@@ -694,14 +761,14 @@ inline int grid_for(size_t n, int bs, int cap) {
 
 // ---------------------------------------------------------------------------------------------------- wrappers
 
-int column_sums_blocks(int n, int D) { return grid_for(static_cast<size_t>(n) * D, 256, 1024); }
+int column_sums_blocks(int n, int D) { return grid_for(static_cast<size_t>(n) * D, 256 * 8, 1024); }
 
 void column_sums(const float *g, int n, int D, const float *center, double *block_partials, int n_blocks, double *out,
                  hipStream_t s) {
     const int bs = D <= 256 ? (256 / D) * D : D;  // multiple of D so a thread owns one column
-    hipLaunchKernelGGL(k_column_sums, dim3(n_blocks), dim3(bs), bs * sizeof(double), s, g, static_cast<size_t>(n) * D, D,
+    hipLaunchKernelGGL(k_column_sums, dim3(n_blocks), dim3(bs), 2 * bs * sizeof(double), s, g, static_cast<size_t>(n) * D, D,
                        center, block_partials);
-    hipLaunchKernelGGL(k_column_sums_final, dim3(D), dim3(256), 0, s, block_partials, n_blocks, D, out);
+    hipLaunchKernelGGL(k_column_sums_final, dim3(2 * D), dim3(256), 0, s, block_partials, n_blocks, D, out);
 }
 
 void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s) {
@@ -788,10 +855,19 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
-    if (D == 8) launch_hist<8, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
-    else if (D == 4) launch_hist<4, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
-    else if (D == 16) launch_hist<16, 2>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
-    else launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
+#ifndef GBRL_HIST_U
+#define GBRL_HIST_U 8
+#endif
+#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s); return;
+    if (FG == 16) {
+        switch (D) {
+            GBRL_HIST_CASE(1) GBRL_HIST_CASE(2) GBRL_HIST_CASE(3) GBRL_HIST_CASE(4) GBRL_HIST_CASE(5) GBRL_HIST_CASE(6)
+            GBRL_HIST_CASE(7) GBRL_HIST_CASE(8) GBRL_HIST_CASE(9) GBRL_HIST_CASE(10) GBRL_HIST_CASE(12) GBRL_HIST_CASE(16)
+            default: break;
+        }
+    }
+#undef GBRL_HIST_CASE
+    launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
 }
 
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,
@@ -834,6 +910,13 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
                   int64_t *n_right, hipStream_t s) {
     hipLaunchKernelGGL(k_child_counts, dim3(n_nodes), dim3(64), 0, s, hist, n_nodes, Fp, NB, D, splits, n_total,
                        n_right);
+}
+
+void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
+                    const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
+                    NodeSplit *out, int64_t *counts4, int max_front, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, best_idx, oblivious ? 1 : 0, ref_to_internal, cand_slot, slots,
+                       hist_local, hist_global, Fp, NB, D, out, counts4, max_front);
 }
 
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows, const Chunk *chunks,

@@ -4,8 +4,8 @@
 // fitter.cpp:77-90, and reads split_candidate_generator.cpp:216-249's ranks).  A full sort is ~100x more work than
 // needed.  Here:
 //   1. k_transpose_keys   obs [N][F] f32  ->  KT [F][N] u32, order-preserving keys (coalesced both ways through LDS)
-//   2. k_sample_splitters per feature: jittered-stratified sample of <= 16384 keys, bitonic sort in LDS, every
-//                         (S/4096)-th sample becomes a splitter (<= 4095 per feature)
+//   2. k_sample_splitters per feature: jittered-stratified sample of <= 16384 keys, bitonic sort in LDS, the
+//                         sorted sample (minus one key) is the splitter set (<= 4095 per feature)
 //   3. k_class_count      class(x) = 2*#{splitters < x} + [x equals the next splitter]; exact class counts per feature.
 //                         Odd ("equality") classes hold copies of ONE value, so heavy duplicates never inflate a list.
 //   4. k_targets          per target rank: its class and rank inside the class; distinct open classes get a list
@@ -110,14 +110,17 @@ __device__ __forceinline__ int classify(const uint32_t *e, int levels, uint32_t 
     const int j = i - ((1 << levels) - 1);
     return 2 * j + ((went_left && last_ge == key) ? 1 : 0);
 }
-// four independent descents in flight per thread (the LDS latency of one dependent chain is ~12 x 64 cycles)
-__device__ __forceinline__ void classify4(const uint32_t *e, int levels, const uint32_t (&key)[4], int (&cls)[4]) {
-    int i[4] = {0, 0, 0, 0};
-    uint32_t ge[4] = {0, 0, 0, 0};
-    bool wl[4] = {false, false, false, false};
+// KQ independent descents in flight per thread (the LDS latency of one dependent chain is ~12 x 64 cycles)
+constexpr int KQ = 8;
+__device__ __forceinline__ void classifyN(const uint32_t *e, int levels, const uint32_t (&key)[KQ], int (&cls)[KQ]) {
+    int i[KQ];
+    uint32_t ge[KQ];
+    bool wl[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) { i[q] = 0; ge[q] = 0; wl[q] = false; }
     for (int l = 0; l < levels; ++l) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < KQ; ++q) {
             const uint32_t v = e[i[q]];
             const bool lt = v < key[q];
             if (!lt) { ge[q] = v; wl[q] = true; }
@@ -125,7 +128,7 @@ __device__ __forceinline__ void classify4(const uint32_t *e, int levels, const u
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cls[q] = 2 * (i[q] - ((1 << levels) - 1)) + ((wl[q] && ge[q] == key[q]) ? 1 : 0);
+    for (int q = 0; q < KQ; ++q) cls[q] = 2 * (i[q] - ((1 << levels) - 1)) + ((wl[q] && ge[q] == key[q]) ? 1 : 0);
 }
 
 // ---- 3. class counts ----------------------------------------------------------------------------------------------
@@ -144,12 +147,14 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
     int levels = 0;
     while ((1 << levels) < n_split + 1) ++levels;
     int i = lo + threadIdx.x;
-    for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {
-        const uint32_t k[4] = {col[i], col[i + kCountThreads], col[i + 2 * kCountThreads], col[i + 3 * kCountThreads]};
-        int cls[4];
-        classify4(sp, levels, k, cls);
+    for (; i + (KQ - 1) * kCountThreads < hi; i += KQ * kCountThreads) {
+        uint32_t k[KQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomicAdd(&cnt[cls[q]], 1u);
+        for (int q = 0; q < KQ; ++q) k[q] = col[i + q * kCountThreads];
+        int cls[KQ];
+        classifyN(sp, levels, k, cls);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) atomicAdd(&cnt[cls[q]], 1u);
     }
     for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, levels, col[i])], 1u);
     __syncthreads();
@@ -263,12 +268,14 @@ __global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__res
     int levels = 0;
     while ((1 << levels) < n_split + 1) ++levels;
     int i = lo + threadIdx.x;
-    for (; i + 3 * kCountThreads < hi; i += 4 * kCountThreads) {
-        const uint32_t k[4] = {col[i], col[i + kCountThreads], col[i + 2 * kCountThreads], col[i + 3 * kCountThreads]};
-        int cls[4];
-        classify4(sp, levels, k, cls);
+    for (; i + (KQ - 1) * kCountThreads < hi; i += KQ * kCountThreads) {
+        uint32_t k[KQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < KQ; ++q) k[q] = col[i + q * kCountThreads];
+        int cls[KQ];
+        classifyN(sp, levels, k, cls);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
             if (cur[cls[q]] != 0xffffffffu) out[atomicAdd(&cur[cls[q]], 1u)] = k[q];
     }
     for (; i < hi; i += kCountThreads) {
@@ -322,20 +329,24 @@ __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ k
     }
     __syncthreads();
     const int r = r0 + threadIdx.x;
-    for (int fl0 = 0; fl0 < kGroup; fl0 += 4) {           // 4 independent descents in flight
-        uint32_t key[4];
-        int idx[4] = {0, 0, 0, 0};
+    const int rr = r < n ? r : n - 1;
+    uint32_t key[kGroup];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int f = g * kGroup + fl0 + q;
-            key[q] = (f < F && r < n) ? kt[static_cast<size_t>(f) * n + r] : 0u;
-        }
+    for (int q = 0; q < kGroup; ++q) {                    // all 16 column loads in flight before the first descent
+        const int f = g * kGroup + q;
+        key[q] = kt[static_cast<size_t>(f < F ? f : F - 1) * n + rr];
+    }
+#pragma unroll
+    for (int fl0 = 0; fl0 < kGroup; fl0 += 8) {           // 8 independent descents in flight
+        int idx[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) idx[q] = 0;
         for (int l = 0; l < levels; ++l) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) idx[q] = 2 * idx[q] + 1 + ((t[(fl0 + q) * P + idx[q]] < key[q]) ? 1 : 0);
+            for (int q = 0; q < 8; ++q) idx[q] = 2 * idx[q] + 1 + ((t[(fl0 + q) * P + idx[q]] < key[fl0 + q]) ? 1 : 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const int f = g * kGroup + fl0 + q;
             int code = idx[q] - P;                        // #{padded thresholds < key}; pads are never < key
             if (code > B) code = B;
@@ -368,7 +379,7 @@ void transpose_keys(const float *obs, int n, int F, uint32_t *kt, hipStream_t s)
 QuantilePlan quantile_plan(int n) {
     QuantilePlan p;
     int S = 64;
-    while (S < n && S < 16384) S <<= 1;   // whole column when n <= S, else a 16384-key jittered-stratified sample
+    while (S < n && S < 4096) S <<= 1;    // whole column when n <= S, else a 4096-key jittered-stratified sample
     p.sample = S;
     p.n_split = S - 1 < kMaxSplit ? S - 1 : kMaxSplit;   // (n_split + 1) divides S: both are powers of two
     p.n_chunks = n >= (1 << 18) ? 8 : (n >= (1 << 15) ? 2 : 1);
