@@ -751,6 +751,148 @@ __global__ __launch_bounds__(256) void k_predict(PredictModel pm, const float *_
         if (j < D) out[static_cast<size_t>(row) * D + j] = p[j];
 }
 
+// Prediction v2: each block stages its R rows of observations in LDS once (coalesced read of the row-major matrix; row
+// stride F+1 words so that lane r reading feature f hits bank (r+f)%32: conflict-free for the wave-uniform f of an
+// oblivious tree), then walks all trees over the tile.  Oblivious ensembles additionally stage, TT trees at a time, the
+// conditions and the leaf values in LDS, so the inner loop touches LDS only.  Per-row accumulation order = tree order,
+// pred = fma(-lr, value, pred) (optimizer.cpp:110-118).
+constexpr int kPredMaxOpts = 4;   // optimisers kept in registers (more fall back to the direct kernel)
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_predict_tiled(PredictModel pm, const float *__restrict__ obs, int F,
+                                                       const int32_t *__restrict__ cat_codes, int Fc, int n, int start_tree,
+                                                       int stop_tree, float *__restrict__ out, int TT) {
+    extern __shared__ float ptile[];
+    const int R = blockDim.x;
+    const int xs = F + 1;
+    const int D = pm.D, md = pm.max_depth;
+    const int vstride = (1 << md) * D;
+    float *xt = ptile;                                        // [R][F+1]
+    float *vt = ptile + static_cast<size_t>(R) * xs;          // [TT][2^md][D]      (oblivious only)
+    int *ct = reinterpret_cast<int *>(vt + static_cast<size_t>(TT) * vstride);   // [TT][1 + 2*md]: depth, then (feature | ~cat, threshold bits | cat id)
+    const int cstride = 1 + 2 * md;
+    const int r0 = blockIdx.x * R;
+    const int rows = min(R, n - r0);
+    {   // coalesced staging of rows [r0, r0+rows)
+        const float *src = obs + static_cast<size_t>(r0) * F;
+        if ((F & 3) == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(src);
+            const int F4 = F >> 2, tot4 = rows * F4;
+            constexpr int UL = 8;   // loads in flight per thread (one block per CU: nothing else hides the HBM latency)
+            for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
+                float4 v[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = i0 + u * R;
+                    v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = i0 + u * R;
+                    if (i < tot4) {
+                        const int r = i / F4, f = (i - r * F4) << 2;
+                        float *dst = xt + r * xs + f;
+                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                    }
+                }
+            }
+        } else {
+            const int tot = rows * F;
+            for (int i = threadIdx.x; i < tot; i += R) {
+                const int r = i / F, f = i - r * F;
+                xt[r * xs + f] = src[i];
+            }
+        }
+    }
+    const int row = r0 + threadIdx.x;
+    const bool live = threadIdx.x < rows;
+    float p[DMAX];
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + pm.bias[j] : 0.0f;
+    const float *x = xt + threadIdx.x * xs;
+    const int32_t *xc = (cat_codes && live) ? cat_codes + static_cast<size_t>(row) * Fc : nullptr;
+    float olr[kPredMaxOpts];
+    int oa[kPredMaxOpts], ob[kPredMaxOpts];
+#pragma unroll
+    for (int o = 0; o < kPredMaxOpts; ++o) {
+        const bool on = o < pm.n_opts;
+        olr[o] = on ? pm.opt_lr[o] : 0.0f;
+        oa[o] = on ? pm.opt_start[o] : 0;
+        ob[o] = on ? pm.opt_stop[o] : 0;
+    }
+    auto apply = [&](const float *v) {
+#pragma unroll
+        for (int o = 0; o < kPredMaxOpts; ++o) {
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j)
+                if (j >= oa[o] && j < ob[o]) p[j] = fmaf(-olr[o], v[j], p[j]);
+        }
+    };
+    __syncthreads();
+    if (stop_tree > start_tree && pm.n_opts > 0) {
+        if (pm.oblivious) {
+            for (int t0 = start_tree; t0 < stop_tree; t0 += TT) {
+                const int tn = min(TT, stop_tree - t0);
+                __syncthreads();   // previous tile fully consumed
+                for (int tt = 0; tt < tn; ++tt) {
+                    const int t = t0 + tt;
+                    const int depth = pm.depths[t];
+                    const int nl = (1 << depth) * D;
+                    const float *srcv = pm.values + static_cast<size_t>(pm.tree_indices[t]) * D;
+                    for (int i = threadIdx.x; i < nl; i += R) vt[tt * vstride + i] = srcv[i];
+                    if (threadIdx.x == 0) ct[tt * cstride] = depth;
+                    if (static_cast<int>(threadIdx.x) < depth) {
+                        const int c = t * md + threadIdx.x;
+                        const bool num = pm.is_numerics[c] != 0;
+                        ct[tt * cstride + 1 + 2 * threadIdx.x] = num ? pm.feature_indices[c] : ~pm.feature_indices[c];
+                        ct[tt * cstride + 2 + 2 * threadIdx.x] = num ? __float_as_int(pm.feature_values[c]) : pm.cat_ids[c];
+                    }
+                }
+                __syncthreads();
+                if (live) {
+                    for (int tt = 0; tt < tn; ++tt) {
+                        const int *cc = ct + tt * cstride;
+                        const int depth = cc[0];
+                        int leaf = 0;
+                        for (int d = 0; d < depth; ++d) {
+                            const int fi = cc[1 + 2 * d], tv = cc[2 + 2 * d];
+                            const bool pass = fi >= 0 ? (x[fi] > __int_as_float(tv)) : (xc != nullptr && xc[~fi] == tv);
+                            leaf |= (pass ? 1 : 0) << (depth - 1 - d);
+                        }
+                        apply(vt + tt * vstride + leaf * D);
+                    }
+                }
+            }
+        } else if (live) {
+            auto test = [&](int c) -> bool {
+                const int f = pm.feature_indices[c];
+                return pm.is_numerics[c] ? (x[f] > pm.feature_values[c]) : (xc != nullptr && xc[f] == pm.cat_ids[c]);
+            };
+            int t = start_tree;
+            int leaf = pm.tree_indices[t];
+            while (leaf < pm.n_leaves && t < stop_tree) {
+                const int depth = pm.depths[leaf], cond = leaf * md;
+                bool passed = false;
+                for (int d = depth - 1; d >= 0; --d) {
+                    passed = (test(cond + d) == (pm.inequality_directions[cond + d] != 0));
+                    if (!passed) break;
+                }
+                if (passed) {
+                    apply(pm.values + static_cast<size_t>(leaf) * D);
+                    ++t;
+                    if (t < stop_tree) leaf = pm.tree_indices[t];
+                } else {
+                    ++leaf;
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j)
+            if (j < D) out[static_cast<size_t>(row) * D + j] = p[j];
+    }
+}
+
 inline int grid_for(size_t n, int bs, int cap) {
     size_t b = (n + bs - 1) / bs;
     if (b < 1) b = 1;
@@ -932,8 +1074,38 @@ void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chun
                        scale, acc);
 }
 
+template <int DMAX>
+static bool launch_predict_tiled(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n,
+                                 int start_tree, int stop_tree, float *out, hipStream_t s) {
+    if (F <= 0 || pm.n_opts > kPredMaxOpts) return false;
+    if (pm.max_depth > 256) return false;
+    const size_t budget = 159 * 1024;
+    const size_t vtree = pm.oblivious ? ((static_cast<size_t>(1) << pm.max_depth) * pm.D + 1 + 2 * pm.max_depth) * sizeof(float) : 0;
+    int R = 256;
+    while (R >= 64 && static_cast<size_t>(R) * (F + 1) * sizeof(float) + vtree > budget) R -= 64;
+    if (R < 64) return false;   // rows too wide for an LDS tile: the caller uses the direct kernel
+    int TT = 1;
+    if (pm.oblivious) {
+        TT = static_cast<int>((budget - static_cast<size_t>(R) * (F + 1) * sizeof(float)) / vtree);
+        if (TT > 64) TT = 64;
+        if (TT < 1) return false;
+    }
+    const size_t lds = static_cast<size_t>(R) * (F + 1) * sizeof(float) + static_cast<size_t>(pm.oblivious ? TT : 0) * vtree;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_tiled<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_predict_tiled<DMAX>, dim3((n + R - 1) / R), dim3(R), lds, s, pm, obs, F, cat_codes, Fc, n, start_tree,
+                       stop_tree, out, TT);
+    return true;
+}
+
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
              int stop_tree, float *out, hipStream_t s) {
+    if (pm.D <= 8) { if (launch_predict_tiled<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+    else if (pm.D <= 32) { if (launch_predict_tiled<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+    else { if (launch_predict_tiled<128>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     dim3 grid((n + 255) / 256), block(256);
     if (pm.D <= 8)
         hipLaunchKernelGGL(k_predict<8>, grid, block, 0, s, pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out);

@@ -135,7 +135,8 @@ __device__ __forceinline__ void classifyN(const uint32_t *e, int levels, const u
 constexpr int kCountThreads = 512;
 __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *__restrict__ kt, int n, int n_split,
                                                                const uint32_t *__restrict__ splitters, int chunk,
-                                                               uint32_t *__restrict__ partial /*[n_chunks][F][8192]*/) {
+                                                               uint32_t *__restrict__ partial /*[n_chunks][F][8192]*/,
+                                                               uint16_t *__restrict__ cls_out /*[F][n]: class of every key*/) {
     __shared__ uint32_t sp[kMaxSplit + 1];
     __shared__ uint32_t cnt[kClasses];
     const int f = blockIdx.y;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
     for (int i = threadIdx.x; i < kClasses; i += kCountThreads) cnt[i] = 0;
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    uint16_t *ccol = cls_out + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
     int levels = 0;
     while ((1 << levels) < n_split + 1) ++levels;
@@ -154,9 +156,16 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
         int cls[KQ];
         classifyN(sp, levels, k, cls);
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) atomicAdd(&cnt[cls[q]], 1u);
+        for (int q = 0; q < KQ; ++q) {
+            atomicAdd(&cnt[cls[q]], 1u);
+            ccol[i + q * kCountThreads] = static_cast<uint16_t>(cls[q]);
+        }
     }
-    for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, levels, col[i])], 1u);
+    for (; i < hi; i += kCountThreads) {
+        const int c = classify(sp, levels, col[i]);
+        atomicAdd(&cnt[c], 1u);
+        ccol[i] = static_cast<uint16_t>(c);
+    }
     __syncthreads();
     // per-chunk partials, plain coalesced stores (no global atomics); k_targets and k_extract sum them
     uint32_t *dst = partial + (static_cast<size_t>(blockIdx.x) * gridDim.y + f) * kClasses;
@@ -245,43 +254,53 @@ __global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ p
 }
 
 // ---- 5. extract -----------------------------------------------------------------------------------------------------
-// Second sweep over the column chunk.  The chunk's write position inside each list is known exactly from the partial
-// counts (list offset + counts of the earlier chunks), so ranks inside the block come from LDS cursors: no global atomics.
-__global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__restrict__ kt, int n, int n_split,
-                                                           const uint32_t *__restrict__ splitters, int chunk,
-                                                           const uint32_t *__restrict__ class_off,
+// Second sweep over the column chunk, driven by the classes stored by k_class_count (no search).  The chunk's write
+// position inside each list is known exactly from the partial counts (list offset + counts of the earlier chunks), so ranks
+// inside the block come from LDS cursors: no global atomics.
+__global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__restrict__ kt, const uint16_t *__restrict__ cls_in, int n,
+                                                           int chunk, const uint32_t *__restrict__ class_off,
                                                            const uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
-    __shared__ uint32_t sp[kMaxSplit + 1];
     __shared__ uint32_t cur[kClasses];
     const int f = blockIdx.y, F = gridDim.y;
-    for (int i = threadIdx.x; i < n_split; i += kCountThreads) sp[i] = splitters[static_cast<size_t>(f) * kMaxSplit + i];
-    for (int c = threadIdx.x; c < kClasses; c += kCountThreads) {
-        uint32_t off = class_off[static_cast<size_t>(f) * kClasses + c];
-        if (off < 0xfffffffeu)
-            for (unsigned q = 0; q < blockIdx.x; ++q) off += partial[(static_cast<size_t>(q) * F + f) * kClasses + c];
-        else off = 0xffffffffu;
-        cur[c] = off;
+    {   // cursor of every class = list offset + counts of the earlier chunks; all loads of a round are issued together
+        constexpr int PER = kClasses / kCountThreads;
+        uint32_t off[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) off[u] = class_off[static_cast<size_t>(f) * kClasses + threadIdx.x + u * kCountThreads];
+        for (unsigned q = 0; q < blockIdx.x; ++q) {
+            uint32_t add[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) add[u] = partial[(static_cast<size_t>(q) * F + f) * kClasses + threadIdx.x + u * kCountThreads];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) off[u] += add[u];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t base = class_off[static_cast<size_t>(f) * kClasses + threadIdx.x + u * kCountThreads];
+            cur[threadIdx.x + u * kCountThreads] = base < 0xfffffffeu ? off[u] : 0xffffffffu;
+        }
     }
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    const uint16_t *ccol = cls_in + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
-    int levels = 0;
-    while ((1 << levels) < n_split + 1) ++levels;
     int i = lo + threadIdx.x;
-    for (; i + (KQ - 1) * kCountThreads < hi; i += KQ * kCountThreads) {
-        uint32_t k[KQ];
+    for (; i + 7 * kCountThreads < hi; i += 8 * kCountThreads) {
+        // classes AND keys are loaded unconditionally up front (coalesced); a key load inside the divergent branch would
+        // serialise eight dependent HBM round trips per iteration
+        uint32_t c[8], k[8];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) k[q] = col[i + q * kCountThreads];
-        int cls[KQ];
-        classifyN(sp, levels, k, cls);
+        for (int q = 0; q < 8; ++q) { c[q] = ccol[i + q * kCountThreads]; k[q] = col[i + q * kCountThreads]; }
+        uint32_t w[8];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q)
-            if (cur[cls[q]] != 0xffffffffu) out[atomicAdd(&cur[cls[q]], 1u)] = k[q];
+        for (int q = 0; q < 8; ++q) w[q] = cur[c[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (w[q] != 0xffffffffu) out[atomicAdd(&cur[c[q]], 1u)] = k[q];
     }
     for (; i < hi; i += kCountThreads) {
-        const uint32_t key = col[i];
-        const int cls = classify(sp, levels, key);
-        if (cur[cls] != 0xffffffffu) out[atomicAdd(&cur[cls], 1u)] = key;
+        const uint32_t c = ccol[i];
+        if (cur[c] != 0xffffffffu) out[atomicAdd(&cur[c], 1u)] = col[i];
     }
 }
 
@@ -299,12 +318,27 @@ __global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lis
     const uint32_t *keys = lists + off;
     const uint32_t m = tgt_len[t], r = tgt_rank[t];
     uint32_t p = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t trial = p | (1u << bit);
-        uint32_t c = 0;
-        for (uint32_t i = lane; i < m; i += kWave) c += keys[i] < trial ? 1u : 0u;
-        for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
-        if (c < r) p = trial;
+    constexpr int R = 16;            // lists up to 64*R keys are held in registers for the 32 bisection steps
+    if (m <= kWave * R) {
+        uint32_t k[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) k[q] = (lane + q * kWave) < m ? keys[lane + q * kWave] : 0xffffffffu;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = p | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) c += k[q] < trial ? 1u : 0u;   // pads (max key) are never < trial... unless trial is max: excluded below
+            for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+            if (c < r) p = trial;
+        }
+    } else {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = p | (1u << bit);
+            uint32_t c = 0;
+            for (uint32_t i = lane; i < m; i += kWave) c += keys[i] < trial ? 1u : 0u;
+            for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+            if (c < r) p = trial;
+        }
     }
     if (lane == 0) thr_keys[t] = p;
 }
@@ -393,8 +427,9 @@ void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, u
     hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters, splitters_bfs);
 }
 
-void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, hipStream_t s) {
-    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, partial);
+void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, uint16_t *cls,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, partial, cls);
 }
 
 void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
@@ -404,10 +439,9 @@ void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const 
                        tgt_rank, thr_keys, alloc, max_elems, overflow);
 }
 
-void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const uint32_t *class_off,
+void quantile_extract(const uint32_t *kt, const uint16_t *cls, int n, int F, const QuantilePlan &p, const uint32_t *class_off,
                       const uint32_t *partial, uint32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, class_off,
-                       partial, out);
+    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, cls, n, p.chunk, class_off, partial, out);
 }
 
 void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
