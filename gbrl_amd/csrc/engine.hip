@@ -101,7 +101,10 @@ void Engine::ensure_device() {
 }
 
 void Engine::set_collective(const gbrl_hip_collective *hooks) {
-    if (hooks == nullptr || hooks->world_size <= 1) {
+    // world_size 1 normally means "no exchange"; GBRL_HIP_FORCE_COLLECTIVE=1 keeps the hooks installed anyway so that the
+    // sharded code path (hook calls, stream hand-over, no sibling subtraction, counting quantiles) can be tested on ONE GPU
+    const char *force = std::getenv("GBRL_HIP_FORCE_COLLECTIVE");
+    if (hooks == nullptr || (hooks->world_size <= 1 && !(force && force[0] == '1'))) {
         has_coll_ = false;
         return;
     }

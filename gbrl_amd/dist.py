@@ -83,5 +83,4 @@ def install_torch_collective(model, device, group=None) -> TorchCollective:
     rc = lib.gbrl_hip_set_collective(C.c_void_p(model._handle()), C.byref(coll.struct))
     if rc != 0:
         raise RuntimeError(lib.gbrl_hip_last_error().decode())
-    model._collective = coll if hasattr(model, "__dict__") else None
-    return coll
+    return coll   # the caller must keep this object alive for as long as the model may call the hooks

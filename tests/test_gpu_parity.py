@@ -212,3 +212,29 @@ def test_fast_quantile_path_equals_bisection_path(monkeypatch):
         outs.append({k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS})
     for k in K.ENSEMBLE_KEYS:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_sharded_code_path_on_one_gpu(monkeypatch):
+    """The row-sharded path of step() (collective hooks at every exchange point, counting quantiles, every node accumulated)
+    run with world_size 1 through torch.distributed/RCCL on the real device pointers: must give the single-GPU tree."""
+    import torch
+    import torch.distributed as dist
+    import gbrl_amd
+    from gbrl_amd.dist import install_torch_collective
+    case, g, (X, Xc, G, y) = load_golden("obl_l2_q_d6")
+    m0, p0 = _run_product(case, X, Xc, G, y, "cpu")
+    monkeypatch.setenv("GBRL_HIP_FORCE_COLLECTIVE", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        m1 = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+        coll = install_torch_collective(m1, torch.device("cuda:0"))
+        p1 = np.asarray(K.drive(m1, case, X, Xc, G, y))
+        assert coll.calls > 50 and coll.bytes > 0
+    finally:
+        dist.destroy_process_group()
+    e0, e1 = m0.get_ensemble_data(), m1.get_ensemble_data()
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(np.asarray(e0[k]), np.asarray(e1[k])), k
+    assert np.array_equal(p0, p1)
