@@ -424,11 +424,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 hip_check(hipMemsetAsync(d_coff, 0xff, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
                 hip_check(hipMemsetAsync(d_qflags, 0, sizeof(uint32_t) * 4, s), "memset");
                 kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
-                uint16_t *d_cls = static_cast<uint16_t *>(d_kcls_.ensure(sizeof(uint16_t) * static_cast<size_t>(N) * F));
-                kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, d_cls, s);
+                kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
                 kern::quantile_targets(d_cc, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
                                        d_qflags + 2, s);
-                kern::quantile_extract(d_kt, d_cls, N, F, plan, d_coff, d_cc, d_lists, s);
+                kern::quantile_extract(d_kt, N, F, plan, d_split_bfs, d_coff, d_cc, d_lists, s);
                 kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
             }
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);

@@ -75,12 +75,12 @@ void transpose_keys(const float *obs, int n, int F, uint32_t *kt /*[F][n]*/, hip
 void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters /*[F][4095] sorted*/,
                       uint32_t *splitters_bfs /*[F][4095] breadth-first order, used by the searches*/, hipStream_t s);
 void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters_bfs,
-                 uint32_t *partial /*[n_chunks][F][8192]*/, uint16_t *cls /*[F][n] class of every key*/, hipStream_t s);
+                 uint32_t *partial /*[n_chunks][F][8192]*/, hipStream_t s);
 void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
                       uint32_t *class_off /*[F][8192], preset 0xff*/, uint32_t *tgt_off, uint32_t *tgt_len, uint32_t *tgt_rank,
                       uint32_t *thr_keys, uint32_t *alloc /*[1], zeroed*/, uint32_t max_elems, uint32_t *overflow /*zeroed*/,
                       hipStream_t s);
-void quantile_extract(const uint32_t *kt, const uint16_t *cls, int n, int F, const QuantilePlan &p, const uint32_t *class_off,
+void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters_bfs, const uint32_t *class_off,
                       const uint32_t *partial, uint32_t *out, hipStream_t s);
 void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
                      uint32_t *thr_keys, hipStream_t s);

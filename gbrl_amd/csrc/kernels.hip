@@ -297,16 +297,22 @@ template <int DT, int U>
 __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
                                                               const int32_t *__restrict__ qg, int D_rt,
                                                               const int32_t *__restrict__ rows,
-                                                              const Chunk *__restrict__ chunks, int FG, int fg_shift,
-                                                              int NB, int32_t *__restrict__ partials) {
+                                                              const Chunk *__restrict__ chunks, int n_chunks, int n_groups,
+                                                              int FG, int fg_shift, int NB, int32_t *__restrict__ partials) {
     extern __shared__ int32_t h[];
     const int D = DT ? DT : D_rt;
     if (DT) { FG = 16; fg_shift = 4; }
+    // XCD-aware block -> (chunk, group) map: the blocks that share a chunk (one per feature group) re-read the same rows'
+    // gradients and row ids.  Block b runs on XCD b % 8 (observed; used for speed only), so all groups of a chunk are
+    // given ids that are congruent mod 8 and adjacent in launch order: the re-reads are served by that XCD's L2.
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int g = jj % n_groups;
+    const int chunk_id = (jj / n_groups) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
     const int n_acc = NB * (D + 1) * FG;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
     __syncthreads();
-    const Chunk ck = chunks[blockIdx.x];
-    const int g = blockIdx.y;
+    const Chunk ck = chunks[chunk_id];
     const int fl = threadIdx.x & (FG - 1);
     const int slot = threadIdx.x >> fg_shift;
     const int n_slots = kHistThreads >> fg_shift;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
         }
     }
     __syncthreads();
-    int32_t *out = partials + (static_cast<size_t>(blockIdx.x) * gridDim.y + g) * n_acc;
+    int32_t *out = partials + (static_cast<size_t>(chunk_id) * n_groups + g) * n_acc;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) out[i] = h[i];
 }
 
@@ -988,8 +994,9 @@ static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, in
                                   160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_hist_build<DT, U>), dim3(n_chunks, n_groups), dim3(kHistThreads), lds, s, codes, n_rows, qg, D, rows,
-                       chunks, FG, shift, NB, partials);
+    const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
+    hipLaunchKernelGGL((k_hist_build<DT, U>), dim3(grid), dim3(kHistThreads), lds, s, codes, n_rows, qg, D, rows, chunks, n_chunks,
+                       n_groups, FG, shift, NB, partials);
 }
 
 void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,

@@ -135,8 +135,7 @@ __device__ __forceinline__ void classifyN(const uint32_t *e, int levels, const u
 constexpr int kCountThreads = 512;
 __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *__restrict__ kt, int n, int n_split,
                                                                const uint32_t *__restrict__ splitters, int chunk,
-                                                               uint32_t *__restrict__ partial /*[n_chunks][F][8192]*/,
-                                                               uint16_t *__restrict__ cls_out /*[F][n]: class of every key*/) {
+                                                               uint32_t *__restrict__ partial /*[n_chunks][F][8192]*/) {
     __shared__ uint32_t sp[kMaxSplit + 1];
     __shared__ uint32_t cnt[kClasses];
     const int f = blockIdx.y;
@@ -144,7 +143,6 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
     for (int i = threadIdx.x; i < kClasses; i += kCountThreads) cnt[i] = 0;
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
-    uint16_t *ccol = cls_out + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
     int levels = 0;
     while ((1 << levels) < n_split + 1) ++levels;
@@ -156,16 +154,9 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
         int cls[KQ];
         classifyN(sp, levels, k, cls);
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            atomicAdd(&cnt[cls[q]], 1u);
-            ccol[i + q * kCountThreads] = static_cast<uint16_t>(cls[q]);
-        }
+        for (int q = 0; q < KQ; ++q) atomicAdd(&cnt[cls[q]], 1u);
     }
-    for (; i < hi; i += kCountThreads) {
-        const int c = classify(sp, levels, col[i]);
-        atomicAdd(&cnt[c], 1u);
-        ccol[i] = static_cast<uint16_t>(c);
-    }
+    for (; i < hi; i += kCountThreads) atomicAdd(&cnt[classify(sp, levels, col[i])], 1u);
     __syncthreads();
     // per-chunk partials, plain coalesced stores (no global atomics); k_targets and k_extract sum them
     uint32_t *dst = partial + (static_cast<size_t>(blockIdx.x) * gridDim.y + f) * kClasses;
@@ -254,14 +245,17 @@ __global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ p
 }
 
 // ---- 5. extract -----------------------------------------------------------------------------------------------------
-// Second sweep over the column chunk, driven by the classes stored by k_class_count (no search).  The chunk's write
-// position inside each list is known exactly from the partial counts (list offset + counts of the earlier chunks), so ranks
-// inside the block come from LDS cursors: no global atomics.
-__global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__restrict__ kt, const uint16_t *__restrict__ cls_in, int n,
-                                                           int chunk, const uint32_t *__restrict__ class_off,
+// Second sweep over the column chunk (same search).  The chunk's write position inside each list is known exactly from the
+// partial counts (list offset + counts of the earlier chunks), so ranks inside the block come from LDS cursors: no global
+// atomics.  (Storing the classes in pass 3 to skip this search was tried: the extra 256 MiB write cost more than it saved.)
+__global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__restrict__ kt, int n, int n_split,
+                                                           const uint32_t *__restrict__ splitters, int chunk,
+                                                           const uint32_t *__restrict__ class_off,
                                                            const uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
+    __shared__ uint32_t sp[kMaxSplit + 1];
     __shared__ uint32_t cur[kClasses];
     const int f = blockIdx.y, F = gridDim.y;
+    for (int i = threadIdx.x; i < n_split; i += kCountThreads) sp[i] = splitters[static_cast<size_t>(f) * kMaxSplit + i];
     {   // cursor of every class = list offset + counts of the earlier chunks; all loads of a round are issued together
         constexpr int PER = kClasses / kCountThreads;
         uint32_t off[PER];
@@ -282,25 +276,24 @@ __global__ __launch_bounds__(kCountThreads) void k_extract(const uint32_t *__res
     }
     __syncthreads();
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
-    const uint16_t *ccol = cls_in + static_cast<size_t>(f) * n;
     const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    int levels = 0;
+    while ((1 << levels) < n_split + 1) ++levels;
     int i = lo + threadIdx.x;
-    for (; i + 7 * kCountThreads < hi; i += 8 * kCountThreads) {
-        // classes AND keys are loaded unconditionally up front (coalesced); a key load inside the divergent branch would
-        // serialise eight dependent HBM round trips per iteration
-        uint32_t c[8], k[8];
+    for (; i + (KQ - 1) * kCountThreads < hi; i += KQ * kCountThreads) {
+        uint32_t k[KQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { c[q] = ccol[i + q * kCountThreads]; k[q] = col[i + q * kCountThreads]; }
-        uint32_t w[8];
+        for (int q = 0; q < KQ; ++q) k[q] = col[i + q * kCountThreads];
+        int cls[KQ];
+        classifyN(sp, levels, k, cls);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = cur[c[q]];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (w[q] != 0xffffffffu) out[atomicAdd(&cur[c[q]], 1u)] = k[q];
+        for (int q = 0; q < KQ; ++q)
+            if (cur[cls[q]] != 0xffffffffu) out[atomicAdd(&cur[cls[q]], 1u)] = k[q];
     }
     for (; i < hi; i += kCountThreads) {
-        const uint32_t c = ccol[i];
-        if (cur[c] != 0xffffffffu) out[atomicAdd(&cur[c], 1u)] = col[i];
+        const uint32_t key = col[i];
+        const int cls = classify(sp, levels, key);
+        if (cur[cls] != 0xffffffffu) out[atomicAdd(&cur[cls], 1u)] = key;
     }
 }
 
@@ -427,9 +420,8 @@ void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, u
     hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters, splitters_bfs);
 }
 
-void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, uint16_t *cls,
-                 hipStream_t s) {
-    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, partial, cls);
+void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, hipStream_t s) {
+    hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, partial);
 }
 
 void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
@@ -439,9 +431,10 @@ void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const 
                        tgt_rank, thr_keys, alloc, max_elems, overflow);
 }
 
-void quantile_extract(const uint32_t *kt, const uint16_t *cls, int n, int F, const QuantilePlan &p, const uint32_t *class_off,
+void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const uint32_t *class_off,
                       const uint32_t *partial, uint32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, cls, n, p.chunk, class_off, partial, out);
+    hipLaunchKernelGGL(k_extract, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, class_off,
+                       partial, out);
 }
 
 void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
