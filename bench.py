@@ -34,12 +34,17 @@ def hist_algorithmic_bytes(n_rows, n_feat, out_dim, depth, n_bins):
     return depth * per_level_read + ((1 << depth) - 1) * hist
 
 
-def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows):
+def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows, budget_s=15.0):
     """Reference CPU path on a bounded sample of the same workload (rows only are reduced).  Cost of the reference's
     brute-force scan is linear in the row count (depth * N * candidates * (1 + D)), so trees/s at the full batch is
-    the sample's trees/s * sample_rows / full_rows."""
+    the sample's trees/s * sample_rows / full_rows.  sample_rows <= 0: probe with 2048 rows, then size the sample for
+    about `budget_s` seconds of wall time on this host."""
     import numpy as np
     import oracle
+    if sample_rows <= 0:
+        probe = cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, 2048)
+        rows = int(2048 * budget_s / max(probe["sample_seconds"], 1e-3))
+        sample_rows = max(4096, min(full_rows, 1 << (rows.bit_length() - 1)))
     rng = np.random.default_rng(0)
     X = rng.standard_normal((sample_rows, n_feat)).astype(np.float32)
     W = rng.standard_normal((8, out_dim)).astype(np.float32)
@@ -62,7 +67,7 @@ def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows):
     t1 = time.perf_counter()
     m.predict(X, None, 0, 0)
     dtp = time.perf_counter() - t1
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return {"value": (1.0 / dt) * sample_rows / full_rows, "unit": "trees/s at batch=2^20 (extrapolated linearly in rows)",
             "cores": cores, "kind": kind,
             "sample": "1 tree on %d of %d rows (same F=%d, D=%d, depth=%d, n_bins=%d): %.2f s; predict 1 tree %.3f s" % (
@@ -81,7 +86,7 @@ def main():
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=8192)
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0: size the CPU sample for ~15 s on this host")
     ap.add_argument("--predict-trees", type=int, default=0, help="0: predict over the ensemble grown by the bench")
     args = ap.parse_args()
 
@@ -169,7 +174,15 @@ def main():
         hist_ms = (phase_acc.get("hist_build", 0.0) + phase_acc.get("hist_reduce", 0.0)) / steps
         build_ms = phase_acc.get("hist_build", 0.0) / steps
         alg = hist_algorithmic_bytes(N, F, D, depth, B)
-        achieved = alg / (hist_ms * 1e-3) / 1e9 if hist_ms > 0 else 0.0
+        # dominant kernel = k_hist_build: `depth` launches per tree; per-launch figures are the per-tree ones / depth
+        achieved = alg / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hist_traffic.json")
+        if os.path.exists(tpath):   # HBM bytes per launch from the committed rocprofv3 PMC passes (scripts/pmc_summary.py)
+            try:
+                traffic = json.load(open(tpath))["bytes_per_launch"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "trees-fit/sec + predict rows/sec at batch=2^20, feat=128, depth=6, out=8",
             "value": steps * world * (N / float(1 << 20)) / dt,
@@ -182,10 +195,14 @@ def main():
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
                         "row_trees_per_s": world * N * n_trees / dtp},
             "phases_ms_per_step": {k: v / steps for k, v in sorted(phase_acc.items())},
-            "roofline": {"bound": "hbm", "kernel": "k_hist_build (+k_hist_reduce), 6 launches per tree",
+            "roofline": {"bound": "hbm", "kernel": "k_hist_build (split-score histogram build), %d launches per tree" % depth,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_tree": alg, "hist_ms_per_tree": hist_ms,
-                         "hist_build_ms_per_tree": build_ms},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg / depth,
+                         "avg_launch_us": build_ms * 1e3 / depth, "launches_per_tree": depth,
+                         "algorithmic_bytes_per_tree": alg, "hist_build_ms_per_tree": build_ms,
+                         "hist_build_plus_reduce_ms_per_tree": hist_ms,
+                         "frac_including_reduce": (alg / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hist_ms > 0 else 0.0,
+                         "note": "LDS-atomic-issue bound in practice: 9 ds_add_u32 per (row, feature); see DESIGN.md section 5"},
         }
         if not args.no_cpu_baseline:
             try:

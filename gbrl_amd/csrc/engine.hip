@@ -405,11 +405,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             const long long per = n_global / (B + 1), rem = n_global % (B + 1);
             long long run = 0;
             for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
-            if (has_coll_ || force_bisection_) {
+            // sharded fast path needs a power-of-two world (union sample of world*4096 keys sorted in LDS)
+            const bool coll_fast = has_coll_ && (coll_.world_size & (coll_.world_size - 1)) == 0 && coll_.world_size <= 8;
+            if (force_bisection_ || (has_coll_ && !coll_fast)) {
                 bisection_quantiles(cum);
             } else {
                 fast_quantile = true;
-                const kern::QuantilePlan plan = kern::quantile_plan(N);
+                kern::QuantilePlan plan = kern::quantile_plan(N);
+                if (has_coll_) { plan.sample = 4096; plan.n_split = kern::kQuantileMaxSplit; }   // identical on every rank
                 const uint32_t max_elems = static_cast<uint32_t>(std::min<size_t>(static_cast<size_t>(N) * F, std::max<size_t>(1u << 20, static_cast<size_t>(N) * F / 4)));
                 int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
                 hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
@@ -423,12 +426,44 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 uint32_t *d_lists = static_cast<uint32_t *>(d_qlists_.ensure(sizeof(uint32_t) * max_elems));
                 hip_check(hipMemsetAsync(d_coff, 0xff, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
                 hip_check(hipMemsetAsync(d_qflags, 0, sizeof(uint32_t) * 4, s), "memset");
-                kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
-                kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
-                kern::quantile_targets(d_cc, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
+                int64_t *d_gcounts = nullptr;
+                if (has_coll_) {
+                    // every rank contributes a 4096-key sample per feature; the union is sorted identically everywhere
+                    const int S = 4096, SU = S * coll_.world_size;
+                    uint32_t *d_samp = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * static_cast<size_t>(F) * S));
+                    int64_t *d_uni = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * std::max<size_t>(static_cast<size_t>(F) * SU, static_cast<size_t>(F) * kern::kQuantileClasses)));
+                    kern::sample_only(d_kt, N, F, S, d_samp, s);
+                    hip_check(hipMemsetAsync(d_uni, 0, sizeof(int64_t) * static_cast<size_t>(F) * SU, s), "memset");
+                    kern::place_sample(d_samp, F, S, coll_.rank, SU, d_uni, s);
+                    hip_check(hipStreamSynchronize(s), "sync");
+                    if (coll_.allreduce_sum_i64(coll_.ctx, d_uni, static_cast<size_t>(F) * SU) != 0) throw HipError("allreduce failed");
+                    kern::union_splitters(d_uni, F, SU, plan.n_split, d_split, d_split_bfs, s);
+                    kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
+                    d_gcounts = d_uni;   // reuse (the union sample is consumed)
+                    kern::counts_to_i64(d_cc, plan.n_chunks, static_cast<size_t>(F) * kern::kQuantileClasses, d_gcounts, s);
+                    hip_check(hipStreamSynchronize(s), "sync");
+                    if (coll_.allreduce_sum_i64(coll_.ctx, d_gcounts, static_cast<size_t>(F) * kern::kQuantileClasses) != 0) throw HipError("allreduce failed");
+                } else {
+                    kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
+                    kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
+                }
+                kern::quantile_targets(d_cc, d_gcounts, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
                                        d_qflags + 2, s);
                 kern::quantile_extract(d_kt, N, F, plan, d_split_bfs, d_coff, d_cc, d_lists, s);
-                kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
+                if (has_coll_) {
+                    // the lists stay on their ranks; the order statistic of their union is found by 32 counting rounds
+                    uint32_t *d_pref = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * static_cast<size_t>(F) * B));
+                    int64_t *d_scnt = static_cast<int64_t *>(d_selcnt_.ensure(sizeof(int64_t) * (static_cast<size_t>(F) * B + 1)));
+                    hip_check(hipMemsetAsync(d_pref, 0, sizeof(uint32_t) * static_cast<size_t>(F) * B, s), "memset");
+                    for (int bit = 31; bit >= 0; --bit) {
+                        kern::select_count(d_lists, d_toff, d_tlen, d_pref, bit, F * B, d_scnt, s);
+                        hip_check(hipStreamSynchronize(s), "sync");
+                        if (coll_.allreduce_sum_i64(coll_.ctx, d_scnt, static_cast<size_t>(F) * B) != 0) throw HipError("allreduce failed");
+                        kern::select_update(d_pref, d_scnt, d_toff, d_tr, bit, F * B, d_thrkeys, s);
+                    }
+                } else {
+                    kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
+                }
             }
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
         }
@@ -437,6 +472,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         if (fast_quantile) {
             hip_check(hipMemcpyAsync(qflags, d_qflags, sizeof(qflags), hipMemcpyDeviceToHost, s), "D2H flags");
             hip_check(hipStreamSynchronize(s), "sync");
+            if (has_coll_) {   // the fallback decision must be the same on every rank
+                int64_t *d_flag = static_cast<int64_t *>(d_selcnt_.ensure(sizeof(int64_t) * 2));
+                int64_t hv = qflags[2];
+                hip_check(hipMemcpy(d_flag, &hv, sizeof(hv), hipMemcpyHostToDevice), "H2D flag");
+                if (coll_.allreduce_sum_i64(coll_.ctx, d_flag, 1) != 0) throw HipError("allreduce failed");
+                hip_check(hipMemcpy(&hv, d_flag, sizeof(hv), hipMemcpyDeviceToHost), "D2H flag");
+                qflags[2] = hv != 0;
+            }
             if (qflags[2] != 0) {  // a class list outgrew its budget (pathological value distribution): redo exactly, slowly
                 bisection_quantiles(cum);
                 kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
@@ -633,12 +676,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // -- histograms.  Level 0: the root.  Deeper levels: of every sibling pair only the child with fewer rows is
         //    accumulated from the data; the other one is parent - sibling (exact integers), which halves the LDS-atomic work.
         //    (Row-sharded runs accumulate every node: the "smaller" child differs per rank.)
-        int64_t *d_hist_local = d_hist_lvl[depth & 1];
+        //    The level buffers hold GLOBAL histograms.  Row-sharded runs pick the "smaller" child by its global row count (the
+        //    same on every rank), all-reduce only those children and subtract globally.
+        int64_t *d_hist = d_hist_lvl[depth & 1];
         const int64_t *d_hist_prev = d_hist_lvl[(depth & 1) ^ 1];
-        int64_t *d_hist = has_coll_ ? d_hist_coll : d_hist_local;
         std::vector<int> compute_ids;
         std::vector<int32_t> slot_map, sub_entries;
-        if (depth == 0 || has_coll_) {
+        if (depth == 0) {
             compute_ids = active;
             for (int k = 0; k < n_act; ++k) slot_map.push_back(k);
         } else {
@@ -649,8 +693,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 const int sib = nodes[par].left == id ? nodes[par].right : nodes[par].left;
                 const bool sib_active = slot_of[sib] >= 0;
                 // the child that is accumulated: fewer local rows; ties -> the left child
-                const bool i_am_small = sib_active && (nodes[id].n_local < nodes[sib].n_local ||
-                                                       (nodes[id].n_local == nodes[sib].n_local && nodes[par].left == id));
+                const long long mine = has_coll_ ? nodes[id].n_global : nodes[id].n_local;
+                const long long theirs = has_coll_ ? nodes[sib].n_global : nodes[sib].n_local;
+                const bool i_am_small = sib_active && (mine < theirs || (mine == theirs && nodes[par].left == id));
                 if (i_am_small) {
                     compute_ids.push_back(id);
                     slot_map.push_back(k);
@@ -662,6 +707,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             }
         }
         for (int k = 0; k < n_act; ++k) nodes[active[k]].hist_slot = k;
+        // chunk table of ALL active nodes (row-sharded runs count the local child sizes from the rows themselves)
+        std::vector<Chunk> count_chunks;
+        if (has_coll_) { make_chunks(active, kern::kPartitionRows, false); count_chunks = h_chunks; }
         make_chunks(compute_ids, chunk_rows, false);
         if (h_chunks.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: chunk table overflow");
         // paths (duplicate-on-path rejection, node.cpp:154-166)
@@ -687,29 +735,43 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         float *d_path_val = sta.put(pv.data(), pv.size());
         int32_t *d_path_bin = sta.put(pb.data(), pb.size());
         int32_t *d_isroot = sta.put(root.data(), root.size());
+        Chunk *d_count_chunks = sta.put(count_chunks.data(), count_chunks.size());
         sta.flush();
         phase_begin();
         if (!h_chunks.empty())
             kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
         phase_end("hist_build");
         phase_begin();
-        if (!compute_ids.empty())
-            kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist_local, s);
-        if (!sub_entries.empty())
-            kern::hist_subtract(d_hist_prev, d_hist_local, d_subent, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
-        phase_end("hist_reduce");
-        if (has_coll_) {
-            hip_check(hipMemcpyAsync(d_hist, d_hist_local, sizeof(int64_t) * n_act * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist");
+        if (!has_coll_) {
+            if (!compute_ids.empty())
+                kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s);
+        } else if (!compute_ids.empty()) {
+            // local sums of the computed nodes, contiguous -> ONE all-reduce -> placed into their level slots
+            const int nc = static_cast<int>(compute_ids.size());
+            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s);
             hip_check(hipStreamSynchronize(s), "sync");
-            if (coll_.allreduce_sum_i64(coll_.ctx, d_hist, static_cast<size_t>(n_act) * hist_node_elems) != 0) throw HipError("allreduce failed");
+            if (coll_.allreduce_sum_i64(coll_.ctx, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems) != 0) throw HipError("allreduce failed");
+            for (int k = 0; k < nc; ++k)
+                hip_check(hipMemcpyAsync(d_hist + static_cast<size_t>(slot_map[k]) * hist_node_elems, d_hist_coll + static_cast<size_t>(k) * hist_node_elems,
+                                         sizeof(int64_t) * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist slot");
         }
+        if (!sub_entries.empty())
+            kern::hist_subtract(d_hist_prev, d_hist, d_subent, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
+        phase_end("hist_reduce");
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
         kern::score_candidates(d_hist, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                1.0 / scale, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
-        kern::resolve_splits(d_best_idx, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist_local,
-                             has_coll_ ? d_hist : nullptr, Fp, NB, D, d_resolved, d_counts4, max_front, s);
+        // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
+        kern::resolve_splits(d_best_idx, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+                             d_counts4, max_front, s);
+        if (has_coll_) {
+            int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
+            hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
+            if (!count_chunks.empty())
+                kern::count_right(d_rows[cur], d_codes, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
+        }
         hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
         phase_end("score_select");
         hip_check(hipStreamSynchronize(s), "sync");
@@ -717,8 +779,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         const int32_t *best_idx_h = reinterpret_cast<const int32_t *>(h_res);
         const float *best_score_h = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
         const int64_t *cnt4 = reinterpret_cast<const int64_t *>(h_res + 8 * static_cast<size_t>(max_front));
-        const int64_t *tot_l = cnt4, *right_l = cnt4 + max_front;
-        const int64_t *right_g = has_coll_ ? cnt4 + 3 * static_cast<size_t>(max_front) : right_l;
+        const int64_t *tot_g = cnt4, *right_g = cnt4 + max_front;
+        const int64_t *right_l = has_coll_ ? cnt4 + 2 * static_cast<size_t>(max_front) : right_g;
         if (oblivious && best_score_h[0] == -INFINITY) break;  // fitter.cpp:458
         // -- decisions (best_idx are REFERENCE candidate indices)
         std::vector<NodeSplit> sp(n_act);
@@ -749,7 +811,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         std::vector<int> next;
         for (int k : splitting) {
             const int id = active[k];
-            if (tot_l[k] != nodes[id].n_local) throw HipError("internal: histogram row count mismatch");
+            if (tot_g[k] != nodes[id].n_global) throw HipError("internal: histogram row count mismatch");
             const NodeSplit &q = sp[k];
             HCond c{};
             c.fslot = q.fslot;
@@ -779,7 +841,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             cr.edge_w = npar > 0 ? static_cast<float>(nr) / static_cast<float>(npar) : 0.0f;
             l.path.push_back(cl);
             r.path.push_back(cr);
-            const int nl_local = static_cast<int>(tot_l[k] - right_l[k]);
+            const int nl_local = static_cast<int>(nodes[id].n_local - right_l[k]);
             l.seg_start = nodes[id].seg_start;
             l.n_local = nl_local;
             l.n_global = nl;

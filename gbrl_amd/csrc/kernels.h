@@ -76,10 +76,20 @@ void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, u
                       uint32_t *splitters_bfs /*[F][4095] breadth-first order, used by the searches*/, hipStream_t s);
 void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters_bfs,
                  uint32_t *partial /*[n_chunks][F][8192]*/, hipStream_t s);
-void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
-                      uint32_t *class_off /*[F][8192], preset 0xff*/, uint32_t *tgt_off, uint32_t *tgt_len, uint32_t *tgt_rank,
-                      uint32_t *thr_keys, uint32_t *alloc /*[1], zeroed*/, uint32_t max_elems, uint32_t *overflow /*zeroed*/,
-                      hipStream_t s);
+// global_counts (nullable): all-reduced class counts of a row-sharded run -- ranks come from them, list lengths stay local
+void quantile_targets(const uint32_t *partial, const int64_t *global_counts, const uint32_t *splitters, const int64_t *cum, int F, int B,
+                      const QuantilePlan &p, uint32_t *class_off /*[F][8192], preset 0xff*/, uint32_t *tgt_off, uint32_t *tgt_len,
+                      uint32_t *tgt_rank, uint32_t *thr_keys, uint32_t *alloc /*[1], zeroed*/, uint32_t max_elems,
+                      uint32_t *overflow /*zeroed*/, hipStream_t s);
+// row-sharded selection: raw local sample -> exchange -> identical splitters on every rank; bisection on the extracted lists
+void sample_only(const uint32_t *kt, int n, int F, int S, uint32_t *sample_out /*[F][S]*/, hipStream_t s);
+void place_sample(const uint32_t *samp, int F, int S, int rank, int SU, int64_t *uni /*[F][SU], zeroed*/, hipStream_t s);
+void union_splitters(const int64_t *uni, int F, int SU, int n_split, uint32_t *splitters, uint32_t *splitters_bfs, hipStream_t s);
+void counts_to_i64(const uint32_t *partial, int n_chunks, size_t fc, int64_t *out, hipStream_t s);
+void select_count(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *prefix, int bit, int n_targets,
+                  int64_t *counts, hipStream_t s);
+void select_update(uint32_t *prefix, const int64_t *counts, const uint32_t *tgt_off, const uint32_t *tgt_rank, int bit, int n_targets,
+                   uint32_t *thr_keys, hipStream_t s);
 void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters_bfs, const uint32_t *class_off,
                       const uint32_t *partial, uint32_t *out, hipStream_t s);
 void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
@@ -117,6 +127,10 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
 void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global /*nullable*/, int Fp, int NB, int D,
                     NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front, hipStream_t s);
+
+// rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
+void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
+                 int64_t *n_right /*[n_nodes], zeroed*/, hipStream_t s);
 
 // ---- partition (A9) ----
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows,

@@ -664,6 +664,28 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__res
     }
 }
 
+__global__ __launch_bounds__(kPartThreads) void k_count_right(const int32_t *__restrict__ rows, const uint16_t *__restrict__ codes,
+                                                              int n_rows, const Chunk *__restrict__ chunks,
+                                                              const NodeSplit *__restrict__ splits, int64_t *__restrict__ n_right) {
+    const Chunk ck = chunks[blockIdx.x];
+    const NodeSplit sp = splits[ck.slot];
+    const uint16_t *cbase = codes + (static_cast<size_t>(sp.fslot >> 4) * n_rows) * kCodeGroup + (sp.fslot & (kCodeGroup - 1));
+    int c = 0;
+    for (int p = threadIdx.x; p < ck.len; p += kPartThreads) {
+        const int code = cbase[static_cast<size_t>(rows[ck.start + p]) * kCodeGroup];
+        c += (sp.is_cat ? (code == sp.bin) : (code > sp.bin)) ? 1 : 0;
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+    __shared__ int wsum[kPartThreads / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tot = 0;
+        for (int w = 0; w < kPartThreads / kWave; ++w) tot += wsum[w];
+        if (tot) atomicAdd(reinterpret_cast<unsigned long long *>(&n_right[ck.slot]), static_cast<unsigned long long>(tot));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // A11  leaf sums of RAW gradients (fixed-point int64, exact) + counts.  acc[leaf][0..D) sums, acc[leaf][D] count.
 // ------------------------------------------------------------------------------------------------------------
@@ -1066,6 +1088,11 @@ void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const 
                     NodeSplit *out, int64_t *counts4, int max_front, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, best_idx, oblivious ? 1 : 0, ref_to_internal, cand_slot, slots,
                        hist_local, hist_global, Fp, NB, D, out, counts4, max_front);
+}
+
+void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
+                 int64_t *n_right, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_right, dim3(n_chunks), dim3(kPartThreads), 0, s, rows, codes, n_rows, chunks, splits, n_right);
 }
 
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows, const Chunk *chunks,

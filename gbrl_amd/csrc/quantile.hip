@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_transpose_keys(const float *__restrict_
 
 // ---- 2. sample + sort + splitters ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__restrict__ kt, int n, int S, int n_split,
-                                                           uint32_t *__restrict__ splitters, uint32_t *__restrict__ splitters_bfs) {
+                                                           uint32_t *__restrict__ splitters, uint32_t *__restrict__ splitters_bfs,
+                                                           uint32_t *__restrict__ sample_out /*nullable: write the raw sample, no sort*/) {
     extern __shared__ uint32_t s[];  // [S], S power of two
     const int f = blockIdx.x;
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
@@ -67,6 +68,10 @@ __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__res
         }
     }
     __syncthreads();
+    if (sample_out) {   // sharded runs: the ranks exchange their raw samples and sort the union (k_union_splitters)
+        for (int i = threadIdx.x; i < S; i += blockDim.x) sample_out[static_cast<size_t>(f) * S + i] = s[i];
+        return;
+    }
     for (int k = 2; k <= S; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < S; i += blockDim.x) {
@@ -93,6 +98,81 @@ __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__res
         const int q = ((2 * pp + 1) << (levels - 1 - L)) - 1;
         splitters_bfs[static_cast<size_t>(f) * kMaxSplit + i] = s[(q + 1) * step - 1];
     }
+}
+
+// Sharded runs: sort the union of all ranks' samples ([F][SU] int64 after the exchange, SU a power of two <= 32768) and
+// take every (SU / (n_split+1))-th key: every rank computes the identical splitter set.
+__global__ __launch_bounds__(1024) void k_union_splitters(const int64_t *__restrict__ uni, int SU, int n_split,
+                                                          uint32_t *__restrict__ splitters, uint32_t *__restrict__ splitters_bfs) {
+    extern __shared__ uint32_t s[];
+    const int f = blockIdx.x;
+    for (int i = threadIdx.x; i < SU; i += blockDim.x) s[i] = static_cast<uint32_t>(uni[static_cast<size_t>(f) * SU + i]);
+    __syncthreads();
+    for (int k = 2; k <= SU; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < SU; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int step = SU / (n_split + 1);
+    for (int j = threadIdx.x; j < n_split; j += blockDim.x) splitters[static_cast<size_t>(f) * kMaxSplit + j] = s[(j + 1) * step - 1];
+    int levels = 0;
+    while ((1 << levels) < n_split + 1) ++levels;
+    for (int i = threadIdx.x; i < n_split; i += blockDim.x) {
+        const int L = 31 - __clz(i + 1), pp = i + 1 - (1 << L);
+        const int q = ((2 * pp + 1) << (levels - 1 - L)) - 1;
+        splitters_bfs[static_cast<size_t>(f) * kMaxSplit + i] = s[(q + 1) * step - 1];
+    }
+}
+// place this rank's [F][S] u32 sample into its slice of the zeroed exchange buffer [F][world*S] int64 (sum == gather)
+__global__ void k_place_sample(const uint32_t *__restrict__ samp, int F, int S, int rank, int SU, int64_t *__restrict__ uni) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<size_t>(F) * S) return;
+    const size_t f = i / S, j = i % S;
+    uni[f * SU + static_cast<size_t>(rank) * S + j] = samp[i];
+}
+// local class counts (summed over chunks) as int64 for the exchange; and back
+__global__ void k_counts_to_i64(const uint32_t *__restrict__ partial, int n_chunks, size_t fc, int64_t *__restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= fc) return;
+    int64_t v = 0;
+    for (int q = 0; q < n_chunks; ++q) v += partial[static_cast<size_t>(q) * fc + i];
+    out[i] = v;
+}
+// distributed bisection step on the extracted lists: counts[t] = #{local keys of target t's list < trial_t}
+__global__ __launch_bounds__(256) void k_select_count(const uint32_t *__restrict__ lists, const uint32_t *__restrict__ tgt_off,
+                                                      const uint32_t *__restrict__ tgt_len, const uint32_t *__restrict__ prefix,
+                                                      int bit, int n_targets, int64_t *__restrict__ counts) {
+    const int t = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    if (t >= n_targets) return;
+    const uint32_t off = tgt_off[t];
+    uint32_t c = 0;
+    if (off < 0xfffffffeu) {
+        const uint32_t trial = prefix[t] | (1u << bit);
+        const uint32_t *keys = lists + off;
+        const uint32_t m = tgt_len[t];
+        for (uint32_t i = lane; i < m; i += kWave) c += keys[i] < trial ? 1u : 0u;
+        for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+    }
+    if (lane == 0) counts[t] = c;
+}
+__global__ void k_select_update(uint32_t *__restrict__ prefix, const int64_t *__restrict__ counts, const uint32_t *__restrict__ tgt_off,
+                                const uint32_t *__restrict__ tgt_rank, int bit, int n_targets, uint32_t *__restrict__ thr_keys) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_targets) return;
+    if (tgt_off[t] >= 0xfffffffeu) return;   // direct answer already in thr_keys
+    uint32_t p = prefix[t];
+    if (counts[t] < static_cast<int64_t>(tgt_rank[t])) p |= (1u << bit);
+    prefix[t] = p;
+    if (bit == 0) thr_keys[t] = p;
 }
 
 // class of a key: 2 * #{splitters < key} + (key equals the first splitter >= key).  `e` holds the n_split = 2^levels - 1
@@ -168,6 +248,7 @@ __global__ __launch_bounds__(kCountThreads) void k_class_count(const uint32_t *_
 // lies in the first class whose inclusive prefix >= cum_k.  Equality classes answer directly; each distinct open target
 // class gets a contiguous list [off, off+len) in the extraction buffer (class_off[f][class], 0xffffffff = not extracted).
 __global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ partial, int n_chunks, int F,
+                                                  const int64_t *__restrict__ global_counts /*nullable [F][8192]: sharded runs*/,
                                                   const uint32_t *__restrict__ splitters, const int64_t *__restrict__ cum, int B,
                                                   uint32_t *__restrict__ class_off /*[F][8192], preset 0xffffffff*/,
                                                   uint32_t *__restrict__ tgt_off /*[F][B] list offset or 0xffffffff*/,
@@ -179,10 +260,12 @@ __global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ p
     __shared__ int32_t tcls[1024];       // class of each target of the current tile of targets
     const int f = blockIdx.x;
     uint32_t *coff = class_off + static_cast<size_t>(f) * kClasses;
+    __shared__ uint32_t loc_cnt[kClasses];   // this rank's class counts (list lengths)
     for (int c = threadIdx.x; c < kClasses; c += blockDim.x) {
         uint32_t v = 0;
         for (int q = 0; q < n_chunks; ++q) v += partial[(static_cast<size_t>(q) * F + f) * kClasses + c];
-        pre[c] = v;
+        loc_cnt[c] = v;
+        pre[c] = global_counts ? static_cast<uint32_t>(global_counts[static_cast<size_t>(f) * kClasses + c]) : v;
     }
     __syncthreads();
     {   // block-wide inclusive scan of 8192 values: 8 per thread
@@ -229,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_targets(const uint32_t *__restrict__ p
                 // targets are sorted by rank, so equal classes are adjacent: the first target of a class allocates its list
                 // (a class shared with the last target of the previous tile was allocated there: coff is already set)
                 const bool first = (threadIdx.x == 0) ? (coff[c] == 0xffffffffu) : (tcls[threadIdx.x - 1] != c);
-                const uint32_t len = pre[c] - before;
+                const uint32_t len = loc_cnt[c];
                 if (first) {
                     const uint32_t off = atomicAdd(&alloc[0], len);
                     if (off + len > max_elems || off + len < off) { atomicExch(overflow, 1u); coff[c] = 0xfffffffeu; }
@@ -417,18 +500,46 @@ QuantilePlan quantile_plan(int n) {
 void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters, uint32_t *splitters_bfs, hipStream_t s) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); attr = true; }
-    hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters, splitters_bfs);
+    hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters, splitters_bfs,
+                       static_cast<uint32_t *>(nullptr));
+}
+
+void sample_only(const uint32_t *kt, int n, int F, int S, uint32_t *sample_out, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); attr = true; }
+    hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), S * sizeof(uint32_t), s, kt, n, S, S - 1, static_cast<uint32_t *>(nullptr),
+                       static_cast<uint32_t *>(nullptr), sample_out);
+}
+void place_sample(const uint32_t *samp, int F, int S, int rank, int SU, int64_t *uni, hipStream_t s) {
+    const size_t tot = static_cast<size_t>(F) * S;
+    hipLaunchKernelGGL(k_place_sample, dim3((tot + 255) / 256), dim3(256), 0, s, samp, F, S, rank, SU, uni);
+}
+void union_splitters(const int64_t *uni, int F, int SU, int n_split, uint32_t *splitters, uint32_t *splitters_bfs, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_union_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_union_splitters, dim3(F), dim3(1024), SU * sizeof(uint32_t), s, uni, SU, n_split, splitters, splitters_bfs);
+}
+void counts_to_i64(const uint32_t *partial, int n_chunks, size_t fc, int64_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_counts_to_i64, dim3((fc + 255) / 256), dim3(256), 0, s, partial, n_chunks, fc, out);
+}
+void select_count(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *prefix, int bit, int n_targets,
+                  int64_t *counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_count, dim3((n_targets + 3) / 4), dim3(256), 0, s, lists, tgt_off, tgt_len, prefix, bit, n_targets, counts);
+}
+void select_update(uint32_t *prefix, const int64_t *counts, const uint32_t *tgt_off, const uint32_t *tgt_rank, int bit, int n_targets,
+                   uint32_t *thr_keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_update, dim3((n_targets + 255) / 256), dim3(256), 0, s, prefix, counts, tgt_off, tgt_rank, bit, n_targets, thr_keys);
 }
 
 void class_count(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, uint32_t *partial, hipStream_t s) {
     hipLaunchKernelGGL(k_class_count, dim3(p.n_chunks, F), dim3(kCountThreads), 0, s, kt, n, p.n_split, splitters, p.chunk, partial);
 }
 
-void quantile_targets(const uint32_t *partial, const uint32_t *splitters, const int64_t *cum, int F, int B, const QuantilePlan &p,
-                      uint32_t *class_off, uint32_t *tgt_off, uint32_t *tgt_len, uint32_t *tgt_rank, uint32_t *thr_keys,
-                      uint32_t *alloc, uint32_t max_elems, uint32_t *overflow, hipStream_t s) {
-    hipLaunchKernelGGL(k_targets, dim3(F), dim3(1024), 0, s, partial, p.n_chunks, F, splitters, cum, B, class_off, tgt_off, tgt_len,
-                       tgt_rank, thr_keys, alloc, max_elems, overflow);
+void quantile_targets(const uint32_t *partial, const int64_t *global_counts, const uint32_t *splitters, const int64_t *cum, int F, int B,
+                      const QuantilePlan &p, uint32_t *class_off, uint32_t *tgt_off, uint32_t *tgt_len, uint32_t *tgt_rank,
+                      uint32_t *thr_keys, uint32_t *alloc, uint32_t max_elems, uint32_t *overflow, hipStream_t s) {
+    hipLaunchKernelGGL(k_targets, dim3(F), dim3(1024), 0, s, partial, p.n_chunks, F, global_counts, splitters, cum, B, class_off, tgt_off,
+                       tgt_len, tgt_rank, thr_keys, alloc, max_elems, overflow);
 }
 
 void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, const uint32_t *splitters, const uint32_t *class_off,
