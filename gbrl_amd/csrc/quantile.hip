@@ -424,13 +424,14 @@ __global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lis
 // 256 rows: reads 16 column segments of 1 KiB (coalesced), searches the 16 threshold rows staged in LDS, and writes the
 // 8 KiB code tile contiguously.
 constexpr int kGroup = 16;
+constexpr int kBinTiles = 16;   // row tiles per block (amortises staging the 16 x 511 threshold tree)
 __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ kt, int n, int F, const uint32_t *__restrict__ thr,
                                                   int B, int levels, uint16_t *__restrict__ codes) {
     extern __shared__ uint32_t lds[];
     const int P = (1 << levels) - 1;                      // thresholds padded with the maximal key to a full tree
     uint32_t *t = lds;                                    // [16][P] in BFS order
-    uint16_t *tile = reinterpret_cast<uint16_t *>(lds + kGroup * P);  // [256][16]
-    const int g = blockIdx.y, r0 = blockIdx.x * 256;
+    uint16_t *tile_buf = reinterpret_cast<uint16_t *>(lds + kGroup * P);  // [256][16]
+    const int g = blockIdx.y;
     for (int i = threadIdx.x; i < kGroup * P; i += 256) {
         const int fl = i / P, e = i % P, f = g * kGroup + fl;
         const int L = 31 - __clz(e + 1), pp = e + 1 - (1 << L);
@@ -438,36 +439,42 @@ __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ k
         t[i] = (f < F && q < B) ? thr[static_cast<size_t>(f) * B + q] : 0xffffffffu;
     }
     __syncthreads();
-    const int r = r0 + threadIdx.x;
-    const int rr = r < n ? r : n - 1;
-    uint32_t key[kGroup];
+    // the threshold tree is staged once and reused for kBinTiles tiles of 256 rows
+    for (int tile = 0; tile < kBinTiles; ++tile) {
+        const int r0 = (blockIdx.x * kBinTiles + tile) * 256;
+        if (r0 >= n) break;
+        const int r = r0 + threadIdx.x;
+        const int rr = r < n ? r : n - 1;
+        uint32_t key[kGroup];
 #pragma unroll
-    for (int q = 0; q < kGroup; ++q) {                    // all 16 column loads in flight before the first descent
-        const int f = g * kGroup + q;
-        key[q] = kt[static_cast<size_t>(f < F ? f : F - 1) * n + rr];
-    }
-#pragma unroll
-    for (int fl0 = 0; fl0 < kGroup; fl0 += 8) {           // 8 independent descents in flight
-        int idx[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) idx[q] = 0;
-        for (int l = 0; l < levels; ++l) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) idx[q] = 2 * idx[q] + 1 + ((t[(fl0 + q) * P + idx[q]] < key[fl0 + q]) ? 1 : 0);
+        for (int q = 0; q < kGroup; ++q) {                    // all 16 column loads in flight before the first descent
+            const int f = g * kGroup + q;
+            key[q] = kt[static_cast<size_t>(f < F ? f : F - 1) * n + rr];
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int f = g * kGroup + fl0 + q;
-            int code = idx[q] - P;                        // #{padded thresholds < key}; pads are never < key
-            if (code > B) code = B;
-            tile[threadIdx.x * kGroup + fl0 + q] = static_cast<uint16_t>((f < F && r < n) ? code : 0);
+        for (int fl0 = 0; fl0 < kGroup; fl0 += 8) {           // 8 independent descents in flight
+            int idx[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) idx[q] = 0;
+            for (int l = 0; l < levels; ++l) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) idx[q] = 2 * idx[q] + 1 + ((t[(fl0 + q) * P + idx[q]] < key[fl0 + q]) ? 1 : 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int f = g * kGroup + fl0 + q;
+                int code = idx[q] - P;                        // #{padded thresholds < key}; pads are never < key
+                if (code > B) code = B;
+                tile_buf[threadIdx.x * kGroup + fl0 + q] = static_cast<uint16_t>((f < F && r < n) ? code : 0);
+            }
         }
+        __syncthreads();
+        const int rows = min(256, n - r0);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(codes + (static_cast<size_t>(g) * n + r0) * kGroup);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tile_buf);
+        for (int i = threadIdx.x; i < rows * kGroup / 2; i += 256) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
-    const int rows = min(256, n - r0);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(codes + (static_cast<size_t>(g) * n + r0) * kGroup);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(tile);
-    for (int i = threadIdx.x; i < rows * kGroup / 2; i += 256) dst[i] = src[i];
 }
 
 __global__ void k_scatter_cat_codes_grouped(const uint16_t *__restrict__ cat_codes, int n, int Fc, int F,
@@ -559,7 +566,7 @@ void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B,
     const size_t lds = static_cast<size_t>(kGroup) * ((1 << levels) - 1) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    dim3 grid((n + 255) / 256, (F + kGroup - 1) / kGroup);
+    dim3 grid((n + 256 * kBinTiles - 1) / (256 * kBinTiles), (F + kGroup - 1) / kGroup);
     hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, levels, codes);
 }
 
