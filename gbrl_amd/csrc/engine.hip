@@ -333,7 +333,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     if (!std::isfinite(hmax[0]) || !std::isfinite(hmax[1])) throw InvalidArgument("non-finite gradients");
     // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: pick the power-of-two scale
     // with chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build)
-    const int chunk_rows = std::max(4096, (N + 63) / 64);
+    // A histogram block accumulates one chunk of one node's rows.  Chunks are sized per level so that the whole level is ONE
+    // balanced round of <= 32 chunks x (feature groups) blocks (k_hist_build keeps one block per CU); `chunk_rows` is the cap
+    // the fixed-point scale is derived from.
+    const int chunk_rows = std::max(4096, 2 * ((N + 31) / 32));
     int sbits = 20;
     if (hmax[0] > 0.f) sbits = std::min(100, ilog2_floor(2147483647.0 / (static_cast<double>(chunk_rows) * hmax[0])) - 1);
     const double scale = std::ldexp(1.0, sbits);
@@ -601,11 +604,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     // leaf sums and the partition without waiting for them.
     const int max_front = 1 << std::max(0, MD - 1);
     const int max_nodes = 2 * (1 << MD);
-    const int max_chunks = std::max((N + chunk_rows - 1) / chunk_rows, (N + kern::kPartitionRows - 1) / kern::kPartitionRows) + 2 * (1 << MD) + 2;
+    const int max_chunks = std::max((N + 1023) / 1024, (N + kern::kPartitionRows - 1) / kern::kPartitionRows) + 2 * (1 << MD) + 2;
     const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
     int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
                           static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
-    int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * max_chunks * n_groups * n_acc));
+    // a level needs at most 32 balanced chunks plus one rounding chunk per node
+    const int hist_max_chunks = 32 + 2 * (1 << MD) + 2;
+    int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * static_cast<size_t>(hist_max_chunks) * n_groups * n_acc));
     const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
     // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
     int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems)),
@@ -659,11 +664,25 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         for (size_t k = 0; k < ids.size(); ++k) {
             const HNode &nd = nodes[ids[k]];
             if (slot_is_node_id && nd.depth == 0) { h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size())); continue; }  // Q7
-            for (int off = 0; off < nd.n_local; off += rows_per_chunk)
+            // equal parts (no short remainder chunk): parts = ceil(n / rows_per_chunk), each ceil(n / parts) rows
+            const int parts = (nd.n_local + rows_per_chunk - 1) / rows_per_chunk;
+            const int each = parts ? (nd.n_local + parts - 1) / parts : 0;
+            for (int off = 0; off < nd.n_local; off += each)
                 h_chunks.push_back({static_cast<int32_t>(slot_is_node_id ? ids[k] : static_cast<int>(k)), nd.seg_start + off,
-                                    std::min(rows_per_chunk, nd.n_local - off), 0});
+                                    std::min(each, nd.n_local - off), 0});
             h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size()));
         }
+    };
+    // smallest chunk length t (<= chunk_rows) for which the nodes `ids` need at most `budget` chunks in total
+    auto balanced_chunk_rows = [&](const std::vector<int> &ids, int budget) {
+        int lo = 1024, hi = chunk_rows;
+        auto parts_at = [&](int t) { long long p = 0; for (int id : ids) p += (nodes[id].n_local + t - 1) / t; return p; };
+        if (parts_at(hi) > budget) return hi;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (parts_at(mid) <= budget) hi = mid; else lo = mid + 1;
+        }
+        return hi;
     };
 
     for (int depth = 0; depth < MD && n_cand > 0; ++depth) {
@@ -710,8 +729,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // chunk table of ALL active nodes (row-sharded runs count the local child sizes from the rows themselves)
         std::vector<Chunk> count_chunks;
         if (has_coll_) { make_chunks(active, kern::kPartitionRows, false); count_chunks = h_chunks; }
-        make_chunks(compute_ids, chunk_rows, false);
-        if (h_chunks.size() > static_cast<size_t>(max_chunks)) throw HipError("internal: chunk table overflow");
+        make_chunks(compute_ids, balanced_chunk_rows(compute_ids, 32), false);
+        if (h_chunks.size() > static_cast<size_t>(hist_max_chunks)) throw HipError("internal: chunk table overflow");
         // paths (duplicate-on-path rejection, node.cpp:154-166)
         std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
         std::vector<float> pv(static_cast<size_t>(n_act) * kern::kMaxPath, 0.f);
