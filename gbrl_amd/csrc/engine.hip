@@ -226,6 +226,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ev_used_ = 0;
     ev_names_.clear();
     if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
+    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
     hipStream_t s = stream_;
     const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
     const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
@@ -412,6 +413,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             const bool coll_fast = has_coll_ && (coll_.world_size & (coll_.world_size - 1)) == 0 && coll_.world_size <= 8;
             if (force_bisection_ || (has_coll_ && !coll_fast)) {
                 bisection_quantiles(cum);
+            } else if (!has_coll_ && !force_sample_select_ && B <= kern::radix_max_targets()) {
+                // one GPU: exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip)
+                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                void *d_rs = d_radix_state_.ensure(kern::radix_state_bytes(F, B));
+                uint32_t *d_rp = static_cast<uint32_t *>(d_radix_partial_.ensure(kern::radix_partial_bytes(F)));
+                kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_thrkeys, s);
+                last_quantile_fallback_ = false;
             } else {
                 fast_quantile = true;
                 kern::QuantilePlan plan = kern::quantile_plan(N);

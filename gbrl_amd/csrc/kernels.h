@@ -95,6 +95,12 @@ void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, c
 void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
                      uint32_t *thr_keys, hipStream_t s);
 // codes[(slot/16)*n*16 + row*16 + slot%16] (u16) = #{k : thr_key[f][k] < key(row, f)}
+// radix_select.hip: exact order statistics by MSD radix counting (one GPU)
+size_t radix_state_bytes(int F, int B);
+size_t radix_partial_bytes(int F);
+int radix_max_targets();
+void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *thr_keys,
+                  hipStream_t s);
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s);
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s);
 constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [group][row][16]

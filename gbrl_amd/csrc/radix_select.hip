@@ -1,0 +1,317 @@
+// radix_select.hip -- exact multi-rank selection (A3) by MSD radix counting on the transposed keys.
+//
+// For every feature the B target ranks are refined together, most significant digit first, in four counting passes over
+// the column (digits of 12 + 7 + 7 + 6 bits of the order-preserving 32-bit key).  After each pass a small per-feature
+// kernel locates, for every target, the digit bucket that contains its rank, subtracts the ranks below it, and gives
+// every DISTINCT prefix that still contains a target a slot (<= B of them); the next pass counts the following digit only
+// for keys whose prefix owns a slot.  No sampling, no sorting, no data movement, no overflow case: exact for any
+// distribution (heavy duplicates simply stay in one slot until the last digit).
+//
+//   counting pass p (k_radix_count<p>) : one block = one feature x one chunk of the column; LDS holds the prefix->slot maps
+//        of the earlier digits and uint32 counters [slot][digit] (<= 256 x 128 = 128 KB); the block's counters are stored
+//        as a partial (no global atomics, nothing to zero), summed by the target pass.
+//   target pass   p (k_radix_targets)  : one block per feature, thread k = target k.
+//
+// Slot lookup is O(1): slot1 = map1[top 12 bits]; every slot keeps a 128-bit set of the next digits that still lead to a
+// target and the id of its first child; child slot = first child + popcount(set bits below the digit).
+#include "kernels.h"
+
+namespace gbrl {
+namespace kern {
+
+namespace {
+
+constexpr int kBins1 = 4096;              // 12-bit first digit
+constexpr int kNone = 0xffff;
+constexpr int kRadixThreads = 1024;
+constexpr int kMaxTargets = 256;
+constexpr int kChunks1 = 8;               // pass 1: small LDS footprint, many blocks
+constexpr int kChunksN = 8;               // upper bound of chunks in passes 2..4 (2 at F >= 128: one 128 KB block per CU)
+constexpr int kSlotStride = 128;          // digits per slot in the partials of passes 2..4
+
+__host__ __device__ constexpr int radix_bins(int pass) { return pass == 1 ? kBins1 : (pass == 4 ? 64 : 128); }
+__host__ __device__ constexpr int radix_shift(int pass) { return pass == 1 ? 20 : (pass == 2 ? 13 : (pass == 3 ? 6 : 0)); }
+
+// Per-feature selection state in global memory (written by k_radix_targets, read by k_radix_count).
+struct RadixState {
+    uint16_t *map1;        // [F][4096]     first digit -> slot1 | kNone
+    uint16_t *child_off;   // [F][2][258]   level L (0: slot1->slot2, 1: slot2->slot3): first child slot of parent slot s
+    uint64_t *child_bits;  // [F][2][256][2] 128-bit set of the digits of parent s that lead to a child; the child's slot is
+                           //               child_off[s] + (number of set bits below the digit): children are in digit order
+    uint32_t *n_slots;     // [F][4]        slots alive after pass 1, 2, 3
+    uint16_t *tgt_slot;    // [F][B]
+    uint32_t *tgt_rank;    // [F][B]        1-based rank inside the slot
+    uint32_t *tgt_prefix;  // [F][B]
+};
+
+// ---- counting pass --------------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *__restrict__ kt, int n, int n_chunks, int B,
+                                                               RadixState st, uint32_t *__restrict__ partial) {
+    extern __shared__ uint32_t rl[];
+    constexpr int NB = radix_bins(PASS);
+    constexpr int SH = radix_shift(PASS);
+    const int f = blockIdx.y;
+    const int n_slots = PASS == 1 ? 1 : static_cast<int>(st.n_slots[f * 4 + (PASS - 2)]);
+    const int n_cnt = n_slots * NB;
+    uint32_t *cnt = rl;                                                        // [n_slots][NB]
+    uint16_t *map1 = reinterpret_cast<uint16_t *>(rl + (PASS == 1 ? kBins1 : kMaxTargets * NB));   // [4096]
+    uint64_t *cbits = reinterpret_cast<uint64_t *>(map1 + kBins1);             // [2][256][2]
+    uint16_t *coff = reinterpret_cast<uint16_t *>(cbits + 2 * 512);            // [2][258]
+    uint32_t *filt = reinterpret_cast<uint32_t *>(coff + 2 * 260);             // [2048] 65536-bit hashed set of the live prefixes
+    constexpr int PS = PASS == 3 ? 13 : 6;                                     // bits below the prefix a pass-3/4 key must match
+    for (int i = threadIdx.x; i < n_cnt; i += kRadixThreads) cnt[i] = 0;
+    if (PASS >= 3) {
+        // Few keys still match a live prefix (a few % in pass 3, ~0.1 % in pass 4): one bit test rejects the rest before the
+        // exact slot chain.  No false negatives; false positives (~B / 65536) fall out of the chain.
+        for (int i = threadIdx.x; i < 2048; i += kRadixThreads) filt[i] = 0;
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < B) {
+            const uint32_t h = ((st.tgt_prefix[static_cast<size_t>(f) * B + threadIdx.x] >> PS) * 0x9E3779B1u) >> 16;
+            atomicOr(&filt[h >> 5], 1u << (h & 31));
+        }
+    }
+    if (PASS >= 2) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(st.map1 + static_cast<size_t>(f) * kBins1);
+        for (int i = threadIdx.x; i < kBins1 / 2; i += kRadixThreads) reinterpret_cast<uint32_t *>(map1)[i] = src[i];
+    }
+    if (PASS >= 3) {
+        const int levels = PASS - 2;
+        for (int i = threadIdx.x; i < levels * 258; i += kRadixThreads) coff[i] = st.child_off[static_cast<size_t>(f) * 2 * 258 + i];
+        for (int i = threadIdx.x; i < levels * 512; i += kRadixThreads) cbits[i] = st.child_bits[static_cast<size_t>(f) * 2 * 512 + i];
+    }
+    __syncthreads();
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    const int chunk = ((n + n_chunks - 1) / n_chunks + 3) & ~3;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    auto child = [&](int level, int slot, int digit) -> int {
+        const uint64_t w0 = cbits[level * 512 + slot * 2], w1 = cbits[level * 512 + slot * 2 + 1];
+        const uint64_t w = digit & 64 ? w1 : w0;
+        const int bit = digit & 63;
+        if (!((w >> bit) & 1)) return kNone;
+        const int below = __popcll(w & ((1ull << bit) - 1)) + (digit & 64 ? __popcll(w0) : 0);
+        return coff[level * 258 + slot] + below;
+    };
+    auto count_one = [&](uint32_t key) {
+        int slot = 0;
+        if (PASS >= 2) {
+            slot = map1[key >> 20];
+            if (PASS >= 3 && slot != kNone) slot = child(0, slot, (key >> 13) & 127);
+            if (PASS >= 4 && slot != kNone) slot = child(1, slot, (key >> 6) & 127);
+        }
+        const int idx = slot == kNone ? -1 : slot * NB + static_cast<int>((key >> SH) & (NB - 1));
+        // a wave whose keys all fall into one counter (constant / mostly-constant columns) adds once instead of 64 times
+        const int first = __builtin_amdgcn_readfirstlane(idx);
+        const unsigned long long active = __ballot(1);
+        const unsigned long long same = __ballot(idx == first);
+        if (same == active) {
+            if (first >= 0 && __lane_id() == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
+                atomicAdd(&cnt[first], static_cast<uint32_t>(__popcll(active)));
+        } else if (idx >= 0) {
+            atomicAdd(&cnt[idx], 1u);
+        }
+    };
+    constexpr int U = 8;
+    int i0 = lo + threadIdx.x;
+    for (; i0 + (U - 1) * kRadixThreads < hi; i0 += kRadixThreads * U) {   // full strips: straight-line loads
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) key[u] = col[i0 + u * kRadixThreads];
+        if (PASS >= 3) {
+            bool hit[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t h = ((key[u] >> PS) * 0x9E3779B1u) >> 16;
+                hit[u] = (filt[h >> 5] >> (h & 31)) & 1;
+            }
+            // per-thread compaction: a lane rarely has more than two candidates among its 8 keys, so the wave runs the exact
+            // chain about twice per strip instead of 8 times
+            uint32_t p0 = 0, p1 = 0;
+            int np = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (hit[u]) {
+                    if (np == 0) p0 = key[u]; else if (np == 1) p1 = key[u]; else count_one(key[u]);
+                    ++np;
+                }
+            if (np > 0) count_one(p0);
+            if (np > 1) count_one(p1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) count_one(key[u]);
+        }
+    }
+    for (; i0 < hi; i0 += kRadixThreads) count_one(col[i0]);
+    __syncthreads();
+    uint32_t *dst = partial + (static_cast<size_t>(f) * n_chunks + blockIdx.x) * (PASS == 1 ? kBins1 : kMaxTargets * kSlotStride);
+    if (PASS == 1) {
+        for (int i = threadIdx.x; i < kBins1; i += kRadixThreads) dst[i] = cnt[i];
+    } else {
+        for (int i = threadIdx.x; i < n_cnt; i += kRadixThreads) dst[(i / NB) * kSlotStride + (i % NB)] = cnt[i];
+    }
+}
+
+// ---- target pass -------------------------------------------------------------------------------------------------------
+constexpr int kTgtThreads = 1024;
+
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *scratch /*[16]*/) {   // over kTgtThreads threads
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_scan_incl(v);
+    if (lane == 63) scratch[w] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; ++i) base += scratch[i];
+    __syncthreads();
+    return v + base;
+}
+
+// One block per feature; thread k < B owns target k.  `pass` = the counting pass being consumed.
+__global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const uint32_t *__restrict__ partial, int n_chunks,
+                                                               const int64_t *__restrict__ cum, int B, RadixState st,
+                                                               uint32_t *__restrict__ thr_keys) {
+    extern __shared__ uint32_t sums[];        // inclusive digit counts: pass 1 [4096]; later [n_slots][NB]
+    __shared__ int tslot[kMaxTargets], tdig[kMaxTargets];
+    __shared__ uint32_t scratch[16], total_slots;
+    const int f = blockIdx.x, k = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NB = radix_bins(pass);
+    const int n_slots = pass == 1 ? 1 : static_cast<int>(st.n_slots[f * 4 + (pass - 2)]);
+    const size_t pstride = pass == 1 ? kBins1 : kMaxTargets * kSlotStride;
+    const uint32_t *p0 = partial + static_cast<size_t>(f) * n_chunks * pstride;
+    if (pass == 1) {
+        // 4 consecutive buckets per thread (one 16-byte load per chunk), block scan of the thread totals
+        uint4 v = make_uint4(0, 0, 0, 0);
+        for (int c = 0; c < n_chunks; ++c) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(p0 + c * pstride + k * 4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        v.y += v.x; v.z += v.y; v.w += v.z;
+        const uint32_t base = block_scan_incl(v.w, scratch) - v.w;
+        sums[k * 4 + 0] = base + v.x; sums[k * 4 + 1] = base + v.y; sums[k * 4 + 2] = base + v.z; sums[k * 4 + 3] = base + v.w;
+    } else {
+        // one wave per slot row: two digits per lane, wave scan
+        for (int row = wave; row < n_slots; row += kTgtThreads / 64) {
+            uint32_t a = 0, b = 0;
+            if (2 * lane < NB)
+                for (int c = 0; c < n_chunks; ++c) {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(p0 + c * pstride + row * kSlotStride + 2 * lane);
+                    a += t.x; b += t.y;
+                }
+            const uint32_t incl = wave_scan_incl(a + b);
+            if (2 * lane < NB) { sums[row * NB + 2 * lane] = incl - b; sums[row * NB + 2 * lane + 1] = incl; }
+        }
+    }
+    __syncthreads();
+    int slot = 0, digit = 0;
+    uint32_t rank = 0, prefix = 0;
+    if (k < B) {
+        if (pass == 1) {
+            rank = static_cast<uint32_t>(cum[k]);
+        } else {
+            slot = st.tgt_slot[static_cast<size_t>(f) * B + k];
+            rank = st.tgt_rank[static_cast<size_t>(f) * B + k];
+            prefix = st.tgt_prefix[static_cast<size_t>(f) * B + k];
+        }
+        const uint32_t *hs = sums + slot * NB;      // first digit whose inclusive count reaches the rank
+        int lo = 0, hi = NB - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (hs[mid] < rank) lo = mid + 1; else hi = mid; }
+        digit = lo;
+        rank -= lo ? hs[lo - 1] : 0u;
+        prefix |= static_cast<uint32_t>(digit) << radix_shift(pass);
+    }
+    if (pass == 4) {
+        if (k < B) thr_keys[static_cast<size_t>(f) * B + k] = prefix;
+        return;
+    }
+    if (k < kMaxTargets) { tslot[k] = k < B ? slot : -1; tdig[k] = digit; }
+    __syncthreads();
+    // targets are sorted by rank => (slot, digit) is non-decreasing: a target opens a new child slot iff it differs from k-1
+    const bool opens = (k < B) && (k == 0 || tslot[k - 1] != slot || tdig[k - 1] != digit);
+    const bool new_parent = (k < B) && (k == 0 || tslot[k - 1] != slot);
+    const uint32_t incl = block_scan_incl(opens ? 1u : 0u, scratch);
+    const int my_slot = static_cast<int>(incl) - 1;        // slot of target k after this pass
+    if (k == B - 1) total_slots = incl;
+    if (k < B) {
+        st.tgt_slot[static_cast<size_t>(f) * B + k] = static_cast<uint16_t>(my_slot);
+        st.tgt_rank[static_cast<size_t>(f) * B + k] = rank;
+        st.tgt_prefix[static_cast<size_t>(f) * B + k] = prefix;
+    }
+    if (pass == 1) {
+        uint16_t *m = st.map1 + static_cast<size_t>(f) * kBins1;
+        for (int i = threadIdx.x; i < kBins1; i += kTgtThreads) m[i] = kNone;
+        __syncthreads();
+        if (opens) m[digit] = static_cast<uint16_t>(my_slot);
+    } else {
+        // children of parent slot s are the new slots off[s] .. off[s+1]-1 in digit order (every parent holds >= 1 target)
+        uint16_t *off = st.child_off + (static_cast<size_t>(f) * 2 + (pass - 2)) * 258;
+        unsigned long long *bits = reinterpret_cast<unsigned long long *>(st.child_bits) + (static_cast<size_t>(f) * 2 + (pass - 2)) * 512;
+        for (int i = threadIdx.x; i < 2 * n_slots; i += kTgtThreads) bits[i] = 0ull;
+        __syncthreads();
+        if (opens) atomicOr(&bits[slot * 2 + (digit >> 6)], 1ull << (digit & 63));
+        if (new_parent) off[slot] = static_cast<uint16_t>(my_slot);
+    }
+    __syncthreads();
+    if (k == 0) st.n_slots[f * 4 + (pass - 1)] = total_slots;
+}
+
+constexpr size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+}  // namespace
+
+size_t radix_state_bytes(int F, int B) {
+    const size_t f = static_cast<size_t>(F);
+    return align16(f * kBins1 * 2) + align16(f * 2 * 258 * 2) + align16(f * 2 * 512 * 8) + align16(f * 4 * 4) + align16(f * B * 2) +
+           2 * align16(f * B * 4);
+}
+size_t radix_partial_bytes(int F) {
+    const size_t a = static_cast<size_t>(F) * kChunks1 * kBins1, b = static_cast<size_t>(F) * kChunksN * kMaxTargets * kSlotStride;
+    return sizeof(uint32_t) * (a > b ? a : b);
+}
+int radix_max_targets() { return kMaxTargets; }
+
+// Exact order statistics of every column: thr_keys[f][k] = key of 1-based rank cum[k] in column f of kt ([F][n] ordered keys).
+// cum must be non-decreasing, 1 <= cum[k] <= n, B <= 256.
+void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *thr_keys,
+                  hipStream_t s) {
+    char *p = static_cast<char *>(state);
+    auto take = [&](size_t bytes) { char *q = p; p += align16(bytes); return q; };
+    const size_t f = static_cast<size_t>(F);
+    RadixState st;
+    st.map1 = reinterpret_cast<uint16_t *>(take(f * kBins1 * 2));
+    st.child_off = reinterpret_cast<uint16_t *>(take(f * 2 * 258 * 2));
+    st.child_bits = reinterpret_cast<uint64_t *>(take(f * 2 * 512 * 8));
+    st.n_slots = reinterpret_cast<uint32_t *>(take(f * 4 * 4));
+    st.tgt_slot = reinterpret_cast<uint16_t *>(take(f * B * 2));
+    st.tgt_rank = reinterpret_cast<uint32_t *>(take(f * B * 4));
+    st.tgt_prefix = reinterpret_cast<uint32_t *>(take(f * B * 4));
+    const size_t aux = kBins1 * 2 + 2 * 512 * 8 + 2 * 260 * 2 + 2048 * 4;
+    const size_t lds1 = kBins1 * 4 + aux, lds23 = static_cast<size_t>(kMaxTargets) * 128 * 4 + aux,
+                 lds4 = static_cast<size_t>(kMaxTargets) * 64 * 4 + aux;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_count<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds23));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_count<3>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds23));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_count<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_targets), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxTargets * 128 * 4);
+        attr = true;
+    }
+    int cn = 1;
+    if (n >= (1 << 16)) { cn = 2; while (cn < kChunksN && cn * F < 256) cn *= 2; }
+    const int c1 = n >= (1 << 16) ? kChunks1 : 1;
+    hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial);
+    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kBins1 * 4, s, 1, partial, c1, cum, B, st, thr_keys);
+    hipLaunchKernelGGL(k_radix_count<2>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
+    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kMaxTargets * 128 * 4, s, 2, partial, cn, cum, B, st, thr_keys);
+    hipLaunchKernelGGL(k_radix_count<3>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
+    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kMaxTargets * 128 * 4, s, 3, partial, cn, cum, B, st, thr_keys);
+    hipLaunchKernelGGL(k_radix_count<4>, dim3(cn, F), dim3(kRadixThreads), lds4, s, kt, n, cn, B, st, partial);
+    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kMaxTargets * 64 * 4, s, 4, partial, cn, cum, B, st, thr_keys);
+}
+
+}  // namespace kern
+}  // namespace gbrl

@@ -193,25 +193,31 @@ def test_full_size_properties_config2_shape():
 
 
 def test_fast_quantile_path_equals_bisection_path(monkeypatch):
-    """The sample-splitter selection (quantile.hip) and the 32-pass bisection (kernels.hip) are both exact: identical trees."""
+    """The MSD radix multi-select (radix_select.hip), the sample-splitter selection (quantile.hip) and the 32-pass bisection
+    (kernels.hip) are all exact: identical trees, also on columns built to stress each of them."""
     import gbrl_amd
     rng = np.random.default_rng(11)
     N, F = 70001, 20
     X = rng.standard_normal((N, F)).astype(np.float32)
-    X[:, 1] = np.round(X[:, 1] * 3) / 3          # heavy duplicates -> equality classes
+    X[:, 1] = np.round(X[:, 1] * 3) / 3          # heavy duplicates -> equality classes / one radix slot to the last digit
     X[:, 2] = (rng.random(N) < 0.97) * 1.0       # one value holds 97 % of the column
     X[:, 4] = np.exp(3 * X[:, 4])                # heavy tail
     X[:, 7] = 0.0
+    X[:, 8] = np.float32(1.0) + np.arange(N, dtype=np.float32) * np.float32(2.0 ** -23)   # all keys share the top 12+ bits
+    X[:, 9] = (rng.integers(0, 2, N) * 2 - 1) * np.float32(1e-38) * rng.random(N).astype(np.float32)   # denormals, both signs
+    X[:, 10] = np.array([-np.inf, -3e38, -0.0, 0.0, 3e38, np.inf], np.float32)[rng.integers(0, 6, N)]   # extremes, few values
     G = (np.tanh(X[:, :3]) + 0.3 * rng.standard_normal((N, 3))).astype(np.float32)
     case = dict(name="qq", seed=0, N=N, F=F, D=3, depth=6, n_bins=256, score="Cosine", gen="Quantile", policy="greedy", trees=2)
     outs = []
-    for force in ("0", "1"):
-        monkeypatch.setenv("GBRL_HIP_FORCE_BISECTION", force)
+    for bisect, sample in (("0", "0"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("GBRL_HIP_FORCE_BISECTION", bisect)
+        monkeypatch.setenv("GBRL_HIP_QUANTILE_SAMPLE", sample)
         m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
         K.drive(m, case, X, None, G, None)
         outs.append({k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS})
     for k in K.ENSEMBLE_KEYS:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[2][k]), ("radix vs bisection", k)
+        assert np.array_equal(outs[1][k], outs[2][k]), ("sample vs bisection", k)
 
 
 def test_sharded_code_path_on_one_gpu(monkeypatch):
