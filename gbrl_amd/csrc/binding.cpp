@@ -457,7 +457,7 @@ PYBIND11_MODULE(gbrl_cpp, m) {
     // GBRL::cuda_available (gbrl.cpp:542-548): here "is a HIP device usable"
     g.def_static("cuda_available", []() { return gbrl_hip_device_count() > 0; });
     // ---- additions (not in the reference) ----
-    g.def("set_profiling", [](PyGBRL &self, bool on) { check(gbrl_hip_set_profiling(self.h, on)); });
+    g.def("set_profiling", [](PyGBRL &self, int level) { check(gbrl_hip_set_profiling(self.h, level)); });   // True == 1
     g.def("last_phase_times", [](PyGBRL &self) {
         const char *names[64];
         float ms[64];

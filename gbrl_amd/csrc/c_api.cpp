@@ -231,7 +231,7 @@ int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float
 
 int gbrl_hip_set_profiling(gbrl_hip_model *m, int enabled) {
     if (!m) return GBRL_HIP_E_INVALID;
-    m->engine.set_profiling(enabled != 0);
+    m->engine.set_profiling(enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled));
     return GBRL_HIP_OK;
 }
 

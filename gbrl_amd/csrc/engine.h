@@ -69,7 +69,7 @@ class Engine {
                  int stop_tree, float *out, bool out_dev);
 
     void set_collective(const gbrl_hip_collective *hooks);
-    void set_profiling(bool on) { profiling_ = on; }
+    void set_profiling(int level) { profiling_ = level; }   // 0 off, 1 histogram build only, 2 every phase
     void set_force_bisection(bool on) { force_bisection_ = on; }   // test hook: exercise the slow exact quantile path
     bool last_quantile_fallback() const { return last_quantile_fallback_; }
     const std::vector<std::pair<std::string, float>> &phase_times() const { return phases_; }
@@ -77,8 +77,8 @@ class Engine {
    private:
     void ensure_device();
     void sync_model_to_device();
-    void phase_begin();
-    void phase_end(const char *name);
+    void phase_begin(bool key = false);
+    void phase_end(const char *name, bool key = false);
     void phases_resolve();
 
     int device_ordinal_ = -1;
@@ -88,7 +88,7 @@ class Engine {
     bool has_coll_ = false;
 
     // measurement
-    bool profiling_ = false;
+    int profiling_ = 0;
     bool force_bisection_ = false, force_sample_select_ = false, last_quantile_fallback_ = false;
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;

@@ -116,8 +116,8 @@ void Engine::set_collective(const gbrl_hip_collective *hooks) {
 
 // Phase timing: HIP events recorded on the model's stream WITHOUT synchronising; resolved once at the end of the call
 // (after the call's final stream synchronisation), so enabling it does not perturb the timed region.
-void Engine::phase_begin() {
-    if (!profiling_) return;
+void Engine::phase_begin(bool key) {
+    if (profiling_ < (key ? 1 : 2)) return;
     if (ev_used_ == ev_pool_.size()) {
         hipEvent_t a, b;
         hip_check(hipEventCreate(&a), "hipEventCreate");
@@ -126,8 +126,8 @@ void Engine::phase_begin() {
     }
     hip_check(hipEventRecord(ev_pool_[ev_used_].first, stream_), "hipEventRecord");
 }
-void Engine::phase_end(const char *name) {
-    if (!profiling_) return;
+void Engine::phase_end(const char *name, bool key) {
+    if (profiling_ < (key ? 1 : 2)) return;
     hip_check(hipEventRecord(ev_pool_[ev_used_].second, stream_), "hipEventRecord");
     ev_names_.push_back(name);
     ++ev_used_;
@@ -765,10 +765,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         int32_t *d_isroot = sta.put(root.data(), root.size());
         Chunk *d_count_chunks = sta.put(count_chunks.data(), count_chunks.size());
         sta.flush();
-        phase_begin();
+        phase_begin(/*key=*/true);
         if (!h_chunks.empty())
             kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
-        phase_end("hist_build");
+        phase_end("hist_build", /*key=*/true);
         phase_begin();
         if (!has_coll_) {
             if (!compute_ids.empty())
@@ -1114,7 +1114,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     float *dout = out;
     if (!out_dev) dout = static_cast<float *>(d_pout_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
     phase_end("inputs");
-    phase_begin();
+    phase_begin(/*key=*/true);
     kern::PredictModel pm{};
     pm.tree_indices = m_tree_indices_.as<int32_t>();
     pm.depths = m_depths_.as<int32_t>();
@@ -1133,7 +1133,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.opt_lr = m_opt_lr_.as<float>();
     kern::predict(pm, dobs, n_num, dcat, n_cat, n, start_tree, stop, dout, s);
     hip_check(hipGetLastError(), "predict launch");
-    phase_end("predict");
+    phase_end("predict", /*key=*/true);
     if (!out_dev) hip_check(hipMemcpyAsync(out, dout, sizeof(float) * static_cast<size_t>(n) * D, hipMemcpyDeviceToHost, s), "D2H preds");
     hip_check(hipStreamSynchronize(s), "sync");
     phases_resolve();

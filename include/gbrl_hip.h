@@ -158,8 +158,10 @@ int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks)
 /* Per-phase GPU time of the LAST step()/predict() call, measured with HIP events on the model's stream.
  * names/ms hold up to `cap` entries; returns the number of phases. */
 int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float *ms, int cap);
-/* When enabled (default off), step()/predict() bracket every kernel phase with HIP events. */
-int gbrl_hip_set_profiling(gbrl_hip_model *m, int enabled);
+/* level 0 (default): no events.  1: only the dominant kernel's launches (histogram build in step(), the traversal kernel in
+ * predict()) are bracketed -- two event records per launch, cheap enough for a timed region.  2: every phase is bracketed
+ * (diagnostic: each record costs a few microseconds of stream bubble, ~60 records per step). */
+int gbrl_hip_set_profiling(gbrl_hip_model *m, int level);
 
 #ifdef __cplusplus
 }
