@@ -92,6 +92,7 @@ class Engine {
     bool force_bisection_ = false, force_sample_select_ = false, last_quantile_fallback_ = false;
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
+    hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;
 

@@ -77,6 +77,7 @@ Engine::~Engine() {
     if (device_ready_) {
         (void)hipSetDevice(device_ordinal_);
         for (auto &e : ev_pool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (ev_level_) (void)hipEventDestroy(ev_level_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
 }
@@ -96,6 +97,7 @@ void Engine::ensure_device() {
     }
     if (device_ordinal_ >= count) throw InvalidArgument("device ordinal out of range");
     hip_check(hipSetDevice(device_ordinal_), "hipSetDevice");
+    hip_check(hipEventCreateWithFlags(&ev_level_, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipStreamCreate(&stream_), "hipStreamCreate");  // blocking stream: ordered with the null stream torch uses by default
     device_ready_ = true;
 }
@@ -764,6 +766,22 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         int32_t *d_path_bin = sta.put(pb.data(), pb.size());
         int32_t *d_isroot = sta.put(root.data(), root.size());
         Chunk *d_count_chunks = sta.put(count_chunks.data(), count_chunks.size());
+        // One GPU: the partition of this level is enqueued right behind the selection kernels, from descriptors the device
+        // completes itself (k_resolve_splits), so that it runs while the host is still waiting for / digesting the read-back.
+        const bool early_partition = !has_coll_;
+        std::vector<Chunk> part_chunks;
+        std::vector<int32_t> seg_starts(n_act);
+        if (early_partition) {
+            for (int k = 0; k < n_act; ++k) seg_starts[k] = nodes[active[k]].seg_start;
+            std::vector<Chunk> keep = h_chunks;
+            std::vector<int32_t> keep_begin = h_chunk_begin;
+            make_chunks(active, kern::kPartitionRows, false);
+            part_chunks = h_chunks;
+            h_chunks = keep;
+            h_chunk_begin = keep_begin;
+        }
+        Chunk *d_part_chunks = sta.put(part_chunks.data(), part_chunks.size());
+        int32_t *d_seg_starts = sta.put(seg_starts.data(), seg_starts.size());
         sta.flush();
         phase_begin(/*key=*/true);
         if (!h_chunks.empty())
@@ -793,7 +811,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
         kern::resolve_splits(d_best_idx, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
-                             d_counts4, max_front, s);
+                             d_counts4, max_front, early_partition ? d_seg_starts : nullptr, d_best_score, d_cursors, s);
         if (has_coll_) {
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
             hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
@@ -802,7 +820,17 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         }
         hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
         phase_end("score_select");
-        hip_check(hipStreamSynchronize(s), "sync");
+        if (early_partition) {
+            hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");
+            phase_begin();
+            if (!part_chunks.empty())
+                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved,
+                                     d_cursors, s);
+            phase_end("partition");
+            hip_check(hipEventSynchronize(ev_level_), "hipEventSynchronize(level results)");
+        } else {
+            hip_check(hipStreamSynchronize(s), "sync");
+        }
         hip_check(hipGetLastError(), "growth kernels");
         const int32_t *best_idx_h = reinterpret_cast<const int32_t *>(h_res);
         const float *best_score_h = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
@@ -897,7 +925,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             }
         }
         if (splitting.empty()) { frontier.clear(); break; }
-        {
+        if (early_partition) {
+            cur ^= 1;   // already enqueued from the device-side descriptors (same decisions: best_score rule, n_left = total - right)
+        } else {
             std::vector<int> split_ids;
             std::vector<NodeSplit> sp2;
             for (int k : splitting) { split_ids.push_back(active[k]); sp2.push_back(sp[k]); }

@@ -132,7 +132,10 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
 // winner -> (feature slot, class) and the child sizes it induces, per active node (one read-back per level)
 void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global /*nullable*/, int Fp, int NB, int D,
-                    NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front, hipStream_t s);
+                    NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front,
+                    const int32_t *seg_start /*nullable: when given, out[] is a complete partition descriptor (do_split from
+                    best_score, seg_start, n_left from hist_local) and cursors[2*node..] are zeroed*/,
+                    const float *best_score, int32_t *cursors, hipStream_t s);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,

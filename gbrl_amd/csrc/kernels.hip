@@ -574,13 +574,16 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const int32_t *__restrict
                                                        const int32_t *__restrict__ ref_to_internal, const int32_t *__restrict__ cand_slot,
                                                        const FeatureSlot *__restrict__ slots, const int64_t *__restrict__ hist_local,
                                                        const int64_t *__restrict__ hist_global, int Fp, int NB, int D,
-                                                       NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front) {
+                                                       NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front,
+                                                       const int32_t *__restrict__ seg_start /*nullable*/,
+                                                       const float *__restrict__ best_score, int32_t *__restrict__ cursors) {
     const int node = blockIdx.x;
     const int j = ref_to_internal[best_idx[oblivious ? 0 : node]];
     const int fs = cand_slot[j];
     const FeatureSlot sl = slots[fs];
     const int bin = sl.is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
     const int W = D + 1;
+    int n_left = 0;
     for (int pass = 0; pass < (hist_global ? 2 : 1); ++pass) {
         const int64_t *src = (pass ? hist_global : hist_local) + (static_cast<size_t>(node) * Fp + fs) * NB * W;
         long long tot = 0, right = 0;
@@ -593,11 +596,22 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const int32_t *__restrict
         if (threadIdx.x == 0) {
             counts4[(2 * pass + 0) * static_cast<size_t>(max_front) + node] = tot;
             counts4[(2 * pass + 1) * static_cast<size_t>(max_front) + node] = right;
+            if (pass == 0) n_left = static_cast<int>(tot - right);
         }
     }
     if (threadIdx.x == 0) {
         NodeSplit q{};
         q.fslot = fs; q.bin = bin; q.is_cat = sl.is_cat;
+        if (seg_start) {
+            // complete descriptor: the partition of this level is enqueued without waiting for the host's read-back.
+            // Same decision rule as the host (fitter.cpp:357 greedy: score >= 0; fitter.cpp:458 oblivious: any finite best)
+            const float bs = best_score[oblivious ? 0 : node];
+            q.do_split = oblivious ? (bs != -INFINITY) : (bs >= 0.0f);
+            q.seg_start = seg_start[node];
+            q.n_left = n_left;
+            cursors[2 * node] = 0;
+            cursors[2 * node + 1] = 0;
+        }
         out[node] = q;
     }
 }
@@ -616,6 +630,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__res
                                                             int32_t *__restrict__ cursors) {
     const Chunk ck = chunks[blockIdx.x];
     const NodeSplit sp = splits[ck.slot];
+    if (!sp.do_split) return;   // the node became a leaf (its segment stays in the input list)
     const int lane = threadIdx.x & (kWave - 1);
     constexpr int U = kPartRows / kPartThreads;
     int row[U];
@@ -1085,9 +1100,10 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
 
 void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
-                    NodeSplit *out, int64_t *counts4, int max_front, hipStream_t s) {
+                    NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, const float *best_score,
+                    int32_t *cursors, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, best_idx, oblivious ? 1 : 0, ref_to_internal, cand_slot, slots,
-                       hist_local, hist_global, Fp, NB, D, out, counts4, max_front);
+                       hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, best_score, cursors);
 }
 
 void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
