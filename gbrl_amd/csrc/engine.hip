@@ -283,7 +283,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const size_t n_el = static_cast<size_t>(N) * D;
     float *d_meanden = static_cast<float *>(d_meanden_.ensure(sizeof(float) * 2 * D));
     const float *d_mean = nullptr, *d_den = nullptr;
-    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 2 * D));
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 4 * D));
     const int nblk = kern::column_sums_blocks(N, D);
     double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
     if (D > 512) throw Unsupported("output_dim > 512");
@@ -309,46 +309,68 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             hip_check(hipStreamSynchronize(s), "sync");
         }
     };
-    // pass 1: column sums and max |g|
-    kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
-    reduce_stats();
-    for (int d = 0; d < D; ++d) hmax[1] = std::max(hmax[1], static_cast<float>(hs[D + d]));
-    if (!cosine) {
-        // fitter.cpp:58-63: mean, centre, unbiased std, divide by (std + 1e-8)
-        std::vector<float> hmd(2 * D);
-        for (int d = 0; d < D; ++d) hmd[d] = static_cast<float>(hs[d] / static_cast<double>(n_global));
-        hip_check(hipMemcpyAsync(d_meanden, hmd.data(), sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D mean");
-        kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat, s);   // pass 2: centred squares, max |g - mean|
-        reduce_stats();
-        const float recip = 1.0f / (static_cast<float>(n_global) - 1.0f);  // math_ops.cpp:464
-        for (int d = 0; d < D; ++d) {
-            const float sd = sqrtf(static_cast<float>(hs[d]) * recip);     // math_ops.cpp:510
-            hmd[D + d] = sd + 1e-8f;                                        // math_ops.cpp:94
-            hmax[0] = std::max(hmax[0], static_cast<float>(hs[D + d]) / hmd[D + d] * 1.0001f);
-        }
-        hip_check(hipMemcpyAsync(d_meanden + D, hmd.data() + D, sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D std");
-        hip_check(hipStreamSynchronize(s), "sync");   // hmd goes out of scope
-        d_mean = d_meanden;
-        d_den = d_meanden + D;
-    } else {
-        hmax[0] = hmax[1];
-    }
-    if (!std::isfinite(hmax[0]) || !std::isfinite(hmax[1])) throw InvalidArgument("non-finite gradients");
-    // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: pick the power-of-two scale
-    // with chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build)
+    // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: the power-of-two scale keeps
+    // chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build).
     // A histogram block accumulates one chunk of one node's rows.  Chunks are sized per level so that the whole level is ONE
     // balanced round of <= 32 chunks x (feature groups) blocks (k_hist_build keeps one block per CU); `chunk_rows` is the cap
-    // the fixed-point scale is derived from.
+    // the fixed-point scale is derived from.  Leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62.
     const int chunk_rows = std::max(4096, 2 * ((N + 31) / 32));
-    int sbits = 20;
-    if (hmax[0] > 0.f) sbits = std::min(100, ilog2_floor(2147483647.0 / (static_cast<double>(chunk_rows) * hmax[0])) - 1);
-    const double scale = std::ldexp(1.0, sbits);
+    kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
+    kern::StepScales h_scales{};
+    bool scales_on_host = false;
+    if (!has_coll_) {
+        // one GPU: sums -> mean -> centred squares -> std, maxima, scales, all on the device; the host reads the scales
+        // together with the thresholds (one synchronisation for both)
+        double *d_stat2 = d_stat + 2 * D;
+        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
+        if (!cosine) {
+            kern::stats_mean(d_stat, n_global, D, d_meanden, s);
+            kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat2, s);
+            kern::stats_finish(d_stat, d_stat2, n_global, D, chunk_rows, d_meanden, d_scales, s);
+            d_mean = d_meanden;
+            d_den = d_meanden + D;
+        } else {
+            kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
+        }
+    } else {
+        // row-sharded: the sums cross ranks, the (identical) arithmetic is done on every host
+        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);   // pass 1: column sums and max |g|
+        reduce_stats();
+        for (int d = 0; d < D; ++d) hmax[1] = std::max(hmax[1], static_cast<float>(hs[D + d]));
+        if (!cosine) {
+            // fitter.cpp:58-63: mean, centre, unbiased std, divide by (std + 1e-8)
+            std::vector<float> hmd(2 * D);
+            for (int d = 0; d < D; ++d) hmd[d] = static_cast<float>(hs[d] / static_cast<double>(n_global));
+            hip_check(hipMemcpyAsync(d_meanden, hmd.data(), sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D mean");
+            kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat, s);   // pass 2: centred squares, max |g - mean|
+            reduce_stats();
+            const float recip = 1.0f / (static_cast<float>(n_global) - 1.0f);  // math_ops.cpp:464
+            for (int d = 0; d < D; ++d) {
+                const float sd = sqrtf(static_cast<float>(hs[d]) * recip);     // math_ops.cpp:510
+                hmd[D + d] = sd + 1e-8f;                                        // math_ops.cpp:94
+                hmax[0] = std::max(hmax[0], static_cast<float>(hs[D + d]) / hmd[D + d] * 1.0001f);
+            }
+            hip_check(hipMemcpyAsync(d_meanden + D, hmd.data() + D, sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D std");
+            hip_check(hipStreamSynchronize(s), "sync");   // hmd goes out of scope
+            d_mean = d_meanden;
+            d_den = d_meanden + D;
+        } else {
+            hmax[0] = hmax[1];
+        }
+        if (!std::isfinite(hmax[0]) || !std::isfinite(hmax[1])) throw InvalidArgument("non-finite gradients");
+        int sbits = 20, lbits = 40;
+        if (hmax[0] > 0.f) sbits = std::min(100, ilog2_floor(2147483647.0 / (static_cast<double>(chunk_rows) * hmax[0])) - 1);
+        if (hmax[1] > 0.f) lbits = std::min(60, ilog2_floor(4.0e18 / (static_cast<double>(n_global) * hmax[1])) - 1);
+        h_scales.sbits = sbits; h_scales.lbits = lbits;
+        h_scales.scale = static_cast<float>(std::ldexp(1.0, sbits));
+        h_scales.inv_scale = std::ldexp(1.0, -sbits);
+        h_scales.leaf_scale = std::ldexp(1.0, lbits);
+        h_scales.hmax_build = hmax[0]; h_scales.hmax_raw = hmax[1];
+        hip_check(hipMemcpy(d_scales, &h_scales, sizeof(h_scales), hipMemcpyHostToDevice), "H2D scales");
+        scales_on_host = true;
+    }
     int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
-    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, static_cast<float>(scale), d_qg, s);
-    // leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62
-    int lbits = 40;
-    if (hmax[1] > 0.f) lbits = std::min(60, ilog2_floor(4.0e18 / (static_cast<double>(n_global) * hmax[1])) - 1);
-    const double leaf_scale = std::ldexp(1.0, lbits);
+    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
     phase_end("grad_stats");
 
     // ---- 2. split candidates ----------------------------------------------------------------------------------------
@@ -658,7 +680,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
     NodeSplit *d_resolved = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
     kern::iota_rows(d_rows[0], N, s);
-    hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr is needed on the host from here on
+    if (!scales_on_host) hip_check(hipMemcpyAsync(&h_scales, d_scales, sizeof(h_scales), hipMemcpyDeviceToHost, s), "D2H scales");
+    hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr and the scales are needed on the host from here on
+    if (!std::isfinite(h_scales.hmax_build) || !std::isfinite(h_scales.hmax_raw)) throw InvalidArgument("non-finite gradients");
+    const double leaf_scale = h_scales.leaf_scale;
 
     std::vector<HNode> nodes;
     nodes.reserve(max_nodes);
@@ -807,7 +832,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
         kern::score_candidates(d_hist, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
-                               1.0 / scale, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
+                               d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
         kern::resolve_splits(d_best_idx, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
@@ -915,12 +940,12 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // -- leaves finalised at this level (their segment is intact in the current list) and the partition: enqueued, not awaited
         stb.reset();
         if (!new_leaves.empty()) {
-            make_chunks(new_leaves, 4096, true);
+            make_chunks(new_leaves, 1024, true);
             if (!h_chunks.empty()) {
                 Chunk *d_lc = stb.put(h_chunks.data(), h_chunks.size());
                 stb.flush();
                 phase_begin();
-                kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), leaf_scale, d_leafacc, s);
+                kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), d_scales, d_leafacc, s);
                 phase_end("leaves");
             }
         }
@@ -951,14 +976,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         for (int id : frontier)
             if (!nodes[id].leaf) { nodes[id].leaf = true; last.push_back(id); }
         if (nodes.size() == 1) nodes[0].leaf = true;
-        make_chunks(last, 4096, true);
+        make_chunks(last, 1024, true);
         if (!h_chunks.empty()) {
             // stage B may still be in flight for the partition of the last level: stage A is free (its level is complete)
             sta.reset();
             Chunk *d_lc = sta.put(h_chunks.data(), h_chunks.size());
             sta.flush();
             phase_begin();
-            kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), leaf_scale, d_leafacc, s);
+            kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), d_scales, d_leafacc, s);
             phase_end("leaves");
         }
     }

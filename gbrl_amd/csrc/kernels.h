@@ -36,6 +36,17 @@ struct NodeSplit {
     int32_t pad0, pad1;
 };
 
+// Fixed-point scales of one step, derived from the gradient statistics.  They live in device memory so that the whole
+// statistics -> scale -> quantisation chain runs without a host round trip (the host reads them once, later).
+struct StepScales {
+    double inv_scale;   // 2^-sbits : histogram sums -> standardised-gradient units (k_score)
+    double leaf_scale;  // 2^lbits  : raw-gradient fixed point of the leaf sums (k_leaf_sums)
+    float scale;        // 2^sbits  (k_quantize)
+    float hmax_build;   // max |standardised gradient| * 1.0001 (or max |g| for Cosine)
+    float hmax_raw;     // max |g|
+    int32_t sbits, lbits, pad;
+};
+
 constexpr int kMaxPath = 32;
 constexpr int kPartitionRows = 4096;  // rows per partition block (chunk size the engine must use)  // max_depth supported by the duplicate-on-path check
 
@@ -47,8 +58,12 @@ void column_sums(const float *g, int n, int D, const float *center /*nullable [D
 int column_sums_blocks(int n, int D);
 // max |standardised g| as float bits in out[0]; mean/inv_std nullable (Cosine: raw grads)
 void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s);
+// Device-side statistics chain (one GPU): mean from the column sums; then std + 1e-8, the maxima and both fixed-point scales.
+void stats_mean(const double *stat /*[2D] sums | max*/, long long n, int D, float *meanden /*[2D] mean | denom*/, hipStream_t s);
+void stats_finish(const double *stat_raw /*[2D] sums | max|g|*/, const double *stat_centred /*nullable [2D] sum sq | max|g-mean|*/,
+                  long long n, int D, int chunk_rows, float *meanden, StepScales *sc, hipStream_t s);
 // qg = rint(((g - mean) / denom) * scale) as int32  (mean/denom nullable)
-void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, float scale,
+void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, const StepScales *sc,
                     int32_t *qg, hipStream_t s);
 
 // ---- split candidates (A3, A4) ----
@@ -117,7 +132,7 @@ void hist_subtract(const int64_t *prev, int64_t *cur, const int32_t *entries, in
 
 // ---- scoring / selection (A6, A7, A8) ----
 void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
-                      const float *thr /*[F][B]*/, int B, int n_cand, int min_data, int cosine, double inv_scale,
+                      const float *thr /*[F][B]*/, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/, hipStream_t s);
 // best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
@@ -147,7 +162,7 @@ void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *c
                     hipStream_t s);
 
 // ---- leaf values (A11) ----
-void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, double scale,
+void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, const StepScales *sc,
                int64_t *acc /*[n_leaves][D+1], zeroed*/, hipStream_t s);
 
 // ---- prediction (A13) ----

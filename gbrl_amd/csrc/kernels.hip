@@ -81,6 +81,54 @@ __global__ __launch_bounds__(256) void k_column_sums_final(const double *__restr
     if (threadIdx.x == 0) out[d] = sh[0];
 }
 
+// Statistics chain on the device, operation for operation what the host path does (fitter.cpp:58-63, math_ops.cpp:464,510,94)
+// with explicitly rounded fp32 intrinsics (no contraction).
+__global__ __launch_bounds__(256) void k_stats_mean(const double *__restrict__ stat, long long n, int D, float *__restrict__ meanden) {
+    for (int d = threadIdx.x; d < D; d += blockDim.x) meanden[d] = static_cast<float>(stat[d] / static_cast<double>(n));
+}
+__device__ __forceinline__ int ilog2_floor_dev(double x) { int e; (void)frexp(x, &e); return e - 1; }
+__global__ __launch_bounds__(256) void k_stats_finish(const double *__restrict__ stat_raw, const double *__restrict__ stat_centred,
+                                                      long long n, int D, int chunk_rows, float *__restrict__ meanden,
+                                                      StepScales *__restrict__ sc) {
+    __shared__ float m0[256], m1[256];
+    float h0 = 0.0f, h1 = 0.0f;
+    const float recip = __fdiv_rn(1.0f, __fsub_rn(static_cast<float>(n), 1.0f));
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        h1 = fmaxf(h1, static_cast<float>(stat_raw[D + d]));
+        if (!(fabs(stat_raw[d]) < INFINITY)) h1 = INFINITY;            // a NaN / inf gradient poisons its column sum
+        if (stat_centred && !(fabs(stat_centred[d]) < INFINITY)) h0 = INFINITY;
+        if (stat_centred) {
+            const float sd = __fsqrt_rn(__fmul_rn(static_cast<float>(stat_centred[d]), recip));
+            const float den = __fadd_rn(sd, 1e-8f);
+            meanden[D + d] = den;
+            h0 = fmaxf(h0, __fmul_rn(__fdiv_rn(static_cast<float>(stat_centred[D + d]), den), 1.0001f));
+        }
+    }
+    // NaN must survive the reduction (fmaxf drops it): carried as +inf, which the host rejects
+    if (h0 != h0) h0 = INFINITY;
+    if (h1 != h1) h1 = INFINITY;
+    m0[threadIdx.x] = h0;
+    m1[threadIdx.x] = h1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { m0[threadIdx.x] = fmaxf(m0[threadIdx.x], m0[threadIdx.x + o]); m1[threadIdx.x] = fmaxf(m1[threadIdx.x], m1[threadIdx.x + o]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float hraw = m1[0], hbuild = stat_centred ? m0[0] : m1[0];
+        int sbits = 20, lbits = 40;
+        if (hbuild > 0.f && hbuild < INFINITY) sbits = min(100, ilog2_floor_dev(2147483647.0 / (static_cast<double>(chunk_rows) * hbuild)) - 1);
+        if (hraw > 0.f && hraw < INFINITY) lbits = min(60, ilog2_floor_dev(4.0e18 / (static_cast<double>(n) * hraw)) - 1);
+        StepScales o{};
+        o.sbits = sbits; o.lbits = lbits;
+        o.scale = static_cast<float>(ldexp(1.0, sbits));
+        o.inv_scale = ldexp(1.0, -sbits);
+        o.leaf_scale = ldexp(1.0, lbits);
+        o.hmax_build = hbuild; o.hmax_raw = hraw;
+        *sc = o;
+    }
+}
+
 __device__ __forceinline__ float standardise(float v, const float *mean, const float *denom, int col) {
     // (g - mean) / (std + 1e-8f) evaluated in fp32 exactly like fitter.cpp:58-63 -> math_ops.cpp:498,94
     if (mean == nullptr) return v;
@@ -100,7 +148,8 @@ __global__ void k_max_abs(const float *__restrict__ g, size_t n_el, int D, const
 }
 
 __global__ void k_quantize(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ mean,
-                           const float *__restrict__ denom, float scale, int32_t *__restrict__ qg) {
+                           const float *__restrict__ denom, const StepScales *__restrict__ sc, int32_t *__restrict__ qg) {
+    const float scale = sc->scale;
     for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n_el;
          e += static_cast<size_t>(gridDim.x) * blockDim.x) {
         const float v = standardise(g[e], mean, denom, static_cast<int>(e % D));
@@ -420,26 +469,39 @@ __device__ __forceinline__ double side_term(const int64_t *S, int D, int64_t n, 
 
 __global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist, int Fp, int NB, int D,
                                                const FeatureSlot *__restrict__ slots, const float *__restrict__ thr,
-                                               int B, int n_cand, int min_data, int cosine, double inv_scale,
+                                               int B, int n_cand, int min_data, int cosine, const StepScales *__restrict__ scp,
                                                const int32_t *__restrict__ path_len, const int32_t *__restrict__ path_slot,
                                                const float *__restrict__ path_val, const int32_t *__restrict__ path_bin,
                                                float *__restrict__ scores, float *__restrict__ parent) {
     extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
+    const double inv_scale = scp->inv_scale;
     const int node = blockIdx.y, fs = blockIdx.x;
     const FeatureSlot sl = slots[fs];
     const int W = D + 1;
     const int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
     for (int i = threadIdx.x; i < NB * W; i += blockDim.x) sh64[i] = src[i];
     __syncthreads();
-    // totals = sum over all classes; also turn numeric features into suffix sums in place
+    // totals = sum over all classes; also turn numeric features into suffix sums in place.  Block-wide scan per field: thread t
+    // of a 256-class tile owns class NB-1-(tile*256+t), so an inclusive prefix over t is the suffix sum over classes.
     int64_t *total = sh64 + static_cast<size_t>(NB) * W;  // [D+1]
-    if (threadIdx.x < W) {
-        int64_t run = 0;
-        for (int c = NB - 1; c >= 0; --c) {
-            run += sh64[c * W + threadIdx.x];
-            if (!sl.is_cat) sh64[c * W + threadIdx.x] = run;
+    __shared__ long long wsum[4];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int w = 0; w < W; ++w) {
+        long long run_base = 0;
+        for (int tile = 0; tile * 256 < NB; ++tile) {
+            const int c = NB - 1 - (tile * 256 + static_cast<int>(threadIdx.x));
+            long long v = c >= 0 ? sh64[c * W + w] : 0;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) { const long long t2 = __shfl_up(v, d, kWave); if (lane >= d) v += t2; }
+            if (lane == kWave - 1) wsum[wave] = v;
+            __syncthreads();
+            long long base = run_base, tile_total = 0;
+            for (int i = 0; i < 4; ++i) { if (i < wave) base += wsum[i]; tile_total += wsum[i]; }
+            if (c >= 0 && !sl.is_cat) sh64[c * W + w] = v + base;
+            run_base += tile_total;
+            __syncthreads();
         }
-        total[threadIdx.x] = run;
+        if (threadIdx.x == 0) total[w] = run_base;
     }
     __syncthreads();
     const int64_t n_tot = total[D];
@@ -705,9 +767,10 @@ __global__ __launch_bounds__(kPartThreads) void k_count_right(const int32_t *__r
 // A11  leaf sums of RAW gradients (fixed-point int64, exact) + counts.  acc[leaf][0..D) sums, acc[leaf][D] count.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_leaf_sums(const float *__restrict__ grads, int D, const int32_t *__restrict__ rows,
-                                                   const Chunk *__restrict__ chunks, double scale,
+                                                   const Chunk *__restrict__ chunks, const StepScales *__restrict__ scp,
                                                    int64_t *__restrict__ acc) {
     extern __shared__ unsigned long long shl[];  // [D+1]
+    const double scale = scp->leaf_scale;
     for (int i = threadIdx.x; i <= D; i += blockDim.x) shl[i] = 0ull;
     __syncthreads();
     const Chunk ck = chunks[blockIdx.x];
@@ -716,7 +779,19 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const float *__restrict__ gra
     const int d = threadIdx.x % D, sub = threadIdx.x / D;
     long long s = 0;
     if (sub < per) {
-        for (int p = sub; p < ck.len; p += per) {
+        // four independent (row id -> gradient) load chains in flight per thread
+        int p = sub;
+        for (; p + 3 * per < ck.len; p += 4 * per) {
+            int r[4];
+            float g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = rows[ck.start + p + u * per];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = grads[static_cast<size_t>(r[u]) * D + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += __double2ll_rn(static_cast<double>(g[u]) * scale);
+        }
+        for (; p < ck.len; p += per) {
             const int row = rows[ck.start + p];
             s += __double2ll_rn(static_cast<double>(grads[static_cast<size_t>(row) * D + d]) * scale);
         }
@@ -960,9 +1035,17 @@ void max_abs(const float *g, size_t n_el, int D, const float *mean, const float 
     hipLaunchKernelGGL(k_max_abs, dim3(grid_for(n_el, 256, 2048)), dim3(256), 0, s, g, n_el, D, mean, denom, out_bits);
 }
 
-void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, float scale, int32_t *qg,
+void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, const StepScales *sc, int32_t *qg,
                     hipStream_t s) {
-    hipLaunchKernelGGL(k_quantize, dim3(grid_for(n_el, 256, 4096)), dim3(256), 0, s, g, n_el, D, mean, denom, scale, qg);
+    hipLaunchKernelGGL(k_quantize, dim3(grid_for(n_el, 256, 4096)), dim3(256), 0, s, g, n_el, D, mean, denom, sc, qg);
+}
+
+void stats_mean(const double *stat, long long n, int D, float *meanden, hipStream_t s) {
+    hipLaunchKernelGGL(k_stats_mean, dim3(1), dim3(256), 0, s, stat, n, D, meanden);
+}
+void stats_finish(const double *stat_raw, const double *stat_centred, long long n, int D, int chunk_rows, float *meanden,
+                  StepScales *sc, hipStream_t s) {
+    hipLaunchKernelGGL(k_stats_finish, dim3(1), dim3(256), 0, s, stat_raw, stat_centred, n, D, chunk_rows, meanden, sc);
 }
 
 void column_minmax(const float *obs, int n, int F, uint32_t *mn, uint32_t *mx, hipStream_t s) {
@@ -1069,7 +1152,7 @@ void hist_subtract(const int64_t *prev, int64_t *cur, const int32_t *entries, in
 }
 
 void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
-                      const float *thr, int B, int n_cand, int min_data, int cosine, double inv_scale,
+                      const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, hipStream_t s) {
     const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
@@ -1079,7 +1162,7 @@ void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, c
         attr_set = true;
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, Fp, NB, D, slots, thr, B, n_cand, min_data,
-                       cosine, inv_scale, path_len, path_slot, path_val, path_bin, scores, parent);
+                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent);
 }
 
 int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }
@@ -1117,11 +1200,11 @@ void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *c
                        cursors);
 }
 
-void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, double scale, int64_t *acc,
+void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, const StepScales *sc, int64_t *acc,
                hipStream_t s) {
     const int bs = D <= 256 ? 256 : ((D + 63) / 64) * 64;
     hipLaunchKernelGGL(k_leaf_sums, dim3(n_chunks), dim3(bs), (D + 1) * sizeof(unsigned long long), s, grads, D, rows, chunks,
-                       scale, acc);
+                       sc, acc);
 }
 
 template <int DMAX>

@@ -220,6 +220,29 @@ def test_fast_quantile_path_equals_bisection_path(monkeypatch):
         assert np.array_equal(outs[1][k], outs[2][k]), ("sample vs bisection", k)
 
 
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_gradients_are_rejected_and_leave_the_model_unchanged(bad):
+    import gbrl_amd
+    rng = np.random.default_rng(3)
+    N, F, D = 5000, 6, 3
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    G = rng.standard_normal((N, D)).astype(np.float32)
+    case = dict(name="nf", seed=0, N=N, F=F, D=D, depth=3, n_bins=64, score="L2", gen="Quantile", policy="greedy", trees=1)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, None, G, None)
+    before = {k: np.asarray(v).copy() for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    Gb = G.copy()
+    Gb[1234, 1] = bad
+    with pytest.raises(RuntimeError):
+        m.step(X, None, Gb)
+    assert m.get_num_trees() == 1
+    after = m.get_ensemble_data()
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(before[k], np.asarray(after[k])), k
+    m.step(X, None, G)                      # the model keeps working afterwards
+    assert m.get_num_trees() == 2
+
+
 def test_sharded_code_path_on_one_gpu(monkeypatch):
     """The row-sharded path of step() (collective hooks at every exchange point, counting quantiles, every node accumulated)
     run with world_size 1 through torch.distributed/RCCL on the real device pointers: must give the single-GPU tree."""
