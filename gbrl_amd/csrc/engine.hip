@@ -835,8 +835,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                                d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
-        kern::resolve_splits(d_best_idx, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
-                             d_counts4, max_front, early_partition ? d_seg_starts : nullptr, d_best_score, d_cursors, s);
+        kern::resolve_splits(d_am_v, d_am_i, am_parts, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+                             d_counts4, max_front, early_partition ? d_seg_starts : nullptr, d_cursors, s);
         if (has_coll_) {
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
             hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");

@@ -145,12 +145,13 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
                   int64_t *n_total, int64_t *n_right, hipStream_t s);
 
 // winner -> (feature slot, class) and the child sizes it induces, per active node (one read-back per level)
-void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
+void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*argmax stage-1 output; the final stage runs here*/,
+                    int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global /*nullable*/, int Fp, int NB, int D,
                     NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front,
                     const int32_t *seg_start /*nullable: when given, out[] is a complete partition descriptor (do_split from
                     best_score, seg_start, n_left from hist_local) and cursors[2*node..] are zeroed*/,
-                    const float *best_score, int32_t *cursors, hipStream_t s);
+                    int32_t *cursors, hipStream_t s);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,

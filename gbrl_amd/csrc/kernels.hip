@@ -481,27 +481,49 @@ __global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist,
     const int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
     for (int i = threadIdx.x; i < NB * W; i += blockDim.x) sh64[i] = src[i];
     __syncthreads();
-    // totals = sum over all classes; also turn numeric features into suffix sums in place.  Block-wide scan per field: thread t
-    // of a 256-class tile owns class NB-1-(tile*256+t), so an inclusive prefix over t is the suffix sum over classes.
+    // totals = sum over all classes; also turn numeric features into suffix sums in place.  Block-wide scan: thread t of a
+    // 256-class tile owns class NB-1-(tile*256+t), so an inclusive prefix over t is the suffix sum over classes.  Up to 9
+    // fields are scanned together so that their cross-lane shuffles overlap.
     int64_t *total = sh64 + static_cast<size_t>(NB) * W;  // [D+1]
-    __shared__ long long wsum[4];
+    constexpr int WCH = 9;
+    __shared__ long long wsum[4][WCH];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    for (int w = 0; w < W; ++w) {
-        long long run_base = 0;
+    for (int w0 = 0; w0 < W; w0 += WCH) {
+        long long run_base[WCH];
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) run_base[j] = 0;
         for (int tile = 0; tile * 256 < NB; ++tile) {
             const int c = NB - 1 - (tile * 256 + static_cast<int>(threadIdx.x));
-            long long v = c >= 0 ? sh64[c * W + w] : 0;
+            long long v[WCH];
 #pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) { const long long t2 = __shfl_up(v, d, kWave); if (lane >= d) v += t2; }
-            if (lane == kWave - 1) wsum[wave] = v;
+            for (int j = 0; j < WCH; ++j) v[j] = (c >= 0 && w0 + j < W) ? sh64[c * W + w0 + j] : 0;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                long long t2[WCH];
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) t2[j] = __shfl_up(v[j], d, kWave);
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) if (lane >= d) v[j] += t2[j];
+            }
+            if (lane == kWave - 1) {
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) wsum[wave][j] = v[j];
+            }
             __syncthreads();
-            long long base = run_base, tile_total = 0;
-            for (int i = 0; i < 4; ++i) { if (i < wave) base += wsum[i]; tile_total += wsum[i]; }
-            if (c >= 0 && !sl.is_cat) sh64[c * W + w] = v + base;
-            run_base += tile_total;
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) {
+                long long base = run_base[j], tile_total = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const long long x = wsum[i][j]; if (i < wave) base += x; tile_total += x; }
+                if (c >= 0 && !sl.is_cat && w0 + j < W) sh64[c * W + w0 + j] = v[j] + base;
+                run_base[j] += tile_total;
+            }
             __syncthreads();
         }
-        if (threadIdx.x == 0) total[w] = run_base;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) if (w0 + j < W) total[w0 + j] = run_base[j];
+        }
     }
     __syncthreads();
     const int64_t n_tot = total[D];
@@ -547,7 +569,7 @@ __device__ __forceinline__ Best better(Best a, Best b) {
     if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
     return a;
 }
-// Two stages: stage 1 (many blocks) reduces a slice of the candidates, stage 2 (one block per node) the per-block bests.
+// Two stages: stage 1 (many blocks) reduces a slice of the candidates; the per-block bests are reduced by k_resolve_splits.
 constexpr int kArgmaxThreads = 256;
 __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *__restrict__ scores, int n_nodes, int n_cand,
                                                                   const float *__restrict__ w, const int32_t *__restrict__ ref,
@@ -587,30 +609,6 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *_
         part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = si[0];
     }
 }
-__global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage2(const float *__restrict__ part_v, const int32_t *__restrict__ part_i,
-                                                                  int n_parts, int32_t *__restrict__ best_idx,
-                                                                  float *__restrict__ best_score) {
-    const int node = blockIdx.x;
-    Best mine{-INFINITY, 0x7fffffff};
-    for (int q = threadIdx.x; q < n_parts; q += kArgmaxThreads)
-        mine = better(mine, Best{part_v[static_cast<size_t>(node) * n_parts + q], part_i[static_cast<size_t>(node) * n_parts + q]});
-    __shared__ float sv[kArgmaxThreads];
-    __shared__ int si[kArgmaxThreads];
-    sv[threadIdx.x] = mine.v;
-    si[threadIdx.x] = mine.i;
-    __syncthreads();
-    for (int o = kArgmaxThreads / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            Best a2{sv[threadIdx.x], si[threadIdx.x]}, b2{sv[threadIdx.x + o], si[threadIdx.x + o]};
-            a2 = better(a2, b2);
-            sv[threadIdx.x] = a2.v;
-            si[threadIdx.x] = a2.i;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { best_idx[node] = si[0] == 0x7fffffff ? 0 : si[0]; best_score[node] = sv[0]; }
-}
-
 __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, int Fp, int NB, int D,
                                const NodeSplit *__restrict__ splits, int64_t *__restrict__ n_total,
                                int64_t *__restrict__ n_right) {
@@ -632,15 +630,28 @@ __global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, in
 // Child sizes of the selected split of every active node, straight from the histograms (one wave per node), so that the
 // host learns the winner AND the sizes of its children with a single read-back.  counts4 = [total_local | right_local |
 // total_global | right_global], each max_front wide.
-__global__ __launch_bounds__(64) void k_resolve_splits(const int32_t *__restrict__ best_idx, int oblivious,
+__global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__ part_v, const int32_t *__restrict__ part_i, int n_parts,
+                                                       int32_t *__restrict__ best_idx, float *__restrict__ best_score, int oblivious,
                                                        const int32_t *__restrict__ ref_to_internal, const int32_t *__restrict__ cand_slot,
                                                        const FeatureSlot *__restrict__ slots, const int64_t *__restrict__ hist_local,
                                                        const int64_t *__restrict__ hist_global, int Fp, int NB, int D,
                                                        NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front,
-                                                       const int32_t *__restrict__ seg_start /*nullable*/,
-                                                       const float *__restrict__ best_score, int32_t *__restrict__ cursors) {
+                                                       const int32_t *__restrict__ seg_start /*nullable*/, int32_t *__restrict__ cursors) {
     const int node = blockIdx.x;
-    const int j = ref_to_internal[best_idx[oblivious ? 0 : node]];
+    // final stage of the argmax (same total order as stage 1: higher score, then lower reference index): every block
+    // reduces the per-block bests of its node (oblivious: of the level); the owner block publishes them for the host
+    const int src_node = oblivious ? 0 : node;
+    Best mine{-INFINITY, 0x7fffffff};
+    for (int q = threadIdx.x; q < n_parts; q += kWave)
+        mine = better(mine, Best{part_v[static_cast<size_t>(src_node) * n_parts + q], part_i[static_cast<size_t>(src_node) * n_parts + q]});
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const Best other{__shfl_xor(mine.v, o, kWave), __shfl_xor(mine.i, o, kWave)};
+        mine = better(mine, other);
+    }
+    const int best = mine.i == 0x7fffffff ? 0 : mine.i;
+    const float best_v = mine.v;
+    if (threadIdx.x == 0 && node == src_node) { best_idx[node] = best; best_score[node] = best_v; }
+    const int j = ref_to_internal[best];
     const int fs = cand_slot[j];
     const FeatureSlot sl = slots[fs];
     const int bin = sl.is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const int32_t *__restrict
         if (seg_start) {
             // complete descriptor: the partition of this level is enqueued without waiting for the host's read-back.
             // Same decision rule as the host (fitter.cpp:357 greedy: score >= 0; fitter.cpp:458 oblivious: any finite best)
-            const float bs = best_score[oblivious ? 0 : node];
+            const float bs = best_v;
             q.do_split = oblivious ? (bs != -INFINITY) : (bs >= 0.0f);
             q.seg_start = seg_start[node];
             q.n_left = n_left;
@@ -1173,7 +1184,7 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const 
     const int out_nodes = oblivious ? 1 : n_nodes;
     hipLaunchKernelGGL(k_argmax_stage1, dim3(parts, out_nodes), dim3(kArgmaxThreads), 0, s, scores, n_nodes, n_cand, w, ref, parent,
                        is_root, oblivious ? 1 : 0, part_v, part_i);
-    hipLaunchKernelGGL(k_argmax_stage2, dim3(out_nodes), dim3(kArgmaxThreads), 0, s, part_v, part_i, parts, best_idx, best_score);
+    (void)best_idx; (void)best_score;   // published by k_resolve_splits, which runs the last reduction stage itself
 }
 void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits, int64_t *n_total,
                   int64_t *n_right, hipStream_t s) {
@@ -1181,12 +1192,11 @@ void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const
                        n_right);
 }
 
-void resolve_splits(const int32_t *best_idx, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
+void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
-                    NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, const float *best_score,
-                    int32_t *cursors, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, best_idx, oblivious ? 1 : 0, ref_to_internal, cand_slot, slots,
-                       hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, best_score, cursors);
+                    NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, part_v, part_i, n_parts, best_idx, best_score, oblivious ? 1 : 0,
+                       ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors);
 }
 
 void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
