@@ -467,6 +467,15 @@ __device__ __forceinline__ double side_term(const int64_t *S, int D, int64_t n, 
     return ss / static_cast<double>(n);
 }
 
+// Wave-wide inclusive scan step on a 64-bit value with DPP (VALU only; __shfl_up would go through the LDS crossbar, which
+// is what k_score is short of).  ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_scan_step(long long x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    return x + ((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 __global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist, int Fp, int NB, int D,
                                                const FeatureSlot *__restrict__ slots, const float *__restrict__ thr,
                                                int B, int n_cand, int min_data, int cosine, const StepScales *__restrict__ scp,
@@ -498,12 +507,15 @@ __global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist,
 #pragma unroll
             for (int j = 0; j < WCH; ++j) v[j] = (c >= 0 && w0 + j < W) ? sh64[c * W + w0 + j] : 0;
 #pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                long long t2[WCH];
-#pragma unroll
-                for (int j = 0; j < WCH; ++j) t2[j] = __shfl_up(v[j], d, kWave);
-#pragma unroll
-                for (int j = 0; j < WCH; ++j) if (lane >= d) v[j] += t2[j];
+            for (int j = 0; j < WCH; ++j) {
+                long long x = v[j];
+                x = dpp_scan_step<0x111, 0xf>(x);   // within rows of 16 lanes
+                x = dpp_scan_step<0x112, 0xf>(x);
+                x = dpp_scan_step<0x114, 0xf>(x);
+                x = dpp_scan_step<0x118, 0xf>(x);
+                x = dpp_scan_step<0x142, 0xa>(x);   // lane 15 of rows 0 / 2 -> rows 1 / 3
+                x = dpp_scan_step<0x143, 0xc>(x);   // lane 31 -> rows 2, 3
+                v[j] = x;
             }
             if (lane == kWave - 1) {
 #pragma unroll
