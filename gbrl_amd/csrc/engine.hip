@@ -443,7 +443,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
                 void *d_rs = d_radix_state_.ensure(kern::radix_state_bytes(F, B));
                 uint32_t *d_rp = static_cast<uint32_t *>(d_radix_partial_.ensure(kern::radix_partial_bytes(F)));
-                kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_thrkeys, s);
+                uint32_t *d_rl = static_cast<uint32_t *>(d_qlists_.ensure(kern::radix_list_bytes(N, F)));
+                kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s);
                 last_quantile_fallback_ = false;
             } else {
                 fast_quantile = true;

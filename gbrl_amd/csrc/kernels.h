@@ -114,8 +114,9 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 size_t radix_state_bytes(int F, int B);
 size_t radix_partial_bytes(int F);
 int radix_max_targets();
-void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *thr_keys,
-                  hipStream_t s);
+size_t radix_list_bytes(int n, int F);
+void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
+                  uint32_t *thr_keys, hipStream_t s);
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s);
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s);
 constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [group][row][16]

@@ -42,6 +42,9 @@ struct RadixState {
     uint16_t *tgt_slot;    // [F][B]
     uint32_t *tgt_rank;    // [F][B]        1-based rank inside the slot
     uint32_t *tgt_prefix;  // [F][B]
+    uint32_t *list_cnt;    // [F][chunks]   keys of the chunk that matched a live 19-bit prefix in pass 3
+    uint32_t *lists;       // [F][chunks][cap] those keys (valid when list_cnt <= cap): pass 4 reads them instead of the column
+    uint32_t list_cap;
 };
 
 // ---- counting pass --------------------------------------------------------------------------------------------------
@@ -60,6 +63,9 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     uint16_t *coff = reinterpret_cast<uint16_t *>(cbits + 2 * 512);            // [2][258]
     uint32_t *filt = reinterpret_cast<uint32_t *>(coff + 2 * 260);             // [2048] 65536-bit hashed set of the live prefixes
     constexpr int PS = PASS == 3 ? 13 : 6;                                     // bits below the prefix a pass-3/4 key must match
+    __shared__ uint32_t list_cursor;
+    if (threadIdx.x == 0) list_cursor = 0;
+    uint32_t *my_list = st.lists + (static_cast<size_t>(f) * n_chunks + blockIdx.x) * st.list_cap;
     for (int i = threadIdx.x; i < n_cnt; i += kRadixThreads) cnt[i] = 0;
     if (PASS >= 3) {
         // Few keys still match a live prefix (a few % in pass 3, ~0.1 % in pass 4): one bit test rejects the rest before the
@@ -100,6 +106,21 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
             if (PASS >= 4 && slot != kNone) slot = child(1, slot, (key >> 6) & 127);
         }
         const int idx = slot == kNone ? -1 : slot * NB + static_cast<int>((key >> SH) & (NB - 1));
+        if (PASS == 3) {
+            // the survivors of this pass (typically a few % of the column) are compacted into the block's own list, so that
+            // the last pass does not stream the column again.  Wave-aggregated reservation on an LDS cursor.
+            const unsigned long long m = __ballot(idx >= 0);
+            if (m) {
+                const int leader = __ffsll(static_cast<long long>(m)) - 1;
+                uint32_t base = 0;
+                if (static_cast<int>(__lane_id()) == leader) base = atomicAdd(&list_cursor, static_cast<uint32_t>(__popcll(m)));
+                base = __builtin_amdgcn_readlane(base, leader);
+                if (idx >= 0) {
+                    const uint32_t pos = base + __popcll(m & ((1ull << __lane_id()) - 1));
+                    if (pos < st.list_cap) my_list[pos] = key;
+                }
+            }
+        }
         // a wave whose keys all fall into one counter (constant / mostly-constant columns) adds once instead of 64 times
         const int first = __builtin_amdgcn_readfirstlane(idx);
         const unsigned long long active = __ballot(1);
@@ -113,6 +134,13 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     };
     constexpr int U = 8;
     int i0 = lo + threadIdx.x;
+    if (PASS == 4) {
+        const uint32_t n_list = st.list_cnt[f * n_chunks + blockIdx.x];
+        if (n_list <= st.list_cap) {   // the chunk's survivors of pass 3 fit their list: count those, skip the column
+            for (uint32_t i = threadIdx.x; i < n_list; i += kRadixThreads) count_one(my_list[i]);
+            i0 = hi;
+        }
+    }
     for (; i0 + (U - 1) * kRadixThreads < hi; i0 += kRadixThreads * U) {   // full strips: straight-line loads
         uint32_t key[U];
 #pragma unroll
@@ -143,6 +171,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     }
     for (; i0 < hi; i0 += kRadixThreads) count_one(col[i0]);
     __syncthreads();
+    if (PASS == 3 && threadIdx.x == 0) st.list_cnt[f * n_chunks + blockIdx.x] = list_cursor;
     uint32_t *dst = partial + (static_cast<size_t>(f) * n_chunks + blockIdx.x) * (PASS == 1 ? kBins1 : kMaxTargets * kSlotStride);
     if (PASS == 1) {
         for (int i = threadIdx.x; i < kBins1; i += kRadixThreads) dst[i] = cnt[i];
@@ -266,8 +295,9 @@ constexpr size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15);
 size_t radix_state_bytes(int F, int B) {
     const size_t f = static_cast<size_t>(F);
     return align16(f * kBins1 * 2) + align16(f * 2 * 258 * 2) + align16(f * 2 * 512 * 8) + align16(f * 4 * 4) + align16(f * B * 2) +
-           2 * align16(f * B * 4);
+           2 * align16(f * B * 4) + align16(f * kChunksN * 4);
 }
+size_t radix_list_bytes(int n, int F) { return sizeof(uint32_t) * (static_cast<size_t>(F) * (static_cast<size_t>(n) / 4 + 64) + 64); }
 size_t radix_partial_bytes(int F) {
     const size_t a = static_cast<size_t>(F) * kChunks1 * kBins1, b = static_cast<size_t>(F) * kChunksN * kMaxTargets * kSlotStride;
     return sizeof(uint32_t) * (a > b ? a : b);
@@ -276,8 +306,8 @@ int radix_max_targets() { return kMaxTargets; }
 
 // Exact order statistics of every column: thr_keys[f][k] = key of 1-based rank cum[k] in column f of kt ([F][n] ordered keys).
 // cum must be non-decreasing, 1 <= cum[k] <= n, B <= 256.
-void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *thr_keys,
-                  hipStream_t s) {
+void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
+                  uint32_t *thr_keys, hipStream_t s) {
     char *p = static_cast<char *>(state);
     auto take = [&](size_t bytes) { char *q = p; p += align16(bytes); return q; };
     const size_t f = static_cast<size_t>(F);
@@ -289,6 +319,8 @@ void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, v
     st.tgt_slot = reinterpret_cast<uint16_t *>(take(f * B * 2));
     st.tgt_rank = reinterpret_cast<uint32_t *>(take(f * B * 4));
     st.tgt_prefix = reinterpret_cast<uint32_t *>(take(f * B * 4));
+    st.list_cnt = reinterpret_cast<uint32_t *>(take(f * kChunksN * 4));
+    st.lists = lists;
     const size_t aux = kBins1 * 2 + 2 * 512 * 8 + 2 * 260 * 2 + 2048 * 4;
     const size_t lds1 = kBins1 * 4 + aux, lds23 = static_cast<size_t>(kMaxTargets) * 128 * 4 + aux,
                  lds4 = static_cast<size_t>(kMaxTargets) * 64 * 4 + aux;
@@ -303,6 +335,8 @@ void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, v
     int cn = 1;
     if (n >= (1 << 16)) { cn = 2; while (cn < kChunksN && cn * F < 256) cn *= 2; }
     const int c1 = n >= (1 << 16) ? kChunks1 : 1;
+    // a list holds up to a quarter of its chunk (radix_list_bytes); a chunk with more survivors is streamed again by pass 4
+    st.list_cap = static_cast<uint32_t>((n / 4) / cn);
     hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial);
     hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kBins1 * 4, s, 1, partial, c1, cum, B, st, thr_keys);
     hipLaunchKernelGGL(k_radix_count<2>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
