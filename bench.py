@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0: size the CPU sample for ~15 s on this host")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic: run the row-sharded code path (collective hooks through RCCL) on ONE GPU")
     ap.add_argument("--predict-trees", type=int, default=0, help="0: predict over the ensemble grown by the bench")
     args = ap.parse_args()
 
@@ -105,6 +107,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif args.force_collective:
+        os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     N, F, D, depth, B = args.rows, args.features, args.out_dim, args.depth, args.bins
     gen = torch.Generator(device=dev)
@@ -126,7 +133,7 @@ def main():
     # step, each a few-microsecond stream bubble, so it is taken in a separate diagnostic pass after the timed region.
     m.set_profiling(1)
     coll = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         from gbrl_amd.dist import install_torch_collective
         coll = install_torch_collective(m, dev)
 
@@ -205,10 +212,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 fixed-point sums / f32 scores",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: oblivious tree, L2 score, quantile candidates", "rows_per_gpu": N,
-                       "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world},
+                       "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world + (" (collective path forced)" if args.force_collective else "")},
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
                         "row_trees_per_s": world * N * n_trees / dtp},
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
+            "collective": ({"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)} if coll is not None else None),
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,
             "roofline": {"bound": "hbm", "kernel": "k_hist_build (split-score histogram build), %d launches per tree" % depth,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -227,6 +235,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

@@ -100,7 +100,7 @@ class Engine {
     DevBuf d_obs_, d_grads_, d_qg_, d_stat_, d_partials_f64_, d_meanden_, d_maxbits_;
     DevBuf d_thr_, d_thrkeys_, d_prefix_, d_trial_, d_counts_, d_cum_, d_minmax_;
     DevBuf d_selcnt_, d_kcls_, d_kt_, d_qflags_, d_splitters_, d_ccounts_, d_c2l_, d_tgt_list_, d_tgt_rank_, d_list_off_, d_qlists_;
-    DevBuf d_radix_state_, d_radix_partial_, d_scales_;
+    DevBuf d_radix_state_, d_radix_partial_, d_radix_global_, d_scales_;
     DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
     DevBuf d_hist_prev_, d_slotmap_, d_am_v_, d_am_i_, d_stage_const_, d_stage_a_, d_stage_b_, d_results_;
     PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_;

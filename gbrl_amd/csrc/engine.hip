@@ -435,16 +435,26 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
             // sharded fast path needs a power-of-two world (union sample of world*4096 keys sorted in LDS)
             const bool coll_fast = has_coll_ && (coll_.world_size & (coll_.world_size - 1)) == 0 && coll_.world_size <= 8;
-            if (force_bisection_ || (has_coll_ && !coll_fast)) {
+            const bool radix_ok = !force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32);
+            if (force_bisection_ || (has_coll_ && !coll_fast && !radix_ok)) {
                 bisection_quantiles(cum);
-            } else if (!has_coll_ && !force_sample_select_ && B <= kern::radix_max_targets()) {
-                // one GPU: exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip)
+            } else if (!force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32)) {
+                // exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip).  Row-sharded
+                // runs sum the digit counts of every pass over ranks (any world size): 4 all-reduces per step.
                 int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
                 hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
                 void *d_rs = d_radix_state_.ensure(kern::radix_state_bytes(F, B));
                 uint32_t *d_rp = static_cast<uint32_t *>(d_radix_partial_.ensure(kern::radix_partial_bytes(F)));
                 uint32_t *d_rl = static_cast<uint32_t *>(d_qlists_.ensure(kern::radix_list_bytes(N, F)));
-                kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s);
+                kern::RadixComm comm{};
+                if (has_coll_) {
+                    comm.ctx = coll_.ctx;
+                    comm.allreduce_sum_i64 = coll_.allreduce_sum_i64;
+                    comm.gbuf = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * kern::radix_exchange_words(F)));
+                    comm.partial_global = static_cast<uint32_t *>(d_radix_global_.ensure(kern::radix_global_partial_bytes(F)));
+                }
+                const int rc = kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s, has_coll_ ? &comm : nullptr);
+                if (rc != 0) throw HipError(rc == 2 ? "allreduce failed" : "radix select failed");
                 last_quantile_fallback_ = false;
             } else {
                 fast_quantile = true;

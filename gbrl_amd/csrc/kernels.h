@@ -115,8 +115,18 @@ size_t radix_state_bytes(int F, int B);
 size_t radix_partial_bytes(int F);
 int radix_max_targets();
 size_t radix_list_bytes(int n, int F);
-void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
-                  uint32_t *thr_keys, hipStream_t s);
+// Row-sharded runs pass the exchange hook and two scratch buffers; cum then holds GLOBAL ranks and every rank ends with the
+// same thresholds.  Returns 0, or non-zero when a HIP call (1) / the all-reduce (2) failed.
+struct RadixComm {
+    void *ctx;
+    int (*allreduce_sum_i64)(void *ctx, int64_t *dev_buf, size_t count);   // called with the stream synchronised
+    int64_t *gbuf;              // radix_exchange_words(F) int64
+    uint32_t *partial_global;   // radix_global_partial_bytes(F)
+};
+size_t radix_exchange_words(int F);
+size_t radix_global_partial_bytes(int F);
+int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
+                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm /*nullable: one GPU*/);
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s);
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s);
 constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [group][row][16]

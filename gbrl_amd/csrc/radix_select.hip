@@ -16,6 +16,9 @@
 // target and the id of its first child; child slot = first child + popcount(set bits below the digit).
 #include "kernels.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace gbrl {
 namespace kern {
 
@@ -288,6 +291,45 @@ __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const u
     if (k == 0) st.n_slots[f * 4 + (pass - 1)] = total_slots;
 }
 
+// ---- row-sharded runs: the digit counts of a pass are summed over ranks before the target pass ---------------------------
+// Exchange format: two uint32 counters per int64 word (global row count < 2^32, so the low field never carries), layout
+// pass 1 [F][2048], later passes [slot][F][NB/2] so that the slots in use on any feature form a contiguous prefix.
+__global__ __launch_bounds__(256) void k_radix_globalize(int pass, const uint32_t *__restrict__ partial, int n_chunks, int F,
+                                                         RadixState st, int64_t *__restrict__ gbuf) {
+    const int NB = radix_bins(pass), NBh = NB / 2;
+    const int rows = pass == 1 ? 1 : kMaxTargets;
+    const size_t pstride = pass == 1 ? kBins1 : kMaxTargets * kSlotStride;
+    const size_t total = static_cast<size_t>(rows) * F * NBh;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int pair = static_cast<int>(i % NBh);
+        const int f = static_cast<int>((i / NBh) % F);
+        const int slot = static_cast<int>(i / (static_cast<size_t>(NBh) * F));
+        uint32_t a = 0, b = 0;
+        const int live = pass == 1 ? 1 : static_cast<int>(st.n_slots[f * 4 + (pass - 2)]);
+        if (slot < live)
+            for (int c = 0; c < n_chunks; ++c) {
+                const uint32_t *p = partial + (static_cast<size_t>(f) * n_chunks + c) * pstride + (pass == 1 ? 0 : slot * kSlotStride) + 2 * pair;
+                a += p[0]; b += p[1];
+            }
+        gbuf[i] = static_cast<int64_t>(static_cast<uint64_t>(a) | (static_cast<uint64_t>(b) << 32));
+    }
+}
+__global__ __launch_bounds__(256) void k_radix_unpack(int pass, const int64_t *__restrict__ gbuf, int F, int rows,
+                                                      uint32_t *__restrict__ partial_global) {
+    const int NB = radix_bins(pass), NBh = NB / 2;
+    const size_t pstride = pass == 1 ? kBins1 : kMaxTargets * kSlotStride;
+    const size_t total = static_cast<size_t>(rows) * F * NBh;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int pair = static_cast<int>(i % NBh);
+        const int f = static_cast<int>((i / NBh) % F);
+        const int slot = static_cast<int>(i / (static_cast<size_t>(NBh) * F));
+        const uint64_t v = static_cast<uint64_t>(gbuf[i]);
+        uint32_t *p = partial_global + static_cast<size_t>(f) * pstride + (pass == 1 ? 0 : slot * kSlotStride) + 2 * pair;
+        p[0] = static_cast<uint32_t>(v);
+        p[1] = static_cast<uint32_t>(v >> 32);
+    }
+}
+
 constexpr size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
 }  // namespace
@@ -303,11 +345,13 @@ size_t radix_partial_bytes(int F) {
     return sizeof(uint32_t) * (a > b ? a : b);
 }
 int radix_max_targets() { return kMaxTargets; }
+size_t radix_exchange_words(int F) { return static_cast<size_t>(kMaxTargets) * F * (kSlotStride / 2); }   // int64 words of gbuf
+size_t radix_global_partial_bytes(int F) { return sizeof(uint32_t) * static_cast<size_t>(F) * kMaxTargets * kSlotStride; }
 
 // Exact order statistics of every column: thr_keys[f][k] = key of 1-based rank cum[k] in column f of kt ([F][n] ordered keys).
 // cum must be non-decreasing, 1 <= cum[k] <= n, B <= 256.
-void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
-                  uint32_t *thr_keys, hipStream_t s) {
+int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
+                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm) {
     char *p = static_cast<char *>(state);
     auto take = [&](size_t bytes) { char *q = p; p += align16(bytes); return q; };
     const size_t f = static_cast<size_t>(F);
@@ -337,14 +381,43 @@ void radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, v
     const int c1 = n >= (1 << 16) ? kChunks1 : 1;
     // a list holds up to a quarter of its chunk (radix_list_bytes); a chunk with more survivors is streamed again by pass 4
     st.list_cap = static_cast<uint32_t>((n / 4) / cn);
+    // Row-sharded runs: after every counting pass the per-rank digit counts are summed over ranks (one all-reduce of packed
+    // counters per pass) and the target pass -- identical on every rank -- works on the global counts.
+    std::vector<uint32_t> h_slots;
+    auto finish_pass = [&](int pass, int n_chunks_pass) -> int {
+        const uint32_t *src = partial;
+        int chunks = n_chunks_pass;
+        if (comm) {
+            int rows = 1;
+            hipLaunchKernelGGL(k_radix_globalize, dim3(1024), dim3(256), 0, s, pass, partial, n_chunks_pass, F, st, comm->gbuf);
+            if (pass >= 2) {
+                h_slots.resize(static_cast<size_t>(F) * 4);
+                if (hipMemcpyAsync(h_slots.data(), st.n_slots, sizeof(uint32_t) * h_slots.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+            }
+            if (hipStreamSynchronize(s) != hipSuccess) return 1;
+            if (pass >= 2) {
+                rows = 0;
+                for (int f2 = 0; f2 < F; ++f2) rows = std::max(rows, static_cast<int>(h_slots[f2 * 4 + (pass - 2)]));
+            }
+            const size_t words = static_cast<size_t>(rows) * F * (radix_bins(pass) / 2);
+            if (comm->allreduce_sum_i64(comm->ctx, comm->gbuf, words) != 0) return 2;
+            hipLaunchKernelGGL(k_radix_unpack, dim3(1024), dim3(256), 0, s, pass, comm->gbuf, F, rows, comm->partial_global);
+            src = comm->partial_global;
+            chunks = 1;
+        }
+        const size_t lds = pass == 1 ? kBins1 * 4 : static_cast<size_t>(kMaxTargets) * radix_bins(pass) * 4;
+        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys);
+        return 0;
+    };
+    int rc = 0;
     hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial);
-    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kBins1 * 4, s, 1, partial, c1, cum, B, st, thr_keys);
+    if ((rc = finish_pass(1, c1)) != 0) return rc;
     hipLaunchKernelGGL(k_radix_count<2>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
-    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kMaxTargets * 128 * 4, s, 2, partial, cn, cum, B, st, thr_keys);
+    if ((rc = finish_pass(2, cn)) != 0) return rc;
     hipLaunchKernelGGL(k_radix_count<3>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
-    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kMaxTargets * 128 * 4, s, 3, partial, cn, cum, B, st, thr_keys);
+    if ((rc = finish_pass(3, cn)) != 0) return rc;
     hipLaunchKernelGGL(k_radix_count<4>, dim3(cn, F), dim3(kRadixThreads), lds4, s, kt, n, cn, B, st, partial);
-    hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), kMaxTargets * 64 * 4, s, 4, partial, cn, cum, B, st, thr_keys);
+    return finish_pass(4, cn);
 }
 
 }  // namespace kern

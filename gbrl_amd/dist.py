@@ -9,7 +9,9 @@ max/min), so every rank grows the same tree bit for bit and the result does not 
 The hooks receive raw device pointers.  They are wrapped zero-copy as torch tensors through ``__cuda_array_interface__``
 and reduced in place with ``torch.distributed.all_reduce`` on the current torch stream; the hook synchronises before it
 returns, which is the contract the engine expects.  With ``device=None`` the pointers are host pointers (used by the
-world_size-2 gloo tests, which exercise the same hook code on CPU buffers).
+world_size-2 gloo tests, which exercise the same hook code on CPU buffers).  With a device and a ``gloo`` process group the
+reduction is staged through host memory -- slow, but it lets two ranks share ONE GPU, which RCCL refuses; the GPU tests
+use it to run the real row-sharded step with world_size 2 on a single-GPU box.
 """
 from __future__ import annotations
 
@@ -39,6 +41,7 @@ class TorchCollective:
         self.torch, self.dist, self.device, self.group = torch, dist, device, group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.stage_through_host = device is not None and str(dist.get_backend(group)).lower() == "gloo"
         self.calls = 0
         self.bytes = 0
         mk = lambda typestr, np_dtype, op: _Coll._I64(lambda ctx, ptr, n: self._reduce(ptr, n, typestr, np_dtype, op))  # noqa: E731
@@ -55,7 +58,12 @@ class TorchCollective:
     def _reduce(self, ptr, n, typestr, np_dtype, op):
         try:
             t = self._tensor(ptr, n, typestr, np_dtype)
-            self.dist.all_reduce(t, op=op, group=self.group)
+            if self.stage_through_host:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=op, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=op, group=self.group)
             if self.device is not None:
                 self.torch.cuda.synchronize(self.device)
             self.calls += 1

@@ -260,7 +260,7 @@ def test_sharded_code_path_on_one_gpu(monkeypatch):
         m1 = gbrl_amd.GBRL(**K.ctor_kwargs(case))
         coll = install_torch_collective(m1, torch.device("cuda:0"))
         p1 = np.asarray(K.drive(m1, case, X, Xc, G, y))
-        assert coll.calls > 50 and coll.bytes > 0
+        assert coll.calls > 10 and coll.bytes > 0
     finally:
         dist.destroy_process_group()
     e0, e1 = m0.get_ensemble_data(), m1.get_ensemble_data()

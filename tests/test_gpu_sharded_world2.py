@@ -1,0 +1,82 @@
+"""Row-sharded step() with world_size 2 and 3 on ONE GPU.
+
+RCCL refuses two ranks on one device, so the ranks are separate processes joined by a gloo process group and
+gbrl_amd.dist stages each reduction through host memory; everything else -- the engine's sharded code path, the hook
+calls, the device kernels on each rank's shard -- is exactly what a multi-GPU run executes.  Every rank must grow the tree
+a single process grows from all the rows, bit for bit (integer sums, identical arithmetic), for uneven shards and for a
+world size that is not a power of two."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import cases as K  # noqa: E402
+from helpers import load_golden  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def _run_world(name, world, tmp_path, extra_env=None):
+    port = _free_port()
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    outs = [str(tmp_path / f"{name}_w{world}_r{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, name, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("name,world", [("obl_l2_q_d6", 2), ("obl_l2_q_d6", 3), ("grd_cos_q_ac", 2), ("obl_cos_u", 2),
+                                        ("cfg1_rmse_loop", 2), ("obl_l2_q_dups", 3), ("grd_l2_q_mdl", 2)])
+def test_sharded_ranks_grow_the_single_process_tree(name, world, tmp_path):
+    import gbrl_amd
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pred = np.asarray(K.drive(m, case, X, None, G, y))
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    ranks = _run_world(name, world, tmp_path)
+    for r, d in enumerate(ranks):
+        for k in K.ENSEMBLE_KEYS:
+            assert np.array_equal(e[k], d[k]), (name, world, r, k)
+        lo, hi = int(d["lo"]), int(d["hi"])
+        assert np.array_equal(pred[lo:hi], d["pred"]), (name, world, r, "pred")
+        assert int(d["calls"]) > 0
+
+
+def test_sharded_sample_and_bisection_quantile_paths_agree(tmp_path):
+    """The older exact selections stay reachable row-sharded (test hooks); all three give the single-process tree."""
+    import gbrl_amd
+    name = "obl_l2_q_dups"
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, None, G, y)
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    for env in ({"GBRL_HIP_QUANTILE_SAMPLE": "1"}, {"GBRL_HIP_FORCE_BISECTION": "1"}):
+        for d in _run_world(name, 2, tmp_path, env):
+            for k in K.ENSEMBLE_KEYS:
+                assert np.array_equal(e[k], d[k]), (env, k)
