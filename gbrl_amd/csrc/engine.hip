@@ -287,87 +287,43 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const int nblk = kern::column_sums_blocks(N, D);
     double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
     if (D > 512) throw Unsupported("output_dim > 512");
-    std::vector<double> hs(2 * D);
-    float hmax[2] = {0.f, 0.f};  // max |build grad|, max |raw grad|
-    auto reduce_stats = [&]() {
-        if (has_coll_) {
-            hip_check(hipStreamSynchronize(s), "sync");
-            float *tmpf = reinterpret_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
-            if (coll_.allreduce_sum_f64(coll_.ctx, d_stat, D) != 0) throw HipError("allreduce failed");
-            // maxima travel as floats (exact)
-            std::vector<double> m(D);
-            hip_check(hipMemcpy(m.data(), d_stat + D, sizeof(double) * D, hipMemcpyDeviceToHost), "D2H");
-            std::vector<float> mf(D);
-            for (int d = 0; d < D; ++d) mf[d] = static_cast<float>(m[d]);
-            hip_check(hipMemcpy(tmpf, mf.data(), sizeof(float) * D, hipMemcpyHostToDevice), "H2D");
-            if (coll_.allreduce_max_f32(coll_.ctx, tmpf, D) != 0) throw HipError("allreduce failed");
-            hip_check(hipMemcpy(mf.data(), tmpf, sizeof(float) * D, hipMemcpyDeviceToHost), "D2H");
-            hip_check(hipMemcpy(hs.data(), d_stat, sizeof(double) * D, hipMemcpyDeviceToHost), "D2H");
-            for (int d = 0; d < D; ++d) hs[D + d] = mf[d];
-        } else {
-            hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * 2 * D, hipMemcpyDeviceToHost, s), "D2H stats");
-            hip_check(hipStreamSynchronize(s), "sync");
-        }
-    };
     // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: the power-of-two scale keeps
     // chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build).
     // A histogram block accumulates one chunk of one node's rows.  Chunks are sized per level so that the whole level is ONE
     // balanced round of <= 32 chunks x (feature groups) blocks (k_hist_build keeps one block per CU); `chunk_rows` is the cap
     // the fixed-point scale is derived from.  Leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62.
-    const int chunk_rows = std::max(4096, 2 * ((N + 31) / 32));
+    // It depends on the GLOBAL row count only (clamped to [4096, 65536]), so the scale -- and with it every integer sum -- is
+    // the same for any sharding of the same rows.
+    const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
     kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
     kern::StepScales h_scales{};
-    bool scales_on_host = false;
-    if (!has_coll_) {
-        // one GPU: sums -> mean -> centred squares -> std, maxima, scales, all on the device; the host reads the scales
-        // together with the thresholds (one synchronisation for both)
+    {
+        // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
+        // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
+        // sums (fp64) and take the maxima (fp32, exact) over ranks between the kernels; the arithmetic stays on the device,
+        // so one GPU and N GPUs execute the same instructions on the same global sums.
         double *d_stat2 = d_stat + 2 * D;
+        float *d_maxf = static_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
+        auto exchange_stats = [&](double *st) {
+            if (!has_coll_) return;
+            kern::f64_to_f32(st + D, d_maxf, D, s);
+            hip_check(hipStreamSynchronize(s), "sync");
+            if (coll_.allreduce_sum_f64(coll_.ctx, st, D) != 0 || coll_.allreduce_max_f32(coll_.ctx, d_maxf, D) != 0)
+                throw HipError("allreduce failed");
+            kern::f32_to_f64(d_maxf, st + D, D, s);
+        };
         kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
+        exchange_stats(d_stat);
         if (!cosine) {
             kern::stats_mean(d_stat, n_global, D, d_meanden, s);
             kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat2, s);
+            exchange_stats(d_stat2);
             kern::stats_finish(d_stat, d_stat2, n_global, D, chunk_rows, d_meanden, d_scales, s);
             d_mean = d_meanden;
             d_den = d_meanden + D;
         } else {
             kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
         }
-    } else {
-        // row-sharded: the sums cross ranks, the (identical) arithmetic is done on every host
-        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);   // pass 1: column sums and max |g|
-        reduce_stats();
-        for (int d = 0; d < D; ++d) hmax[1] = std::max(hmax[1], static_cast<float>(hs[D + d]));
-        if (!cosine) {
-            // fitter.cpp:58-63: mean, centre, unbiased std, divide by (std + 1e-8)
-            std::vector<float> hmd(2 * D);
-            for (int d = 0; d < D; ++d) hmd[d] = static_cast<float>(hs[d] / static_cast<double>(n_global));
-            hip_check(hipMemcpyAsync(d_meanden, hmd.data(), sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D mean");
-            kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat, s);   // pass 2: centred squares, max |g - mean|
-            reduce_stats();
-            const float recip = 1.0f / (static_cast<float>(n_global) - 1.0f);  // math_ops.cpp:464
-            for (int d = 0; d < D; ++d) {
-                const float sd = sqrtf(static_cast<float>(hs[d]) * recip);     // math_ops.cpp:510
-                hmd[D + d] = sd + 1e-8f;                                        // math_ops.cpp:94
-                hmax[0] = std::max(hmax[0], static_cast<float>(hs[D + d]) / hmd[D + d] * 1.0001f);
-            }
-            hip_check(hipMemcpyAsync(d_meanden + D, hmd.data() + D, sizeof(float) * D, hipMemcpyHostToDevice, s), "H2D std");
-            hip_check(hipStreamSynchronize(s), "sync");   // hmd goes out of scope
-            d_mean = d_meanden;
-            d_den = d_meanden + D;
-        } else {
-            hmax[0] = hmax[1];
-        }
-        if (!std::isfinite(hmax[0]) || !std::isfinite(hmax[1])) throw InvalidArgument("non-finite gradients");
-        int sbits = 20, lbits = 40;
-        if (hmax[0] > 0.f) sbits = std::min(100, ilog2_floor(2147483647.0 / (static_cast<double>(chunk_rows) * hmax[0])) - 1);
-        if (hmax[1] > 0.f) lbits = std::min(60, ilog2_floor(4.0e18 / (static_cast<double>(n_global) * hmax[1])) - 1);
-        h_scales.sbits = sbits; h_scales.lbits = lbits;
-        h_scales.scale = static_cast<float>(std::ldexp(1.0, sbits));
-        h_scales.inv_scale = std::ldexp(1.0, -sbits);
-        h_scales.leaf_scale = std::ldexp(1.0, lbits);
-        h_scales.hmax_build = hmax[0]; h_scales.hmax_raw = hmax[1];
-        hip_check(hipMemcpy(d_scales, &h_scales, sizeof(h_scales), hipMemcpyHostToDevice), "H2D scales");
-        scales_on_host = true;
     }
     int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
     kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
@@ -653,7 +609,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
                           static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
     // a level needs at most 32 balanced chunks plus one rounding chunk per node
-    const int hist_max_chunks = 32 + 2 * (1 << MD) + 2;
+    const int hist_max_chunks = std::max(32, (N + chunk_rows - 1) / chunk_rows) + 2 * (1 << MD) + 2;
     int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * static_cast<size_t>(hist_max_chunks) * n_groups * n_acc));
     const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
     // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
@@ -691,7 +647,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
     NodeSplit *d_resolved = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
     kern::iota_rows(d_rows[0], N, s);
-    if (!scales_on_host) hip_check(hipMemcpyAsync(&h_scales, d_scales, sizeof(h_scales), hipMemcpyDeviceToHost, s), "D2H scales");
+    hip_check(hipMemcpyAsync(&h_scales, d_scales, sizeof(h_scales), hipMemcpyDeviceToHost, s), "D2H scales");
     hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr and the scales are needed on the host from here on
     if (!std::isfinite(h_scales.hmax_build) || !std::isfinite(h_scales.hmax_raw)) throw InvalidArgument("non-finite gradients");
     const double leaf_scale = h_scales.leaf_scale;

@@ -76,6 +76,8 @@ void qsel_init(uint32_t *prefix, uint32_t *trial, int F, int B, hipStream_t s);
 // one bisection step on bit `bit`: uses counts of trial = prefix|bit; then prepares trial for `next_bit` (or final keys if <0)
 void qsel_update(uint32_t *prefix, uint32_t *trial, const int64_t *counts, const int64_t *cum_ranks, int F, int B,
                  int bit, int next_bit, hipStream_t s);
+void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
+void f32_to_f64(const float *in, double *out, int n, hipStream_t s);
 void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s);
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
 void scatter_cat_codes(const uint16_t *cat_codes, int n, int Fc, uint16_t *codes, int code_stride, int code_off, hipStream_t s);

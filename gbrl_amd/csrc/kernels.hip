@@ -1063,6 +1063,20 @@ void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const
     hipLaunchKernelGGL(k_quantize, dim3(grid_for(n_el, 256, 4096)), dim3(256), 0, s, g, n_el, D, mean, denom, sc, qg);
 }
 
+__global__ void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = static_cast<float>(in[i]);
+}
+__global__ void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = static_cast<double>(in[i]);
+}
+void f64_to_f32(const double *in, float *out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_f64_to_f32, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+}
+void f32_to_f64(const float *in, double *out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_to_f64, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+}
 void stats_mean(const double *stat, long long n, int D, float *meanden, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_mean, dim3(1), dim3(256), 0, s, stat, n, D, meanden);
 }

@@ -220,6 +220,37 @@ def test_fast_quantile_path_equals_bisection_path(monkeypatch):
         assert np.array_equal(outs[1][k], outs[2][k]), ("sample vs bisection", k)
 
 
+def test_more_rows_than_one_round_of_histogram_chunks():
+    """N > 32 x 65536 rows: a level needs several rounds of histogram chunks (the per-block row cap is fixed by the
+    fixed-point scale).  Leaf populations must add up and leaf values must be the exact leaf means."""
+    import gbrl_amd
+    rng = np.random.default_rng(5)
+    N, F, D = 3 * (1 << 20) + 17, 16, 2
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    G = (np.sign(X[:, :D]) + 0.25 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    case = dict(name="big", seed=0, N=N, F=F, D=D, depth=4, n_bins=256, score="L2", gen="Quantile", policy="oblivious", trees=1,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=1.0, start_idx=0, stop_idx=D)])
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pred = np.asarray(K.drive(m, case, X, None, G, None))
+    e = m.get_ensemble_data()
+    depth = int(e["depths"][0])
+    assert depth == 4
+    fi, fv = np.asarray(e["feature_indices"])[0], np.asarray(e["feature_values"])[0]
+    assert set(fi[:2].tolist()) <= {0, 1}          # the signal lives in the first two features
+    leaf = np.zeros(N, np.int64)
+    for d in range(depth):
+        leaf |= (X[:, fi[d]] > fv[d]).astype(np.int64) << (depth - 1 - d)
+    vals = np.asarray(e["values"])
+    assert np.array_equal(pred, (np.float32(0) - vals[leaf]).astype(np.float32))
+    cnt = np.bincount(leaf, minlength=16)
+    ew = np.asarray(e["edge_weights"]).astype(np.float64)
+    assert np.allclose(np.prod(ew, axis=1) * N, cnt, rtol=1e-5, atol=0.5)
+    for l in range(16):
+        if cnt[l]:
+            want = G[leaf == l].astype(np.float64).mean(axis=0)
+            assert np.max(np.abs(vals[l] - want) / np.maximum(np.abs(want), 0.5)) < 1e-6
+
+
 @pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
 def test_non_finite_gradients_are_rejected_and_leave_the_model_unchanged(bad):
     import gbrl_amd
