@@ -1,5 +1,9 @@
 // c_api.cpp -- the extern "C" surface declared in include/gbrl_hip.h.  Exceptions never cross the boundary: they are
 // turned into status codes + a thread-local message (the reference throws std::runtime_error at the same places).
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -51,13 +55,69 @@ int gbrl_hip_device_count(void) {
 
 const char *gbrl_hip_last_error(void) { return g_err.c_str(); }
 
+// Output buffers of predict() on the device are recycled: hipMalloc + hipFree (which synchronises the device) cost about
+// a millisecond per call, more than the prediction kernel itself for small ensembles.  A freed buffer is kept (up to a few
+// buffers / 1 GiB) and handed out again for a request of the same size class after a device synchronisation, so that no
+// consumer kernel of its previous life can still be reading it.
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;            // every buffer handed out -> its capacity
+    std::vector<std::pair<void *, size_t>> idle;
+    size_t idle_bytes = 0;
+    static constexpr size_t kMaxIdleBytes = size_t(1) << 30;
+    static constexpr size_t kMaxIdle = 8;
+    ~DevPool() { /* process exit: the runtime reclaims device memory; calling hipFree here can race with its teardown */ }
+};
+DevPool &pool() { static DevPool *p = new DevPool(); return *p; }
+}  // namespace
+
 void *gbrl_hip_device_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    DevPool &P = pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (size_t i = 0; i < P.idle.size(); ++i) {
+            if (P.idle[i].second >= bytes && P.idle[i].second <= bytes + bytes / 4 + 4096) {
+                void *p = P.idle[i].first;
+                const size_t cap = P.idle[i].second;
+                P.idle_bytes -= cap;
+                P.idle.erase(P.idle.begin() + static_cast<long>(i));
+                P.live[p] = cap;
+                (void)hipDeviceSynchronize();
+                return p;
+            }
+        }
+    }
     void *p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        // memory pressure: drop the idle buffers and retry once
+        std::vector<std::pair<void *, size_t>> drop;
+        { std::lock_guard<std::mutex> lk(P.mu); drop.swap(P.idle); P.idle_bytes = 0; }
+        for (auto &d : drop) (void)hipFree(d.first);
+        if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[p] = bytes;
     return p;
 }
 void gbrl_hip_device_free(void *ptr) {
-    if (ptr) (void)hipFree(ptr);
+    if (!ptr) return;
+    DevPool &P = pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(ptr);
+        if (it != P.live.end()) {
+            const size_t cap = it->second;
+            P.live.erase(it);
+            if (P.idle.size() < DevPool::kMaxIdle && P.idle_bytes + cap <= DevPool::kMaxIdleBytes) {
+                P.idle.emplace_back(ptr, cap);
+                P.idle_bytes += cap;
+                return;
+            }
+        }
+    }
+    (void)hipFree(ptr);
 }
 
 gbrl_hip_model *gbrl_hip_create(const gbrl_hip_config *cfg) {

@@ -1041,7 +1041,7 @@ void Engine::sync_model_to_device() {
     const size_t T = md.n_trees, L = md.n_leaves, S = model.split_rows(), MD = md.max_depth, D = md.output_dim;
     if (mirror_version_ == model.version) return;
     // dictionary ids for the categorical conditions (strings are compared on the host once; the device compares ids)
-    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); }
+    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); cond_pack_host_.clear(); }
     cat_ids_host_.resize(S * MD, 0);
     for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
         if (model.is_numerics[c]) continue;
@@ -1064,6 +1064,17 @@ void Engine::sync_model_to_device() {
     append(m_feature_values_, model.feature_values.data(), 4, up_splits_ * MD, S * MD);
     append(m_is_numerics_, model.is_numerics.data(), 1, up_splits_ * MD, S * MD);
     append(m_cat_ids_, cat_ids_host_.data(), 4, up_splits_ * MD, S * MD);
+    // packed (feature | ~categorical feature, threshold bits | category id) pairs per split row: read through the scalar cache
+    // by the fast oblivious predict kernel
+    cond_pack_host_.resize(S * MD * 2, 0);
+    for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
+        const bool num = model.is_numerics[c] != 0;
+        int32_t tv;
+        std::memcpy(&tv, &model.feature_values[c], sizeof(tv));
+        cond_pack_host_[2 * c] = num ? model.feature_indices[c] : ~model.feature_indices[c];
+        cond_pack_host_[2 * c + 1] = num ? tv : cat_ids_host_[c];
+    }
+    append(m_cond_pack_, cond_pack_host_.data(), 4, up_splits_ * MD * 2, S * MD * 2);
     append(m_values_, model.values.data(), 4, up_leaves_ * D, L * D);
     append(m_ineq_, model.inequality_directions.data(), 1, up_leaves_ * MD, L * MD);
     up_trees_ = T; up_leaves_ = L; up_splits_ = S;
@@ -1153,6 +1164,18 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.opt_start = m_opt_start_.as<int32_t>();
     pm.opt_stop = m_opt_stop_.as<int32_t>();
     pm.opt_lr = m_opt_lr_.as<float>();
+    pm.cond_pack = m_cond_pack_.as<int32_t>();
+    pm.all_numeric = md.n_cat_features == 0 ? 1 : 0;
+    pm.coef_ok = D <= 32 ? 1 : 0;
+    pm.coef_cover = 0;
+    for (int j = 0; j < 32; ++j) pm.coef[j] = 0.0f;
+    for (const auto &o : model.opts) {   // one learning rate per output unless two optimisers share an output
+        for (int j = o.start_idx; j < o.stop_idx && pm.coef_ok; ++j) {
+            if (j < 0 || j >= D || ((pm.coef_cover >> j) & 1u)) { pm.coef_ok = 0; break; }
+            pm.coef_cover |= 1u << j;
+            pm.coef[j] = o.init_lr;
+        }
+    }
     kern::predict(pm, dobs, n_num, dcat, n_cat, n, start_tree, stop, dout, s);
     hip_check(hipGetLastError(), "predict launch");
     phase_end("predict", /*key=*/true);

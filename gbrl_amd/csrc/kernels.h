@@ -188,6 +188,12 @@ struct PredictModel {
     int n_opts;
     const int32_t *opt_start, *opt_stop;
     const float *opt_lr;
+    // fast oblivious path (k_predict_obl): per split row 2*max_depth ints (feature index | ~categorical index, threshold bits |
+    // category id), and -- when the optimisers' output ranges do not overlap -- one learning rate per output
+    const int32_t *cond_pack;
+    int all_numeric, coef_ok;
+    uint32_t coef_cover;
+    float coef[32];
 };
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
              int stop_tree, float *out, hipStream_t s);

@@ -906,7 +906,8 @@ __global__ __launch_bounds__(256) void k_predict_tiled(PredictModel pm, const fl
     const int R = blockDim.x;
     const int xs = F + 1;
     const int D = pm.D, md = pm.max_depth;
-    const int vstride = (1 << md) * D;
+    const int DS = D | 1;                                     // odd leaf stride: a wave's random leaves spread over all LDS banks
+    const int vstride = (1 << md) * DS;
     float *xt = ptile;                                        // [R][F+1]
     float *vt = ptile + static_cast<size_t>(R) * xs;          // [TT][2^md][D]      (oblivious only)
     int *ct = reinterpret_cast<int *>(vt + static_cast<size_t>(TT) * vstride);   // [TT][1 + 2*md]: depth, then (feature | ~cat, threshold bits | cat id)
@@ -961,11 +962,14 @@ __global__ __launch_bounds__(256) void k_predict_tiled(PredictModel pm, const fl
         ob[o] = on ? pm.opt_stop[o] : 0;
     }
     auto apply = [&](const float *v) {
+        float vv[DMAX];
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) vv[j] = j < D ? v[j] : 0.0f;
 #pragma unroll
         for (int o = 0; o < kPredMaxOpts; ++o) {
 #pragma unroll
             for (int j = 0; j < DMAX; ++j)
-                if (j >= oa[o] && j < ob[o]) p[j] = fmaf(-olr[o], v[j], p[j]);
+                if (j >= oa[o] && j < ob[o]) p[j] = fmaf(-olr[o], vv[j], p[j]);
         }
     };
     __syncthreads();
@@ -974,32 +978,103 @@ __global__ __launch_bounds__(256) void k_predict_tiled(PredictModel pm, const fl
             for (int t0 = start_tree; t0 < stop_tree; t0 += TT) {
                 const int tn = min(TT, stop_tree - t0);
                 __syncthreads();   // previous tile fully consumed
-                for (int tt = 0; tt < tn; ++tt) {
-                    const int t = t0 + tt;
-                    const int depth = pm.depths[t];
-                    const int nl = (1 << depth) * D;
-                    const float *srcv = pm.values + static_cast<size_t>(pm.tree_indices[t]) * D;
-                    for (int i = threadIdx.x; i < nl; i += R) vt[tt * vstride + i] = srcv[i];
-                    if (threadIdx.x == 0) ct[tt * cstride] = depth;
-                    if (static_cast<int>(threadIdx.x) < depth) {
-                        const int c = t * md + threadIdx.x;
-                        const bool num = pm.is_numerics[c] != 0;
-                        ct[tt * cstride + 1 + 2 * threadIdx.x] = num ? pm.feature_indices[c] : ~pm.feature_indices[c];
-                        ct[tt * cstride + 2 + 2 * threadIdx.x] = num ? __float_as_int(pm.feature_values[c]) : pm.cat_ids[c];
+                // staging of the group's trees, flattened over (tree, element) so that the loads of different trees are in
+                // flight together (a per-tree loop costs one global-memory round trip per tree and block)
+                {
+                    const int vmax = (1 << md) * D;
+                    constexpr int US = 4;
+                    for (int i0 = threadIdx.x; i0 < tn * vmax; i0 += R * US) {
+                        float v[US];
+                        int dst[US];
+#pragma unroll
+                        for (int u = 0; u < US; ++u) {
+                            const int i = i0 + u * R;
+                            dst[u] = -1;
+                            v[u] = 0.0f;
+                            if (i < tn * vmax) {
+                                const int tt = i / vmax, e = i - tt * vmax, t = t0 + tt;
+                                if (e < (D << pm.depths[t])) {
+                                    v[u] = pm.values[static_cast<size_t>(pm.tree_indices[t]) * D + e];
+                                    dst[u] = tt * vstride + (e / D) * DS + (e % D);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < US; ++u)
+                            if (dst[u] >= 0) vt[dst[u]] = v[u];
+                    }
+                    for (int i = threadIdx.x; i < tn * (md + 1); i += R) {
+                        const int tt = i / (md + 1), d = i - tt * (md + 1) - 1, t = t0 + tt;
+                        const int depth = pm.depths[t];
+                        if (d < 0) {
+                            ct[tt * cstride] = depth;
+                        } else if (d < depth) {
+                            const int c = t * md + d;
+                            const bool num = pm.is_numerics[c] != 0;
+                            ct[tt * cstride + 1 + 2 * d] = num ? pm.feature_indices[c] : ~pm.feature_indices[c];
+                            ct[tt * cstride + 2 + 2 * d] = num ? __float_as_int(pm.feature_values[c]) : pm.cat_ids[c];
+                        }
                     }
                 }
                 __syncthreads();
                 if (live) {
-                    for (int tt = 0; tt < tn; ++tt) {
-                        const int *cc = ct + tt * cstride;
-                        const int depth = cc[0];
-                        int leaf = 0;
-                        for (int d = 0; d < depth; ++d) {
-                            const int fi = cc[1 + 2 * d], tv = cc[2 + 2 * d];
-                            const bool pass = fi >= 0 ? (x[fi] > __int_as_float(tv)) : (xc != nullptr && xc[~fi] == tv);
-                            leaf |= (pass ? 1 : 0) << (depth - 1 - d);
+                    if (md <= 8) {
+                        // All (feature, threshold) pairs of a tree are fetched before the first comparison and the row's
+                        // features after them, two trees at a time: a thread's LDS round trips per tree drop from 2*depth
+                        // dependent ones to ~2 (the block is one wave per SIMD, so nothing else hides that latency).
+                        auto leaf_of = [&](const int *cc, int depth, const int (&fi)[8], const int (&tv)[8]) -> int {
+                            (void)cc;
+                            float xv[8];
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) xv[d] = (d < depth && fi[d] >= 0) ? x[fi[d]] : 0.0f;
+                            int leaf = 0;
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                if (d < depth) {
+                                    const bool pass = fi[d] >= 0 ? (xv[d] > __int_as_float(tv[d])) : (xc != nullptr && xc[~fi[d]] == tv[d]);
+                                    leaf |= (pass ? 1 : 0) << (depth - 1 - d);
+                                }
+                            }
+                            return leaf;
+                        };
+                        auto load_conds = [&](const int *cc, int depth, int (&fi)[8], int (&tv)[8]) {
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) {
+                                fi[d] = d < depth ? cc[1 + 2 * d] : 0;
+                                tv[d] = d < depth ? cc[2 + 2 * d] : 0;
+                            }
+                        };
+                        int tt = 0;
+                        for (; tt + 1 < tn; tt += 2) {
+                            const int *c0 = ct + tt * cstride, *c1 = c0 + cstride;
+                            const int d0 = c0[0], d1 = c1[0];
+                            int fi0[8], tv0[8], fi1[8], tv1[8];
+                            load_conds(c0, d0, fi0, tv0);
+                            load_conds(c1, d1, fi1, tv1);
+                            const int l0 = leaf_of(c0, d0, fi0, tv0);
+                            const int l1 = leaf_of(c1, d1, fi1, tv1);
+                            apply(vt + tt * vstride + l0 * DS);          // per-row accumulation stays in tree order (Q14)
+                            apply(vt + (tt + 1) * vstride + l1 * DS);
                         }
-                        apply(vt + tt * vstride + leaf * D);
+                        if (tt < tn) {
+                            const int *c0 = ct + tt * cstride;
+                            const int d0 = c0[0];
+                            int fi0[8], tv0[8];
+                            load_conds(c0, d0, fi0, tv0);
+                            apply(vt + tt * vstride + leaf_of(c0, d0, fi0, tv0) * DS);
+                        }
+                    } else {
+                        for (int tt = 0; tt < tn; ++tt) {
+                            const int *cc = ct + tt * cstride;
+                            const int depth = cc[0];
+                            int leaf = 0;
+                            for (int d = 0; d < depth; ++d) {
+                                const int fi = cc[1 + 2 * d], tv = cc[2 + 2 * d];
+                                const bool pass = fi >= 0 ? (x[fi] > __int_as_float(tv)) : (xc != nullptr && xc[~fi] == tv);
+                                leaf |= (pass ? 1 : 0) << (depth - 1 - d);
+                            }
+                            apply(vt + tt * vstride + leaf * DS);
+                        }
                     }
                 }
             }
@@ -1243,13 +1318,202 @@ void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chun
                        sc, acc);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// A13 fast path: oblivious, all-numeric ensembles with non-overlapping optimiser ranges (the common case).
+// The traversal is VALU-issue bound (one wave per SIMD: a block's row tile fills the LDS), so the work per (row, tree) is cut
+// to the minimum: the tree's (feature, threshold) pairs come through the SCALAR cache (uniform addresses -> s_load, no
+// vector or LDS instruction), a level costs an address add, an LDS read of the row's feature, a compare and a select/or,
+// the leaf's D values sit transposed in LDS ([tree][d][leaf]: one base address, immediate offsets) and the optimiser ranges
+// are folded into one learning rate per output.  Accumulation order per row is still tree order (Q14).
+// ------------------------------------------------------------------------------------------------------------
+template <int DMAX>
+struct OblCoef { float lr[DMAX]; };   // one learning rate per output (0 for the padded outputs j >= D)
+
+template <int DMAX, int MAXD>
+__global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ values, const int32_t *__restrict__ tree_indices,
+                                                     const int32_t *__restrict__ cond_pack, const int32_t *__restrict__ depths,
+                                                     const float *__restrict__ bias, OblCoef<DMAX> coef, int D, int md,
+                                                     const float *__restrict__ obs, int F, int n, int start_tree, int stop_tree,
+                                                     float *__restrict__ out, int TT) {
+    extern __shared__ float ptile[];
+    const int R = blockDim.x;
+    const int xs = F | 1;
+    const int LS = 1 << md;
+    float *xt = ptile;                                        // [R][xs]
+    float *vt = ptile + static_cast<size_t>(R) * xs;          // [TT][DMAX][LS]  (outputs j >= D are zero columns)
+    int *tmeta = reinterpret_cast<int *>(vt + static_cast<size_t>(TT) * DMAX * LS);   // [TT][2]: first leaf, leaves of the tree
+    const int r0 = blockIdx.x * R;
+    const int rows = min(R, n - r0);
+    {   // coalesced staging of rows [r0, r0+rows)
+        const float *src = obs + static_cast<size_t>(r0) * F;
+        if ((F & 3) == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(src);
+            const int F4 = F >> 2, tot4 = rows * F4;
+            constexpr int UL = 8;
+            for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
+                float4 v[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = i0 + u * R;
+                    v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = i0 + u * R;
+                    if (i < tot4) {
+                        const int r = i / F4, f = (i - r * F4) << 2;
+                        float *dst = xt + r * xs + f;
+                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                    }
+                }
+            }
+        } else {
+            const int tot = rows * F;
+            for (int i = threadIdx.x; i < tot; i += R) {
+                const int r = i / F, f = i - r * F;
+                xt[r * xs + f] = src[i];
+            }
+        }
+    }
+    const bool live = static_cast<int>(threadIdx.x) < rows;
+    float p[DMAX];
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + bias[j] : 0.0f;
+    const float *x = xt + threadIdx.x * xs;
+    constexpr int kTreeElems = DMAX;   // per leaf
+    const int vtree = kTreeElems * LS;
+    for (int t0 = start_tree; t0 < stop_tree; t0 += TT) {
+        const int tn = min(TT, stop_tree - t0);
+        __syncthreads();   // row tile staged / previous group fully consumed
+        // per-tree (first leaf, leaf count) of the group go to LDS first, so that the value loads below depend on nothing but
+        // an LDS read and all of a thread's loads are in flight together (a dependent global load chain per element costs a
+        // memory round trip per tree and block -- the whole kernel's time for small ensembles)
+        int full_depth = 1;
+        if (static_cast<int>(threadIdx.x) < tn) {
+            const int t = t0 + threadIdx.x;
+            const int dep = depths[t];
+            tmeta[2 * threadIdx.x] = tree_indices[t];
+            tmeta[2 * threadIdx.x + 1] = 1 << dep;
+            full_depth = dep == MAXD;
+        }
+        const bool group_full = __syncthreads_and(full_depth) != 0;   // every tree of the group has MAXD levels (the usual case)
+        {
+            constexpr int US = 8;
+            for (int i0 = threadIdx.x; i0 < tn * vtree; i0 += R * US) {
+                float v[US];
+                int dst[US];
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+                    const int i = i0 + u * R;
+                    dst[u] = -1;
+                    v[u] = 0.0f;
+                    if (i < tn * vtree) {
+                        // i = (tt, leaf, j) with j fastest: consecutive threads read consecutive values of a leaf row
+                        const int tt = i / vtree, e = i - tt * vtree;
+                        const int leaf = e / DMAX, j = e - leaf * DMAX;
+                        dst[u] = (tt * DMAX + j) * LS + leaf;
+                        if (j < D && leaf < tmeta[2 * tt + 1]) v[u] = values[(static_cast<size_t>(tmeta[2 * tt]) + leaf) * D + j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < US; ++u)
+                    if (dst[u] >= 0) vt[dst[u]] = v[u];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            auto apply = [&](int tt, int leaf) {   // DMAX reads at immediate offsets from one address, DMAX fused multiply-adds
+                const float *v = vt + tt * vtree + leaf;
+                float vv[DMAX];
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) vv[j] = v[j * LS];
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) p[j] = fmaf(-coef.lr[j], vv[j], p[j]);
+            };
+            // Full-depth groups run branch-free: the 2*MAXD condition words of a tree arrive in wide scalar loads, its MAXD
+            // feature reads are issued back to back, and four trees are in flight at once (independent chains, so their scalar /
+            // LDS latencies overlap -- a block is one wave per SIMD, nothing else hides them).  Leaf values are applied strictly
+            // in tree order.
+            auto leaf_full = [&](int t) -> int {
+                const int32_t *cp = cond_pack + static_cast<size_t>(t) * 2 * MAXD;
+                int fi[MAXD];
+                float tv[MAXD], xv[MAXD];
+#pragma unroll
+                for (int d = 0; d < MAXD; ++d) { fi[d] = cp[2 * d]; tv[d] = __int_as_float(cp[2 * d + 1]); }
+#pragma unroll
+                for (int d = 0; d < MAXD; ++d) xv[d] = x[fi[d]];
+                int leaf = 0;
+#pragma unroll
+                for (int d = 0; d < MAXD; ++d) leaf |= (xv[d] > tv[d]) ? (1 << (MAXD - 1 - d)) : 0;
+                return leaf;
+            };
+            auto leaf_any = [&](int t) -> int {    // shallower trees (growth stopped early) or max_depth < MAXD
+                const int depth = depths[t];
+                const int32_t *cp = cond_pack + static_cast<size_t>(t) * 2 * md;
+                int leaf = 0;
+                for (int d = 0; d < depth; ++d) leaf |= (x[cp[2 * d]] > __int_as_float(cp[2 * d + 1])) ? (1 << (depth - 1 - d)) : 0;
+                return leaf;
+            };
+            int tt = 0;
+            if (group_full && md == MAXD) {
+                for (; tt + 3 < tn; tt += 4) {
+                    const int l0 = leaf_full(t0 + tt), l1 = leaf_full(t0 + tt + 1), l2 = leaf_full(t0 + tt + 2), l3 = leaf_full(t0 + tt + 3);
+                    apply(tt, l0); apply(tt + 1, l1); apply(tt + 2, l2); apply(tt + 3, l3);
+                }
+                for (; tt < tn; ++tt) apply(tt, leaf_full(t0 + tt));
+            } else {
+                for (; tt < tn; ++tt) apply(tt, leaf_any(t0 + tt));
+            }
+        }
+    }
+    if (live) {
+        float *o = out + static_cast<size_t>(r0 + threadIdx.x) * D;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j)
+            if (j < D) o[j] = p[j];
+    }
+}
+
+template <int DMAX, int MAXD>
+static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, int n, int start_tree, int stop_tree, float *out,
+                               hipStream_t s) {
+    const size_t budget = 156 * 1024;   // leaves room for the kernel's small static LDS (block-wide vote)
+    const size_t vtree = (static_cast<size_t>(1) << pm.max_depth) * DMAX * sizeof(float);
+    const int xs = F | 1;
+    const size_t meta = 2 * 64 * sizeof(int);
+    int R = 256;
+    while (R >= 64 && static_cast<size_t>(R) * xs * sizeof(float) + vtree + meta > budget) R -= 64;
+    if (R < 64) return false;
+    int TT = static_cast<int>((budget - meta - static_cast<size_t>(R) * xs * sizeof(float)) / vtree);
+    TT = std::max(1, std::min(TT, 64));
+    const size_t lds = static_cast<size_t>(R) * xs * sizeof(float) + static_cast<size_t>(TT) * vtree + meta;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl<DMAX, MAXD>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        attr = true;
+    }
+    OblCoef<DMAX> coef;
+    for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
+    hipLaunchKernelGGL((k_predict_obl<DMAX, MAXD>), dim3((n + R - 1) / R), dim3(R), lds, s, pm.values, pm.tree_indices, pm.cond_pack,
+                       pm.depths, pm.bias, coef, pm.D, pm.max_depth, obs, F, n, start_tree, stop_tree, out, TT);
+    return true;
+}
+template <int DMAX>
+static bool launch_predict_obl_d(const PredictModel &pm, const float *obs, int F, int n, int start_tree, int stop_tree, float *out,
+                                 hipStream_t s) {
+    if (pm.max_depth <= 4) return launch_predict_obl<DMAX, 4>(pm, obs, F, n, start_tree, stop_tree, out, s);
+    if (pm.max_depth <= 6) return launch_predict_obl<DMAX, 6>(pm, obs, F, n, start_tree, stop_tree, out, s);
+    if (pm.max_depth <= 8) return launch_predict_obl<DMAX, 8>(pm, obs, F, n, start_tree, stop_tree, out, s);
+    return false;
+}
+
 template <int DMAX>
 static bool launch_predict_tiled(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n,
                                  int start_tree, int stop_tree, float *out, hipStream_t s) {
     if (F <= 0 || pm.n_opts > kPredMaxOpts) return false;
     if (pm.max_depth > 256) return false;
     const size_t budget = 159 * 1024;
-    const size_t vtree = pm.oblivious ? ((static_cast<size_t>(1) << pm.max_depth) * pm.D + 1 + 2 * pm.max_depth) * sizeof(float) : 0;
+    const size_t vtree = pm.oblivious ? ((static_cast<size_t>(1) << pm.max_depth) * (pm.D | 1) + 1 + 2 * pm.max_depth) * sizeof(float) : 0;
     int R = 256;
     while (R >= 64 && static_cast<size_t>(R) * (F + 1) * sizeof(float) + vtree > budget) R -= 64;
     if (R < 64) return false;   // rows too wide for an LDS tile: the caller uses the direct kernel
@@ -1272,6 +1536,14 @@ static bool launch_predict_tiled(const PredictModel &pm, const float *obs, int F
 
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
              int stop_tree, float *out, hipStream_t s) {
+    // fast path: oblivious, numeric-only, every output updated by exactly one optimiser
+    const uint32_t all_out = pm.D >= 32 ? 0xffffffffu : ((1u << pm.D) - 1u);
+    if (pm.oblivious && pm.all_numeric && pm.coef_ok && pm.coef_cover == all_out && Fc == 0 && F > 0 && pm.D <= 32 && stop_tree > start_tree) {
+        if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 8) { if (launch_predict_obl_d<8>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 16) { if (launch_predict_obl_d<16>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
+        else { if (launch_predict_obl_d<32>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
+    }
     if (pm.D <= 8) { if (launch_predict_tiled<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     else if (pm.D <= 32) { if (launch_predict_tiled<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     else { if (launch_predict_tiled<128>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }

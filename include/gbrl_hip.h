@@ -86,7 +86,9 @@ int gbrl_hip_abi_version(void);
 /* number of usable HIP devices (0 when none); replaces GBRL::cuda_available (gbrl.cpp:542-548) */
 int gbrl_hip_device_count(void);
 const char *gbrl_hip_last_error(void);
-/* device buffers handed to callers (predict results) -- replaces cudaMalloc/cudaFree in binding.cpp:208-219 */
+/* device buffers handed to callers (predict results) -- replaces cudaMalloc/cudaFree in binding.cpp:208-219.
+ * Freed buffers are recycled (a few buffers, <= 1 GiB); a recycled buffer is handed out only after a device
+ * synchronisation, so a consumer kernel of its previous life cannot still be reading it. */
 void *gbrl_hip_device_alloc(size_t bytes);
 void gbrl_hip_device_free(void *ptr);
 
