@@ -34,17 +34,22 @@ def hist_algorithmic_bytes(n_rows, n_feat, out_dim, depth, n_bins):
     return depth * per_level_read + ((1 << depth) - 1) * hist
 
 
-def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows, budget_s=15.0):
-    """Reference CPU path on a bounded sample of the same workload (rows only are reduced).  Cost of the reference's
-    brute-force scan is linear in the row count (depth * N * candidates * (1 + D)), so trees/s at the full batch is
-    the sample's trees/s * sample_rows / full_rows.  sample_rows <= 0: probe with 2048 rows, then size the sample for
-    about `budget_s` seconds of wall time on this host."""
+def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows, budget_s=20.0):
+    """Reference CPU path on a bounded sample of the same workload (rows only are reduced).  The reference's brute-force
+    scan is linear in the row count (depth * N * candidates * (1 + D)), so trees/s at the full batch is reported as the
+    sample's trees/s * sample_rows / full_rows (optimistic for the CPU: larger samples fall out of its caches and run
+    slower per row).  sample_rows <= 0: the sample is grown 4x at a time from 4096 rows for as long as the next size is
+    predicted (at 6x the last time) to keep the whole leg within `budget_s` seconds; the largest sample is reported."""
     import numpy as np
     import oracle
     if sample_rows <= 0:
-        probe = cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, 2048)
-        rows = int(2048 * budget_s / max(probe["sample_seconds"], 1e-3))
-        sample_rows = max(4096, min(full_rows, 1 << (rows.bit_length() - 1)))
+        spent, rows, best = 0.0, 4096, None
+        while True:
+            best = cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, rows)
+            spent += best["sample_seconds"]
+            if rows * 4 > full_rows or spent + 6.0 * best["sample_seconds"] > budget_s:
+                return best
+            rows *= 4
     rng = np.random.default_rng(0)
     X = rng.standard_normal((sample_rows, n_feat)).astype(np.float32)
     W = rng.standard_normal((8, out_dim)).astype(np.float32)
@@ -86,10 +91,13 @@ def main():
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0: size the CPU sample for ~15 s on this host")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0: grow the CPU sample while the leg stays within ~20 s on this host")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the row-sharded code path (collective hooks through RCCL) on ONE GPU")
     ap.add_argument("--predict-trees", type=int, default=0, help="0: predict over the ensemble grown by the bench")
+    ap.add_argument("--large-ensemble", type=int, default=10000,
+                    help="also time predict() over an ensemble of this many trees (BASELINE configs[4] scale; the extra trees are "
+                         "grown on 4096-row minibatches after the timed region; 0 disables)")
     args = ap.parse_args()
 
     import numpy as np
@@ -189,6 +197,32 @@ def main():
     dtp = (time.perf_counter() - t1) / reps
     pk = m.last_phase_times().get("predict", 0.0)
 
+    # predict over a large ensemble (configs[4] scale): trees grown on small minibatches, outside every timed region above
+    large = None
+    if args.large_ensemble > n_trees:
+        m.set_profiling(0)
+        xs_, gs_ = X[:4096].contiguous(), G[:4096].contiguous()
+        xso, gso = tup(xs_), tup(gs_)
+        t2 = time.perf_counter()
+        for _ in range(args.large_ensemble - n_trees):
+            m.step(xso, None, gso)
+        torch.cuda.synchronize()
+        grow_s = time.perf_counter() - t2
+        m.set_profiling(1)
+        p = m.predict(xo, None, 0, 0)
+        del p
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(2):
+            p = m.predict(xo, None, 0, 0)
+            del p
+        torch.cuda.synchronize()
+        dtl = (time.perf_counter() - t3) / 2
+        T2 = m.get_num_trees()
+        large = {"trees": T2, "ms_per_call": dtl * 1e3, "rows_per_s": world * N / dtl, "row_trees_per_s": world * N * T2 / dtl,
+                 "kernel_ms": m.last_phase_times().get("predict", 0.0),
+                 "grown": "%d extra trees on 4096-row minibatches in %.1f s (%.2f ms/step)" % (T2 - n_trees, grow_s, grow_s * 1e3 / max(1, T2 - n_trees))}
+
     if rank == 0:
         steps = args.steps
         ms_per_step = dt / steps * 1e3
@@ -215,6 +249,7 @@ def main():
                        "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world + (" (collective path forced)" if args.force_collective else "")},
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
                         "row_trees_per_s": world * N * n_trees / dtp},
+            "predict_large_ensemble": large,
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
             "collective": ({"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)} if coll is not None else None),
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,
