@@ -26,8 +26,13 @@ def assert_structure_equal(e, g, what=""):
         a, b = np.asarray(e[k]), np.asarray(g[k])
         assert a.shape == b.shape, f"{what}{k}: shape {a.shape} != {b.shape}"
         if a.dtype.kind == "f":
-            assert np.array_equal(a.view(np.uint32), b.astype(np.float32).view(np.uint32)), \
-                f"{what}{k}: threshold bits differ at {np.argwhere(a != b)[:5].tolist()}"
+            # Signed zeros are canonicalised on both sides: -0.0 and +0.0 are ONE order statistic (they compare equal), the
+            # reference stores whichever of the two its std::sort happens to leave at the rank, the product stores +0.0; no
+            # comparison `x > t` the model ever makes can tell them apart.  Every other threshold must match bit for bit.
+            a = (a.astype(np.float32) + np.float32(0.0)).astype(np.float32)
+            b = (b.astype(np.float32) + np.float32(0.0)).astype(np.float32)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+                f"{what}{k}: threshold bits differ at {np.argwhere(a.view(np.uint32) != b.view(np.uint32))[:5].tolist()}"
         else:
             assert np.array_equal(a, b), f"{what}{k}: differs at {np.argwhere(a != b)[:5].tolist()}"
 

@@ -48,6 +48,8 @@ def first_mismatch(e_a, e_b, policy):
                     best = (t, leaf, min(da, db))
             if policy == "oblivious":
                 break
+            if best is not None:
+                break   # greedy leaves are in depth-first order: once one differs, later leaf indices no longer correspond
         if best is not None:
             return best
         if n_a != n_b:
@@ -97,7 +99,24 @@ def explain_first_mismatch(case, X, Xc, G_t, e_ref, e_prod):
     d_ref = int(e_ref["depths"][t if policy == "oblivious" else leaf])
     d_prod = int(e_prod["depths"][t if policy == "oblivious" else leaf])
     if d >= d_ref or d >= d_prod:
-        return dict(tree=t, leaf=leaf, depth=d, explained=False, why="one side stopped splitting here")
+        # One side made this node a leaf, the other split it (greedy: split iff best gain >= 0, fitter.cpp:357).  That happens
+        # when the best candidate's gain is zero in exact arithmetic -- typically a node whose rows all fall on one side of
+        # every candidate, so that the "split" score equals the parent score -- and the reference's float32 sums land a hair
+        # below or above zero.  Explained iff the gain of the split that one side took is within the rounding tolerance.
+        if policy != "greedy":
+            return dict(tree=t, leaf=leaf, depth=d, explained=False, why="one side stopped splitting here")
+        taker = e_ref if d < d_ref else e_prod
+        sel = node_ids >= 0
+        n_rows = int(sel.sum())
+        S = bg[sel].sum(axis=0)
+        parent = float((S ** 2).sum()) / max(n_rows, 1)
+        if case["score"].lower() == "cosine":
+            parent = float(np.sqrt(parent))
+        s_split = score(_conds(taker, policy, t, leaf, d))
+        gain = s_split - (0.0 if d == 0 else parent)
+        tol = (4.0 * EPS32 * np.sqrt(max(n_rows, 1)) + 4.0 * EPS32) * max(abs(parent), abs(s_split), 1e-300)
+        return dict(tree=t, leaf=leaf, depth=d, n_rows=n_rows, gain=gain, tol=tol, gap_rel=abs(gain) / max(abs(parent), 1e-300),
+                    explained=bool(abs(gain) <= tol), product_is_true_max=True, why="zero-gain split decided by rounding")
     s_ref, s_prod = score(_conds(e_ref, policy, t, leaf, d)), score(_conds(e_prod, policy, t, leaf, d))
     n_rows = int((node_ids >= 0).sum())
     gap = abs(s_ref - s_prod) / max(abs(s_ref), abs(s_prod), 1e-300)

@@ -6,6 +6,8 @@ Bar (BASELINE.json north_star): tree STRUCTURE bit-identical (split feature indi
 layout); leaf values and predictions within 1e-5 relative, where "relative" is |a-b| / max(|b|, gradient scale)
 (SURVEY.md hard part 5: the oracle's own float32 sequential sums limit what a relative error of a near-zero mean means).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -272,6 +274,17 @@ def test_non_finite_gradients_are_rejected_and_leave_the_model_unchanged(bad):
         assert np.array_equal(before[k], np.asarray(after[k])), k
     m.step(X, None, G)                      # the model keeps working afterwards
     assert m.get_num_trees() == 2
+
+
+def test_random_sweep_against_the_oracle_has_no_unexplained_mismatch():
+    """60 random configurations (shape, policy, score, generator, bins, depth, min_data_in_leaf, categorical columns, discrete
+    columns): bit-identical structure or an explained near-tie (tests/neartie.py), values / predictions within 1e-5."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "parity_sweep.py"), "60", "31000"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_sharded_code_path_on_one_gpu(monkeypatch):
