@@ -199,7 +199,7 @@ def main():
 
     # predict over a large ensemble (configs[4] scale): trees grown on small minibatches, outside every timed region above
     large = None
-    if args.large_ensemble > n_trees:
+    if args.large_ensemble > n_trees and world == 1:   # single-GPU leg (growing 10^4 trees through the collective path is slow)
         m.set_profiling(0)
         xs_, gs_ = X[:4096].contiguous(), G[:4096].contiguous()
         xso, gso = tup(xs_), tup(gs_)
@@ -262,7 +262,7 @@ def main():
                          "frac_including_reduce": (alg / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hist_ms > 0 else 0.0,
                          "note": "LDS-atomic-issue bound in practice: 9 ds_add_u32 per (row, feature); see DESIGN.md section 5"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(F, D, depth, B, 1 << 20, args.cpu_sample_rows)
             except Exception as e:  # the baseline is reporting only; never let it hide the measurement
