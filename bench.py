@@ -110,11 +110,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available() or not gbrl_amd.cuda_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    # BENCH_SHARE_DEVICE=1 (test hook): every rank uses cuda:0 and the ranks talk through gloo (reductions staged through the
+    # host by gbrl_amd.dist) -- lets the multi-rank code path of this script run on a single-GPU box.  Numbers are meaningless.
+    share = os.environ.get("BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     elif args.force_collective:
         os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = "1"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,7 +176,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
