@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0: grow the CPU sample while the leg stays within ~20 s on this host")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the row-sharded code path (collective hooks through RCCL) on ONE GPU")
+    ap.add_argument("--exchange", choices=["rccl", "hooks"], default="rccl",
+                    help="multi-GPU exchange: the model's own RCCL communicator (default) or torch.distributed hooks")
     ap.add_argument("--predict-trees", type=int, default=0, help="0: predict over the ensemble grown by the bench")
     ap.add_argument("--large-ensemble", type=int, default=10000,
                     help="also time predict() over an ensemble of this many trees (BASELINE configs[4] scale; the extra trees are "
@@ -148,10 +150,18 @@ def main():
     # resolved after each call -- no sync inside the step, 12 records per step.  The full phase table needs ~60 records per
     # step, each a few-microsecond stream bubble, so it is taken in a separate diagnostic pass after the timed region.
     m.set_profiling(1)
-    coll = None
+    coll, exchange = None, None
     if world > 1 or args.force_collective:
-        from gbrl_amd.dist import install_torch_collective
-        coll = install_torch_collective(m, dev)
+        from gbrl_amd.dist import install_rccl, install_torch_collective
+        if args.exchange == "rccl" and not share:
+            try:   # the model's own RCCL communicator: all-reduces enqueued on its stream, no host synchronisation
+                install_rccl(m, dev)
+                exchange = "rccl (native, stream-ordered)"
+            except Exception as e:
+                print("bench: native RCCL exchange unavailable (%r); falling back to torch.distributed hooks" % (e,), flush=True)
+        if exchange is None:
+            coll = install_torch_collective(m, dev)
+            exchange = "torch.distributed hooks (host-synchronous)"
 
     def tup(t):
         return (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
@@ -254,7 +264,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 fixed-point sums / f32 scores",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: oblivious tree, L2 score, quantile candidates", "rows_per_gpu": N,
-                       "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world + (" (collective path forced)" if args.force_collective else "")},
+                       "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world + (" (collective path forced)" if args.force_collective else ""), "exchange": exchange},
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
                         "row_trees_per_s": world * N * n_trees / dtp},
             "predict_large_ensemble": large,

@@ -12,6 +12,7 @@
 
 #include "../../include/gbrl_hip.h"
 #include "engine.h"
+#include "rccl_dyn.h"
 
 struct gbrl_hip_model {
     gbrl::Engine engine;
@@ -275,6 +276,23 @@ int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks)
     return guarded([&] {
         if (!m) throw gbrl::InvalidArgument("null model");
         m->engine.set_collective(hooks);
+    });
+}
+
+int gbrl_hip_rccl_unique_id(void *id128) {
+    return guarded([&] {
+        if (!id128) throw gbrl::InvalidArgument("null id buffer");
+        const gbrl::RcclApi &api = gbrl::rccl_api();
+        if (!api.ok) throw gbrl::Unsupported("RCCL is not available in this process");
+        gbrl::RcclApi::UniqueId id;
+        if (api.GetUniqueId(&id) != 0) throw gbrl::HipError("ncclGetUniqueId failed");
+        std::memcpy(id128, id.internal, sizeof(id.internal));
+    });
+}
+int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int rank) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.set_rccl(id128, world_size, rank);
     });
 }
 

@@ -69,6 +69,9 @@ class Engine {
                  int stop_tree, float *out, bool out_dev);
 
     void set_collective(const gbrl_hip_collective *hooks);
+    // Native exchange: an RCCL communicator of this engine's own, collectives enqueued on its stream (no host sync).
+    // id128 = gbrl_hip_rccl_unique_id() of rank 0, distributed by the caller.  Collective call (all ranks).
+    void set_rccl(const void *id128, int world_size, int rank);
     void set_profiling(int level) { profiling_ = level; }   // 0 off, 1 histogram build only, 2 every phase
     void set_force_bisection(bool on) { force_bisection_ = on; }   // test hook: exercise the slow exact quantile path
     bool last_quantile_fallback() const { return last_quantile_fallback_; }
@@ -86,6 +89,10 @@ class Engine {
     hipStream_t stream_ = nullptr;
     gbrl_hip_collective coll_{};
     bool has_coll_ = false;
+    void *rccl_comm_ = nullptr;          // non-null: the exchanges below are RCCL calls on stream_
+    enum class Red { SumI64, SumF64, MaxF32, MinF32 };
+    void exchange(Red op, void *dev_buf, size_t count);   // all-reduce in place; stream-ordered (RCCL) or host-synchronous (hooks)
+    static int radix_exchange_trampoline(void *self, int64_t *dev_buf, size_t count);
 
     // measurement
     int profiling_ = 0;

@@ -10,6 +10,7 @@
 // The reference grows greedy trees depth-first; the split chosen for a node depends only on that node's rows, so growing
 // level by level and emitting the leaves in depth-first (left first) order afterwards gives the identical tree.
 #include "engine.h"
+#include "rccl_dyn.h"
 
 #include <algorithm>
 #include <cmath>
@@ -77,6 +78,7 @@ Engine::~Engine() {
     if (device_ready_) {
         (void)hipSetDevice(device_ordinal_);
         for (auto &e : ev_pool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (rccl_comm_ && rccl_api().ok) (void)rccl_api().CommDestroy(rccl_comm_);
         if (ev_level_) (void)hipEventDestroy(ev_level_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -106,6 +108,7 @@ void Engine::set_collective(const gbrl_hip_collective *hooks) {
     // world_size 1 normally means "no exchange"; GBRL_HIP_FORCE_COLLECTIVE=1 keeps the hooks installed anyway so that the
     // sharded code path (hook calls, stream hand-over, no sibling subtraction, counting quantiles) can be tested on ONE GPU
     const char *force = std::getenv("GBRL_HIP_FORCE_COLLECTIVE");
+    if (rccl_comm_ && rccl_api().ok) { (void)rccl_api().CommDestroy(rccl_comm_); rccl_comm_ = nullptr; }
     if (hooks == nullptr || (hooks->world_size <= 1 && !(force && force[0] == '1'))) {
         has_coll_ = false;
         return;
@@ -114,6 +117,60 @@ void Engine::set_collective(const gbrl_hip_collective *hooks) {
         throw InvalidArgument("collective hooks incomplete");
     coll_ = *hooks;
     has_coll_ = true;
+}
+
+void Engine::set_rccl(const void *id128, int world_size, int rank) {
+    const RcclApi &api = rccl_api();
+    if (!api.ok) throw Unsupported("RCCL is not available in this process");
+    if (world_size < 1 || rank < 0 || rank >= world_size || id128 == nullptr) throw InvalidArgument("invalid RCCL communicator arguments");
+    ensure_device();
+    if (rccl_comm_) { (void)api.CommDestroy(rccl_comm_); rccl_comm_ = nullptr; }
+    RcclApi::UniqueId id;
+    std::memcpy(id.internal, id128, sizeof(id.internal));
+    RcclApi::Comm comm = nullptr;
+    const int rc = api.CommInitRank(&comm, world_size, id, rank);
+    if (rc != 0 || comm == nullptr) throw HipError(std::string("ncclCommInitRank failed: ") + (api.GetErrorString ? api.GetErrorString(rc) : "?"));
+    rccl_comm_ = comm;
+    coll_ = gbrl_hip_collective{};
+    coll_.world_size = world_size;
+    coll_.rank = rank;
+    const char *force = std::getenv("GBRL_HIP_FORCE_COLLECTIVE");
+    has_coll_ = world_size > 1 || (force && force[0] == '1');
+}
+
+// One exchange point: in-place all-reduce of a device buffer.  With an RCCL communicator the call is enqueued on the engine's
+// stream and the host does not wait; with caller-provided hooks the stream is drained first (the hook's contract).
+void Engine::exchange(Red op, void *dev_buf, size_t count) {
+    if (rccl_comm_) {
+        const RcclApi &api = rccl_api();
+        int dt = RcclApi::kInt64, ro = RcclApi::kSum;
+        switch (op) {
+            case Red::SumI64: dt = RcclApi::kInt64; ro = RcclApi::kSum; break;
+            case Red::SumF64: dt = RcclApi::kFloat64; ro = RcclApi::kSum; break;
+            case Red::MaxF32: dt = RcclApi::kFloat32; ro = RcclApi::kMax; break;
+            case Red::MinF32: dt = RcclApi::kFloat32; ro = RcclApi::kMin; break;
+        }
+        const int rc = api.AllReduce(dev_buf, dev_buf, count, dt, ro, rccl_comm_, stream_);
+        if (rc != 0) throw HipError(std::string("ncclAllReduce failed: ") + (api.GetErrorString ? api.GetErrorString(rc) : "?"));
+        return;
+    }
+    hip_check(hipStreamSynchronize(stream_), "sync before exchange");
+    int rc = -1;
+    switch (op) {
+        case Red::SumI64: rc = coll_.allreduce_sum_i64(coll_.ctx, static_cast<int64_t *>(dev_buf), count); break;
+        case Red::SumF64: rc = coll_.allreduce_sum_f64(coll_.ctx, static_cast<double *>(dev_buf), count); break;
+        case Red::MaxF32: rc = coll_.allreduce_max_f32(coll_.ctx, static_cast<float *>(dev_buf), count); break;
+        case Red::MinF32: rc = coll_.allreduce_min_f32(coll_.ctx, static_cast<float *>(dev_buf), count); break;
+    }
+    if (rc != 0) throw HipError("allreduce failed");
+}
+int Engine::radix_exchange_trampoline(void *self, int64_t *dev_buf, size_t count) {
+    try {
+        static_cast<Engine *>(self)->exchange(Red::SumI64, dev_buf, count);
+        return 0;
+    } catch (...) {
+        return 2;
+    }
 }
 
 // Phase timing: HIP events recorded on the model's stream WITHOUT synchronising; resolved once at the end of the call
@@ -241,9 +298,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         int64_t *tmp = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t)));
         int64_t hv = N;
         hip_check(hipMemcpyAsync(tmp, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D n");
+        exchange(Red::SumI64, tmp, 1);
+        hip_check(hipMemcpyAsync(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H n");
         hip_check(hipStreamSynchronize(s), "sync");
-        if (coll_.allreduce_sum_i64(coll_.ctx, tmp, 1) != 0) throw HipError("allreduce failed");
-        hip_check(hipMemcpy(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost), "D2H n");
         n_global = hv;
     }
 
@@ -307,9 +364,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         auto exchange_stats = [&](double *st) {
             if (!has_coll_) return;
             kern::f64_to_f32(st + D, d_maxf, D, s);
-            hip_check(hipStreamSynchronize(s), "sync");
-            if (coll_.allreduce_sum_f64(coll_.ctx, st, D) != 0 || coll_.allreduce_max_f32(coll_.ctx, d_maxf, D) != 0)
-                throw HipError("allreduce failed");
+            exchange(Red::SumF64, st, D);
+            exchange(Red::MaxF32, d_maxf, D);
             kern::f32_to_f64(d_maxf, st + D, D, s);
         };
         kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
@@ -355,11 +411,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         for (int bit = 31; bit >= 0; --bit) {
             hip_check(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * F * (B + 1), s), "memset");
             kern::bin_rows(dobs, N, F, d_trial, B, /*strict=*/false, d_counts, nullptr, 0, 0, s);
-            if (has_coll_) {
-                hip_check(hipStreamSynchronize(s), "sync");
-                if (coll_.allreduce_sum_i64(coll_.ctx, d_counts, static_cast<size_t>(F) * (B + 1)) != 0)
-                    throw HipError("allreduce failed");
-            }
+            if (has_coll_) exchange(Red::SumI64, d_counts, static_cast<size_t>(F) * (B + 1));
             kern::qsel_update(d_prefix, d_trial, d_counts, d_cum, F, B, bit, bit - 1, s);
         }
         hip_check(hipMemcpyAsync(d_thrkeys, d_trial, sizeof(uint32_t) * F * B, hipMemcpyDeviceToDevice, s), "D2D keys");
@@ -375,9 +427,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 // exchange as floats (max / min are exact)
                 float *tmp = static_cast<float *>(d_trial_.ensure(sizeof(float) * 2 * F));
                 kern::keys_to_floats(d_mm, tmp, 2 * static_cast<size_t>(F), s);
-                hip_check(hipStreamSynchronize(s), "sync");
-                if (coll_.allreduce_min_f32(coll_.ctx, tmp, F) != 0 || coll_.allreduce_max_f32(coll_.ctx, tmp + F, F) != 0)
-                    throw HipError("allreduce failed");
+                exchange(Red::MinF32, tmp, F);
+                exchange(Red::MaxF32, tmp + F, F);
                 kern::floats_to_keys(tmp, d_mm, 2 * static_cast<size_t>(F), s);
             }
             kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s);
@@ -404,8 +455,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                 uint32_t *d_rl = static_cast<uint32_t *>(d_qlists_.ensure(kern::radix_list_bytes(N, F)));
                 kern::RadixComm comm{};
                 if (has_coll_) {
-                    comm.ctx = coll_.ctx;
-                    comm.allreduce_sum_i64 = coll_.allreduce_sum_i64;
+                    comm.ctx = this;
+                    comm.allreduce_sum_i64 = &Engine::radix_exchange_trampoline;
                     comm.gbuf = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * kern::radix_exchange_words(F)));
                     comm.partial_global = static_cast<uint32_t *>(d_radix_global_.ensure(kern::radix_global_partial_bytes(F)));
                 }
@@ -438,14 +489,12 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                     kern::sample_only(d_kt, N, F, S, d_samp, s);
                     hip_check(hipMemsetAsync(d_uni, 0, sizeof(int64_t) * static_cast<size_t>(F) * SU, s), "memset");
                     kern::place_sample(d_samp, F, S, coll_.rank, SU, d_uni, s);
-                    hip_check(hipStreamSynchronize(s), "sync");
-                    if (coll_.allreduce_sum_i64(coll_.ctx, d_uni, static_cast<size_t>(F) * SU) != 0) throw HipError("allreduce failed");
+                    exchange(Red::SumI64, d_uni, static_cast<size_t>(F) * SU);
                     kern::union_splitters(d_uni, F, SU, plan.n_split, d_split, d_split_bfs, s);
                     kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
                     d_gcounts = d_uni;   // reuse (the union sample is consumed)
                     kern::counts_to_i64(d_cc, plan.n_chunks, static_cast<size_t>(F) * kern::kQuantileClasses, d_gcounts, s);
-                    hip_check(hipStreamSynchronize(s), "sync");
-                    if (coll_.allreduce_sum_i64(coll_.ctx, d_gcounts, static_cast<size_t>(F) * kern::kQuantileClasses) != 0) throw HipError("allreduce failed");
+                    exchange(Red::SumI64, d_gcounts, static_cast<size_t>(F) * kern::kQuantileClasses);
                 } else {
                     kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
                     kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
@@ -460,8 +509,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                     hip_check(hipMemsetAsync(d_pref, 0, sizeof(uint32_t) * static_cast<size_t>(F) * B, s), "memset");
                     for (int bit = 31; bit >= 0; --bit) {
                         kern::select_count(d_lists, d_toff, d_tlen, d_pref, bit, F * B, d_scnt, s);
-                        hip_check(hipStreamSynchronize(s), "sync");
-                        if (coll_.allreduce_sum_i64(coll_.ctx, d_scnt, static_cast<size_t>(F) * B) != 0) throw HipError("allreduce failed");
+                        exchange(Red::SumI64, d_scnt, static_cast<size_t>(F) * B);
                         kern::select_update(d_pref, d_scnt, d_toff, d_tr, bit, F * B, d_thrkeys, s);
                     }
                 } else {
@@ -478,9 +526,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             if (has_coll_) {   // the fallback decision must be the same on every rank
                 int64_t *d_flag = static_cast<int64_t *>(d_selcnt_.ensure(sizeof(int64_t) * 2));
                 int64_t hv = qflags[2];
-                hip_check(hipMemcpy(d_flag, &hv, sizeof(hv), hipMemcpyHostToDevice), "H2D flag");
-                if (coll_.allreduce_sum_i64(coll_.ctx, d_flag, 1) != 0) throw HipError("allreduce failed");
-                hip_check(hipMemcpy(&hv, d_flag, sizeof(hv), hipMemcpyDeviceToHost), "D2H flag");
+                hip_check(hipMemcpyAsync(d_flag, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D flag");
+                exchange(Red::SumI64, d_flag, 1);
+                hip_check(hipMemcpyAsync(&hv, d_flag, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H flag");
+                hip_check(hipStreamSynchronize(s), "sync");
                 qflags[2] = hv != 0;
             }
             if (qflags[2] != 0) {  // a class list outgrew its budget (pathological value distribution): redo exactly, slowly
@@ -760,11 +809,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         Chunk *d_count_chunks = sta.put(count_chunks.data(), count_chunks.size());
         // One GPU: the partition of this level is enqueued right behind the selection kernels, from descriptors the device
         // completes itself (k_resolve_splits), so that it runs while the host is still waiting for / digesting the read-back.
-        const bool early_partition = !has_coll_;
         std::vector<Chunk> part_chunks;
-        std::vector<int32_t> seg_starts(n_act);
-        if (early_partition) {
-            for (int k = 0; k < n_act; ++k) seg_starts[k] = nodes[active[k]].seg_start;
+        std::vector<int32_t> seg_starts(n_act), n_locals(n_act);
+        {
+            for (int k = 0; k < n_act; ++k) { seg_starts[k] = nodes[active[k]].seg_start; n_locals[k] = nodes[active[k]].n_local; }
             std::vector<Chunk> keep = h_chunks;
             std::vector<int32_t> keep_begin = h_chunk_begin;
             make_chunks(active, kern::kPartitionRows, false);
@@ -774,6 +822,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         }
         Chunk *d_part_chunks = sta.put(part_chunks.data(), part_chunks.size());
         int32_t *d_seg_starts = sta.put(seg_starts.data(), seg_starts.size());
+        int32_t *d_n_locals = sta.put(n_locals.data(), n_locals.size());
         sta.flush();
         phase_begin(/*key=*/true);
         if (!h_chunks.empty())
@@ -787,11 +836,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             // local sums of the computed nodes, contiguous -> ONE all-reduce -> placed into their level slots
             const int nc = static_cast<int>(compute_ids.size());
             kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s);
-            hip_check(hipStreamSynchronize(s), "sync");
-            if (coll_.allreduce_sum_i64(coll_.ctx, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems) != 0) throw HipError("allreduce failed");
-            for (int k = 0; k < nc; ++k)
-                hip_check(hipMemcpyAsync(d_hist + static_cast<size_t>(slot_map[k]) * hist_node_elems, d_hist_coll + static_cast<size_t>(k) * hist_node_elems,
-                                         sizeof(int64_t) * hist_node_elems, hipMemcpyDeviceToDevice, s), "D2D hist slot");
+            exchange(Red::SumI64, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems);
+            kern::hist_place(d_hist_coll, d_hist, d_slotmap, nc, hist_node_elems, s);
         }
         if (!sub_entries.empty())
             kern::hist_subtract(d_hist_prev, d_hist, d_subent, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
@@ -803,16 +849,17 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
         kern::resolve_splits(d_am_v, d_am_i, am_parts, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
-                             d_counts4, max_front, early_partition ? d_seg_starts : nullptr, d_cursors, s);
+                             d_counts4, max_front, d_seg_starts, d_cursors, s);
         if (has_coll_) {
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
             hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
             if (!count_chunks.empty())
                 kern::count_right(d_rows[cur], d_codes, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
+            kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);   // global left sizes -> this rank's
         }
         hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
         phase_end("score_select");
-        if (early_partition) {
+        {
             hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");
             phase_begin();
             if (!part_chunks.empty())
@@ -820,8 +867,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
                                      d_cursors, s);
             phase_end("partition");
             hip_check(hipEventSynchronize(ev_level_), "hipEventSynchronize(level results)");
-        } else {
-            hip_check(hipStreamSynchronize(s), "sync");
         }
         hip_check(hipGetLastError(), "growth kernels");
         const int32_t *best_idx_h = reinterpret_cast<const int32_t *>(h_res);
@@ -917,23 +962,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             }
         }
         if (splitting.empty()) { frontier.clear(); break; }
-        if (early_partition) {
-            cur ^= 1;   // already enqueued from the device-side descriptors (same decisions: best_score rule, n_left = total - right)
-        } else {
-            std::vector<int> split_ids;
-            std::vector<NodeSplit> sp2;
-            for (int k : splitting) { split_ids.push_back(active[k]); sp2.push_back(sp[k]); }
-            make_chunks(split_ids, kern::kPartitionRows, false);
-            Chunk *d_pc = stb.put(h_chunks.data(), h_chunks.size());
-            NodeSplit *d_sp2 = stb.put(sp2.data(), sp2.size());
-            stb.flush();
-            hip_check(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * 2 * sp2.size(), s), "memset cursors");
-            phase_begin();
-            if (!h_chunks.empty())
-                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_pc, static_cast<int>(h_chunks.size()), d_sp2, d_cursors, s);
-            phase_end("partition");
-            cur ^= 1;
-        }
+        cur ^= 1;   // the partition was enqueued from the device-side descriptors (same decisions: best_score rule, n_left)
         frontier = next;
     }
 
@@ -955,8 +984,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         }
     }
     if (has_coll_) {
-        hip_check(hipStreamSynchronize(s), "sync");
-        if (coll_.allreduce_sum_i64(coll_.ctx, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1)) != 0) throw HipError("allreduce failed");
+        exchange(Red::SumI64, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1));
     }
     std::vector<int64_t> acc(nodes.size() * (D + 1));
     hip_check(hipMemcpyAsync(acc.data(), d_leafacc, sizeof(int64_t) * acc.size(), hipMemcpyDeviceToHost, s), "D2H leaf acc");

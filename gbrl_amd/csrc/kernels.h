@@ -167,6 +167,8 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
                     int32_t *cursors, hipStream_t s);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
+void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);
+void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n, size_t node_elems, hipStream_t s);
 void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
                  int64_t *n_right /*[n_nodes], zeroed*/, hipStream_t s);
 

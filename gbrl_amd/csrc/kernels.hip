@@ -1300,6 +1300,28 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int
                        ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors);
 }
 
+// Row-sharded runs: k_resolve_splits wrote GLOBAL left sizes; the partition needs this rank's.
+__global__ void k_localize_splits(NodeSplit *__restrict__ splits, const int32_t *__restrict__ n_local,
+                                  const int64_t *__restrict__ right_local, int n_nodes) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_nodes) splits[k].n_left = n_local[k] - static_cast<int32_t>(right_local[k]);
+}
+void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s) {
+    hipLaunchKernelGGL(k_localize_splits, dim3((n_nodes + 63) / 64), dim3(64), 0, s, splits, n_local, right_local, n_nodes);
+}
+// Copies `n` contiguous node histograms into their level slots (dst slot = slot_map[k]).
+__global__ void k_hist_place(const int64_t *__restrict__ src, int64_t *__restrict__ dst, const int32_t *__restrict__ slot_map,
+                             size_t node_elems) {
+    const int32_t slot = slot_map[blockIdx.y];
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < node_elems;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        dst[static_cast<size_t>(slot) * node_elems + i] = src[static_cast<size_t>(blockIdx.y) * node_elems + i];
+}
+void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n, size_t node_elems, hipStream_t s) {
+    const int bx = static_cast<int>(std::min<size_t>(256, (node_elems + 255) / 256));
+    hipLaunchKernelGGL(k_hist_place, dim3(bx, n), dim3(256), 0, s, src, dst, slot_map, node_elems);
+}
+
 void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
                  int64_t *n_right, hipStream_t s) {
     hipLaunchKernelGGL(k_count_right, dim3(n_chunks), dim3(kPartThreads), 0, s, rows, codes, n_rows, chunks, splits, n_right);

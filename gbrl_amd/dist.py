@@ -92,3 +92,31 @@ def install_torch_collective(model, device, group=None) -> TorchCollective:
     if rc != 0:
         raise RuntimeError(lib.gbrl_hip_last_error().decode())
     return coll   # the caller must keep this object alive for as long as the model may call the hooks
+
+
+def install_rccl(model, device, group=None) -> None:
+    """Native exchange: give the model its own RCCL communicator (collectives enqueued on the model's stream, no host
+    synchronisation at the exchange points).  Collective call: every rank of `group` must make it.  The unique id is created
+    by rank 0 and distributed with torch.distributed.broadcast."""
+    import torch
+    import torch.distributed as dist
+    from . import LIB_PATH
+    lib = C.CDLL(LIB_PATH)
+    lib.gbrl_hip_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.gbrl_hip_rccl_unique_id.restype = C.c_int
+    lib.gbrl_hip_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.gbrl_hip_set_rccl.restype = C.c_int
+    lib.gbrl_hip_last_error.restype = C.c_char_p
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    buf = (C.c_char * 128)()
+    if rank == 0 and lib.gbrl_hip_rccl_unique_id(buf) != 0:
+        raise RuntimeError(lib.gbrl_hip_last_error().decode())
+    on_dev = str(dist.get_backend(group)).lower() == "nccl"
+    t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+    if on_dev:
+        t = t.to(device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    raw = bytes(t.cpu().numpy().tobytes())
+    idbuf = C.create_string_buffer(raw, 128)
+    if lib.gbrl_hip_set_rccl(C.c_void_p(model._handle()), idbuf, world, rank) != 0:
+        raise RuntimeError(lib.gbrl_hip_last_error().decode())

@@ -156,6 +156,15 @@ typedef struct {
 } gbrl_hip_collective;
 int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks);
 
+/* Native exchange (preferred on multi-GPU nodes): the model creates its own RCCL communicator and enqueues every all-reduce
+ * on its stream -- no host synchronisation at the exchange points.  RCCL is bound at run time (the librccl.so the process
+ * already loaded, e.g. PyTorch's, else the system one).  Rank 0 calls gbrl_hip_rccl_unique_id and hands the 128 bytes to the
+ * other ranks by any means (torch.distributed.broadcast in gbrl_amd/dist.py); then EVERY rank calls gbrl_hip_set_rccl
+ * (a collective call: it returns when all ranks have joined).  Replaces hooks installed earlier; installing hooks later
+ * destroys the communicator. */
+int gbrl_hip_rccl_unique_id(void *id128);
+int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int rank);
+
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* Per-phase GPU time of the LAST step()/predict() call, measured with HIP events on the model's stream.
  * names/ms hold up to `cap` entries; returns the number of phases. */

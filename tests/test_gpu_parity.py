@@ -311,3 +311,30 @@ def test_sharded_code_path_on_one_gpu(monkeypatch):
     for k in K.ENSEMBLE_KEYS:
         assert np.array_equal(np.asarray(e0[k]), np.asarray(e1[k])), k
     assert np.array_equal(p0, p1)
+
+
+def test_native_rccl_exchange_on_one_gpu(monkeypatch):
+    """The sharded code path with the model's OWN RCCL communicator (gbrl_hip_set_rccl: all-reduces enqueued on the engine's
+    stream, no host synchronisation), world size 1: must give the single-GPU tree."""
+    import torch
+    import torch.distributed as dist
+    import gbrl_amd
+    from gbrl_amd.dist import install_rccl
+    for name in ("obl_l2_q_d6", "grd_cos_u", "cfg1_rmse_loop"):
+        case, g, (X, Xc, G, y) = load_golden(name)
+        m0, p0 = _run_product(case, X, Xc, G, y, "cpu")
+        monkeypatch.setenv("GBRL_HIP_FORCE_COLLECTIVE", "1")
+        monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+        monkeypatch.setenv("MASTER_PORT", "29579")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        try:
+            m1 = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+            install_rccl(m1, torch.device("cuda:0"))
+            p1 = np.asarray(K.drive(m1, case, X, Xc, G, y))
+        finally:
+            dist.destroy_process_group()
+        monkeypatch.delenv("GBRL_HIP_FORCE_COLLECTIVE")
+        e0, e1 = m0.get_ensemble_data(), m1.get_ensemble_data()
+        for k in K.ENSEMBLE_KEYS:
+            assert np.array_equal(np.asarray(e0[k]), np.asarray(e1[k])), (name, k)
+        assert np.array_equal(p0, p1)
