@@ -10,6 +10,8 @@
 // The reference grows greedy trees depth-first; the split chosen for a node depends only on that node's rows, so growing
 // level by level and emitting the leaves in depth-first (left first) order afterwards gives the identical tree.
 #include "engine.h"
+
+#include <functional>
 #include "rccl_dyn.h"
 
 #include <algorithm>
@@ -1069,7 +1071,7 @@ void Engine::sync_model_to_device() {
     const size_t T = md.n_trees, L = md.n_leaves, S = model.split_rows(), MD = md.max_depth, D = md.output_dim;
     if (mirror_version_ == model.version) return;
     // dictionary ids for the categorical conditions (strings are compared on the host once; the device compares ids)
-    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); cond_pack_host_.clear(); }
+    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; grd_up_nodes_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); cond_pack_host_.clear(); }
     cat_ids_host_.resize(S * MD, 0);
     for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
         if (model.is_numerics[c]) continue;
@@ -1105,6 +1107,62 @@ void Engine::sync_model_to_device() {
     append(m_cond_pack_, cond_pack_host_.data(), 4, up_splits_ * MD * 2, S * MD * 2);
     append(m_values_, model.values.data(), 4, up_leaves_ * D, L * D);
     append(m_ineq_, model.inequality_directions.data(), 1, up_leaves_ * MD, L * MD);
+    // Greedy ensembles: rebuild every new tree as a binary tree from its leaves' paths (leaves are stored depth-first, left
+    // first; fitter.cpp:364-365), for the descent of k_predict_grd.  A tree whose leaves do not form a proper binary tree (a
+    // hand-edited model file), or a depth-0 tree (Q7), switches the fast path off for the whole ensemble.
+    if (!model.oblivious()) {
+        if (up_trees_ == 0) { grd_nodes_host_.clear(); grd_off_host_.assign(1, 0); grd_ok_ = true; grd_max_nodes_ = 0; grd_max_leaves_ = 1; }
+        for (size_t t = up_trees_; t < T; ++t) {
+            const int l0 = model.tree_indices[t], l1 = t + 1 < T ? model.tree_indices[t + 1] : static_cast<int>(L);
+            const size_t base = grd_nodes_host_.size() / 4;
+            bool ok = l1 > l0;
+            // same condition (depth d) for two leaves?
+            auto same_cond = [&](int a, int b, int d) {
+                const size_t ca = static_cast<size_t>(a) * MD + d, cb = static_cast<size_t>(b) * MD + d;
+                if (model.is_numerics[ca] != model.is_numerics[cb] || model.feature_indices[ca] != model.feature_indices[cb]) return false;
+                if (model.is_numerics[ca]) return std::memcmp(&model.feature_values[ca], &model.feature_values[cb], 4) == 0;
+                return cat_ids_host_[ca] == cat_ids_host_[cb];
+            };
+            // build(lo, hi, d): leaves [lo, hi) share their first d conditions; returns the child code
+            std::function<int(int, int, int)> build = [&](int lo, int hi, int d) -> int {
+                if (!ok) return -1;
+                if (hi - lo == 1) {
+                    if (model.depths[lo] != d) ok = false;
+                    return ~(lo - l0);
+                }
+                if (d >= static_cast<int>(MD)) { ok = false; return -1; }
+                int mid = lo;
+                for (int q = lo; q < hi; ++q) {
+                    if (model.depths[q] <= d || !same_cond(lo, q, d)) { ok = false; return -1; }
+                    const bool right = model.inequality_directions[static_cast<size_t>(q) * MD + d] != 0;
+                    if (!right) { if (q != mid) { ok = false; return -1; } ++mid; }   // left leaves first, contiguous
+                }
+                if (mid == lo || mid == hi) { ok = false; return -1; }
+                const size_t me = grd_nodes_host_.size() / 4 - base;
+                grd_nodes_host_.insert(grd_nodes_host_.end(), {0, 0, 0, 0});
+                const size_t c = static_cast<size_t>(lo) * MD + d;
+                int32_t tv;
+                std::memcpy(&tv, &model.feature_values[c], sizeof(tv));
+                const bool num = model.is_numerics[c] != 0;
+                const int left = build(lo, mid, d + 1), right = build(mid, hi, d + 1);
+                int32_t *nd = &grd_nodes_host_[(base + me) * 4];
+                nd[0] = num ? model.feature_indices[c] : ~model.feature_indices[c];
+                nd[1] = num ? tv : cat_ids_host_[c];
+                nd[2] = left;
+                nd[3] = right;
+                return static_cast<int>(me);
+            };
+            if (ok && l1 - l0 == 1) ok = false;                 // depth-0 tree: its leaf never passes in the reference (Q7)
+            if (ok) { const int root = build(l0, l1, 0); if (root != 0) ok = false; }
+            if (!ok) { grd_ok_ = false; grd_nodes_host_.resize(base * 4); }
+            grd_off_host_.push_back(static_cast<int32_t>(grd_nodes_host_.size() / 4));
+            grd_max_nodes_ = std::max<int>(grd_max_nodes_, static_cast<int>(grd_nodes_host_.size() / 4 - base));
+            grd_max_leaves_ = std::max(grd_max_leaves_, l1 - l0);
+        }
+        append(m_grd_nodes_, grd_nodes_host_.data(), 4, grd_up_nodes_ * 4, grd_nodes_host_.size());
+        append(m_grd_off_, grd_off_host_.data(), 4, 0, grd_off_host_.size());
+        grd_up_nodes_ = grd_nodes_host_.size() / 4;
+    }
     up_trees_ = T; up_leaves_ = L; up_splits_ = S;
     // small, mutable state: always refreshed
     append(m_bias_, model.bias.data(), 4, 0, D);
@@ -1193,7 +1251,15 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.opt_stop = m_opt_stop_.as<int32_t>();
     pm.opt_lr = m_opt_lr_.as<float>();
     pm.cond_pack = m_cond_pack_.as<int32_t>();
-    pm.all_numeric = md.n_cat_features == 0 ? 1 : 0;
+    pm.grd_nodes = m_grd_nodes_.as<int32_t>();
+    pm.grd_node_off = m_grd_off_.as<int32_t>();
+    pm.grd_ok = (!model.oblivious() && grd_ok_) ? 1 : 0;
+    pm.grd_max_nodes = grd_max_nodes_;
+    pm.grd_max_leaves = grd_max_leaves_;
+    if (const char *e = std::getenv("GBRL_HIP_PREDICT_GENERIC")) {   // test hook: the general kernels only
+        if (e[0] == '1') { pm.grd_ok = 0; pm.obl_ok = 0; }
+    }
+    pm.obl_ok = model.oblivious() ? 1 : 0;
     pm.coef_ok = D <= 32 ? 1 : 0;
     pm.coef_cover = 0;
     for (int j = 0; j < 32; ++j) pm.coef[j] = 0.0f;

@@ -193,7 +193,14 @@ struct PredictModel {
     // fast oblivious path (k_predict_obl): per split row 2*max_depth ints (feature index | ~categorical index, threshold bits |
     // category id), and -- when the optimisers' output ranges do not overlap -- one learning rate per output
     const int32_t *cond_pack;
-    int all_numeric, coef_ok;
+    // fast greedy path (k_predict_grd): every greedy tree rebuilt as a binary tree from its leaves' paths.  Node = int4
+    // (feature | ~categorical feature, threshold bits | category id, left child, right child); a child >= 0 is a node of the
+    // same tree, < 0 encodes ~(leaf index within the tree).  grd_node_off[t] .. grd_node_off[t+1] are tree t's nodes (root
+    // first); grd_ok == 0 when some tree is not a proper binary tree (or has depth 0, Q7): the generic walk is used then.
+    const int32_t *grd_nodes;
+    const int32_t *grd_node_off;
+    int grd_ok, grd_max_nodes, grd_max_leaves;
+    int obl_ok, coef_ok;
     uint32_t coef_cover;
     float coef[32];
 };

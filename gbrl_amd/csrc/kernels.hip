@@ -1351,12 +1351,12 @@ void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chun
 template <int DMAX>
 struct OblCoef { float lr[DMAX]; };   // one learning rate per output (0 for the padded outputs j >= D)
 
-template <int DMAX, int MAXD>
+template <int DMAX, int MAXD, bool CAT>
 __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ values, const int32_t *__restrict__ tree_indices,
                                                      const int32_t *__restrict__ cond_pack, const int32_t *__restrict__ depths,
                                                      const float *__restrict__ bias, OblCoef<DMAX> coef, int D, int md,
-                                                     const float *__restrict__ obs, int F, int n, int start_tree, int stop_tree,
-                                                     float *__restrict__ out, int TT) {
+                                                     const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc, int n,
+                                                     int start_tree, int stop_tree, float *__restrict__ out, int TT) {
     extern __shared__ float ptile[];
     const int R = blockDim.x;
     const int xs = F | 1;
@@ -1402,6 +1402,8 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
 #pragma unroll
     for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + bias[j] : 0.0f;
     const float *x = xt + threadIdx.x * xs;
+    // categorical conditions (feature word < 0) compare the row's dictionary id; the branch is uniform (scalar condition words)
+    const int32_t *xc = (CAT && live) ? cat_codes + static_cast<size_t>(r0 + threadIdx.x) * Fc : nullptr;
     constexpr int kTreeElems = DMAX;   // per leaf
     const int vtree = kTreeElems * LS;
     for (int t0 = start_tree; t0 < stop_tree; t0 += TT) {
@@ -1463,17 +1465,24 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
 #pragma unroll
                 for (int d = 0; d < MAXD; ++d) { fi[d] = cp[2 * d]; tv[d] = __int_as_float(cp[2 * d + 1]); }
 #pragma unroll
-                for (int d = 0; d < MAXD; ++d) xv[d] = x[fi[d]];
+                for (int d = 0; d < MAXD; ++d) xv[d] = (!CAT || fi[d] >= 0) ? x[fi[d]] : 0.0f;
                 int leaf = 0;
 #pragma unroll
-                for (int d = 0; d < MAXD; ++d) leaf |= (xv[d] > tv[d]) ? (1 << (MAXD - 1 - d)) : 0;
+                for (int d = 0; d < MAXD; ++d) {
+                    const bool pass = (!CAT || fi[d] >= 0) ? (xv[d] > tv[d]) : (xc[~fi[d]] == __float_as_int(tv[d]));
+                    leaf |= pass ? (1 << (MAXD - 1 - d)) : 0;
+                }
                 return leaf;
             };
             auto leaf_any = [&](int t) -> int {    // shallower trees (growth stopped early) or max_depth < MAXD
                 const int depth = depths[t];
                 const int32_t *cp = cond_pack + static_cast<size_t>(t) * 2 * md;
                 int leaf = 0;
-                for (int d = 0; d < depth; ++d) leaf |= (x[cp[2 * d]] > __int_as_float(cp[2 * d + 1])) ? (1 << (depth - 1 - d)) : 0;
+                for (int d = 0; d < depth; ++d) {
+                    const int fi = cp[2 * d], tv = cp[2 * d + 1];
+                    const bool pass = (!CAT || fi >= 0) ? (x[fi] > __int_as_float(tv)) : (xc[~fi] == tv);
+                    leaf |= pass ? (1 << (depth - 1 - d)) : 0;
+                }
                 return leaf;
             };
             int tt = 0;
@@ -1496,9 +1505,9 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
     }
 }
 
-template <int DMAX, int MAXD>
-static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, int n, int start_tree, int stop_tree, float *out,
-                               hipStream_t s) {
+template <int DMAX, int MAXD, bool CAT>
+static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
+                               int stop_tree, float *out, hipStream_t s) {
     const size_t budget = 156 * 1024;   // leaves room for the kernel's small static LDS (block-wide vote)
     const size_t vtree = (static_cast<size_t>(1) << pm.max_depth) * DMAX * sizeof(float);
     const int xs = F | 1;
@@ -1511,22 +1520,204 @@ static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, 
     const size_t lds = static_cast<size_t>(R) * xs * sizeof(float) + static_cast<size_t>(TT) * vtree + meta;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl<DMAX, MAXD>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl<DMAX, MAXD, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr = true;
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
-    hipLaunchKernelGGL((k_predict_obl<DMAX, MAXD>), dim3((n + R - 1) / R), dim3(R), lds, s, pm.values, pm.tree_indices, pm.cond_pack,
-                       pm.depths, pm.bias, coef, pm.D, pm.max_depth, obs, F, n, start_tree, stop_tree, out, TT);
+    hipLaunchKernelGGL((k_predict_obl<DMAX, MAXD, CAT>), dim3((n + R - 1) / R), dim3(R), lds, s, pm.values, pm.tree_indices, pm.cond_pack,
+                       pm.depths, pm.bias, coef, pm.D, pm.max_depth, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, TT);
     return true;
 }
-template <int DMAX>
-static bool launch_predict_obl_d(const PredictModel &pm, const float *obs, int F, int n, int start_tree, int stop_tree, float *out,
-                                 hipStream_t s) {
-    if (pm.max_depth <= 4) return launch_predict_obl<DMAX, 4>(pm, obs, F, n, start_tree, stop_tree, out, s);
-    if (pm.max_depth <= 6) return launch_predict_obl<DMAX, 6>(pm, obs, F, n, start_tree, stop_tree, out, s);
-    if (pm.max_depth <= 8) return launch_predict_obl<DMAX, 8>(pm, obs, F, n, start_tree, stop_tree, out, s);
+template <int DMAX, bool CAT>
+static bool launch_predict_obl_c(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
+                                 int stop_tree, float *out, hipStream_t s) {
+    if (pm.max_depth <= 4) return launch_predict_obl<DMAX, 4, CAT>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
+    if (pm.max_depth <= 6) return launch_predict_obl<DMAX, 6, CAT>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
+    if (pm.max_depth <= 8) return launch_predict_obl<DMAX, 8, CAT>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
     return false;
+}
+template <int DMAX>
+static bool launch_predict_obl_d(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
+                                 int stop_tree, float *out, hipStream_t s) {
+    return Fc > 0 ? launch_predict_obl_c<DMAX, true>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)
+                  : launch_predict_obl_c<DMAX, false>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A13 fast path for GREEDY ensembles.  The reference finds a row's leaf by testing the leaves of a tree one after the other
+// until all conditions of one pass (predictor.cpp:188-229): up to leaves x depth tests.  Leaves of a proper tree partition
+// the space, so the first leaf that passes is THE leaf the row reaches by descending the tree; the host rebuilds that tree from
+// the leaves' paths (Engine::sync_model_to_device) and the kernel descends it: <= depth steps per (row, tree).  Ensembles that
+// are not proper trees, or contain a depth-0 tree (whose leaf never passes and lets the reference's walk run on, Q7), keep the
+// generic kernel.  Same row tile / transposed leaf values / per-output learning rates / tree-order accumulation as
+// k_predict_obl; a group's nodes are staged in LDS next to its values.
+// ------------------------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_predict_grd(const float *__restrict__ values, const int32_t *__restrict__ tree_indices,
+                                                     const int32_t *__restrict__ nodes, const int32_t *__restrict__ node_off,
+                                                     const float *__restrict__ bias, OblCoef<DMAX> coef, int D, int n_leaves_total,
+                                                     int n_trees_total, int max_nodes, int max_leaves,
+                                                     const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc,
+                                                     int n, int start_tree, int stop_tree, float *__restrict__ out, int TT) {
+    extern __shared__ float ptile[];
+    const int R = blockDim.x;
+    const int xs = F | 1;
+    const int LS = max_leaves;
+    float *xt = ptile;                                              // [R][xs]
+    float *vt = ptile + static_cast<size_t>(R) * xs;                // [TT][DMAX][LS]
+    int4 *nt = reinterpret_cast<int4 *>(vt + static_cast<size_t>(TT) * DMAX * LS);   // [TT][max_nodes]
+    int *tmeta = reinterpret_cast<int *>(nt + static_cast<size_t>(TT) * max_nodes);  // [TT][4]: first leaf, leaves, first node, nodes
+    const int r0 = blockIdx.x * R;
+    const int rows = min(R, n - r0);
+    {
+        const float *src = obs + static_cast<size_t>(r0) * F;
+        if (F > 0 && (F & 3) == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(src);
+            const int F4 = F >> 2, tot4 = rows * F4;
+            constexpr int UL = 8;
+            for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
+                float4 v[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = i0 + u * R;
+                    v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = i0 + u * R;
+                    if (i < tot4) {
+                        const int r = i / F4, f = (i - r * F4) << 2;
+                        float *dst = xt + r * xs + f;
+                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                    }
+                }
+            }
+        } else {
+            const int tot = rows * F;
+            for (int i = threadIdx.x; i < tot; i += R) {
+                const int r = i / F, f = i - r * F;
+                xt[r * xs + f] = src[i];
+            }
+        }
+    }
+    const bool live = static_cast<int>(threadIdx.x) < rows;
+    float p[DMAX];
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + bias[j] : 0.0f;
+    const float *x = xt + threadIdx.x * xs;
+    const int32_t *xc = (cat_codes && live) ? cat_codes + static_cast<size_t>(r0 + threadIdx.x) * Fc : nullptr;
+    const int vtree = DMAX * LS;
+    for (int t0 = start_tree; t0 < stop_tree; t0 += TT) {
+        const int tn = min(TT, stop_tree - t0);
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < tn) {
+            const int t = t0 + threadIdx.x;
+            const int l0 = tree_indices[t], l1 = t + 1 < n_trees_total ? tree_indices[t + 1] : n_leaves_total;
+            tmeta[4 * threadIdx.x + 0] = l0;
+            tmeta[4 * threadIdx.x + 1] = l1 - l0;
+            tmeta[4 * threadIdx.x + 2] = node_off[t];
+            tmeta[4 * threadIdx.x + 3] = node_off[t + 1] - node_off[t];
+        }
+        __syncthreads();
+        {
+            constexpr int US = 8;
+            for (int i0 = threadIdx.x; i0 < tn * vtree; i0 += R * US) {
+                float v[US];
+                int dst[US];
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+                    const int i = i0 + u * R;
+                    dst[u] = -1;
+                    v[u] = 0.0f;
+                    if (i < tn * vtree) {
+                        const int tt = i / vtree, e = i - tt * vtree;
+                        const int leaf = e / DMAX, j = e - leaf * DMAX;
+                        dst[u] = (tt * DMAX + j) * LS + leaf;
+                        if (j < D && leaf < tmeta[4 * tt + 1]) v[u] = values[(static_cast<size_t>(tmeta[4 * tt]) + leaf) * D + j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < US; ++u)
+                    if (dst[u] >= 0) vt[dst[u]] = v[u];
+            }
+            const int4 *gn = reinterpret_cast<const int4 *>(nodes);
+            for (int i = threadIdx.x; i < tn * max_nodes; i += R) {
+                const int tt = i / max_nodes, k = i - tt * max_nodes;
+                if (k < tmeta[4 * tt + 3]) nt[i] = gn[tmeta[4 * tt + 2] + k];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            auto leaf_of = [&](int tt) -> int {
+                const int4 *tn_ = nt + tt * max_nodes;
+                int node = tmeta[4 * tt + 3] > 0 ? 0 : -1;   // a single-leaf tree has no node (never reaches here: grd_ok excludes it)
+                while (node >= 0) {
+                    const int4 nd = tn_[node];
+                    const bool right = nd.x >= 0 ? (x[nd.x] > __int_as_float(nd.y)) : (xc != nullptr && xc[~nd.x] == nd.y);
+                    node = right ? nd.w : nd.z;
+                }
+                return ~node;
+            };
+            auto apply = [&](int tt, int leaf) {
+                const float *v = vt + tt * vtree + leaf;
+                float vv[DMAX];
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) vv[j] = v[j * LS];
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) p[j] = fmaf(-coef.lr[j], vv[j], p[j]);
+            };
+            int tt = 0;
+            for (; tt + 3 < tn; tt += 4) {   // four descents in flight (independent chains); values applied in tree order
+                int nd0 = 0, nd1 = 0, nd2 = 0, nd3 = 0;
+                const int4 *b0 = nt + tt * max_nodes, *b1 = b0 + max_nodes, *b2 = b1 + max_nodes, *b3 = b2 + max_nodes;
+                auto step = [&](const int4 *base, int &node) {
+                    if (node >= 0) {
+                        const int4 nd = base[node];
+                        const bool right = nd.x >= 0 ? (x[nd.x] > __int_as_float(nd.y)) : (xc != nullptr && xc[~nd.x] == nd.y);
+                        node = right ? nd.w : nd.z;
+                    }
+                };
+                while ((nd0 & nd1 & nd2 & nd3) >= 0) {   // until all four are leaves (negative)
+                    step(b0, nd0); step(b1, nd1); step(b2, nd2); step(b3, nd3);
+                }
+                apply(tt, ~nd0); apply(tt + 1, ~nd1); apply(tt + 2, ~nd2); apply(tt + 3, ~nd3);
+            }
+            for (; tt < tn; ++tt) apply(tt, leaf_of(tt));
+        }
+    }
+    if (live) {
+        float *o = out + static_cast<size_t>(r0 + threadIdx.x) * D;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j)
+            if (j < D) o[j] = p[j];
+    }
+}
+
+template <int DMAX>
+static bool launch_predict_grd(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n,
+                               int start_tree, int stop_tree, float *out, hipStream_t s) {
+    const size_t budget = 156 * 1024;
+    const int LS = pm.grd_max_leaves, MN = std::max(1, pm.grd_max_nodes);
+    const size_t per_tree = static_cast<size_t>(LS) * DMAX * sizeof(float) + static_cast<size_t>(MN) * 16 + 16;
+    const int xs = F | 1;
+    int R = 256;
+    while (R >= 64 && static_cast<size_t>(R) * xs * sizeof(float) + per_tree > budget) R -= 64;
+    if (R < 64) return false;
+    int TT = static_cast<int>((budget - static_cast<size_t>(R) * xs * sizeof(float)) / per_tree);
+    TT = std::max(1, std::min(TT, 64));
+    const size_t lds = static_cast<size_t>(R) * xs * sizeof(float) + static_cast<size_t>(TT) * per_tree;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_grd<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        attr = true;
+    }
+    OblCoef<DMAX> coef;
+    for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
+    hipLaunchKernelGGL((k_predict_grd<DMAX>), dim3((n + R - 1) / R), dim3(R), lds, s, pm.values, pm.tree_indices, pm.grd_nodes,
+                       pm.grd_node_off, pm.bias, coef, pm.D, pm.n_leaves, pm.n_trees, MN, LS, obs, F, cat_codes, Fc, n, start_tree,
+                       stop_tree, out, TT);
+    return true;
 }
 
 template <int DMAX>
@@ -1560,11 +1751,19 @@ void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat
              int stop_tree, float *out, hipStream_t s) {
     // fast path: oblivious, numeric-only, every output updated by exactly one optimiser
     const uint32_t all_out = pm.D >= 32 ? 0xffffffffu : ((1u << pm.D) - 1u);
-    if (pm.oblivious && pm.all_numeric && pm.coef_ok && pm.coef_cover == all_out && Fc == 0 && F > 0 && pm.D <= 32 && stop_tree > start_tree) {
-        if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 8) { if (launch_predict_obl_d<8>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 16) { if (launch_predict_obl_d<16>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
-        else { if (launch_predict_obl_d<32>(pm, obs, F, n, start_tree, stop_tree, out, s)) return; }
+    if (pm.oblivious && pm.obl_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 32 && stop_tree > start_tree) {
+        if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 8) { if (launch_predict_obl_d<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 16) { if (launch_predict_obl_d<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else { if (launch_predict_obl_d<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+    }
+    // fast path: greedy ensembles whose trees were rebuilt as binary trees (descent instead of the leaf-by-leaf walk)
+    if (!pm.oblivious && pm.grd_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 32 && stop_tree > start_tree &&
+        pm.grd_max_leaves <= 256) {
+        if (pm.D <= 4) { if (launch_predict_grd<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 8) { if (launch_predict_grd<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 16) { if (launch_predict_grd<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else { if (launch_predict_grd<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     }
     if (pm.D <= 8) { if (launch_predict_tiled<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     else if (pm.D <= 32) { if (launch_predict_tiled<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }

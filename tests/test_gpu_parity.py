@@ -276,6 +276,27 @@ def test_non_finite_gradients_are_rejected_and_leave_the_model_unchanged(bad):
     assert m.get_num_trees() == 2
 
 
+@pytest.mark.parametrize("policy,Fc", [("greedy", 0), ("greedy", 2), ("oblivious", 0), ("oblivious", 2)])
+def test_fast_predict_kernels_equal_the_general_kernel(policy, Fc, monkeypatch):
+    """k_predict_obl (oblivious, numeric) and k_predict_grd (greedy: descent of the tree rebuilt from the leaves' paths,
+    numeric and categorical conditions) against the general kernel that walks conditions / leaves like the reference: the same
+    fused multiply-adds in the same order, so the outputs must be bitwise equal -- over sub-ranges of trees too."""
+    import gbrl_amd
+    case = dict(name="pk", seed=77, N=6000, F=9, Fc=Fc, D=5, depth=5, n_bins=64, score="Cosine", gen="Quantile", policy=policy, trees=9,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=4),
+                      dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=4, stop_idx=5)])
+    X, Xc, G, y = K.make_inputs(case)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, Xc, G, y)
+    outs = {}
+    for generic in ("0", "1"):
+        monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", generic)
+        outs[generic] = [np.asarray(m.predict(X, Xc, a, b)) for a, b in ((0, 0), (2, 7), (8, 9), (0, 1))]
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b)
+    assert np.abs(outs["0"][0]).max() > 0
+
+
 def test_random_sweep_against_the_oracle_has_no_unexplained_mismatch():
     """60 random configurations (shape, policy, score, generator, bins, depth, min_data_in_leaf, categorical columns, discrete
     columns): bit-identical structure or an explained near-tie (tests/neartie.py), values / predictions within 1e-5."""
