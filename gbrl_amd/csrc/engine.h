@@ -126,6 +126,9 @@ class Engine {
     int grd_max_nodes_ = 0, grd_max_leaves_ = 1;
     size_t grd_up_nodes_ = 0;
     std::vector<std::pair<int, std::string>> cat_dict_;
+    size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
+    int dict_fc_ = -1;
+    DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
 };
 
 }  // namespace gbrl

@@ -13,6 +13,7 @@
 
 #include <functional>
 #include "rccl_dyn.h"
+#include "cat_hash.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1071,7 +1072,7 @@ void Engine::sync_model_to_device() {
     const size_t T = md.n_trees, L = md.n_leaves, S = model.split_rows(), MD = md.max_depth, D = md.output_dim;
     if (mirror_version_ == model.version) return;
     // dictionary ids for the categorical conditions (strings are compared on the host once; the device compares ids)
-    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; grd_up_nodes_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); cond_pack_host_.clear(); }
+    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; grd_up_nodes_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); cond_pack_host_.clear(); dict_version_ = static_cast<size_t>(-1); }
     cat_ids_host_.resize(S * MD, 0);
     for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
         if (model.is_numerics[c]) continue;
@@ -1205,30 +1206,46 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     }
     int32_t *dcat = nullptr;
     if (n_cat > 0) {
-        std::vector<char> buf;
-        const char *hc = cat;
-        if (cat_dev) {
-            buf.resize(static_cast<size_t>(n) * n_cat * kCat);
-            hip_check(hipMemcpy(buf.data(), cat, buf.size(), hipMemcpyDeviceToHost), "D2H cat");
-            hc = buf.data();
+        // dictionary encoding on the device: the cells are hashed (strcmp semantics: bytes before the first NUL), looked up in
+        // the per-feature, hash-sorted dictionary of the categories the model's conditions mention, and confirmed word by word
+        const char *dcells = cat;
+        if (!cat_dev) {
+            char *tmp = static_cast<char *>(d_pcells_.ensure(static_cast<size_t>(n) * n_cat * kCat));
+            hip_check(hipMemcpyAsync(tmp, cat, static_cast<size_t>(n) * n_cat * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+            dcells = tmp;
         }
-        std::unordered_map<std::string, int> ids;
-        for (size_t z = 0; z < cat_dict_.size(); ++z) ids[cat_dict_[z].second + "_" + std::to_string(cat_dict_[z].first)] = static_cast<int>(z) + 1;
-        std::vector<int32_t> codes(static_cast<size_t>(n) * n_cat, 0);
-        if (!ids.empty())
-            for (int i = 0; i < n; ++i)
-                for (int f = 0; f < n_cat; ++f) {
-                    std::string key(hc + (static_cast<size_t>(i) * n_cat + f) * kCat, kCat);
-                    // the reference compares with strcmp: only the bytes up to the first NUL matter (node.cpp:75, predictor.cpp:215)
-                    const size_t z = key.find('\0');
-                    if (z != std::string::npos) key.resize(z);
-                    key.resize(kCat, '\0');
-                    auto it = ids.find(key + "_" + std::to_string(f));
-                    if (it != ids.end()) codes[static_cast<size_t>(i) * n_cat + f] = it->second;
-                }
-        dcat = static_cast<int32_t *>(d_pcat_.ensure(sizeof(int32_t) * codes.size()));
-        hip_check(hipMemcpyAsync(dcat, codes.data(), sizeof(int32_t) * codes.size(), hipMemcpyHostToDevice, s), "H2D cat ids");
-        hip_check(hipStreamSynchronize(s), "sync");
+        if (dict_version_ != cat_dict_.size() || dict_fc_ != n_cat) {
+            struct E { uint64_t h; int id; uint64_t w[16]; };
+            std::vector<std::vector<E>> per(n_cat);
+            for (size_t z = 0; z < cat_dict_.size(); ++z) {
+                const int f = cat_dict_[z].first;
+                if (f < 0 || f >= n_cat) continue;
+                E e{};
+                uint64_t raw[16];
+                std::memcpy(raw, cat_dict_[z].second.data(), kCat);
+                e.h = cat_cell_hash(raw, e.w);
+                e.id = static_cast<int>(z) + 1;
+                per[f].push_back(e);
+            }
+            std::vector<int32_t> off(n_cat + 1, 0), ids;
+            std::vector<uint64_t> hs, ws;
+            for (int f = 0; f < n_cat; ++f) {
+                std::sort(per[f].begin(), per[f].end(), [](const E &a, const E &b) { return a.h < b.h || (a.h == b.h && a.id < b.id); });
+                for (const E &e : per[f]) { hs.push_back(e.h); ids.push_back(e.id); ws.insert(ws.end(), e.w, e.w + 16); }
+                off[f + 1] = static_cast<int32_t>(hs.size());
+            }
+            hs.push_back(0); ids.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
+            hip_check(hipMemcpyAsync(d_dict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipMemcpyAsync(d_dict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipMemcpyAsync(d_dict_id_.ensure(ids.size() * 4), ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipMemcpyAsync(d_dict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
+            dict_version_ = cat_dict_.size();
+            dict_fc_ = n_cat;
+        }
+        dcat = static_cast<int32_t *>(d_pcat_.ensure(sizeof(int32_t) * static_cast<size_t>(n) * n_cat));
+        kern::encode_categories(dcells, n, n_cat, d_dict_off_.as<int32_t>(), d_dict_hash_.as<uint64_t>(), d_dict_id_.as<int32_t>(),
+                                d_dict_words_.as<uint64_t>(), dcat, s);
     }
     float *dout = out;
     if (!out_dev) dout = static_cast<float *>(d_pout_.ensure(sizeof(float) * static_cast<size_t>(n) * D));

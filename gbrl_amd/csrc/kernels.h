@@ -204,6 +204,11 @@ struct PredictModel {
     uint32_t coef_cover;
     float coef[32];
 };
+// Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
+// categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words
+// (16 uint64 per entry, normalised).  codes[i*Fc+f] = id of the matching entry, 0 when the cell is not in the dictionary.
+void encode_categories(const char *cells, int n, int Fc, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_id,
+                       const uint64_t *dict_words, int32_t *codes, hipStream_t s);
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
              int stop_tree, float *out, hipStream_t s);
 

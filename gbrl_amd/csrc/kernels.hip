@@ -5,6 +5,7 @@
 // (deterministic, and bit-identical for 1/2/4/8 row shards).  Scores are evaluated in fp64 from those exact sums and
 // rounded to fp32 once, then compared the way the reference compares them (fitter.cpp:332-341, 435-444).
 #include "kernels.h"
+#include "cat_hash.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1745,6 +1746,38 @@ static bool launch_predict_tiled(const PredictModel &pm, const float *obs, int F
     hipLaunchKernelGGL(k_predict_tiled<DMAX>, dim3((n + R - 1) / R), dim3(R), lds, s, pm, obs, F, cat_codes, Fc, n, start_tree,
                        stop_tree, out, TT);
     return true;
+}
+
+// One thread per (row, categorical feature): normalise + hash the 128-byte cell, binary-search the feature's hash-sorted
+// dictionary, confirm with a full comparison of the normalised words.
+__global__ __launch_bounds__(256) void k_encode_categories(const char *__restrict__ cells, size_t n_cells, int Fc,
+                                                           const int32_t *__restrict__ feat_off, const uint64_t *__restrict__ dict_hash,
+                                                           const int32_t *__restrict__ dict_id, const uint64_t *__restrict__ dict_words,
+                                                           int32_t *__restrict__ codes) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    const int f = static_cast<int>(i % Fc);
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(cells + i * 128);
+    uint64_t w[16], nw[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const ulonglong2 v = src[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    const uint64_t h = cat_cell_hash(w, nw);
+    int lo = feat_off[f], hi = feat_off[f + 1];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (dict_hash[mid] < h) lo = mid + 1; else hi = mid; }
+    int code = 0;
+    for (int e = lo; e < feat_off[f + 1] && dict_hash[e] == h; ++e) {   // equal hashes (practically one entry): compare the words
+        bool same = true;
+        for (int k = 0; k < 16; ++k) same &= dict_words[static_cast<size_t>(e) * 16 + k] == nw[k];
+        if (same) { code = dict_id[e]; break; }
+    }
+    codes[i] = code;
+}
+void encode_categories(const char *cells, int n, int Fc, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_id,
+                       const uint64_t *dict_words, int32_t *codes, hipStream_t s) {
+    const size_t n_cells = static_cast<size_t>(n) * Fc;
+    if (n_cells == 0) return;
+    hipLaunchKernelGGL(k_encode_categories, dim3(static_cast<unsigned>((n_cells + 255) / 256)), dim3(256), 0, s, cells, n_cells, Fc, feat_off,
+                       dict_hash, dict_id, dict_words, codes);
 }
 
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,

@@ -276,6 +276,28 @@ def test_non_finite_gradients_are_rejected_and_leave_the_model_unchanged(bad):
     assert m.get_num_trees() == 2
 
 
+def test_categorical_cells_are_matched_like_strcmp_on_the_device():
+    """predict() encodes categorical cells on the device (hash of the bytes before the first NUL, dictionary of the model's
+    categories).  Bytes after the first NUL must not matter (the reference compares with strcmp, predictor.cpp:215), unknown
+    categories must match nothing."""
+    import gbrl_amd
+    case, g, (X, Xc, G, y) = load_golden("grd_cos_u_cat")
+    m, pred = _run_product(case, X, Xc, G, y, "cpu")
+    assert (~np.asarray(m.get_ensemble_data()["is_numerics"])).any()          # the ensemble does use categorical conditions
+    raw = np.ascontiguousarray(Xc).view(np.uint8).reshape(Xc.shape[0], Xc.shape[1], 128).copy()
+    junk = raw.copy()
+    rng = np.random.default_rng(0)
+    for i in range(junk.shape[0]):
+        for f in range(junk.shape[1]):
+            z = int(np.argmax(junk[i, f] == 0))
+            junk[i, f, z + 1:] = rng.integers(1, 255, 127 - z, dtype=np.uint8)      # garbage behind the terminator
+    Xj = junk.reshape(Xc.shape[0], Xc.shape[1] * 128).view("S128").reshape(Xc.shape)
+    assert np.array_equal(np.asarray(m.predict(X, Xj, 0, 0)), pred)
+    unknown = np.full(Xc.shape, b"never-seen", dtype="S128")
+    pu = np.asarray(m.predict(X, unknown, 0, 0))
+    assert not np.array_equal(pu, pred)
+
+
 @pytest.mark.parametrize("policy,Fc", [("greedy", 0), ("greedy", 2), ("oblivious", 0), ("oblivious", 2)])
 def test_fast_predict_kernels_equal_the_general_kernel(policy, Fc, monkeypatch):
     """k_predict_obl (oblivious, numeric) and k_predict_grd (greedy: descent of the tree rebuilt from the leaves' paths,
