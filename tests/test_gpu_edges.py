@@ -1,0 +1,146 @@
+"""Edge cases of step() / predict() on the GPU against the oracle restatement: tiny inputs, degenerate gradients and features,
+splits that cannot happen (depth-0 trees, Q7), wide outputs, shallow and deep limits, tree sub-ranges."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import cases as K  # noqa: E402
+from helpers import assert_structure_equal, assert_values_close, rel_err  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _both(case, X, Xc, G, y=None):
+    import gbrl_amd
+    import oracle
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pm = np.asarray(K.drive(m, case, X, Xc, G, y))
+    r = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    pr = np.asarray(K.drive(r, case, X, Xc, G, y))
+    return m, r, pm, pr
+
+
+def _check(case, X, Xc, G, y=None):
+    m, r, pm, pr = _both(case, X, Xc, G, y)
+    e, o = m.get_ensemble_data(), r.get_ensemble_data()
+    assert_structure_equal(e, o, what=case["name"] + ": ")
+    scale = max(float(np.abs(G).mean()), 1e-30)
+    assert_values_close(e, o, scale, TOL)
+    assert rel_err(pm, pr, scale) <= TOL
+    return m, r
+
+
+def _case(name, **kw):
+    base = dict(name=name, seed=0, N=500, F=4, Fc=0, D=2, depth=3, n_bins=16, score="L2", gen="Quantile", policy="greedy", trees=2)
+    base.update(kw)
+    return base
+
+
+@pytest.mark.parametrize("policy", ["greedy", "oblivious"])
+@pytest.mark.parametrize("score", ["L2", "Cosine"])
+def test_splits_that_cannot_happen_give_depth0_trees(policy, score):
+    """min_data_in_leaf larger than half the rows: every candidate is rejected, the tree is a single depth-0 leaf whose value
+    stays 0 (Q7) and predict walks past it exactly like the reference."""
+    case = _case("nosplit", policy=policy, score=score, min_data_in_leaf=400, trees=3)
+    X, Xc, G, y = K.make_inputs(case)
+    m, r = _check(case, X, Xc, G)
+    assert int(np.asarray(m.get_ensemble_data()["depths"]).max()) == 0
+
+
+@pytest.mark.parametrize("policy", ["greedy", "oblivious"])
+def test_depth0_tree_in_the_middle_of_an_ensemble(policy):
+    """Normal trees, then a step whose gradients allow no split, then normal trees again: predict over every sub-range."""
+    import gbrl_amd
+    import oracle
+    case = _case("mid0", policy=policy, min_data_in_leaf=60, N=300, trees=1)
+    X, Xc, G, y = K.make_inputs(case)
+    models = [gbrl_amd.GBRL(**K.ctor_kwargs(case)), oracle.OracleGBRL(**K.ctor_kwargs(case))]
+    for mdl in models:
+        K.drive(mdl, case, X, Xc, G, y)
+        mdl.step(X, None, G)
+        mdl.step(X[:100], None, G[:100])           # 100 rows, min_data_in_leaf 60: no candidate survives -> depth-0 tree
+        mdl.step(X, None, (G * np.float32(0.5)).astype(np.float32))
+    e, o = models[0].get_ensemble_data(), models[1].get_ensemble_data()
+    assert_structure_equal(e, o)
+    assert 0 in np.asarray(e["depths"]).tolist()
+    T = models[0].get_num_trees()
+    for a, b in [(0, 0), (0, 1), (1, 3), (2, 3), (2, T), (3, T)]:
+        pa, pb = np.asarray(models[0].predict(X, None, a, b)), np.asarray(models[1].predict(X, None, a, b))
+        assert rel_err(pa, pb, float(np.abs(G).mean())) <= TOL, (a, b)
+
+
+def test_tiny_inputs():
+    for N, B in ((3, 2), (5, 4), (17, 16), (2, 1)):
+        for policy in ("greedy", "oblivious"):
+            case = _case("tiny%d" % N, N=N, F=2, D=1, n_bins=B, depth=2, policy=policy, trees=2)
+            X, Xc, G, y = K.make_inputs(case)
+            _check(case, X, Xc, G)
+
+
+def test_too_few_rows_for_the_quantile_bins_is_an_error_not_a_crash():
+    import gbrl_amd
+    case = _case("few", N=8, n_bins=16)
+    X, Xc, G, y = K.make_inputs(case)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    m.set_feature_weights(np.ones(case["F"], np.float32))
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=case["D"])
+    m.set_feature_mapping(np.arange(case["F"], dtype=np.int32), np.ones(case["F"], dtype=bool))
+    with pytest.raises(RuntimeError):
+        m.step(X, None, G)
+    assert m.get_num_trees() == 0
+
+
+@pytest.mark.parametrize("gen", ["Quantile", "Uniform"])
+def test_constant_features_and_constant_gradients(gen):
+    rng = np.random.default_rng(3)
+    N = 400
+    X = np.ones((N, 3), np.float32) * np.float32(2.5)
+    X[:, 1] = rng.standard_normal(N).astype(np.float32)
+    G = np.ones((N, 2), np.float32) * np.float32(0.75)                   # zero variance: L2 divides by (0 + 1e-8)
+    case = _case("const", N=N, F=3, gen=gen, policy="oblivious", trees=2)
+    _check(case, X, None, G)
+    G2 = rng.standard_normal((N, 2)).astype(np.float32)
+    X2 = np.ones((N, 3), np.float32)                                      # nothing to split on at all
+    case2 = _case("const2", N=N, F=3, gen=gen, policy="greedy", trees=2)
+    _check(case2, X2, None, G2)
+
+
+def test_wide_outputs_use_the_general_predict_kernels():
+    case = _case("wide", D=40, F=5, N=800, depth=4, policy="oblivious", trees=3)
+    X, Xc, G, y = K.make_inputs(case)
+    _check(case, X, Xc, G)
+    case = _case("wide_g", D=33, F=5, N=800, depth=3, policy="greedy", score="Cosine", trees=2)
+    X, Xc, G, y = K.make_inputs(case)
+    _check(case, X, Xc, G)
+
+
+def test_depth_limits():
+    case = _case("d1", depth=1, N=600, trees=3, policy="greedy")
+    X, Xc, G, y = K.make_inputs(case)
+    _check(case, X, Xc, G)
+    case = _case("d9", depth=9, N=5000, F=6, n_bins=64, trees=1, policy="oblivious")      # deeper than the fast predict kernels go
+    X, Xc, G, y = K.make_inputs(case)
+    _check(case, X, Xc, G)
+
+
+def test_overlapping_optimizer_ranges_fall_back_to_the_general_kernel():
+    case = _case("ovl", D=3, policy="oblivious", trees=3,
+                 opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=3),
+                       dict(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=1, stop_idx=2)])
+    X, Xc, G, y = K.make_inputs(case)
+    _check(case, X, Xc, G)
+
+
+def test_outputs_without_an_optimizer_keep_the_bias():
+    case = _case("part", D=4, policy="greedy", trees=2, bias=[0.5, -1.0, 2.0, 0.25],
+                 opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=1, stop_idx=3)])
+    X, Xc, G, y = K.make_inputs(case)
+    m, r = _check(case, X, Xc, G)
+    p = np.asarray(m.predict(X, None, 0, 0))
+    assert np.all(p[:, 0] == np.float32(0.5)) and np.all(p[:, 3] == np.float32(0.25))
