@@ -289,6 +289,59 @@ void step_impl(PyGBRL &self, py::object &obs, py::object &cat, py::object &grads
     check(rc);
 }
 
+float fit_impl(PyGBRL &self, py::object &obs, py::object &cat, py::object &targets, int iterations, bool shuffle,
+               const std::string &loss_type) {
+    if (loss_type != "MultiRMSE") fail("Invalid loss function! Options are: MultiRMSE");   // stringTolossType, types.cpp:52-56
+    const gbrl_hip_metadata md = self.meta();
+    Input t = read_input(targets, "targets", false, "fit", false);
+    int n, tdim;   // binding.cpp:541-556
+    if (t.shape.size() == 1) {
+        if (md.output_dim > 1) { n = 1; tdim = static_cast<int>(t.shape[0]); } else { n = static_cast<int>(t.shape[0]); tdim = 1; }
+    } else { n = static_cast<int>(t.shape[0]); tdim = static_cast<int>(t.shape[1]); }
+    if (tdim != md.output_dim) {
+        std::stringstream ss;
+        ss << "Targets output dim " << tdim << " != correct output dim " << md.output_dim;
+        fail(ss.str());
+    }
+    int n_num = 0, n_cat = 0;
+    Input o = read_input(obs, "obs", true, "fit", false);
+    if (o.ptr) {
+        int no;
+        if (o.shape.size() == 1) { n_num = (n == 1) ? static_cast<int>(o.shape[0]) : 1; no = (n == 1) ? 1 : static_cast<int>(o.shape[0]); }
+        else { no = static_cast<int>(o.shape[0]); n_num = static_cast<int>(o.shape[1]); }
+        if (no != n) {
+            std::stringstream ss;
+            ss << "Number of observations " << no << " != number of gradient samples " << n;
+            fail(ss.str());
+        }
+    }
+    Input c = read_input(cat, "cat_obs", true, "fit", true);
+    if (c.ptr) {
+        int nc;
+        if (c.shape.size() == 1) { n_cat = (n == 1) ? static_cast<int>(c.shape[0]) : 1; nc = (n == 1) ? 1 : static_cast<int>(c.shape[0]); }
+        else { nc = static_cast<int>(c.shape[0]); n_cat = static_cast<int>(c.shape[1]); }
+        if (nc != n) {
+            std::stringstream ss;
+            ss << "Number of categorical observations " << nc << " != number of gradient samples " << n;
+            fail(ss.str());
+        }
+    }
+    if (n_cat + n_num != md.input_dim) {
+        std::stringstream ss;
+        ss << "Total number of features " << n_cat + n_num << " != correct input dim " << md.input_dim;
+        fail(ss.str());
+    }
+    float loss = 0.0f;
+    int rc;
+    {
+        py::gil_scoped_release release;
+        rc = gbrl_hip_fit(self.h, static_cast<const float *>(o.ptr), o.on_device, static_cast<const char *>(c.ptr), c.on_device,
+                          static_cast<const float *>(t.ptr), t.on_device, n, n_num, n_cat, iterations, shuffle ? 1 : 0, &loss);
+    }
+    check(rc);
+    return loss;
+}
+
 [[noreturn]] void not_on_path(const char *what) {
     fail(std::string(what) + " is outside the accelerated step/predict path of gbrl_amd (SURVEY.md section 8f); "
          "use the reference CPU build for it");
@@ -315,7 +368,8 @@ PYBIND11_MODULE(gbrl_cpp, m) {
     g.def("step", &step_impl, py::arg("obs"), py::arg("categorical_obs"), py::arg("grads"));
     g.def("predict", &predict_impl, py::arg("obs"), py::arg("categorical_obs"), py::arg("start_tree_idx") = 0,
           py::arg("stop_tree_idx") = 0, py::arg("return_torch") = false);
-    g.def("fit", [](PyGBRL &, py::args, py::kwargs) { not_on_path("fit"); });
+    g.def("fit", &fit_impl, py::arg("obs"), py::arg("categorical_obs"), py::arg("targets"), py::arg("iterations"),
+          py::arg("shuffle") = true, py::arg("loss_type") = "MultiRMSE");
     g.def("set_bias", [](PyGBRL &self, py::object &bias) {
         const gbrl_hip_metadata md = self.meta();
         Input b = read_input(bias, "bias", false, "set_bias", false);

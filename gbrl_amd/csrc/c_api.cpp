@@ -262,6 +262,17 @@ int gbrl_hip_step(gbrl_hip_model *m, const float *obs, int obs_on_device, const 
     });
 }
 
+int gbrl_hip_fit(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs, int cat_on_device,
+                 const float *targets, int targets_on_device, int n_samples, int n_num_features, int n_cat_features,
+                 int iterations, int shuffle, float *loss_out) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        const float loss = m->engine.fit(obs, obs_on_device != 0, cat_obs, cat_on_device != 0, targets, targets_on_device != 0, n_samples,
+                                         n_num_features, n_cat_features, iterations, shuffle != 0);
+        if (loss_out) *loss_out = loss;
+    });
+}
+
 int gbrl_hip_predict(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs, int cat_on_device,
                      int n_samples, int n_num_features, int n_cat_features, int start_tree, int stop_tree, float *out,
                      int out_on_device) {

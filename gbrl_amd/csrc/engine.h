@@ -67,6 +67,11 @@ class Engine {
               int n_num, int n_cat);
     void predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
                  int stop_tree, float *out, bool out_dev);
+    // GBRL::fit (gbrl.cpp:983-1104) + Fitter::fit_cpu (fitter.cpp:117-261): bias = mean(targets), split candidates from the
+    // WHOLE data set once, then `iterations` boosting rounds over consecutive batches of metadata.batch_size rows
+    // (predict -> MultiRMSE gradients -> one tree per batch); returns the final MultiRMSE loss on the whole data set.
+    float fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *targets, bool targets_dev, int n, int n_num,
+              int n_cat, int iterations, bool shuffle);
 
     void set_collective(const gbrl_hip_collective *hooks);
     // Native exchange: an RCCL communicator of this engine's own, collectives enqueued on its stream (no host sync).
@@ -97,6 +102,9 @@ class Engine {
     // measurement
     int profiling_ = 0;
     bool force_bisection_ = false, force_sample_select_ = false, last_quantile_fallback_ = false;
+    // fit(): numeric thresholds computed once from the whole data set and reused by every batch's step()
+    std::vector<float> fixed_thr_;
+    bool candidates_only_ = false;
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
     hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back
@@ -129,6 +137,7 @@ class Engine {
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
+    DevBuf d_fit_obs_, d_fit_targets_, d_fit_obs2_, d_fit_targets2_, d_fit_perm_, d_fit_preds_, d_fit_grads_, d_fit_zero_;
 };
 
 }  // namespace gbrl

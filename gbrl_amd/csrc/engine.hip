@@ -11,6 +11,8 @@
 // level by level and emitting the leaves in depth-first (left first) order afterwards gives the identical tree.
 #include "engine.h"
 
+#include <numeric>
+#include <random>
 #include <functional>
 #include "rccl_dyn.h"
 #include "cat_hash.h"
@@ -420,7 +422,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         hip_check(hipMemcpyAsync(d_thrkeys, d_trial, sizeof(uint32_t) * F * B, hipMemcpyDeviceToDevice, s), "D2D keys");
     };
     std::vector<int64_t> cum;
-    if (F > 0) {
+    if (F > 0 && !fixed_thr_.empty()) {
+        // fit(): the candidates were generated from the whole data set (fitter.cpp:134-150); this batch only bins against them
+        if (fixed_thr_.size() != h_thr.size()) throw HipError("internal: fixed thresholds do not match this model");
+        h_thr = fixed_thr_;
+        hip_check(hipMemcpyAsync(d_thr, h_thr.data(), sizeof(float) * h_thr.size(), hipMemcpyHostToDevice, s), "H2D thresholds");
+        kern::floats_to_keys(d_thr, d_thrkeys, h_thr.size(), s);
+    } else if (F > 0) {
         if (md.generator_type == GBRL_HIP_GEN_UNIFORM) {
             uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
             hip_check(hipMemsetAsync(d_mm, 0xff, sizeof(uint32_t) * F, s), "memset");
@@ -546,6 +554,12 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         }
     }
     phase_end("candidates");
+    if (candidates_only_) {   // fit(): only the thresholds of this (whole) data set are wanted
+        hip_check(hipStreamSynchronize(s), "sync");
+        fixed_thr_ = h_thr;
+        phases_resolve();
+        return;
+    }
 
     // categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
     // same container, same insertion order => same candidate order (Q8)
@@ -1063,6 +1077,103 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     (void)world;
     hip_check(hipGetLastError(), "step kernels");
     phases_resolve();
+}
+
+// ===================================================================================================== fit
+float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *targets, bool targets_dev, int n, int n_num,
+                  int n_cat, int iterations, bool shuffle) {
+    (void)cat; (void)cat_dev;
+    gbrl_hip_metadata &md = model.meta;
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }                      // gbrl.cpp:996-999
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n <= 0 || targets == nullptr) throw InvalidArgument("Cannot call fit without targets!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call fit without obs!");
+    if (iterations < 0) throw InvalidArgument("iterations must be >= 0");
+    if (n_cat > 0) throw Unsupported("fit() with categorical features is not supported by this build (step()/predict() are)");
+    if (has_coll_) throw Unsupported("fit() is not supported on a row-sharded model");
+    if (md.batch_size <= 0) throw InvalidArgument("batch_size must be positive");
+    ensure_device();
+    hipStream_t s = stream_;
+    const int F = n_num, D = md.output_dim;
+    struct Guard { Engine *e; ~Guard() { e->fixed_thr_.clear(); e->candidates_only_ = false; } } guard{this};
+
+    // the data set on the device, optionally in shuffled order (gbrl.cpp:1016-1024, 1039-1067; the reference seeds
+    // std::mt19937 from std::random_device, i.e. the order differs from run to run there too)
+    const float *dobs = obs, *dtar = targets;
+    if (!obs_dev) {
+        float *t = static_cast<float *>(d_fit_obs_.ensure(sizeof(float) * static_cast<size_t>(n) * F));
+        hip_check(hipMemcpyAsync(t, obs, sizeof(float) * static_cast<size_t>(n) * F, hipMemcpyHostToDevice, s), "H2D obs");
+        dobs = t;
+    }
+    if (!targets_dev) {
+        float *t = static_cast<float *>(d_fit_targets_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+        hip_check(hipMemcpyAsync(t, targets, sizeof(float) * static_cast<size_t>(n) * D, hipMemcpyHostToDevice, s), "H2D targets");
+        dtar = t;
+    }
+    if (shuffle) {
+        std::vector<int32_t> perm(n);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::random_device rd;
+        std::mt19937 gen(rd());
+        std::shuffle(perm.begin(), perm.end(), gen);
+        int32_t *d_perm = static_cast<int32_t *>(d_fit_perm_.ensure(sizeof(int32_t) * n));
+        hip_check(hipMemcpyAsync(d_perm, perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s), "H2D perm");
+        float *o2 = static_cast<float *>(d_fit_obs2_.ensure(sizeof(float) * static_cast<size_t>(n) * F));
+        float *t2 = static_cast<float *>(d_fit_targets2_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+        kern::gather_rows(dobs, d_perm, o2, n, F, s);
+        kern::gather_rows(dtar, d_perm, t2, n, D, s);
+        hip_check(hipStreamSynchronize(s), "sync");   // perm goes out of scope
+        dobs = o2;
+        dtar = t2;
+    }
+    float *d_zero = static_cast<float *>(d_fit_zero_.ensure(sizeof(float) * D));
+    hip_check(hipMemsetAsync(d_zero, 0, sizeof(float) * D, s), "memset");
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 4 * D));
+    std::vector<double> hs(2 * D);
+    auto column_stat = [&](const float *g, int rows, const float *center) {   // column sums (center null) or sums of squares
+        const int nblk = kern::column_sums_blocks(rows, D);
+        double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
+        kern::column_sums(g, rows, D, center, d_part, nblk, d_stat, s);
+        hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * 2 * D, hipMemcpyDeviceToHost, s), "D2H stat");
+        hip_check(hipStreamSynchronize(s), "sync");
+    };
+    auto rmse = [&](const float *grads_dev, int rows) {                       // MultiRMSE, loss.cpp:42-56: sqrt(0.5 * sum g^2 / rows)
+        column_stat(grads_dev, rows, d_zero);
+        double tot = 0.0;
+        for (int d = 0; d < D; ++d) tot += hs[d];
+        return sqrtf(0.5f * static_cast<float>(tot) * (1.0f / static_cast<float>(rows)));
+    };
+    // bias = column means of the targets (gbrl.cpp:1075-1077)
+    column_stat(dtar, n, nullptr);
+    for (int d = 0; d < D; ++d) model.bias[d] = static_cast<float>(hs[d] / static_cast<double>(n));
+    ++model.version;
+
+    // split candidates from the whole data set, once (fitter.cpp:134-150)
+    if (F > 0) {
+        candidates_only_ = true;
+        step(dobs, true, nullptr, false, dtar, true, n, F, 0);   // returns right after the thresholds; `dtar` only feeds the (unused) statistics
+        candidates_only_ = false;
+    }
+    const int bs = md.batch_size;
+    float *d_preds = static_cast<float *>(d_fit_preds_.ensure(sizeof(float) * static_cast<size_t>(std::max(n, 1)) * D));
+    float *d_grads = static_cast<float *>(d_fit_grads_.ensure(sizeof(float) * static_cast<size_t>(std::min(n, bs)) * D));
+    int start = 0;
+    int bn = start + bs < n ? bs : n - start;                                   // fitter.cpp:120
+    for (int i = 0; i < iterations; ++i) {
+        const float *ob = dobs + static_cast<size_t>(start) * F;
+        const float *tb = dtar + static_cast<size_t>(start) * D;
+        predict(ob, true, nullptr, false, bn, F, 0, 0, i, d_preds, true);      // trees [0, i) -- i == 0 means "all" (fitter.cpp:187)
+        kern::sub_arrays(d_preds, tb, d_grads, static_cast<size_t>(bn) * D, s);
+        step(ob, true, nullptr, false, d_grads, true, bn, F, 0);
+        start += bn;                                                            // fitter.cpp:228-231
+        if (start >= n) start = 0;
+        bn = start + bs < n ? bs : n - start;
+    }
+    // loss on the whole data set over trees [0, iterations) (fitter.cpp:246-251)
+    predict(dobs, true, nullptr, false, n, F, 0, 0, iterations, d_preds, true);
+    float *d_full_grads = static_cast<float *>(d_fit_grads_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+    kern::sub_arrays(d_preds, dtar, d_full_grads, static_cast<size_t>(n) * D, s);
+    return rmse(d_full_grads, n);
 }
 
 // ===================================================================================================== predict

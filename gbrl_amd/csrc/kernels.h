@@ -76,6 +76,9 @@ void qsel_init(uint32_t *prefix, uint32_t *trial, int F, int B, hipStream_t s);
 // one bisection step on bit `bit`: uses counts of trial = prefix|bit; then prepares trial for `next_bit` (or final keys if <0)
 void qsel_update(uint32_t *prefix, uint32_t *trial, const int64_t *counts, const int64_t *cum_ranks, int F, int B,
                  int bit, int next_bit, hipStream_t s);
+// fit(): MultiRMSE gradients g = pred - target (loss.cpp:42-56) and a row gather for the shuffled copy of the data set
+void sub_arrays(const float *a, const float *b, float *out, size_t n, hipStream_t s);
+void gather_rows(const float *src, const int32_t *perm, float *dst, int n, int width, hipStream_t s);
 void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
 void f32_to_f64(const float *in, double *out, int n, hipStream_t s);
 void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s);

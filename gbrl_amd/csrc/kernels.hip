@@ -1139,6 +1139,26 @@ void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const
     hipLaunchKernelGGL(k_quantize, dim3(grid_for(n_el, 256, 4096)), dim3(256), 0, s, g, n_el, D, mean, denom, sc, qg);
 }
 
+__global__ void k_sub_arrays(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, size_t n) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        out[i] = a[i] - b[i];
+}
+void sub_arrays(const float *a, const float *b, float *out, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_sub_arrays, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, a, b, out, n);
+}
+__global__ void k_gather_rows(const float *__restrict__ src, const int32_t *__restrict__ perm, float *__restrict__ dst, int n, int width) {
+    const size_t total = static_cast<size_t>(n) * width;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t r = i / width, c = i - r * width;
+        dst[i] = src[static_cast<size_t>(perm[r]) * width + c];
+    }
+}
+void gather_rows(const float *src, const int32_t *perm, float *dst, int n, int width, hipStream_t s) {
+    const size_t total = static_cast<size_t>(n) * width;
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, src, perm, dst, n, width);
+}
 __global__ void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = static_cast<float>(in[i]);

@@ -133,6 +133,15 @@ int gbrl_hip_step(gbrl_hip_model *m, const float *obs, int obs_on_device, const 
                   int cat_on_device, const float *grads, int grads_on_device, int n_samples,
                   int n_num_features, int n_cat_features);
 
+/* GBRL::fit (gbrl.cpp:983-1104) == Fitter::fit_cpu semantics (fitter.cpp:117-261), MultiRMSE loss (loss.cpp:42-56), computed
+ * on the GPU: bias = column means of `targets`; split candidates from the WHOLE data set once; then `iterations` boosting
+ * rounds over consecutive batches of metadata.batch_size rows (predict over trees [0, i) -> gradients pred - target -> one
+ * tree); *loss_out = sqrt(0.5 * sum (pred - target)^2 / n_samples) over the whole data set afterwards.  shuffle != 0 fits
+ * a randomly permuted copy (seeded from std::random_device like the reference).  Numeric features only in this build. */
+int gbrl_hip_fit(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs, int cat_on_device,
+                 const float *targets, int targets_on_device, int n_samples, int n_num_features, int n_cat_features,
+                 int iterations, int shuffle, float *loss_out);
+
 /* GBRL::predict (gbrl.cpp:369-422) == Predictor::predict_cpu semantics (predictor.cpp:122-265) + SGDOptimizer::step
  * (optimizer.cpp:110-118): out[i,:] = bias - sum_t lr_k * leaf_value(i, t) over trees [start_tree, stop_tree)
  * (stop_tree == 0 means n_trees).  `out` is float32 [n_samples, output_dim], host or device per out_on_device. */

@@ -75,7 +75,7 @@ def ctor_kwargs(case, device="cpu"):
                 max_depth=case["depth"], min_data_in_leaf=case.get("min_data_in_leaf", 0),
                 n_bins=case.get("n_bins", 256), par_th=case.get("par_th", 10), cv_beta=0.9,
                 split_score_func=case["score"], generator_type=case["gen"], use_control_variates=False,
-                batch_size=5000, grow_policy=case["policy"], verbose=0, device=device,
+                batch_size=case.get("batch_size", 5000), grow_policy=case["policy"], verbose=0, device=device,
                 learner_name=case["name"])
 
 
@@ -104,6 +104,17 @@ def drive(model, case, X, Xc, G, y, to_input=lambda a: a, to_numpy=np.asarray):
             g = G
         model.step(xi, Xc, to_input(np.ascontiguousarray(g.copy())))
     return to_numpy(model.predict(xi, Xc, 0, 0))
+
+
+def drive_fit(model, case, X, y):
+    """GBTLearner.fit-style call (gbt_learner.py:502-551): setters, then ONE fit() over the whole data set, no shuffle."""
+    F = case["F"]
+    model.set_feature_weights(np.asarray(case.get("feature_weights", np.ones(F)), np.float32))
+    for o in optimizers(case):
+        model.set_optimizer(**o)
+    model.set_feature_mapping(np.arange(F, dtype=np.int32), np.array([True] * F, dtype=bool))
+    loss = model.fit(X, None, y, case["fit_iterations"], False, "MultiRMSE")
+    return float(loss), np.asarray(model.predict(X, None, 0, 0))
 
 
 def _c(name, **kw):
@@ -148,7 +159,19 @@ CASES = [
     _c("obl_cos_q_cat_rmse", seed=19, N=1024, F=5, Fc=2, D=1, score="Cosine", loop="rmse", trees=5),
 ]
 
-BY_NAME = {c["name"]: c for c in CASES}
+# GBRL.fit (gbrl.cpp:983-1104): candidates from the whole data set, one tree per batch of `batch_size` rows, MultiRMSE.
+# Batch sizes are multiples of 24 elements so that the reference's MultiRMSE (which silently skips the
+# n_elements % n_threads trailing elements, loss.cpp:47-60) covers every element at 1, 3 and 8 threads.
+FIT_CASES = [
+    _c("fit_obl_l2_q", seed=31, N=3000, F=6, D=2, depth=4, n_bins=64, loop="rmse", batch_size=1200, fit_iterations=7,
+       opts=[dict(algo="SGD", scheduler="Const", init_lr=0.5, start_idx=0, stop_idx=2)]),
+    _c("fit_grd_cos_u", seed=32, N=2640, F=5, D=1, depth=4, n_bins=32, policy="greedy", score="Cosine", gen="Uniform", loop="rmse",
+       batch_size=1200, fit_iterations=8, opts=[dict(algo="SGD", scheduler="Const", init_lr=0.3, start_idx=0, stop_idx=1)]),
+    _c("fit_grd_l2_q_onebatch", seed=33, N=2400, F=8, D=3, depth=3, policy="greedy", loop="rmse", batch_size=5000, fit_iterations=5,
+       opts=[dict(algo="SGD", scheduler="Const", init_lr=0.4, start_idx=0, stop_idx=3)]),
+]
+
+BY_NAME = {c["name"]: c for c in CASES + FIT_CASES}
 
 ENSEMBLE_KEYS = ("tree_indices", "depths", "values", "feature_indices", "feature_values", "edge_weights",
                  "is_numerics", "inequality_directions", "categorical_values")

@@ -29,10 +29,17 @@ import oracle  # noqa: E402
 def run(mod, case):
     X, Xc, G, y = K.make_inputs(case)
     m = mod.GBRL(**K.ctor_kwargs(case))
-    pred = K.drive(m, case, X, Xc, G, y)
+    fit_loss = None
+    if "fit_iterations" in case:
+        fit_loss, pred = K.drive_fit(m, case, X, y)
+    else:
+        pred = K.drive(m, case, X, Xc, G, y)
     e = m.get_ensemble_data()
     out = {k: np.array(e[k]) for k in K.ENSEMBLE_KEYS}
     out["pred"] = np.array(pred, np.float32)
+    if fit_loss is not None:
+        out["fit_loss"] = np.float32(fit_loss)
+        out["bias"] = np.array(m.get_bias(), np.float32)
     out["n_trees"] = np.int32(m.get_num_trees())
     out["iteration"] = np.int32(m.get_iteration())
     out["inputs_sha256"] = np.array(K.inputs_digest(X, Xc, G, y))
@@ -47,10 +54,17 @@ def run(mod, case):
     return out
 
 
+STRUCTURE_KEYS = ("tree_indices", "depths", "feature_indices", "feature_values", "is_numerics", "inequality_directions",
+                  "categorical_values", "edge_weights")
+
+
 def digest(a):
     import hashlib
     h = hashlib.sha256()
-    for k in K.ENSEMBLE_KEYS + ("pred",):
+    # fit(): the bias is a thread-count dependent float32 mean (math_ops.cpp:255-300), so leaf values and predictions differ in
+    # their last bits between thread counts by construction; what must be stable there is the tree STRUCTURE
+    keys = STRUCTURE_KEYS if "fit_loss" in a else K.ENSEMBLE_KEYS + ("pred",)
+    for k in keys:
         h.update(np.ascontiguousarray(a[k]).tobytes())
     return h.hexdigest()
 
@@ -63,7 +77,7 @@ def main():
         return
     assert os.environ.get("OMP_NUM_THREADS") == "8", "fixtures are defined at OMP_NUM_THREADS=8"
     nat = oracle.load_ref(native=True)
-    names = sys.argv[1:] or [c["name"] for c in K.CASES]
+    names = sys.argv[1:] or [c["name"] for c in K.CASES + K.FIT_CASES]
     for name in names:
         case = K.BY_NAME[name]
         a = run(ref, case)

@@ -59,6 +59,54 @@ def test_product_matches_reference_golden(name):
     assert rel_err(pred.reshape(g["pred"].shape), g["pred"], scale) <= TOL
 
 
+@pytest.mark.parametrize("name", [c["name"] for c in K.FIT_CASES])
+def test_fit_matches_reference_golden(name):
+    """GBRL.fit (gbrl.cpp:983-1104, fitter.cpp:117-261): candidates from the whole data set, one tree per batch, MultiRMSE.
+    Structure bit-identical to the reference's fit(); bias / leaf values / predictions / returned loss within 1e-5 (the
+    reference's bias is a thread-count dependent float32 mean)."""
+    import gbrl_amd
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    loss, pred = K.drive_fit(m, case, X, y)
+    e = m.get_ensemble_data()
+    assert m.get_num_trees() == int(g["n_trees"]) == case["fit_iterations"] and m.get_iteration() == int(g["iteration"])
+    assert_structure_equal(e, g)
+    scale = float(np.abs(y).mean())
+    assert_values_close(e, g, scale, TOL)
+    assert rel_err(np.asarray(m.get_bias()), g["bias"], scale) <= TOL
+    assert rel_err(pred, g["pred"], scale) <= TOL
+    assert abs(loss - float(g["fit_loss"])) <= TOL * max(1.0, abs(float(g["fit_loss"])))
+    # the returned loss is the MultiRMSE of the final predictions
+    want = np.sqrt(0.5 * float(((pred.reshape(len(X), -1) - y.reshape(len(X), -1)).astype(np.float64) ** 2).sum()) / len(X))
+    assert abs(loss - want) <= 1e-5 * max(1.0, want)
+
+
+def test_fit_api_behaviour():
+    import gbrl_amd
+    case, g, (X, Xc, G, y) = load_golden("fit_obl_l2_q")
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    with pytest.raises(RuntimeError, match="Invalid loss function"):
+        m.fit(X, None, y, 2, False, "L1")
+    with pytest.raises(RuntimeError, match="Targets output dim"):
+        m.fit(X, None, y[:, :1], 2, False, "MultiRMSE")
+    with pytest.raises(RuntimeError, match="Number of observations"):
+        m.fit(X[:-1], None, y, 2, False, "MultiRMSE")
+    l1, _ = K.drive_fit(m, case, X, y)
+    # shuffled fit: same data in another order -> a model of comparable quality, one tree per iteration, bias = mean(targets)
+    m2 = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    m2.set_feature_weights(np.ones(case["F"], np.float32))
+    for o in K.optimizers(case):
+        m2.set_optimizer(**o)
+    m2.set_feature_mapping(np.arange(case["F"], dtype=np.int32), np.ones(case["F"], dtype=bool))
+    l2 = m2.fit(X, None, y, case["fit_iterations"], True, "MultiRMSE")
+    assert m2.get_num_trees() == case["fit_iterations"]
+    assert np.allclose(np.asarray(m2.get_bias()), y.mean(axis=0), rtol=1e-5, atol=1e-6)
+    assert abs(l2 - l1) < 0.25 * l1
+    # fit() continues an existing ensemble: more iterations keep lowering the training loss
+    l3 = m.fit(X, None, y, 4, False, "MultiRMSE")
+    assert m.get_num_trees() == case["fit_iterations"] + 4 and np.isfinite(l3)
+
+
 @pytest.mark.parametrize("name", [c["name"] for c in K.CASES if c.get("fragile")])
 def test_fragile_case_is_exact_or_an_explained_near_tie(name):
     """Inputs on which the reference disagrees with ITSELF between OMP_NUM_THREADS 3 and 8 (make_golden.py flags them):
