@@ -140,7 +140,7 @@ def test_step_and_predict_shape_checks():
         m.predict(None, None)
     with pytest.raises(RuntimeError, match="stop_tree_idx is out of bounds"):
         m.predict(X, None, 0, 5)
-    for fn in ("fit", "export", "tree_shap", "ensemble_shap", "plot_tree", "print_tree"):
+    for fn in ("export", "tree_shap", "ensemble_shap", "plot_tree", "print_tree"):
         with pytest.raises(RuntimeError, match="outside the accelerated"):
             getattr(m, fn)()
 
