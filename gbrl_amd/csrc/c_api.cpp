@@ -44,18 +44,6 @@ int copy_in(void *dst, const void *src, size_t bytes, int on_device) {
 }
 }  // namespace
 
-extern "C" {
-
-int gbrl_hip_abi_version(void) { return GBRL_HIP_ABI_VERSION; }
-
-int gbrl_hip_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-const char *gbrl_hip_last_error(void) { return g_err.c_str(); }
-
 // Output buffers of predict() on the device are recycled: hipMalloc + hipFree (which synchronises the device) cost about
 // a millisecond per call, more than the prediction kernel itself for small ensembles.  A freed buffer is kept (up to a few
 // buffers / 1 GiB) and handed out again for a request of the same size class after a device synchronisation, so that no
@@ -72,6 +60,19 @@ struct DevPool {
 };
 DevPool &pool() { static DevPool *p = new DevPool(); return *p; }
 }  // namespace
+
+
+extern "C" {
+
+int gbrl_hip_abi_version(void) { return GBRL_HIP_ABI_VERSION; }
+
+int gbrl_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *gbrl_hip_last_error(void) { return g_err.c_str(); }
 
 void *gbrl_hip_device_alloc(size_t bytes) {
     if (bytes == 0) bytes = 1;

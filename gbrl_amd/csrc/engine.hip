@@ -269,7 +269,6 @@ class Stager {
     size_t cap_ = 0, used_ = 0;
 };
 
-inline int ilog2_floor(double x) { int e; std::frexp(x, &e); return e - 1; }
 
 }  // namespace
 

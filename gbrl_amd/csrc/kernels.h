@@ -57,7 +57,6 @@ void column_sums(const float *g, int n, int D, const float *center /*nullable [D
                  int n_blocks, double *out /*[2D]*/, hipStream_t s);
 int column_sums_blocks(int n, int D);
 // max |standardised g| as float bits in out[0]; mean/inv_std nullable (Cosine: raw grads)
-void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s);
 // Device-side statistics chain (one GPU): mean from the column sums; then std + 1e-8, the maxima and both fixed-point scales.
 void stats_mean(const double *stat /*[2D] sums | max*/, long long n, int D, float *meanden /*[2D] mean | denom*/, hipStream_t s);
 void stats_finish(const double *stat_raw /*[2D] sums | max|g|*/, const double *stat_centred /*nullable [2D] sum sq | max|g-mean|*/,
@@ -83,7 +82,6 @@ void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
 void f32_to_f64(const float *in, double *out, int n, hipStream_t s);
 void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s);
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
-void scatter_cat_codes(const uint16_t *cat_codes, int n, int Fc, uint16_t *codes, int code_stride, int code_off, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 
 // ---- exact quantile selection and binning on transposed keys (quantile.hip) ----
@@ -157,8 +155,6 @@ int argmax_parts(int n_cand);
 void argmax(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref, const float *parent,
             const int32_t *is_root, bool oblivious, float *part_v, int32_t *part_i, int32_t *best_idx, float *best_score,
             hipStream_t s);
-void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits,
-                  int64_t *n_total, int64_t *n_right, hipStream_t s);
 
 // winner -> (feature slot, class) and the child sizes it induces, per active node (one read-back per level)
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*argmax stage-1 output; the final stage runs here*/,

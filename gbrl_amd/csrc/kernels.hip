@@ -136,18 +136,6 @@ __device__ __forceinline__ float standardise(float v, const float *mean, const f
     return (v - mean[col]) / denom[col];
 }
 
-__global__ void k_max_abs(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ mean,
-                          const float *__restrict__ denom, uint32_t *__restrict__ out_bits) {
-    float m = 0.0f;
-    for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n_el;
-         e += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        const float v = fabsf(standardise(g[e], mean, denom, static_cast<int>(e % D)));
-        m = fmaxf(m, v);  // fmaxf drops NaN
-    }
-    for (int o = kWave / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, kWave));
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order as uints
-}
-
 __global__ void k_quantize(const float *__restrict__ g, size_t n_el, int D, const float *__restrict__ mean,
                            const float *__restrict__ denom, const StepScales *__restrict__ sc, int32_t *__restrict__ qg) {
     const float scale = sc->scale;
@@ -292,13 +280,6 @@ __global__ void k_floats_to_keys(const float *__restrict__ in, uint32_t *__restr
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = float_to_key(in[i]);
 }
-__global__ void k_scatter_cat_codes(const uint16_t *__restrict__ cat_codes, int n, int Fc, uint16_t *__restrict__ codes,
-                                    int code_stride, int code_off) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= static_cast<size_t>(n) * Fc) return;
-    const size_t r = i / Fc, f = i % Fc;
-    codes[r * code_stride + code_off + f] = cat_codes[i];
-}
 __global__ void k_iota(int32_t *__restrict__ rows, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rows[i] = i;
@@ -316,10 +297,6 @@ __global__ void k_iota(int32_t *__restrict__ rows, int n) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kHistThreads = 1024;
 
-__device__ __forceinline__ size_t code_index(int slot, int row, int n_rows) {
-    // group-major code layout written by bin_cols: [slot/16][row][slot%16]
-    return (static_cast<size_t>(slot >> 4) * n_rows + row) * kCodeGroup + (slot & (kCodeGroup - 1));
-}
 
 // Broadcast lane `SRC` of every 16-lane row to the whole row (v_mov_b32_dpp row_newbcast: a VALU move, no LDS traffic).
 template <int SRC>
@@ -622,24 +599,6 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *_
         part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = si[0];
     }
 }
-__global__ void k_child_counts(const int64_t *__restrict__ hist, int n_nodes, int Fp, int NB, int D,
-                               const NodeSplit *__restrict__ splits, int64_t *__restrict__ n_total,
-                               int64_t *__restrict__ n_right) {
-    const int node = blockIdx.x;   // one wave per node
-    if (node >= n_nodes) return;
-    const NodeSplit sp = splits[node];
-    const int W = D + 1;
-    const int64_t *src = hist + (static_cast<size_t>(node) * Fp + sp.fslot) * NB * W;
-    long long tot = 0, right = 0;
-    for (int c = threadIdx.x; c < NB; c += kWave) {
-        const long long n = src[c * W + D];
-        tot += n;
-        if (sp.is_cat ? (c == sp.bin) : (c > sp.bin)) right += n;
-    }
-    for (int o = kWave / 2; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, kWave); right += __shfl_xor(right, o, kWave); }
-    if (threadIdx.x == 0) { n_total[node] = tot; n_right[node] = right; }
-}
-
 // Child sizes of the selected split of every active node, straight from the histograms (one wave per node), so that the
 // host learns the winner AND the sizes of its children with a single read-back.  counts4 = [total_local | right_local |
 // total_global | right_global], each max_front wide.
@@ -898,6 +857,42 @@ __global__ __launch_bounds__(256) void k_predict(PredictModel pm, const float *_
 // oblivious tree), then walks all trees over the tile.  Oblivious ensembles additionally stage, TT trees at a time, the
 // conditions and the leaf values in LDS, so the inner loop touches LDS only.  Per-row accumulation order = tree order,
 // pred = fma(-lr, value, pred) (optimizer.cpp:110-118).
+// Coalesced staging of rows [r0, r0+rows) of a row-major f32 matrix into an LDS tile with row stride xs (odd: a wave that
+// reads one feature of 64 consecutive rows touches 64 different banks).  8 x 16-byte loads in flight per thread: a block of
+// the predict kernels is one wave per SIMD, nothing else hides the HBM latency.
+__device__ __forceinline__ void stage_row_tile(const float *__restrict__ obs, int r0, int rows, int F, int xs, float *__restrict__ xt) {
+    const int R = blockDim.x;
+    const float *src = obs + static_cast<size_t>(r0) * F;
+    if (F > 0 && (F & 3) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        const int F4 = F >> 2, tot4 = rows * F4;
+        constexpr int UL = 8;
+        for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
+            float4 v[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = i0 + u * R;
+                v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = i0 + u * R;
+                if (i < tot4) {
+                    const int r = i / F4, f = (i - r * F4) << 2;
+                    float *dst = xt + r * xs + f;
+                    dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                }
+            }
+        }
+    } else {
+        const int tot = rows * F;
+        for (int i = threadIdx.x; i < tot; i += R) {
+            const int r = i / F, f = i - r * F;
+            xt[r * xs + f] = src[i];
+        }
+    }
+}
+
 constexpr int kPredMaxOpts = 4;   // optimisers kept in registers (more fall back to the direct kernel)
 template <int DMAX>
 __global__ __launch_bounds__(256) void k_predict_tiled(PredictModel pm, const float *__restrict__ obs, int F,
@@ -915,37 +910,7 @@ __global__ __launch_bounds__(256) void k_predict_tiled(PredictModel pm, const fl
     const int cstride = 1 + 2 * md;
     const int r0 = blockIdx.x * R;
     const int rows = min(R, n - r0);
-    {   // coalesced staging of rows [r0, r0+rows)
-        const float *src = obs + static_cast<size_t>(r0) * F;
-        if ((F & 3) == 0) {
-            const float4 *src4 = reinterpret_cast<const float4 *>(src);
-            const int F4 = F >> 2, tot4 = rows * F4;
-            constexpr int UL = 8;   // loads in flight per thread (one block per CU: nothing else hides the HBM latency)
-            for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
-                float4 v[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = i0 + u * R;
-                    v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = i0 + u * R;
-                    if (i < tot4) {
-                        const int r = i / F4, f = (i - r * F4) << 2;
-                        float *dst = xt + r * xs + f;
-                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
-                    }
-                }
-            }
-        } else {
-            const int tot = rows * F;
-            for (int i = threadIdx.x; i < tot; i += R) {
-                const int r = i / F, f = i - r * F;
-                xt[r * xs + f] = src[i];
-            }
-        }
-    }
+    stage_row_tile(obs, r0, rows, F, xs, xt);
     const int row = r0 + threadIdx.x;
     const bool live = threadIdx.x < rows;
     float p[DMAX];
@@ -1130,10 +1095,6 @@ void column_sums(const float *g, int n, int D, const float *center, double *bloc
     hipLaunchKernelGGL(k_column_sums_final, dim3(2 * D), dim3(256), 0, s, block_partials, n_blocks, D, out);
 }
 
-void max_abs(const float *g, size_t n_el, int D, const float *mean, const float *denom, uint32_t *out_bits, hipStream_t s) {
-    hipLaunchKernelGGL(k_max_abs, dim3(grid_for(n_el, 256, 2048)), dim3(256), 0, s, g, n_el, D, mean, denom, out_bits);
-}
-
 void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, const StepScales *sc, int32_t *qg,
                     hipStream_t s) {
     hipLaunchKernelGGL(k_quantize, dim3(grid_for(n_el, 256, 4096)), dim3(256), 0, s, g, n_el, D, mean, denom, sc, qg);
@@ -1226,12 +1187,6 @@ void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s) {
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_floats_to_keys, dim3((n + 255) / 256), dim3(256), 0, s, in, keys, n);
 }
-void scatter_cat_codes(const uint16_t *cat_codes, int n, int Fc, uint16_t *codes, int code_stride, int code_off,
-                       hipStream_t s) {
-    const size_t tot = static_cast<size_t>(n) * Fc;
-    hipLaunchKernelGGL(k_scatter_cat_codes, dim3((tot + 255) / 256), dim3(256), 0, s, cat_codes, n, Fc, codes, code_stride,
-                       code_off);
-}
 void iota_rows(int32_t *rows, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, rows, n);
 }
@@ -1308,12 +1263,6 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const 
                        is_root, oblivious ? 1 : 0, part_v, part_i);
     (void)best_idx; (void)best_score;   // published by k_resolve_splits, which runs the last reduction stage itself
 }
-void child_counts(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const NodeSplit *splits, int64_t *n_total,
-                  int64_t *n_right, hipStream_t s) {
-    hipLaunchKernelGGL(k_child_counts, dim3(n_nodes), dim3(64), 0, s, hist, n_nodes, Fp, NB, D, splits, n_total,
-                       n_right);
-}
-
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
                     NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, hipStream_t s) {
@@ -1387,37 +1336,7 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
     int *tmeta = reinterpret_cast<int *>(vt + static_cast<size_t>(TT) * DMAX * LS);   // [TT][2]: first leaf, leaves of the tree
     const int r0 = blockIdx.x * R;
     const int rows = min(R, n - r0);
-    {   // coalesced staging of rows [r0, r0+rows)
-        const float *src = obs + static_cast<size_t>(r0) * F;
-        if ((F & 3) == 0) {
-            const float4 *src4 = reinterpret_cast<const float4 *>(src);
-            const int F4 = F >> 2, tot4 = rows * F4;
-            constexpr int UL = 8;
-            for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
-                float4 v[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = i0 + u * R;
-                    v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = i0 + u * R;
-                    if (i < tot4) {
-                        const int r = i / F4, f = (i - r * F4) << 2;
-                        float *dst = xt + r * xs + f;
-                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
-                    }
-                }
-            }
-        } else {
-            const int tot = rows * F;
-            for (int i = threadIdx.x; i < tot; i += R) {
-                const int r = i / F, f = i - r * F;
-                xt[r * xs + f] = src[i];
-            }
-        }
-    }
+    stage_row_tile(obs, r0, rows, F, xs, xt);
     const bool live = static_cast<int>(threadIdx.x) < rows;
     float p[DMAX];
 #pragma unroll
@@ -1591,37 +1510,7 @@ __global__ __launch_bounds__(256) void k_predict_grd(const float *__restrict__ v
     int *tmeta = reinterpret_cast<int *>(nt + static_cast<size_t>(TT) * max_nodes);  // [TT][4]: first leaf, leaves, first node, nodes
     const int r0 = blockIdx.x * R;
     const int rows = min(R, n - r0);
-    {
-        const float *src = obs + static_cast<size_t>(r0) * F;
-        if (F > 0 && (F & 3) == 0) {
-            const float4 *src4 = reinterpret_cast<const float4 *>(src);
-            const int F4 = F >> 2, tot4 = rows * F4;
-            constexpr int UL = 8;
-            for (int i0 = threadIdx.x; i0 < tot4; i0 += R * UL) {
-                float4 v[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = i0 + u * R;
-                    v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = i0 + u * R;
-                    if (i < tot4) {
-                        const int r = i / F4, f = (i - r * F4) << 2;
-                        float *dst = xt + r * xs + f;
-                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
-                    }
-                }
-            }
-        } else {
-            const int tot = rows * F;
-            for (int i = threadIdx.x; i < tot; i += R) {
-                const int r = i / F, f = i - r * F;
-                xt[r * xs + f] = src[i];
-            }
-        }
-    }
+    stage_row_tile(obs, r0, rows, F, xs, xt);
     const bool live = static_cast<int>(threadIdx.x) < rows;
     float p[DMAX];
 #pragma unroll
