@@ -291,6 +291,7 @@ int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks)
     });
 }
 
+int gbrl_hip_rccl_available(void) { return gbrl::rccl_api().ok ? 1 : 0; }
 int gbrl_hip_rccl_unique_id(void *id128) {
     return guarded([&] {
         if (!id128) throw gbrl::InvalidArgument("null id buffer");

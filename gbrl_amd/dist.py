@@ -97,26 +97,38 @@ def install_torch_collective(model, device, group=None) -> TorchCollective:
 def install_rccl(model, device, group=None) -> None:
     """Native exchange: give the model its own RCCL communicator (collectives enqueued on the model's stream, no host
     synchronisation at the exchange points).  Collective call: every rank of `group` must make it.  The unique id is created
-    by rank 0 and distributed with torch.distributed.broadcast."""
+    by rank 0 and distributed with torch.distributed.broadcast.  Ranks agree (all-reduce of a flag) before and after the
+    communicator is created, so a rank that cannot take part makes EVERY rank raise instead of leaving the others waiting."""
     import torch
     import torch.distributed as dist
     from . import LIB_PATH
     lib = C.CDLL(LIB_PATH)
+    lib.gbrl_hip_rccl_available.restype = C.c_int
     lib.gbrl_hip_rccl_unique_id.argtypes = [C.c_void_p]
     lib.gbrl_hip_rccl_unique_id.restype = C.c_int
     lib.gbrl_hip_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.gbrl_hip_set_rccl.restype = C.c_int
+    lib.gbrl_hip_set_collective.argtypes = [C.c_void_p, C.c_void_p]
     lib.gbrl_hip_last_error.restype = C.c_char_p
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    buf = (C.c_char * 128)()
-    if rank == 0 and lib.gbrl_hip_rccl_unique_id(buf) != 0:
-        raise RuntimeError(lib.gbrl_hip_last_error().decode())
     on_dev = str(dist.get_backend(group)).lower() == "nccl"
-    t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
-    if on_dev:
-        t = t.to(device)
+    where = device if on_dev else "cpu"
+
+    def all_ok(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=where)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item())
+
+    buf = (C.c_char * 128)()
+    ok = lib.gbrl_hip_rccl_available() == 1
+    if ok and rank == 0:
+        ok = lib.gbrl_hip_rccl_unique_id(buf) == 0
+    if not all_ok(ok):
+        raise RuntimeError("native RCCL exchange is not available on every rank: " + (lib.gbrl_hip_last_error() or b"").decode())
+    t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone().to(where)
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    raw = bytes(t.cpu().numpy().tobytes())
-    idbuf = C.create_string_buffer(raw, 128)
-    if lib.gbrl_hip_set_rccl(C.c_void_p(model._handle()), idbuf, world, rank) != 0:
-        raise RuntimeError(lib.gbrl_hip_last_error().decode())
+    idbuf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+    ok = lib.gbrl_hip_set_rccl(C.c_void_p(model._handle()), idbuf, world, rank) == 0
+    if not all_ok(ok):
+        lib.gbrl_hip_set_collective(C.c_void_p(model._handle()), None)   # drop a communicator that only some ranks hold
+        raise RuntimeError("gbrl_hip_set_rccl failed on some rank: " + (lib.gbrl_hip_last_error() or b"").decode())

@@ -171,6 +171,7 @@ int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks)
  * other ranks by any means (torch.distributed.broadcast in gbrl_amd/dist.py); then EVERY rank calls gbrl_hip_set_rccl
  * (a collective call: it returns when all ranks have joined).  Replaces hooks installed earlier; installing hooks later
  * destroys the communicator. */
+int gbrl_hip_rccl_available(void);   /* 1 when an RCCL library could be bound in this process */
 int gbrl_hip_rccl_unique_id(void *id128);
 int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int rank);
 
