@@ -54,6 +54,11 @@ class PinnedBuf {
     size_t cap_ = 0;
 };
 
+namespace detail {
+struct GrowCtx;
+struct HNode;
+}  // namespace detail
+
 class Engine {
    public:
     explicit Engine(const gbrl_hip_config &cfg);
@@ -85,6 +90,10 @@ class Engine {
    private:
     void ensure_device();
     void sync_model_to_device();
+    void grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
+                   double &leaf_scale);
+    void numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
+                            uint32_t *d_thrkeys, std::vector<float> &h_thr);
     void phase_begin(bool key = false);
     void phase_end(const char *name, bool key = false);
     void phases_resolve();

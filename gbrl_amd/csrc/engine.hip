@@ -212,7 +212,7 @@ void Engine::phases_resolve() {
     ev_names_.clear();
 }
 
-namespace {
+namespace detail {
 
 struct HCond {       // splitCondition (types.h:64-70) + what the kernels need
     int fslot;       // feature slot (numeric f, or F + categorical c)
@@ -238,6 +238,33 @@ struct HNode {
 };
 
 struct CatCandidate { int feat; std::string name; int cls; };
+
+// Everything Engine::grow_tree needs from the preparation stages of step().
+struct GrowCtx {
+    int N, F, Fc, D, B, MD, NB, FG, Fp, n_groups, n_slots, n_cand, chunk_rows;
+    long long n_global;
+    bool cosine, oblivious;
+    const std::vector<kern::FeatureSlot> *slots;
+    const std::vector<float> *cand_w;
+    const std::vector<int32_t> *cand_ref;
+    const std::vector<int> *ref_to_internal;
+    const std::vector<CatCandidate> *cat_cands;
+    const std::vector<float> *h_thr;
+    const float *d_thr;
+    const uint16_t *d_codes;
+    const int32_t *d_qg;
+    const float *dgrads;
+    kern::StepScales *d_scales;
+};
+
+}  // namespace detail
+
+using detail::CatCandidate;
+using detail::GrowCtx;
+using detail::HCond;
+using detail::HNode;
+
+namespace {
 
 // Packs many small host arrays into one pinned block and uploads them with ONE async copy; put() returns the DEVICE
 // address the array will have.  The pinned block must not be refilled before the copy has executed (the caller's
@@ -270,140 +297,143 @@ class Stager {
 };
 
 
+// ---- A5: categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
+// same container, same insertion order => same candidate order (Q8).  cat_classes[f] = number of candidate categories of
+// feature f (class ids 1..), h_catcodes[i*Fc+f] = class of the cell (0: not a candidate).
+void categorical_candidates(const char *hcat, const float *hgrads, int N, int Fc, int D, int B, std::vector<CatCandidate> &cat_cands,
+                            std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes) {
+    struct Info { float total = 0.f; int count = 0; int feat = 0; std::string name; };
+    std::vector<float> norms(N, 0.0f);
+    for (int i = 0; i < N; ++i) {  // calculate_squared_norm (math_ops.cpp:726-749), contracted like the reference build
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) { const float g = hgrads[static_cast<size_t>(i) * D + d]; acc = fmaf(g, g, acc); }
+        norms[i] = acc;
+    }
+    std::unordered_map<std::string, Info> uniq;
+    for (int f = 0; f < Fc; ++f)
+        for (int i = 0; i < N; ++i) {
+            std::string name(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+            Info &ci = uniq[name + "_" + std::to_string(f)];
+            ci.total += norms[i];
+            ci.count += 1;
+            ci.feat = f;
+            ci.name = name;
+        }
+    std::vector<std::pair<std::string, float>> vec;
+    for (const auto &kv : uniq) vec.emplace_back(kv.first, kv.second.total / kv.second.count);
+    int n_unique = static_cast<int>(vec.size());
+    if (n_unique > Fc * B) {
+        std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, float> &a, const std::pair<std::string, float> &b) {
+            return a.second > b.second;
+        });
+        n_unique = Fc * B;
+    }
+    std::unordered_map<std::string, int> cls_of;  // key -> class id within its feature
+    for (int i = 0; i < n_unique; ++i) {
+        const Info &ci = uniq[vec[i].first];
+        const int cls = ++cat_classes[ci.feat];
+        if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+        cat_cands.push_back({ci.feat, ci.name, cls});
+        cls_of[vec[i].first] = cls;
+    }
+    h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
+    for (int i = 0; i < N; ++i)
+        for (int f = 0; f < Fc; ++f) {
+            std::string key(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+            key += "_" + std::to_string(f);
+            auto it = cls_of.find(key);
+            if (it != cls_of.end()) h_catcodes[static_cast<size_t>(i) * Fc + f] = static_cast<uint16_t>(it->second);
+        }
+}
+
+// ---- A10/A11: the grown tree joins the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) with exact leaf
+// means of the raw gradients (acc[node] = int64 fixed-point sums | count; fitter.cpp:545-582).
+void append_tree(Model &model, const std::vector<HNode> &nodes, const std::vector<int> &frontier, const std::vector<int64_t> &acc,
+                 double leaf_scale, const std::vector<CatCandidate> &cat_cands) {
+    gbrl_hip_metadata &md = model.meta;
+    const bool oblivious = model.oblivious();
+    const int MD = md.max_depth, D = md.output_dim;
+// leaf order: oblivious = level order of the last level (child slots 2k, 2k+1, fitter.cpp:469-470); greedy = depth-first,
+// left first (fitter.cpp:364-365)
+std::vector<int> leaf_order;
+if (oblivious) {
+    if (nodes.size() == 1) leaf_order.push_back(0);
+    else leaf_order = frontier;
+} else {
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int id = stack.back();
+        stack.pop_back();
+        if (nodes[id].left < 0) { leaf_order.push_back(id); continue; }
+        stack.push_back(nodes[id].right);
+        stack.push_back(nodes[id].left);
+    }
+}
+
+// ---- append to the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) -----------------------------
+model.begin_tree();
+const size_t tree = md.n_trees;
+model.tree_indices.push_back(md.n_leaves);
+auto write_conditions = [&](const HNode &nd, size_t split_row, size_t leaf_row) {
+    for (size_t i = 0; i < nd.path.size(); ++i) {
+        const HCond &c = nd.path[i];
+        if (c.is_cat && c.cat_cand >= 0)
+            std::memcpy(&model.categorical_values[(split_row * MD + i) * kCat], cat_cands[c.cat_cand].name.data(), kCat);
+        model.is_numerics[split_row * MD + i] = c.is_cat ? 0 : 1;
+        model.feature_indices[split_row * MD + i] = c.feat_idx;
+        model.feature_values[split_row * MD + i] = c.value;
+        model.inequality_directions[leaf_row * MD + i] = c.dir ? 1 : 0;
+        model.edge_weights[leaf_row * MD + i] = c.edge_w;
+    }
+};
+const size_t n_new = leaf_order.size();
+const size_t L0 = md.n_leaves;
+const size_t S_new = oblivious ? tree + 1 : L0 + n_new;
+model.depths.resize(S_new, 0);
+model.feature_indices.resize(S_new * MD, 0);
+model.feature_values.resize(S_new * MD, 0.0f);
+model.is_numerics.resize(S_new * MD, 0);
+model.categorical_values.resize(S_new * MD * kCat, 0);
+model.values.resize((L0 + n_new) * D, 0.0f);
+model.edge_weights.resize((L0 + n_new) * MD, 0.0f);
+model.inequality_directions.resize((L0 + n_new) * MD, 0);
+for (size_t q = 0; q < n_new; ++q) {
+    const HNode &nd = nodes[leaf_order[q]];
+    const size_t leaf_row = L0 + q;
+    if (oblivious) {
+        model.depths[tree] = nd.depth;
+        write_conditions(nd, tree, leaf_row);
+    } else {
+        model.depths[leaf_row] = nd.depth;
+        write_conditions(nd, leaf_row, leaf_row);
+    }
+    const int64_t *a = &acc[static_cast<size_t>(leaf_order[q]) * (D + 1)];
+    const int64_t cnt = a[D];
+    for (int d = 0; d < D; ++d) {
+        float v = 0.0f;
+        if (cnt > 0 && nd.depth > 0)  // fitter.cpp:574-578; depth-0 leaf keeps 0 (Q7)
+            v = static_cast<float>((static_cast<double>(a[d]) / leaf_scale) / static_cast<double>(cnt));
+        model.values[leaf_row * D + d] = v;
+    }
+}
+md.n_leaves += static_cast<int32_t>(n_new);
+md.n_trees += 1;
+md.iteration += 1;  // fitter.cpp:114
+++model.version;
+}
+
 }  // namespace
 
-// ======================================================================================================== step
-void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *grads, bool grads_dev, int n,
-                  int n_num, int n_cat) {
-    gbrl_hip_metadata &md = model.meta;
-    // GBRL::step, gbrl.cpp:946-958
-    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
-    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
-    if (n_num + n_cat != md.input_dim) throw InvalidArgument("Total number of features != correct input dim");
-    if (n <= 0 || grads == nullptr) throw InvalidArgument("Cannot call step without grads!");
-    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call step without obs!");
-    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call step without cat_obs!");
-    if (md.max_depth > kern::kMaxPath) throw Unsupported("max_depth > 32 is not supported");
-    if (md.n_bins < 1 || md.n_bins > 65534) throw Unsupported("n_bins must be in [1, 65534]");
-    ensure_device();
-    ev_used_ = 0;
-    ev_names_.clear();
-    if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
-    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
+// ---- A3/A4: numeric split candidates ------------------------------------------------------------------------------------
+// thresholds [F][B] of the rows in dobs (keys already transposed into d_kt): fixed ones (fit()), uniform (min/max + fma), or
+// exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
+// On return d_thr / d_thrkeys hold them on the device and the copy into h_thr is enqueued (valid after the next sync).
+void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
+                                uint32_t *d_thrkeys, std::vector<float> &h_thr) {
     hipStream_t s = stream_;
-    const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
-    const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
-    const bool oblivious = model.oblivious();
-    const int world = has_coll_ ? coll_.world_size : 1;
-
-    // global row count (rows are sharded over ranks)
-    long long n_global = N;
-    if (has_coll_) {
-        int64_t *tmp = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t)));
-        int64_t hv = N;
-        hip_check(hipMemcpyAsync(tmp, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D n");
-        exchange(Red::SumI64, tmp, 1);
-        hip_check(hipMemcpyAsync(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H n");
-        hip_check(hipStreamSynchronize(s), "sync");
-        n_global = hv;
-    }
-
-    // ---- inputs on the device -------------------------------------------------------------------------------------
-    phase_begin();
-    const float *dobs = obs;
-    if (F > 0 && !obs_dev) {
-        dobs = static_cast<float *>(d_obs_.ensure(sizeof(float) * N * F));
-        hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * N * F, hipMemcpyHostToDevice, s), "H2D obs");
-    }
-    const float *dgrads = grads;
-    if (!grads_dev) {
-        dgrads = static_cast<float *>(d_grads_.ensure(sizeof(float) * N * D));
-        hip_check(hipMemcpyAsync(const_cast<float *>(dgrads), grads, sizeof(float) * N * D, hipMemcpyHostToDevice, s), "H2D grads");
-    }
-    // categorical features are pre-processed on the host (strings); bring them and the raw grads there if needed
-    std::vector<char> cat_host_buf;
-    const char *hcat = cat;
-    std::vector<float> grads_host_buf;
-    const float *hgrads = grads;
-    if (Fc > 0) {
-        if (cat_dev) {
-            cat_host_buf.resize(static_cast<size_t>(N) * Fc * kCat);
-            hip_check(hipMemcpy(cat_host_buf.data(), cat, cat_host_buf.size(), hipMemcpyDeviceToHost), "D2H cat");
-            hcat = cat_host_buf.data();
-        }
-        if (grads_dev) {
-            grads_host_buf.resize(static_cast<size_t>(N) * D);
-            hip_check(hipMemcpy(grads_host_buf.data(), grads, grads_host_buf.size() * 4, hipMemcpyDeviceToHost), "D2H grads");
-            hgrads = grads_host_buf.data();
-        }
-    }
-    phase_end("inputs");
-
-    // ---- 1. gradient statistics and quantisation (A2) -----------------------------------------------------------------
-    phase_begin();
-    const size_t n_el = static_cast<size_t>(N) * D;
-    float *d_meanden = static_cast<float *>(d_meanden_.ensure(sizeof(float) * 2 * D));
-    const float *d_mean = nullptr, *d_den = nullptr;
-    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 4 * D));
-    const int nblk = kern::column_sums_blocks(N, D);
-    double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
-    if (D > 512) throw Unsupported("output_dim > 512");
-    // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: the power-of-two scale keeps
-    // chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build).
-    // A histogram block accumulates one chunk of one node's rows.  Chunks are sized per level so that the whole level is ONE
-    // balanced round of <= 32 chunks x (feature groups) blocks (k_hist_build keeps one block per CU); `chunk_rows` is the cap
-    // the fixed-point scale is derived from.  Leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62.
-    // It depends on the GLOBAL row count only (clamped to [4096, 65536]), so the scale -- and with it every integer sum -- is
-    // the same for any sharding of the same rows.
-    const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
-    kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
-    kern::StepScales h_scales{};
-    {
-        // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
-        // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
-        // sums (fp64) and take the maxima (fp32, exact) over ranks between the kernels; the arithmetic stays on the device,
-        // so one GPU and N GPUs execute the same instructions on the same global sums.
-        double *d_stat2 = d_stat + 2 * D;
-        float *d_maxf = static_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
-        auto exchange_stats = [&](double *st) {
-            if (!has_coll_) return;
-            kern::f64_to_f32(st + D, d_maxf, D, s);
-            exchange(Red::SumF64, st, D);
-            exchange(Red::MaxF32, d_maxf, D);
-            kern::f32_to_f64(d_maxf, st + D, D, s);
-        };
-        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
-        exchange_stats(d_stat);
-        if (!cosine) {
-            kern::stats_mean(d_stat, n_global, D, d_meanden, s);
-            kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat2, s);
-            exchange_stats(d_stat2);
-            kern::stats_finish(d_stat, d_stat2, n_global, D, chunk_rows, d_meanden, d_scales, s);
-            d_mean = d_meanden;
-            d_den = d_meanden + D;
-        } else {
-            kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
-        }
-    }
-    int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
-    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
-    phase_end("grad_stats");
-
-    // ---- 2. split candidates ----------------------------------------------------------------------------------------
-    phase_begin();
-    std::vector<float> h_thr(static_cast<size_t>(F) * B);
-    float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, h_thr.size())));
-    uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, h_thr.size())));
-    uint32_t *d_kt = nullptr;
+    const gbrl_hip_metadata &md = model.meta;
     uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
     bool fast_quantile = false;
-    if (F > 0) {
-        // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
-        d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
-        kern::transpose_keys(dobs, N, F, d_kt, s);
-    }
-    phase_end("transpose");
-    phase_begin();
     auto bisection_quantiles = [&](const std::vector<int64_t> &cum) {
         // exact but slow: 32 counting passes (also the multi-GPU path: only integer counts cross ranks)
         int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
@@ -552,117 +582,35 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             }
         }
     }
-    phase_end("candidates");
-    if (candidates_only_) {   // fit(): only the thresholds of this (whole) data set are wanted
-        hip_check(hipStreamSynchronize(s), "sync");
-        fixed_thr_ = h_thr;
-        phases_resolve();
-        return;
-    }
+}
 
-    // categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
-    // same container, same insertion order => same candidate order (Q8)
-    std::vector<CatCandidate> cat_cands;
-    std::vector<uint16_t> h_catcodes;
-    std::vector<int> cat_classes(Fc, 0);
-    if (Fc > 0) {
-        if (has_coll_) throw Unsupported("categorical features with row-sharded multi-GPU are not supported yet");
-        struct Info { float total = 0.f; int count = 0; int feat = 0; std::string name; };
-        std::vector<float> norms(N, 0.0f);
-        for (int i = 0; i < N; ++i) {  // calculate_squared_norm (math_ops.cpp:726-749), contracted like the reference build
-            float acc = 0.0f;
-            for (int d = 0; d < D; ++d) { const float g = hgrads[static_cast<size_t>(i) * D + d]; acc = fmaf(g, g, acc); }
-            norms[i] = acc;
-        }
-        std::unordered_map<std::string, Info> uniq;
-        for (int f = 0; f < Fc; ++f)
-            for (int i = 0; i < N; ++i) {
-                std::string name(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
-                Info &ci = uniq[name + "_" + std::to_string(f)];
-                ci.total += norms[i];
-                ci.count += 1;
-                ci.feat = f;
-                ci.name = name;
-            }
-        std::vector<std::pair<std::string, float>> vec;
-        for (const auto &kv : uniq) vec.emplace_back(kv.first, kv.second.total / kv.second.count);
-        int n_unique = static_cast<int>(vec.size());
-        if (n_unique > Fc * B) {
-            std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, float> &a, const std::pair<std::string, float> &b) {
-                return a.second > b.second;
-            });
-            n_unique = Fc * B;
-        }
-        std::unordered_map<std::string, int> cls_of;  // key -> class id within its feature
-        for (int i = 0; i < n_unique; ++i) {
-            const Info &ci = uniq[vec[i].first];
-            const int cls = ++cat_classes[ci.feat];
-            if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
-            cat_cands.push_back({ci.feat, ci.name, cls});
-            cls_of[vec[i].first] = cls;
-        }
-        h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
-        for (int i = 0; i < N; ++i)
-            for (int f = 0; f < Fc; ++f) {
-                std::string key(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
-                key += "_" + std::to_string(f);
-                auto it = cls_of.find(key);
-                if (it != cls_of.end()) h_catcodes[static_cast<size_t>(i) * Fc + f] = static_cast<uint16_t>(it->second);
-            }
-    }
-
-    // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
-    const int n_slots = F + Fc;
-    int NB = F > 0 ? B + 1 : 1;
-    for (int c = 0; c < Fc; ++c) NB = std::max(NB, cat_classes[c] + 1);
-    int FG = 16;
-    while (FG > 1 && kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512) FG >>= 1;
-    if (kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512)
-        throw Unsupported("(classes per feature) x (output_dim + 1) does not fit the 160 KiB LDS");
-    if (static_cast<size_t>(NB + 1) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");
-    const int Fp = ((n_slots + FG - 1) / FG) * FG;
-    const int n_groups = Fp / FG;
-    // internal candidate order = slot-grouped; cand_ref maps to the reference's candidate index (numeric f-major, then the
-    // categorical candidates in the hash-map order) which decides ties (lowest reference index wins)
-    std::vector<FeatureSlot> slots(n_slots);
-    int n_cand = 0;
-    for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
-    for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
-    std::vector<int32_t> cand_ref(n_cand);
-    std::vector<float> cand_w(n_cand);
-    std::vector<int> ref_to_internal(n_cand);
-    for (int f = 0; f < F; ++f)
-        for (int k = 0; k < B; ++k) {
-            const int j = slots[f].cand_base + k;
-            cand_ref[j] = f * B + k;
-            // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
-            const int wi = oblivious ? model.reverse_num[f] : f;
-            cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
-        }
-    for (size_t q = 0; q < cat_cands.size(); ++q) {
-        const CatCandidate &cc = cat_cands[q];
-        const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
-        cand_ref[j] = F * B + static_cast<int>(q);
-        const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
-        cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
-    }
-    for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
-
-    // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
-    phase_begin();
-    const int n_code_groups = (n_slots + kern::kCodeGroup - 1) / kern::kCodeGroup;
-    const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
-    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
-    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
-    if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
-    if (Fc > 0) {
-        uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
-        hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
-        kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
-    }
-    phase_end("binning");
-
-    // ---- 4. growth ---------------------------------------------------------------------------------------------------
+// ---- A6-A9, A11: level-synchronous growth of one tree from the class codes and the quantised gradients ---------------------
+// Per level the host (1) uploads ONE packed descriptor block (chunk tables, slot maps, paths, partition chunks) from pinned
+// memory, (2) enqueues histogram / reduce / subtract / score / argmax / resolve kernels, the read-back of ONE small result block
+// (best candidate, child sizes) and -- from descriptors the device completes itself -- the partition, (3) waits for the result
+// block only (an event, not the stream) and books the children while the partition runs.  Leaf sums are enqueued when a node
+// becomes a leaf.  On return `nodes` is the tree, `frontier` the unsplit nodes of the last level, acc the per-node int64
+// fixed-point sums of the raw gradients (| count) and leaf_scale their scale.
+void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
+                       double &leaf_scale) {
+    using namespace detail;
+    hipStream_t s = stream_;
+    const gbrl_hip_metadata &md = model.meta;
+    const int N = c.N, F = c.F, D = c.D, B = c.B, MD = c.MD, NB = c.NB, FG = c.FG, Fp = c.Fp, n_groups = c.n_groups, n_slots = c.n_slots,
+              n_cand = c.n_cand, chunk_rows = c.chunk_rows;
+    const long long n_global = c.n_global;
+    const bool cosine = c.cosine, oblivious = c.oblivious;
+    const std::vector<FeatureSlot> &slots = *c.slots;
+    const std::vector<float> &cand_w = *c.cand_w;
+    const std::vector<int32_t> &cand_ref = *c.cand_ref;
+    const std::vector<int> &ref_to_internal = *c.ref_to_internal;
+    const std::vector<CatCandidate> &cat_cands = *c.cat_cands;
+    const std::vector<float> &h_thr = *c.h_thr;
+    const float *d_thr = c.d_thr, *dgrads = c.dgrads;
+    const uint16_t *d_codes = c.d_codes;
+    const int32_t *d_qg = c.d_qg;
+    kern::StepScales *d_scales = c.d_scales;
+    kern::StepScales h_scales{};
     // Level-synchronous.  Per level the host (1) uploads ONE packed descriptor block (chunk tables, slot maps, paths) from
     // pinned memory, (2) enqueues histogram / score / argmax / resolve kernels, (3) reads back ONE small result block (best
     // candidate, child sizes) -- the only synchronisation of the level -- and (4) uploads the split descriptors and enqueues
@@ -715,14 +663,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     hip_check(hipMemcpyAsync(&h_scales, d_scales, sizeof(h_scales), hipMemcpyDeviceToHost, s), "D2H scales");
     hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr and the scales are needed on the host from here on
     if (!std::isfinite(h_scales.hmax_build) || !std::isfinite(h_scales.hmax_raw)) throw InvalidArgument("non-finite gradients");
-    const double leaf_scale = h_scales.leaf_scale;
+    leaf_scale = h_scales.leaf_scale;
 
-    std::vector<HNode> nodes;
+    nodes.clear();
     nodes.reserve(max_nodes);
     nodes.push_back(HNode{});
     nodes[0].n_local = N;
     nodes[0].n_global = n_global;
-    std::vector<int> frontier{0};
+    frontier.assign(1, 0);
     int cur = 0;  // which row list is current
     std::vector<Chunk> h_chunks;
     std::vector<int32_t> h_chunk_begin;
@@ -1002,77 +950,223 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     if (has_coll_) {
         exchange(Red::SumI64, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1));
     }
-    std::vector<int64_t> acc(nodes.size() * (D + 1));
+    acc.assign(nodes.size() * (D + 1), 0);
     hip_check(hipMemcpyAsync(acc.data(), d_leafacc, sizeof(int64_t) * acc.size(), hipMemcpyDeviceToHost, s), "D2H leaf acc");
     hip_check(hipStreamSynchronize(s), "sync");
 
-    // leaf order: oblivious = level order of the last level (child slots 2k, 2k+1, fitter.cpp:469-470); greedy = depth-first,
-    // left first (fitter.cpp:364-365)
-    std::vector<int> leaf_order;
-    if (oblivious) {
-        if (nodes.size() == 1) leaf_order.push_back(0);
-        else leaf_order = frontier;
-    } else {
-        std::vector<int> stack{0};
-        while (!stack.empty()) {
-            const int id = stack.back();
-            stack.pop_back();
-            if (nodes[id].left < 0) { leaf_order.push_back(id); continue; }
-            stack.push_back(nodes[id].right);
-            stack.push_back(nodes[id].left);
-        }
+}
+
+// ======================================================================================================== step
+void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *grads, bool grads_dev, int n,
+                  int n_num, int n_cat) {
+    gbrl_hip_metadata &md = model.meta;
+    // GBRL::step, gbrl.cpp:946-958
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n_num + n_cat != md.input_dim) throw InvalidArgument("Total number of features != correct input dim");
+    if (n <= 0 || grads == nullptr) throw InvalidArgument("Cannot call step without grads!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call step without obs!");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call step without cat_obs!");
+    if (md.max_depth > kern::kMaxPath) throw Unsupported("max_depth > 32 is not supported");
+    if (md.n_bins < 1 || md.n_bins > 65534) throw Unsupported("n_bins must be in [1, 65534]");
+    ensure_device();
+    ev_used_ = 0;
+    ev_names_.clear();
+    if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
+    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
+    hipStream_t s = stream_;
+    const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
+    const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
+    const bool oblivious = model.oblivious();
+    const int world = has_coll_ ? coll_.world_size : 1;
+
+    // global row count (rows are sharded over ranks)
+    long long n_global = N;
+    if (has_coll_) {
+        int64_t *tmp = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t)));
+        int64_t hv = N;
+        hip_check(hipMemcpyAsync(tmp, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D n");
+        exchange(Red::SumI64, tmp, 1);
+        hip_check(hipMemcpyAsync(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H n");
+        hip_check(hipStreamSynchronize(s), "sync");
+        n_global = hv;
     }
 
-    // ---- append to the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) -----------------------------
-    model.begin_tree();
-    const size_t tree = md.n_trees;
-    model.tree_indices.push_back(md.n_leaves);
-    auto write_conditions = [&](const HNode &nd, size_t split_row, size_t leaf_row) {
-        for (size_t i = 0; i < nd.path.size(); ++i) {
-            const HCond &c = nd.path[i];
-            if (c.is_cat && c.cat_cand >= 0)
-                std::memcpy(&model.categorical_values[(split_row * MD + i) * kCat], cat_cands[c.cat_cand].name.data(), kCat);
-            model.is_numerics[split_row * MD + i] = c.is_cat ? 0 : 1;
-            model.feature_indices[split_row * MD + i] = c.feat_idx;
-            model.feature_values[split_row * MD + i] = c.value;
-            model.inequality_directions[leaf_row * MD + i] = c.dir ? 1 : 0;
-            model.edge_weights[leaf_row * MD + i] = c.edge_w;
+    // ---- inputs on the device -------------------------------------------------------------------------------------
+    phase_begin();
+    const float *dobs = obs;
+    if (F > 0 && !obs_dev) {
+        dobs = static_cast<float *>(d_obs_.ensure(sizeof(float) * N * F));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * N * F, hipMemcpyHostToDevice, s), "H2D obs");
+    }
+    const float *dgrads = grads;
+    if (!grads_dev) {
+        dgrads = static_cast<float *>(d_grads_.ensure(sizeof(float) * N * D));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dgrads), grads, sizeof(float) * N * D, hipMemcpyHostToDevice, s), "H2D grads");
+    }
+    // categorical features are pre-processed on the host (strings); bring them and the raw grads there if needed
+    std::vector<char> cat_host_buf;
+    const char *hcat = cat;
+    std::vector<float> grads_host_buf;
+    const float *hgrads = grads;
+    if (Fc > 0) {
+        if (cat_dev) {
+            cat_host_buf.resize(static_cast<size_t>(N) * Fc * kCat);
+            hip_check(hipMemcpy(cat_host_buf.data(), cat, cat_host_buf.size(), hipMemcpyDeviceToHost), "D2H cat");
+            hcat = cat_host_buf.data();
         }
-    };
-    const size_t n_new = leaf_order.size();
-    const size_t L0 = md.n_leaves;
-    const size_t S_new = oblivious ? tree + 1 : L0 + n_new;
-    model.depths.resize(S_new, 0);
-    model.feature_indices.resize(S_new * MD, 0);
-    model.feature_values.resize(S_new * MD, 0.0f);
-    model.is_numerics.resize(S_new * MD, 0);
-    model.categorical_values.resize(S_new * MD * kCat, 0);
-    model.values.resize((L0 + n_new) * D, 0.0f);
-    model.edge_weights.resize((L0 + n_new) * MD, 0.0f);
-    model.inequality_directions.resize((L0 + n_new) * MD, 0);
-    for (size_t q = 0; q < n_new; ++q) {
-        const HNode &nd = nodes[leaf_order[q]];
-        const size_t leaf_row = L0 + q;
-        if (oblivious) {
-            model.depths[tree] = nd.depth;
-            write_conditions(nd, tree, leaf_row);
-        } else {
-            model.depths[leaf_row] = nd.depth;
-            write_conditions(nd, leaf_row, leaf_row);
-        }
-        const int64_t *a = &acc[static_cast<size_t>(leaf_order[q]) * (D + 1)];
-        const int64_t cnt = a[D];
-        for (int d = 0; d < D; ++d) {
-            float v = 0.0f;
-            if (cnt > 0 && nd.depth > 0)  // fitter.cpp:574-578; depth-0 leaf keeps 0 (Q7)
-                v = static_cast<float>((static_cast<double>(a[d]) / leaf_scale) / static_cast<double>(cnt));
-            model.values[leaf_row * D + d] = v;
+        if (grads_dev) {
+            grads_host_buf.resize(static_cast<size_t>(N) * D);
+            hip_check(hipMemcpy(grads_host_buf.data(), grads, grads_host_buf.size() * 4, hipMemcpyDeviceToHost), "D2H grads");
+            hgrads = grads_host_buf.data();
         }
     }
-    md.n_leaves += static_cast<int32_t>(n_new);
-    md.n_trees += 1;
-    md.iteration += 1;  // fitter.cpp:114
-    ++model.version;
+    phase_end("inputs");
+
+    // ---- 1. gradient statistics and quantisation (A2) -----------------------------------------------------------------
+    phase_begin();
+    const size_t n_el = static_cast<size_t>(N) * D;
+    float *d_meanden = static_cast<float *>(d_meanden_.ensure(sizeof(float) * 2 * D));
+    const float *d_mean = nullptr, *d_den = nullptr;
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 4 * D));
+    const int nblk = kern::column_sums_blocks(N, D);
+    double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
+    if (D > 512) throw Unsupported("output_dim > 512");
+    // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: the power-of-two scale keeps
+    // chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build).
+    // A histogram block accumulates one chunk of one node's rows.  Chunks are sized per level so that the whole level is ONE
+    // balanced round of <= 32 chunks x (feature groups) blocks (k_hist_build keeps one block per CU); `chunk_rows` is the cap
+    // the fixed-point scale is derived from.  Leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62.
+    // It depends on the GLOBAL row count only (clamped to [4096, 65536]), so the scale -- and with it every integer sum -- is
+    // the same for any sharding of the same rows.
+    const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
+    kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
+    {
+        // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
+        // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
+        // sums (fp64) and take the maxima (fp32, exact) over ranks between the kernels; the arithmetic stays on the device,
+        // so one GPU and N GPUs execute the same instructions on the same global sums.
+        double *d_stat2 = d_stat + 2 * D;
+        float *d_maxf = static_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
+        auto exchange_stats = [&](double *st) {
+            if (!has_coll_) return;
+            kern::f64_to_f32(st + D, d_maxf, D, s);
+            exchange(Red::SumF64, st, D);
+            exchange(Red::MaxF32, d_maxf, D);
+            kern::f32_to_f64(d_maxf, st + D, D, s);
+        };
+        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
+        exchange_stats(d_stat);
+        if (!cosine) {
+            kern::stats_mean(d_stat, n_global, D, d_meanden, s);
+            kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat2, s);
+            exchange_stats(d_stat2);
+            kern::stats_finish(d_stat, d_stat2, n_global, D, chunk_rows, d_meanden, d_scales, s);
+            d_mean = d_meanden;
+            d_den = d_meanden + D;
+        } else {
+            kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
+        }
+    }
+    int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
+    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
+    phase_end("grad_stats");
+
+    // ---- 2. split candidates ----------------------------------------------------------------------------------------
+    phase_begin();
+    std::vector<float> h_thr(static_cast<size_t>(F) * B);
+    float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, h_thr.size())));
+    uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, h_thr.size())));
+    uint32_t *d_kt = nullptr;
+    if (F > 0) {
+        // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
+        d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
+        kern::transpose_keys(dobs, N, F, d_kt, s);
+    }
+    phase_end("transpose");
+    phase_begin();
+    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, h_thr);
+    phase_end("candidates");
+    if (candidates_only_) {   // fit(): only the thresholds of this (whole) data set are wanted
+        hip_check(hipStreamSynchronize(s), "sync");
+        fixed_thr_ = h_thr;
+        phases_resolve();
+        return;
+    }
+
+    // categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
+    // same container, same insertion order => same candidate order (Q8)
+    std::vector<CatCandidate> cat_cands;
+    std::vector<uint16_t> h_catcodes;
+    std::vector<int> cat_classes(Fc, 0);
+    if (Fc > 0) {
+        if (has_coll_) throw Unsupported("categorical features with row-sharded multi-GPU are not supported yet");
+        categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
+    }
+
+    // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
+    const int n_slots = F + Fc;
+    int NB = F > 0 ? B + 1 : 1;
+    for (int c = 0; c < Fc; ++c) NB = std::max(NB, cat_classes[c] + 1);
+    int FG = 16;
+    while (FG > 1 && kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512) FG >>= 1;
+    if (kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512)
+        throw Unsupported("(classes per feature) x (output_dim + 1) does not fit the 160 KiB LDS");
+    if (static_cast<size_t>(NB + 1) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");
+    const int Fp = ((n_slots + FG - 1) / FG) * FG;
+    const int n_groups = Fp / FG;
+    // internal candidate order = slot-grouped; cand_ref maps to the reference's candidate index (numeric f-major, then the
+    // categorical candidates in the hash-map order) which decides ties (lowest reference index wins)
+    std::vector<FeatureSlot> slots(n_slots);
+    int n_cand = 0;
+    for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
+    for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
+    std::vector<int32_t> cand_ref(n_cand);
+    std::vector<float> cand_w(n_cand);
+    std::vector<int> ref_to_internal(n_cand);
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < B; ++k) {
+            const int j = slots[f].cand_base + k;
+            cand_ref[j] = f * B + k;
+            // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
+            const int wi = oblivious ? model.reverse_num[f] : f;
+            cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+        }
+    for (size_t q = 0; q < cat_cands.size(); ++q) {
+        const CatCandidate &cc = cat_cands[q];
+        const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
+        cand_ref[j] = F * B + static_cast<int>(q);
+        const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
+        cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+    }
+    for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
+
+    // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
+    phase_begin();
+    const int n_code_groups = (n_slots + kern::kCodeGroup - 1) / kern::kCodeGroup;
+    const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
+    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
+    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
+    if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
+    if (Fc > 0) {
+        uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
+        hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
+        kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
+    }
+    phase_end("binning");
+
+    // ---- 4. growth (level-synchronous; Engine::grow_tree) and 5. leaf sums --------------------------------------------------
+    GrowCtx gc{};
+    gc.N = N; gc.F = F; gc.Fc = Fc; gc.D = D; gc.B = B; gc.MD = MD; gc.NB = NB; gc.FG = FG; gc.Fp = Fp; gc.n_groups = n_groups;
+    gc.n_slots = n_slots; gc.n_cand = n_cand; gc.chunk_rows = chunk_rows; gc.n_global = n_global; gc.cosine = cosine; gc.oblivious = oblivious;
+    gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cat_cands = &cat_cands;
+    gc.h_thr = &h_thr; gc.d_thr = d_thr; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    std::vector<HNode> nodes;
+    std::vector<int> frontier;
+    std::vector<int64_t> acc;
+    double leaf_scale = 1.0;
+    grow_tree(gc, nodes, frontier, acc, leaf_scale);
+    append_tree(model, nodes, frontier, acc, leaf_scale, cat_cands);
     (void)world;
     hip_check(hipGetLastError(), "step kernels");
     phases_resolve();
