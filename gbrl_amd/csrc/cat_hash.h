@@ -36,4 +36,16 @@ GBRL_HD uint64_t cat_cell_hash(const uint64_t *words, uint64_t *norm /*nullable 
     return h;
 }
 
+// Hash of the RAW 128 bytes (no normalisation): the reference keys its candidate map by std::string(cell, 128)
+// (split_candidate_generator.cpp:121), so cells that differ only behind the first NUL are different candidates there.
+GBRL_HD uint64_t cat_cell_hash_raw(const uint64_t *words) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < 16; ++k) {
+        h ^= words[k] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xFF51AFD7ED558CCDull;
+        h ^= h >> 33;
+    }
+    return h ? h : 1ull;   // 0 marks an empty hash-table slot
+}
+
 }  // namespace gbrl

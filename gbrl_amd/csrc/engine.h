@@ -57,6 +57,7 @@ class PinnedBuf {
 namespace detail {
 struct GrowCtx;
 struct HNode;
+struct CatCandidate;
 }  // namespace detail
 
 class Engine {
@@ -92,6 +93,8 @@ class Engine {
     void sync_model_to_device();
     void grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
                    double &leaf_scale);
+    bool device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
+                                       std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes);
     void numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
                             uint32_t *d_thrkeys, std::vector<float> &h_thr);
     void phase_begin(bool key = false);
@@ -110,7 +113,7 @@ class Engine {
 
     // measurement
     int profiling_ = 0;
-    bool force_bisection_ = false, force_sample_select_ = false, last_quantile_fallback_ = false;
+    bool force_bisection_ = false, force_sample_select_ = false, force_host_categorical_ = false, last_quantile_fallback_ = false;
     // fit(): numeric thresholds computed once from the whole data set and reused by every batch's step()
     std::vector<float> fixed_thr_;
     bool candidates_only_ = false;
@@ -146,6 +149,8 @@ class Engine {
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
+    DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lfeat_, d_cat_lhash_, d_cat_names_, d_sdict_off_, d_sdict_hash_, d_sdict_cls_,
+        d_sdict_words_;
     DevBuf d_fit_obs_, d_fit_targets_, d_fit_obs2_, d_fit_targets2_, d_fit_perm_, d_fit_preds_, d_fit_grads_, d_fit_zero_;
 };
 

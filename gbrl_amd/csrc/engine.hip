@@ -424,6 +424,100 @@ md.iteration += 1;  // fitter.cpp:114
 
 }  // namespace
 
+// ---- A5 on the device ------------------------------------------------------------------------------------------------------
+// Finds the distinct (feature, cell) pairs of the batch and their first rows with per-feature hash tables on the device, hands
+// the few distinct cells to the host, which inserts them into the SAME container in the SAME order as the reference's scan
+// (feature-major, first occurrence; split_candidate_generator.cpp:119-129) -- so the candidate order (Q8) is the reference's --
+// and uploads the candidate dictionary for k_cat_step_codes.  Returns false (caller falls back to the host scan) when the
+// batch has more distinct categories than the Fc*B the reference keeps (it then ranks them by mean gradient norm), a table
+// overflowed, or two different cells collided on their 64-bit hash.
+bool Engine::device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
+                                           std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes) {
+    hipStream_t s = stream_;
+    const long long keep = static_cast<long long>(Fc) * B;
+    if (keep > (1 << 20)) return false;
+    int log2_cap = 8;
+    while ((1ll << log2_cap) < 4 * std::min<long long>(N, keep + 1) && log2_cap < 20) ++log2_cap;
+    const size_t slots = static_cast<size_t>(Fc) << log2_cap;
+    const int list_cap = static_cast<int>(keep) + 1;
+    uint64_t *d_keys = static_cast<uint64_t *>(d_cat_keys_.ensure(sizeof(uint64_t) * slots));
+    int32_t *d_first = static_cast<int32_t *>(d_cat_first_.ensure(sizeof(int32_t) * slots));
+    int32_t *d_meta = static_cast<int32_t *>(d_cat_meta_.ensure(sizeof(int32_t) * 4));               // flags[2], counter
+    int32_t *d_lfeat = static_cast<int32_t *>(d_cat_lfeat_.ensure(sizeof(int32_t) * list_cap * 2));   // feat | first
+    int32_t *d_lfirst = d_lfeat + list_cap;
+    uint64_t *d_lhash = static_cast<uint64_t *>(d_cat_lhash_.ensure(sizeof(uint64_t) * list_cap));
+    hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
+    hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
+    hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
+    kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+    kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+    kern::cat_distinct_compact(d_keys, d_first, Fc, log2_cap, d_lfeat, d_lhash, d_lfirst, d_meta + 2, list_cap, d_meta, s);
+    int32_t meta[4];
+    hip_check(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s), "D2H cat meta");
+    hip_check(hipStreamSynchronize(s), "sync");
+    const int n_distinct = meta[2];
+    if (meta[0] != 0 || meta[1] != 0 || n_distinct > keep) return false;
+    std::vector<int32_t> lfeat(n_distinct), lfirst(n_distinct);
+    std::vector<uint64_t> lhash(n_distinct);
+    if (n_distinct > 0) {
+        hip_check(hipMemcpyAsync(lfeat.data(), d_lfeat, sizeof(int32_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(lfirst.data(), d_lfirst, sizeof(int32_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(lhash.data(), d_lhash, sizeof(uint64_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    // the reference's insertion order: feature-major, then row of first occurrence
+    std::vector<int> order(n_distinct);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return lfeat[a] != lfeat[b] ? lfeat[a] < lfeat[b] : lfirst[a] < lfirst[b]; });
+    // the distinct cells themselves
+    std::vector<char> names(static_cast<size_t>(n_distinct) * kCat);
+    if (hcells) {
+        for (int q = 0; q < n_distinct; ++q)
+            std::memcpy(&names[static_cast<size_t>(q) * kCat], hcells + (static_cast<size_t>(lfirst[q]) * Fc + lfeat[q]) * kCat, kCat);
+    } else if (n_distinct > 0) {
+        char *d_names = static_cast<char *>(d_cat_names_.ensure(names.size()));
+        kern::gather_cells(dcells, Fc, d_lfirst, d_lfeat, n_distinct, d_names, s);
+        hip_check(hipMemcpyAsync(names.data(), d_names, names.size(), hipMemcpyDeviceToHost, s), "D2H names");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    struct Info { int feat; int item; };
+    std::unordered_map<std::string, Info> uniq;
+    for (int q : order) {
+        std::string key(&names[static_cast<size_t>(q) * kCat], kCat);
+        key += "_" + std::to_string(lfeat[q]);
+        uniq.emplace(std::move(key), Info{lfeat[q], q});
+    }
+    struct DictE { uint64_t h; int cls; int item; };
+    std::vector<std::vector<DictE>> per(Fc);
+    for (const auto &kv : uniq) {                                  // candidate order = the container's iteration order (Q8)
+        const Info &ci = kv.second;
+        const int cls = ++cat_classes[ci.feat];
+        if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+        cat_cands.push_back({ci.feat, std::string(&names[static_cast<size_t>(ci.item) * kCat], kCat), cls});
+        per[ci.feat].push_back({lhash[ci.item], cls, ci.item});
+    }
+    std::vector<int32_t> off(Fc + 1, 0), clss;
+    std::vector<uint64_t> hs, ws;
+    for (int f = 0; f < Fc; ++f) {
+        std::sort(per[f].begin(), per[f].end(), [](const DictE &a, const DictE &b) { return a.h < b.h || (a.h == b.h && a.cls < b.cls); });
+        for (const DictE &e : per[f]) {
+            hs.push_back(e.h);
+            clss.push_back(e.cls);
+            uint64_t w[16];
+            std::memcpy(w, &names[static_cast<size_t>(e.item) * kCat], kCat);
+            ws.insert(ws.end(), w, w + 16);
+        }
+        off[f + 1] = static_cast<int32_t>(hs.size());
+    }
+    hs.push_back(0); clss.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
+    hip_check(hipMemcpyAsync(d_sdict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipMemcpyAsync(d_sdict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipMemcpyAsync(d_sdict_cls_.ensure(clss.size() * 4), clss.data(), clss.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipMemcpyAsync(d_sdict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
+    return true;
+}
+
 // ---- A3/A4: numeric split candidates ------------------------------------------------------------------------------------
 // thresholds [F][B] of the rows in dobs (keys already transposed into d_kt): fixed ones (fit()), uniform (min/max + fma), or
 // exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
@@ -973,6 +1067,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ev_used_ = 0;
     ev_names_.clear();
     if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
+    if (const char *e = std::getenv("GBRL_HIP_HOST_CATEGORICAL")) force_host_categorical_ = e[0] == '1';   // test hook: host scan of every cell
     if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
     hipStream_t s = stream_;
     const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
@@ -1004,22 +1099,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         dgrads = static_cast<float *>(d_grads_.ensure(sizeof(float) * N * D));
         hip_check(hipMemcpyAsync(const_cast<float *>(dgrads), grads, sizeof(float) * N * D, hipMemcpyHostToDevice, s), "H2D grads");
     }
-    // categorical features are pre-processed on the host (strings); bring them and the raw grads there if needed
-    std::vector<char> cat_host_buf;
-    const char *hcat = cat;
-    std::vector<float> grads_host_buf;
-    const float *hgrads = grads;
-    if (Fc > 0) {
-        if (cat_dev) {
-            cat_host_buf.resize(static_cast<size_t>(N) * Fc * kCat);
-            hip_check(hipMemcpy(cat_host_buf.data(), cat, cat_host_buf.size(), hipMemcpyDeviceToHost), "D2H cat");
-            hcat = cat_host_buf.data();
-        }
-        if (grads_dev) {
-            grads_host_buf.resize(static_cast<size_t>(N) * D);
-            hip_check(hipMemcpy(grads_host_buf.data(), grads, grads_host_buf.size() * 4, hipMemcpyDeviceToHost), "D2H grads");
-            hgrads = grads_host_buf.data();
-        }
+    // categorical cells on the device: the distinct categories of the batch are found there (device_categorical_candidates);
+    // the host-side scan of every cell is only the fallback
+    const char *dcells = cat;
+    if (Fc > 0 && !cat_dev) {
+        char *t = static_cast<char *>(d_pcells_.ensure(static_cast<size_t>(N) * Fc * kCat));
+        hip_check(hipMemcpyAsync(t, cat, static_cast<size_t>(N) * Fc * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+        dcells = t;
     }
     phase_end("inputs");
 
@@ -1094,14 +1180,35 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         return;
     }
 
-    // categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
-    // same container, same insertion order => same candidate order (Q8)
+    // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the
+    // reference's insertion order on the host => same candidate order (Q8).  Falls back to the host scan of every cell when
+    // the batch holds more distinct categories than candidates are kept (the reference then ranks them by mean gradient norm).
     std::vector<CatCandidate> cat_cands;
     std::vector<uint16_t> h_catcodes;
     std::vector<int> cat_classes(Fc, 0);
+    bool cat_codes_on_device = false;
     if (Fc > 0) {
         if (has_coll_) throw Unsupported("categorical features with row-sharded multi-GPU are not supported yet");
-        categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
+        cat_codes_on_device = !force_host_categorical_ && device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
+        if (!cat_codes_on_device) {
+            std::vector<char> cat_host_buf;
+            const char *hcat = cat;
+            std::vector<float> grads_host_buf;
+            const float *hgrads = grads;
+            if (cat_dev) {
+                cat_host_buf.resize(static_cast<size_t>(N) * Fc * kCat);
+                hip_check(hipMemcpy(cat_host_buf.data(), cat, cat_host_buf.size(), hipMemcpyDeviceToHost), "D2H cat");
+                hcat = cat_host_buf.data();
+            }
+            if (grads_dev) {
+                grads_host_buf.resize(static_cast<size_t>(N) * D);
+                hip_check(hipMemcpy(grads_host_buf.data(), grads, grads_host_buf.size() * 4, hipMemcpyDeviceToHost), "D2H grads");
+                hgrads = grads_host_buf.data();
+            }
+            cat_cands.clear();
+            std::fill(cat_classes.begin(), cat_classes.end(), 0);
+            categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
+        }
     }
 
     // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
@@ -1148,7 +1255,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
     if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
     if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
-    if (Fc > 0) {
+    if (Fc > 0 && cat_codes_on_device) {
+        kern::cat_step_codes(dcells, N, Fc, F, d_sdict_off_.as<int32_t>(), d_sdict_hash_.as<uint64_t>(), d_sdict_cls_.as<int32_t>(),
+                             d_sdict_words_.as<uint64_t>(), d_codes, s);
+    } else if (Fc > 0) {
         uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
         hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
         kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);

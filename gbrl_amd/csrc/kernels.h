@@ -206,6 +206,19 @@ struct PredictModel {
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words
 // (16 uint64 per entry, normalised).  codes[i*Fc+f] = id of the matching entry, 0 when the cell is not in the dictionary.
+// Distinct categorical cells of a batch (A5 on the device).  cat_distinct_insert fills per-feature open-addressing tables
+// (keys = raw 128-byte hash, first = smallest row that holds the key); cat_distinct_verify confirms that every cell equals the
+// cell of its key's first row (flags[1] = 1 on a 64-bit hash collision); cat_distinct_compact lists the occupied slots.
+// flags[0] = 1 when a table or the list overflowed.  cat_step_codes writes the class of every cell (dictionary sorted by
+// hash per feature, id = class, words = raw cell) straight into the grouped u16 code array (slot F+f).
+void cat_distinct_insert(const char *cells, int n, int Fc, uint64_t *keys, int32_t *first, int log2_cap, int32_t *flags, hipStream_t s);
+void cat_distinct_verify(const char *cells, int n, int Fc, const uint64_t *keys, const int32_t *first, int log2_cap, int32_t *flags,
+                         hipStream_t s);
+void cat_distinct_compact(const uint64_t *keys, const int32_t *first, int Fc, int log2_cap, int32_t *out_feat, uint64_t *out_hash,
+                          int32_t *out_first, int32_t *counter, int list_cap, int32_t *flags, hipStream_t s);
+void gather_cells(const char *cells, int Fc, const int32_t *rows, const int32_t *feats, int n_items, char *out, hipStream_t s);
+void cat_step_codes(const char *cells, int n, int Fc, int F, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_cls,
+                    const uint64_t *dict_words, uint16_t *codes, hipStream_t s);
 void encode_categories(const char *cells, int n, int Fc, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_id,
                        const uint64_t *dict_words, int32_t *codes, hipStream_t s);
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,

@@ -324,6 +324,44 @@ def test_non_finite_gradients_are_rejected_and_leave_the_model_unchanged(bad):
     assert m.get_num_trees() == 2
 
 
+@pytest.mark.parametrize("name", ["obl_l2_q_cat", "grd_cos_u_cat", "grd_l2_q_catonly", "obl_cos_q_cat_rmse"])
+def test_device_and_host_categorical_candidates_agree(name, monkeypatch):
+    """step() finds the distinct categories of a batch on the device and replays them into the reference's container in the
+    reference's insertion order; the fallback scans every cell on the host like the reference.  Same candidates, same order,
+    same trees -- and both equal the reference fixture."""
+    case, g, (X, Xc, G, y) = load_golden(name)
+    outs = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("GBRL_HIP_HOST_CATEGORICAL", host)
+        m, pred = _run_product(case, X, Xc, G, y, "cpu")
+        e = m.get_ensemble_data()
+        assert_structure_equal(e, g)
+        outs.append(({k: np.asarray(e[k]) for k in K.ENSEMBLE_KEYS}, pred))
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_more_distinct_categories_than_candidates_falls_back_to_the_reference_ranking():
+    """More distinct categories than Fc * n_bins: the reference keeps the Fc * n_bins with the largest mean gradient norm
+    (split_candidate_generator.cpp:141-149); the device path declines and the host path reproduces it (checked against the
+    oracle restatement)."""
+    import gbrl_amd
+    import oracle
+    rng = np.random.default_rng(5)
+    N, Fc, B = 600, 2, 8
+    toks = np.array([("t%03d" % i).encode() for i in range(40)], dtype="S128")
+    Xc = toks[rng.integers(0, 40, size=(N, Fc))]
+    G = rng.standard_normal((N, 2)).astype(np.float32)
+    case = dict(name="trunc", seed=0, N=N, F=0, Fc=Fc, D=2, depth=3, n_bins=B, score="L2", gen="Quantile", policy="greedy", trees=2)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pm = np.asarray(K.drive(m, case, None, Xc, G, None))
+    r = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    pr = np.asarray(K.drive(r, case, None, Xc, G, None))
+    assert_structure_equal(m.get_ensemble_data(), r.get_ensemble_data())
+    assert rel_err(pm, pr, float(np.abs(G).mean())) <= TOL
+
+
 def test_categorical_cells_are_matched_like_strcmp_on_the_device():
     """predict() encodes categorical cells on the device (hash of the bytes before the first NUL, dictionary of the model's
     categories).  Bytes after the first NUL must not matter (the reference compares with strcmp, predictor.cpp:215), unknown
