@@ -150,7 +150,7 @@ class Engine {
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
     DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lfeat_, d_cat_lhash_, d_cat_names_, d_sdict_off_, d_sdict_hash_, d_sdict_cls_,
-        d_sdict_words_;
+        d_sdict_words_, d_cat_xchg_;
     DevBuf d_fit_obs_, d_fit_targets_, d_fit_obs2_, d_fit_targets2_, d_fit_perm_, d_fit_preds_, d_fit_grads_, d_fit_zero_;
 };
 

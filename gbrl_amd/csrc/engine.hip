@@ -455,8 +455,18 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     int32_t meta[4];
     hip_check(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s), "D2H cat meta");
     hip_check(hipStreamSynchronize(s), "sync");
-    const int n_distinct = meta[2];
-    if (meta[0] != 0 || meta[1] != 0 || n_distinct > keep) return false;
+    int n_distinct = meta[2];
+    bool declined = meta[0] != 0 || meta[1] != 0 || n_distinct > keep;
+    if (has_coll_) {   // every rank must take the same path
+        int64_t *d_flag = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t)));
+        int64_t hv = declined ? 1 : 0;
+        hip_check(hipMemcpyAsync(d_flag, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D");
+        exchange(Red::SumI64, d_flag, 1);
+        hip_check(hipMemcpyAsync(&hv, d_flag, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        declined = hv != 0;
+    }
+    if (declined) return false;
     std::vector<int32_t> lfeat(n_distinct), lfirst(n_distinct);
     std::vector<uint64_t> lhash(n_distinct);
     if (n_distinct > 0) {
@@ -480,6 +490,52 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         hip_check(hipMemcpyAsync(names.data(), d_names, names.size(), hipMemcpyDeviceToHost, s), "D2H names");
         hip_check(hipStreamSynchronize(s), "sync");
     }
+    if (has_coll_) {
+        // Row-sharded: every rank needs the distinct cells of ALL ranks, in the order a single process would meet them (rank
+        // after rank = global row order).  All-gather through the sum exchange: counts first, then 18-word records
+        // (feature, first row, the 128 bytes) written into rank-indexed slots of a zeroed buffer.
+        const int world = coll_.world_size, rank = coll_.rank;
+        int64_t *d_cnt = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * (world + 1)));
+        std::vector<int64_t> cnt(world + 1, 0);
+        cnt[rank] = n_distinct;
+        hip_check(hipMemcpyAsync(d_cnt, cnt.data(), sizeof(int64_t) * (world + 1), hipMemcpyHostToDevice, s), "H2D");
+        exchange(Red::SumI64, d_cnt, world + 1);
+        hip_check(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int64_t) * (world + 1), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        long long total = 0, my_off = 0;
+        for (int r = 0; r < world; ++r) { if (r < rank) my_off += cnt[r]; total += cnt[r]; }
+        if (total > (1ll << 20)) throw Unsupported("too many distinct categories for a row-sharded step");
+        std::vector<int64_t> rec(static_cast<size_t>(total) * 18, 0);
+        for (int q = 0; q < n_distinct; ++q) {
+            int64_t *r18 = &rec[(static_cast<size_t>(my_off) + q) * 18];
+            r18[0] = lfeat[order[q]];
+            r18[1] = lfirst[order[q]];
+            std::memcpy(r18 + 2, &names[static_cast<size_t>(order[q]) * kCat], kCat);
+        }
+        if (total > 0) {
+            int64_t *d_rec = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * rec.size()));
+            hip_check(hipMemcpyAsync(d_rec, rec.data(), sizeof(int64_t) * rec.size(), hipMemcpyHostToDevice, s), "H2D");
+            exchange(Red::SumI64, d_rec, rec.size());
+            hip_check(hipMemcpyAsync(rec.data(), d_rec, sizeof(int64_t) * rec.size(), hipMemcpyDeviceToHost, s), "D2H");
+            hip_check(hipStreamSynchronize(s), "sync");
+        }
+        // global list, already rank-major and (feature, first row)-sorted inside a rank: stable sort by feature keeps that order
+        n_distinct = static_cast<int>(total);
+        lfeat.resize(n_distinct); lfirst.resize(n_distinct); lhash.resize(n_distinct);
+        names.resize(static_cast<size_t>(n_distinct) * kCat);
+        for (int q = 0; q < n_distinct; ++q) {
+            const int64_t *r18 = &rec[static_cast<size_t>(q) * 18];
+            lfeat[q] = static_cast<int32_t>(r18[0]);
+            lfirst[q] = q;                                             // position in global order
+            std::memcpy(&names[static_cast<size_t>(q) * kCat], r18 + 2, kCat);
+            uint64_t w[16];
+            std::memcpy(w, r18 + 2, kCat);
+            lhash[q] = cat_cell_hash_raw(w);
+        }
+        order.resize(n_distinct);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lfeat[a] < lfeat[b]; });
+    }
     struct Info { int feat; int item; };
     std::unordered_map<std::string, Info> uniq;
     for (int q : order) {
@@ -487,6 +543,8 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         key += "_" + std::to_string(lfeat[q]);
         uniq.emplace(std::move(key), Info{lfeat[q], q});
     }
+    if (static_cast<long long>(uniq.size()) > keep)
+        throw Unsupported("more distinct categories than Fc * n_bins in a row-sharded step (the reference's mean-gradient ranking is not available sharded)");
     struct DictE { uint64_t h; int cls; int item; };
     std::vector<std::vector<DictE>> per(Fc);
     for (const auto &kv : uniq) {                                  // candidate order = the container's iteration order (Q8)
@@ -1188,8 +1246,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     std::vector<int> cat_classes(Fc, 0);
     bool cat_codes_on_device = false;
     if (Fc > 0) {
-        if (has_coll_) throw Unsupported("categorical features with row-sharded multi-GPU are not supported yet");
-        cat_codes_on_device = !force_host_categorical_ && device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
+        cat_codes_on_device = (has_coll_ || !force_host_categorical_) &&
+                              device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
+        if (!cat_codes_on_device && has_coll_)
+            throw Unsupported("this batch needs the reference's mean-gradient ranking of categories (more distinct categories than Fc * n_bins), which is not available row-sharded");
         if (!cat_codes_on_device) {
             std::vector<char> cat_host_buf;
             const char *hcat = cat;

@@ -23,8 +23,7 @@ def main():
     from helpers import load_golden
     dist.init_process_group("gloo", rank=rank, world_size=world)
     case, g, (X, Xc, G, y) = load_golden(name)
-    assert Xc is None, "categorical features are not supported row-sharded"
-    N = X.shape[0]
+    N = case["N"]
     # deliberately uneven contiguous shards
     cuts = [0] + [int(N * (r + 1) / world * 0.8) for r in range(world - 1)] + [N]
     lo, hi = cuts[rank], cuts[rank + 1]
@@ -32,7 +31,9 @@ def main():
     coll = install_torch_collective(m, torch.device("cuda:0"))
     Gs = None if G is None else G[lo:hi]
     ys = None if y is None else y[lo:hi]
-    pred = np.asarray(K.drive(m, case, np.ascontiguousarray(X[lo:hi]), None, Gs, ys))
+    Xs = None if X is None else np.ascontiguousarray(X[lo:hi])
+    Xcs = None if Xc is None else np.ascontiguousarray(Xc[lo:hi])
+    pred = np.asarray(K.drive(m, case, Xs, Xcs, Gs, ys))
     e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
     np.savez(out, lo=lo, hi=hi, pred=pred, calls=coll.calls, **e)
     dist.barrier()

@@ -2,7 +2,8 @@
 
 RCCL refuses two ranks on one device, so the ranks are separate processes joined by a gloo process group and
 gbrl_amd.dist stages each reduction through host memory; everything else -- the engine's sharded code path, the hook
-calls, the device kernels on each rank's shard -- is exactly what a multi-GPU run executes.  Every rank must grow the tree
+calls, the device kernels on each rank's shard -- is exactly what a multi-GPU run executes (categorical columns included: the
+ranks gather each other's distinct categories and replay them in global row order).  Every rank must grow the tree
 a single process grows from all the rows, bit for bit (integer sums, identical arithmetic), for uneven shards and for a
 world size that is not a power of two."""
 import os
@@ -52,12 +53,13 @@ def _run_world(name, world, tmp_path, extra_env=None):
 
 
 @pytest.mark.parametrize("name,world", [("obl_l2_q_d6", 2), ("obl_l2_q_d6", 3), ("grd_cos_q_ac", 2), ("obl_cos_u", 2),
-                                        ("cfg1_rmse_loop", 2), ("obl_l2_q_dups", 3), ("grd_l2_q_mdl", 2)])
+                                        ("cfg1_rmse_loop", 2), ("obl_l2_q_dups", 3), ("grd_l2_q_mdl", 2),
+                                        ("obl_l2_q_cat", 2), ("grd_cos_u_cat", 3), ("grd_l2_q_catonly", 2), ("obl_cos_q_cat_rmse", 2)])
 def test_sharded_ranks_grow_the_single_process_tree(name, world, tmp_path):
     import gbrl_amd
     case, g, (X, Xc, G, y) = load_golden(name)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
-    pred = np.asarray(K.drive(m, case, X, None, G, y))
+    pred = np.asarray(K.drive(m, case, X, Xc, G, y))
     e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
     ranks = _run_world(name, world, tmp_path)
     for r, d in enumerate(ranks):
