@@ -116,6 +116,9 @@ class Engine {
     bool force_bisection_ = false, force_sample_select_ = false, force_host_categorical_ = false, last_quantile_fallback_ = false;
     // fit(): numeric thresholds computed once from the whole data set and reused by every batch's step()
     std::vector<float> fixed_thr_;
+    std::vector<detail::CatCandidate> fixed_cat_cands_;
+    std::vector<int> fixed_cat_classes_;
+    bool fixed_cat_valid_ = false;
     bool candidates_only_ = false;
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
@@ -151,6 +154,7 @@ class Engine {
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
     DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lfeat_, d_cat_lhash_, d_cat_names_, d_sdict_off_, d_sdict_hash_, d_sdict_cls_,
         d_sdict_words_, d_cat_xchg_;
+    DevBuf d_fit_cells_, d_fit_cells2_;
     DevBuf d_fit_obs_, d_fit_targets_, d_fit_obs2_, d_fit_targets2_, d_fit_perm_, d_fit_preds_, d_fit_grads_, d_fit_zero_;
 };
 

@@ -1231,12 +1231,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     phase_begin();
     if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, h_thr);
     phase_end("candidates");
-    if (candidates_only_) {   // fit(): only the thresholds of this (whole) data set are wanted
-        hip_check(hipStreamSynchronize(s), "sync");
-        fixed_thr_ = h_thr;
-        phases_resolve();
-        return;
-    }
 
     // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the
     // reference's insertion order on the host => same candidate order (Q8).  Falls back to the host scan of every cell when
@@ -1246,8 +1240,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     std::vector<int> cat_classes(Fc, 0);
     bool cat_codes_on_device = false;
     if (Fc > 0) {
-        cat_codes_on_device = (has_coll_ || !force_host_categorical_) &&
-                              device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
+        if (fixed_cat_valid_) {   // fit(): candidates of the whole data set (fitter.cpp:152-164); the dictionary is still on the device
+            cat_cands = fixed_cat_cands_;
+            cat_classes = fixed_cat_classes_;
+            cat_codes_on_device = true;
+        } else {
+            cat_codes_on_device = (has_coll_ || !force_host_categorical_) &&
+                                  device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
+        }
         if (!cat_codes_on_device && has_coll_)
             throw Unsupported("this batch needs the reference's mean-gradient ranking of categories (more distinct categories than Fc * n_bins), which is not available row-sharded");
         if (!cat_codes_on_device) {
@@ -1269,6 +1269,20 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             std::fill(cat_classes.begin(), cat_classes.end(), 0);
             categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
         }
+    }
+
+    if (candidates_only_) {   // fit(): only the candidates of this (whole) data set are wanted
+        hip_check(hipStreamSynchronize(s), "sync");
+        fixed_thr_ = h_thr;
+        if (Fc > 0) {
+            if (!cat_codes_on_device)
+                throw Unsupported("fit(): the data set holds more distinct categories than Fc * n_bins (mean-gradient ranking of the whole data set is not implemented)");
+            fixed_cat_cands_ = cat_cands;
+            fixed_cat_classes_ = cat_classes;
+            fixed_cat_valid_ = true;
+        }
+        phases_resolve();
+        return;
     }
 
     // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
@@ -1345,25 +1359,30 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
 // ===================================================================================================== fit
 float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *targets, bool targets_dev, int n, int n_num,
                   int n_cat, int iterations, bool shuffle) {
-    (void)cat; (void)cat_dev;
     gbrl_hip_metadata &md = model.meta;
     if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }                      // gbrl.cpp:996-999
     if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
     if (n <= 0 || targets == nullptr) throw InvalidArgument("Cannot call fit without targets!");
     if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call fit without obs!");
     if (iterations < 0) throw InvalidArgument("iterations must be >= 0");
-    if (n_cat > 0) throw Unsupported("fit() with categorical features is not supported by this build (step()/predict() are)");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call fit without cat_obs!");
     if (has_coll_) throw Unsupported("fit() is not supported on a row-sharded model");
     if (md.batch_size <= 0) throw InvalidArgument("batch_size must be positive");
     ensure_device();
     hipStream_t s = stream_;
-    const int F = n_num, D = md.output_dim;
-    struct Guard { Engine *e; ~Guard() { e->fixed_thr_.clear(); e->candidates_only_ = false; } } guard{this};
+    const int F = n_num, Fc = n_cat, D = md.output_dim;
+    struct Guard { Engine *e; ~Guard() { e->fixed_thr_.clear(); e->fixed_cat_valid_ = false; e->fixed_cat_cands_.clear(); e->candidates_only_ = false; } } guard{this};
 
     // the data set on the device, optionally in shuffled order (gbrl.cpp:1016-1024, 1039-1067; the reference seeds
     // std::mt19937 from std::random_device, i.e. the order differs from run to run there too)
     const float *dobs = obs, *dtar = targets;
-    if (!obs_dev) {
+    const char *dcat = cat;
+    if (Fc > 0 && !cat_dev) {
+        char *t = static_cast<char *>(d_fit_cells_.ensure(static_cast<size_t>(n) * Fc * kCat));
+        hip_check(hipMemcpyAsync(t, cat, static_cast<size_t>(n) * Fc * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+        dcat = t;
+    }
+    if (F > 0 && !obs_dev) {
         float *t = static_cast<float *>(d_fit_obs_.ensure(sizeof(float) * static_cast<size_t>(n) * F));
         hip_check(hipMemcpyAsync(t, obs, sizeof(float) * static_cast<size_t>(n) * F, hipMemcpyHostToDevice, s), "H2D obs");
         dobs = t;
@@ -1385,6 +1404,11 @@ float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         float *t2 = static_cast<float *>(d_fit_targets2_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
         kern::gather_rows(dobs, d_perm, o2, n, F, s);
         kern::gather_rows(dtar, d_perm, t2, n, D, s);
+        if (Fc > 0) {   // whole 128-byte cells travel with their row (the reference's shuffled copy keeps only their first byte, Q12)
+            char *c2 = static_cast<char *>(d_fit_cells2_.ensure(static_cast<size_t>(n) * Fc * kCat));
+            kern::gather_rows(reinterpret_cast<const float *>(dcat), d_perm, reinterpret_cast<float *>(c2), n, Fc * (kCat / 4), s);
+            dcat = c2;
+        }
         hip_check(hipStreamSynchronize(s), "sync");   // perm goes out of scope
         dobs = o2;
         dtar = t2;
@@ -1412,9 +1436,9 @@ float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ++model.version;
 
     // split candidates from the whole data set, once (fitter.cpp:134-150)
-    if (F > 0) {
+    {
         candidates_only_ = true;
-        step(dobs, true, nullptr, false, dtar, true, n, F, 0);   // returns right after the thresholds; `dtar` only feeds the (unused) statistics
+        step(dobs, true, dcat, true, dtar, true, n, F, Fc);   // returns right after the candidates; `dtar` only feeds the (unused) statistics
         candidates_only_ = false;
     }
     const int bs = md.batch_size;
@@ -1425,15 +1449,16 @@ float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     for (int i = 0; i < iterations; ++i) {
         const float *ob = dobs + static_cast<size_t>(start) * F;
         const float *tb = dtar + static_cast<size_t>(start) * D;
-        predict(ob, true, nullptr, false, bn, F, 0, 0, i, d_preds, true);      // trees [0, i) -- i == 0 means "all" (fitter.cpp:187)
+        const char *cb = Fc > 0 ? dcat + static_cast<size_t>(start) * Fc * kCat : nullptr;
+        predict(ob, true, cb, true, bn, F, Fc, 0, i, d_preds, true);           // trees [0, i) -- i == 0 means "all" (fitter.cpp:187)
         kern::sub_arrays(d_preds, tb, d_grads, static_cast<size_t>(bn) * D, s);
-        step(ob, true, nullptr, false, d_grads, true, bn, F, 0);
+        step(ob, true, cb, true, d_grads, true, bn, F, Fc);
         start += bn;                                                            // fitter.cpp:228-231
         if (start >= n) start = 0;
         bn = start + bs < n ? bs : n - start;
     }
     // loss on the whole data set over trees [0, iterations) (fitter.cpp:246-251)
-    predict(dobs, true, nullptr, false, n, F, 0, 0, iterations, d_preds, true);
+    predict(dobs, true, Fc > 0 ? dcat : nullptr, true, n, F, Fc, 0, iterations, d_preds, true);
     float *d_full_grads = static_cast<float *>(d_fit_grads_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
     kern::sub_arrays(d_preds, dtar, d_full_grads, static_cast<size_t>(n) * D, s);
     return rmse(d_full_grads, n);

@@ -137,7 +137,7 @@ int gbrl_hip_step(gbrl_hip_model *m, const float *obs, int obs_on_device, const 
  * on the GPU: bias = column means of `targets`; split candidates from the WHOLE data set once; then `iterations` boosting
  * rounds over consecutive batches of metadata.batch_size rows (predict over trees [0, i) -> gradients pred - target -> one
  * tree); *loss_out = sqrt(0.5 * sum (pred - target)^2 / n_samples) over the whole data set afterwards.  shuffle != 0 fits
- * a randomly permuted copy (seeded from std::random_device like the reference).  Numeric features only in this build. */
+ * a randomly permuted copy (seeded from std::random_device like the reference).  */
 int gbrl_hip_fit(gbrl_hip_model *m, const float *obs, int obs_on_device, const char *cat_obs, int cat_on_device,
                  const float *targets, int targets_on_device, int n_samples, int n_num_features, int n_cat_features,
                  int iterations, int shuffle, float *loss_out);

@@ -106,15 +106,15 @@ def drive(model, case, X, Xc, G, y, to_input=lambda a: a, to_numpy=np.asarray):
     return to_numpy(model.predict(xi, Xc, 0, 0))
 
 
-def drive_fit(model, case, X, y):
+def drive_fit(model, case, X, y, Xc=None):
     """GBTLearner.fit-style call (gbt_learner.py:502-551): setters, then ONE fit() over the whole data set, no shuffle."""
-    F = case["F"]
-    model.set_feature_weights(np.asarray(case.get("feature_weights", np.ones(F)), np.float32))
+    F, Fc = case["F"], case.get("Fc", 0)
+    model.set_feature_weights(np.asarray(case.get("feature_weights", np.ones(F + Fc)), np.float32))
     for o in optimizers(case):
         model.set_optimizer(**o)
-    model.set_feature_mapping(np.arange(F, dtype=np.int32), np.array([True] * F, dtype=bool))
-    loss = model.fit(X, None, y, case["fit_iterations"], False, "MultiRMSE")
-    return float(loss), np.asarray(model.predict(X, None, 0, 0))
+    model.set_feature_mapping(np.arange(F + Fc, dtype=np.int32), np.array([True] * F + [False] * Fc, dtype=bool))
+    loss = model.fit(X, Xc, y, case["fit_iterations"], False, "MultiRMSE")
+    return float(loss), np.asarray(model.predict(X, Xc, 0, 0))
 
 
 def _c(name, **kw):
@@ -167,6 +167,8 @@ FIT_CASES = [
        opts=[dict(algo="SGD", scheduler="Const", init_lr=0.5, start_idx=0, stop_idx=2)]),
     _c("fit_grd_cos_u", seed=32, N=2640, F=5, D=1, depth=4, n_bins=32, policy="greedy", score="Cosine", gen="Uniform", loop="rmse",
        batch_size=1200, fit_iterations=8, opts=[dict(algo="SGD", scheduler="Const", init_lr=0.3, start_idx=0, stop_idx=1)]),
+    _c("fit_obl_cos_q_cat", seed=34, N=2400, F=4, Fc=2, D=1, depth=4, n_bins=32, score="Cosine", loop="rmse", batch_size=1200,
+       fit_iterations=6, opts=[dict(algo="SGD", scheduler="Const", init_lr=0.4, start_idx=0, stop_idx=1)]),
     _c("fit_grd_l2_q_onebatch", seed=33, N=2400, F=8, D=3, depth=3, policy="greedy", loop="rmse", batch_size=5000, fit_iterations=5,
        opts=[dict(algo="SGD", scheduler="Const", init_lr=0.4, start_idx=0, stop_idx=3)]),
 ]

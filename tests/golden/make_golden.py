@@ -31,7 +31,7 @@ def run(mod, case):
     m = mod.GBRL(**K.ctor_kwargs(case))
     fit_loss = None
     if "fit_iterations" in case:
-        fit_loss, pred = K.drive_fit(m, case, X, y)
+        fit_loss, pred = K.drive_fit(m, case, X, y, Xc)
     else:
         pred = K.drive(m, case, X, Xc, G, y)
     e = m.get_ensemble_data()

@@ -67,7 +67,7 @@ def test_fit_matches_reference_golden(name):
     import gbrl_amd
     case, g, (X, Xc, G, y) = load_golden(name)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
-    loss, pred = K.drive_fit(m, case, X, y)
+    loss, pred = K.drive_fit(m, case, X, y, Xc)
     e = m.get_ensemble_data()
     assert m.get_num_trees() == int(g["n_trees"]) == case["fit_iterations"] and m.get_iteration() == int(g["iteration"])
     assert_structure_equal(e, g)
