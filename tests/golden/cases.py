@@ -57,6 +57,9 @@ def make_inputs(case):
     if case.get("loop") == "rmse":                       # tests/test_gbt_single.py:46-61 pattern
         x0 = np.clip(X[:, 0], np.float32(-2), np.float32(2))
         y = (x0 - x0 * x0 * x0 / np.float32(6.0) + _normalish(rng, (N,)) * np.float32(0.1)).astype(np.float32)
+        if case.get("y_cat_weight") and Fc > 0:         # make the categorical columns matter for the supervised target
+            y = (y + (Xc[:, 0] == TOKENS[0]).astype(np.float32) * np.float32(case["y_cat_weight"])
+                 - (Xc[:, Fc - 1] == TOKENS[1]).astype(np.float32) * np.float32(case["y_cat_weight"])).astype(np.float32)
         if D > 1:
             y = np.stack([y * np.float32(d + 1) for d in range(D)], axis=1).astype(np.float32)
     return X, Xc, np.ascontiguousarray(G), y
@@ -167,7 +170,7 @@ FIT_CASES = [
        opts=[dict(algo="SGD", scheduler="Const", init_lr=0.5, start_idx=0, stop_idx=2)]),
     _c("fit_grd_cos_u", seed=32, N=2640, F=5, D=1, depth=4, n_bins=32, policy="greedy", score="Cosine", gen="Uniform", loop="rmse",
        batch_size=1200, fit_iterations=8, opts=[dict(algo="SGD", scheduler="Const", init_lr=0.3, start_idx=0, stop_idx=1)]),
-    _c("fit_obl_cos_q_cat", seed=34, N=2400, F=4, Fc=2, D=1, depth=4, n_bins=32, score="Cosine", loop="rmse", batch_size=1200,
+    _c("fit_obl_cos_q_cat", seed=34, N=2400, F=4, Fc=2, D=1, depth=4, n_bins=32, score="Cosine", loop="rmse", y_cat_weight=1.5, batch_size=1200,
        fit_iterations=6, opts=[dict(algo="SGD", scheduler="Const", init_lr=0.4, start_idx=0, stop_idx=1)]),
     _c("fit_grd_l2_q_onebatch", seed=33, N=2400, F=8, D=3, depth=3, policy="greedy", loop="rmse", batch_size=5000, fit_iterations=5,
        opts=[dict(algo="SGD", scheduler="Const", init_lr=0.4, start_idx=0, stop_idx=3)]),
