@@ -249,7 +249,8 @@ struct GrowCtx {
     const std::vector<int32_t> *cand_ref;
     const std::vector<int> *ref_to_internal;
     const std::vector<CatCandidate> *cat_cands;
-    const std::vector<float> *h_thr;
+    const float *h_thr;                 // pinned; valid once the stream has passed the copy enqueued behind the binning
+    const kern::StepScales *h_scales;   // pinned, same
     const float *d_thr;
     const uint16_t *d_codes;
     const int32_t *d_qg;
@@ -579,9 +580,9 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
 // ---- A3/A4: numeric split candidates ------------------------------------------------------------------------------------
 // thresholds [F][B] of the rows in dobs (keys already transposed into d_kt): fixed ones (fit()), uniform (min/max + fma), or
 // exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
-// On return d_thr / d_thrkeys hold them on the device and the copy into h_thr is enqueued (valid after the next sync).
+// On return d_thr / d_thrkeys hold them on the device (the caller copies them to the host when it needs them there).
 void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
-                                uint32_t *d_thrkeys, std::vector<float> &h_thr) {
+                                uint32_t *d_thrkeys) {
     hipStream_t s = stream_;
     const gbrl_hip_metadata &md = model.meta;
     uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
@@ -605,10 +606,9 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
     std::vector<int64_t> cum;
     if (F > 0 && !fixed_thr_.empty()) {
         // fit(): the candidates were generated from the whole data set (fitter.cpp:134-150); this batch only bins against them
-        if (fixed_thr_.size() != h_thr.size()) throw HipError("internal: fixed thresholds do not match this model");
-        h_thr = fixed_thr_;
-        hip_check(hipMemcpyAsync(d_thr, h_thr.data(), sizeof(float) * h_thr.size(), hipMemcpyHostToDevice, s), "H2D thresholds");
-        kern::floats_to_keys(d_thr, d_thrkeys, h_thr.size(), s);
+        if (fixed_thr_.size() != static_cast<size_t>(F) * B) throw HipError("internal: fixed thresholds do not match this model");
+        hip_check(hipMemcpyAsync(d_thr, fixed_thr_.data(), sizeof(float) * fixed_thr_.size(), hipMemcpyHostToDevice, s), "H2D thresholds");
+        kern::floats_to_keys(d_thr, d_thrkeys, fixed_thr_.size(), s);
     } else if (F > 0) {
         if (md.generator_type == GBRL_HIP_GEN_UNIFORM) {
             uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
@@ -711,7 +711,6 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
         }
         uint32_t qflags[4] = {0, 0, 0, 0};
-        hip_check(hipMemcpyAsync(h_thr.data(), d_thr, sizeof(float) * F * B, hipMemcpyDeviceToHost, s), "D2H thr");
         if (fast_quantile) {
             hip_check(hipMemcpyAsync(qflags, d_qflags, sizeof(qflags), hipMemcpyDeviceToHost, s), "D2H flags");
             hip_check(hipStreamSynchronize(s), "sync");
@@ -727,7 +726,6 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             if (qflags[2] != 0) {  // a class list outgrew its budget (pathological value distribution): redo exactly, slowly
                 bisection_quantiles(cum);
                 kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
-                hip_check(hipMemcpyAsync(h_thr.data(), d_thr, sizeof(float) * F * B, hipMemcpyDeviceToHost, s), "D2H thr");
                 last_quantile_fallback_ = true;
             } else {
                 last_quantile_fallback_ = false;
@@ -757,12 +755,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const std::vector<int32_t> &cand_ref = *c.cand_ref;
     const std::vector<int> &ref_to_internal = *c.ref_to_internal;
     const std::vector<CatCandidate> &cat_cands = *c.cat_cands;
-    const std::vector<float> &h_thr = *c.h_thr;
+    const float *h_thr = c.h_thr;
     const float *d_thr = c.d_thr, *dgrads = c.dgrads;
     const uint16_t *d_codes = c.d_codes;
     const int32_t *d_qg = c.d_qg;
     kern::StepScales *d_scales = c.d_scales;
-    kern::StepScales h_scales{};
     // Level-synchronous.  Per level the host (1) uploads ONE packed descriptor block (chunk tables, slot maps, paths) from
     // pinned memory, (2) enqueues histogram / score / argmax / resolve kernels, (3) reads back ONE small result block (best
     // candidate, child sizes) -- the only synchronisation of the level -- and (4) uploads the split descriptors and enqueues
@@ -812,10 +809,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
     NodeSplit *d_resolved = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
     kern::iota_rows(d_rows[0], N, s);
-    hip_check(hipMemcpyAsync(&h_scales, d_scales, sizeof(h_scales), hipMemcpyDeviceToHost, s), "D2H scales");
-    hip_check(hipStreamSynchronize(s), "sync before growth");  // h_thr and the scales are needed on the host from here on
-    if (!std::isfinite(h_scales.hmax_build) || !std::isfinite(h_scales.hmax_raw)) throw InvalidArgument("non-finite gradients");
-    leaf_scale = h_scales.leaf_scale;
+    // No synchronisation here: thresholds and scales are on their way to pinned memory; the first level's event wait (or the
+    // final synchronisation) covers them.  Non-finite gradients are rejected after the loop, before anything joins the model.
 
     nodes.clear();
     nodes.reserve(max_nodes);
@@ -1105,6 +1100,9 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     acc.assign(nodes.size() * (D + 1), 0);
     hip_check(hipMemcpyAsync(acc.data(), d_leafacc, sizeof(int64_t) * acc.size(), hipMemcpyDeviceToHost, s), "D2H leaf acc");
     hip_check(hipStreamSynchronize(s), "sync");
+    // everything enqueued for this tree has completed: scales are in pinned memory
+    if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
+    leaf_scale = c.h_scales->leaf_scale;
 
 }
 
@@ -1218,9 +1216,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
 
     // ---- 2. split candidates ----------------------------------------------------------------------------------------
     phase_begin();
-    std::vector<float> h_thr(static_cast<size_t>(F) * B);
-    float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, h_thr.size())));
-    uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, h_thr.size())));
+    // thresholds and scales reach the host through ONE pinned block, copied behind the binning kernel: nothing waits for them
+    // until the first level's result block has arrived
+    const size_t n_thr = static_cast<size_t>(F) * B;
+    char *pin_ts = static_cast<char *>(pin_thr_.ensure(sizeof(float) * std::max<size_t>(1, n_thr) + sizeof(kern::StepScales) + 64));
+    float *h_thr = reinterpret_cast<float *>(pin_ts);
+    kern::StepScales *h_scales_pin = reinterpret_cast<kern::StepScales *>(pin_ts + ((sizeof(float) * std::max<size_t>(1, n_thr) + 63) & ~static_cast<size_t>(63)));
+    float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, n_thr)));
+    uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, n_thr)));
     uint32_t *d_kt = nullptr;
     if (F > 0) {
         // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
@@ -1229,7 +1232,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     }
     phase_end("transpose");
     phase_begin();
-    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, h_thr);
+    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys);
     phase_end("candidates");
 
     // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the
@@ -1272,8 +1275,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     }
 
     if (candidates_only_) {   // fit(): only the candidates of this (whole) data set are wanted
+        if (n_thr) hip_check(hipMemcpyAsync(h_thr, d_thr, sizeof(float) * n_thr, hipMemcpyDeviceToHost, s), "D2H thr");
         hip_check(hipStreamSynchronize(s), "sync");
-        fixed_thr_ = h_thr;
+        fixed_thr_.assign(h_thr, h_thr + n_thr);
         if (Fc > 0) {
             if (!cat_codes_on_device)
                 throw Unsupported("fit(): the data set holds more distinct categories than Fc * n_bins (mean-gradient ranking of the whole data set is not implemented)");
@@ -1338,13 +1342,15 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
     }
     phase_end("binning");
+    if (n_thr) hip_check(hipMemcpyAsync(h_thr, d_thr, sizeof(float) * n_thr, hipMemcpyDeviceToHost, s), "D2H thr");
+    hip_check(hipMemcpyAsync(h_scales_pin, d_scales, sizeof(kern::StepScales), hipMemcpyDeviceToHost, s), "D2H scales");
 
     // ---- 4. growth (level-synchronous; Engine::grow_tree) and 5. leaf sums --------------------------------------------------
     GrowCtx gc{};
     gc.N = N; gc.F = F; gc.Fc = Fc; gc.D = D; gc.B = B; gc.MD = MD; gc.NB = NB; gc.FG = FG; gc.Fp = Fp; gc.n_groups = n_groups;
     gc.n_slots = n_slots; gc.n_cand = n_cand; gc.chunk_rows = chunk_rows; gc.n_global = n_global; gc.cosine = cosine; gc.oblivious = oblivious;
     gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cat_cands = &cat_cands;
-    gc.h_thr = &h_thr; gc.d_thr = d_thr; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;
     std::vector<int64_t> acc;
