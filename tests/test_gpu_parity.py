@@ -200,15 +200,15 @@ def test_quantile_thresholds_bit_exact_at_scale():
 
 
 def test_full_size_properties_config2_shape():
-    """BASELINE configs[1] shape (oblivious / L2 / quantile, F=128, D=8, depth 6) at N=2^18 through size-independent
+    """BASELINE configs[1] at its FULL size (oblivious / L2 / quantile, N=2^20, F=128, D=8, depth 6) through size-independent
     properties: (1) predict(X) after one tree with lr=1 returns -(leaf mean) so the per-leaf means of G reproduce the
     stored values; (2) leaf counts from edge weights multiply to the leaf population; (3) the tree is a proper
     oblivious tree (same condition per level for all leaves); (4) adding a constant to G leaves the structure unchanged
     (L2 standardisation is shift invariant)."""
     import gbrl_amd
     rng = np.random.default_rng(0)
-    N, F, D = 1 << 18, 128, 8
-    X = rng.standard_normal((N, F)).astype(np.float32)
+    N, F, D = 1 << 20, 128, 8
+    X = rng.standard_normal((N, F), dtype=np.float32)
     W = rng.standard_normal((8, D)).astype(np.float32)
     G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((N, D))).astype(np.float32)
     case = dict(name="c2", seed=0, N=N, F=F, D=D, depth=6, n_bins=256, score="L2", gen="Quantile", policy="oblivious",
@@ -240,6 +240,53 @@ def test_full_size_properties_config2_shape():
     e2 = m2.get_ensemble_data()
     assert np.array_equal(np.asarray(e2["feature_indices"]), np.asarray(e["feature_indices"]))
     assert np.array_equal(np.asarray(e2["feature_values"]), np.asarray(e["feature_values"]))
+
+
+def test_full_size_properties_config3_shape():
+    """BASELINE configs[2] at its FULL size (greedy / Cosine / quantile, N=2^20, F=128, D=8 = policy [0,7) lr 0.1 + value [7,8)
+    lr 0.01, depth 6): (1) the leaves partition the rows (every row satisfies exactly one leaf's path); (2) leaf values are the
+    exact means of the raw gradients over the leaf's rows; (3) edge weights multiply to the leaf's share of the rows; (4) predict
+    returns bias - lr_k * value[leaf(row)] per optimiser range, bit for bit."""
+    import gbrl_amd
+    rng = np.random.default_rng(1)
+    N, F, D = 1 << 20, 128, 8
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    W = rng.standard_normal((8, D)).astype(np.float32)
+    G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    case = dict(name="c3", seed=0, N=N, F=F, D=D, depth=6, n_bins=256, score="Cosine", gen="Quantile", policy="greedy", trees=1,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
+                      dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)])
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pred = np.asarray(K.drive(m, case, X, None, G, None))
+    e = m.get_ensemble_data()
+    fi, fv = np.asarray(e["feature_indices"]), np.asarray(e["feature_values"])
+    dirs, dep, vals = np.asarray(e["inequality_directions"]), np.asarray(e["depths"]), np.asarray(e["values"])
+    L = vals.shape[0]
+    assert 2 <= L <= 64 and int(dep.max()) <= 6
+    owner = np.full(N, -1, np.int64)
+    hits = np.zeros(N, np.int32)
+    cols = {}
+    for leaf in range(L):
+        ok = np.ones(N, bool)
+        for d in range(int(dep[leaf])):
+            key = (int(fi[leaf, d]), float(fv[leaf, d]))
+            if key not in cols:
+                cols[key] = X[:, key[0]] > np.float32(key[1])
+            ok &= cols[key] == bool(dirs[leaf, d])
+        hits += ok
+        owner[ok] = leaf
+    assert hits.min() == 1 and hits.max() == 1                                             # (1)
+    cnt = np.bincount(owner, minlength=L)
+    for leaf in range(L):                                                                  # (2)
+        if cnt[leaf]:
+            want = G[owner == leaf].astype(np.float64).mean(axis=0)
+            assert np.max(np.abs(vals[leaf] - want) / np.maximum(np.abs(want), 0.5)) < 1e-6
+    ew = np.asarray(e["edge_weights"]).astype(np.float64)                                  # (3)
+    share = np.array([np.prod(ew[leaf, :int(dep[leaf])]) for leaf in range(L)])
+    assert np.allclose(share * N, cnt, rtol=1e-5, atol=0.5)
+    lr = np.array([0.1] * 7 + [0.01], np.float32)                                          # (4)
+    want_pred = (np.float32(0) - lr[None, :] * vals[owner]).astype(np.float32)
+    assert np.array_equal(pred, want_pred)
 
 
 def test_fast_quantile_path_equals_bisection_path(monkeypatch):
