@@ -521,15 +521,35 @@ __global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist,
         double x = side_term(total, D, n_tot, inv_scale);
         parent[node] = static_cast<float>(cosine ? sqrt(x) : x);
     }
-    const int plen = path_len[node];
+    // the node's path conditions on THIS feature slot, staged once per block (a candidate that repeats one of them is rejected,
+    // node.cpp:154-166); reading the path arrays from global memory inside the candidate loop costs a memory round trip per
+    // path entry and thread at the deep levels
+    __shared__ float s_pval[kMaxPath];
+    __shared__ int s_pbin[kMaxPath];
+    __shared__ int s_np;
+    if (threadIdx.x == 0) {
+        const int plen = path_len[node];
+        int np = 0;
+        for (int p = 0; p < plen; ++p)
+            if (path_slot[node * kMaxPath + p] == fs) {
+                s_pval[np] = path_val[node * kMaxPath + p];
+                s_pbin[np] = path_bin[node * kMaxPath + p];
+                ++np;
+            }
+        s_np = np;
+    }
+    __syncthreads();
+    const int np = s_np;
     for (int k = threadIdx.x; k < sl.n_cand; k += blockDim.x) {
         const int64_t *R = sh64 + (k + 1) * W;
         const int64_t n_r = R[D], n_l = n_tot - n_r;
         bool reject = (n_l < min_data) || (n_r < min_data);
-        for (int p = 0; p < plen; ++p) {
-            if (path_slot[node * kMaxPath + p] != fs) continue;
-            if (sl.is_cat) reject |= (path_bin[node * kMaxPath + p] == k + 1);
-            else reject |= (path_val[node * kMaxPath + p] == thr[static_cast<size_t>(fs) * B + k]);
+        if (np > 0) {
+            const float tk = sl.is_cat ? 0.0f : thr[static_cast<size_t>(fs) * B + k];
+            for (int p = 0; p < np; ++p) {
+                if (sl.is_cat) reject |= (s_pbin[p] == k + 1);
+                else reject |= (s_pval[p] == tk);
+            }
         }
         float out;
         if (reject) {
