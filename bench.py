@@ -147,9 +147,10 @@ def main():
     m.set_feature_weights(np.ones(F, np.float32))
     m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
     m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
-    # level 1: HIP events around the dominant kernel's launches only (k_hist_build), recorded on the engine's own stream and
-    # resolved after each call -- no sync inside the step, 12 records per step.  The full phase table needs ~60 records per
-    # step, each a few-microsecond stream bubble, so it is taken in a separate diagnostic pass after the timed region.
+    # level 1: one HIP event pair per k_hist_build launch, attached to the dispatch itself (hipExtLaunchKernelGGL start/stop
+    # events on the engine's own stream: the kernel's begin/end timestamps, no extra packet in the stream), resolved after each
+    # call -- no sync inside the step.  The full phase table needs ~60 hipEventRecord calls per step, each a few-microsecond
+    # stream bubble, so it is taken in a separate diagnostic pass after the timed region.
     m.set_profiling(1)
     coll, exchange = None, None
     if world > 1 or args.force_collective:

@@ -100,6 +100,7 @@ class Engine {
     void phase_begin(bool key = false);
     void phase_end(const char *name, bool key = false);
     void phases_resolve();
+    std::pair<hipEvent_t, hipEvent_t> kernel_events(const char *name, bool key);   // event pair for one dispatch's own timestamps
 
     int device_ordinal_ = -1;
     bool device_ready_ = false;

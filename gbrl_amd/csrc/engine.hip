@@ -196,6 +196,17 @@ void Engine::phase_end(const char *name, bool key) {
     ev_names_.push_back(name);
     ++ev_used_;
 }
+std::pair<hipEvent_t, hipEvent_t> Engine::kernel_events(const char *name, bool key) {
+    if (profiling_ < (key ? 1 : 2)) return {nullptr, nullptr};
+    if (ev_used_ == ev_pool_.size()) {
+        hipEvent_t a, b;
+        hip_check(hipEventCreate(&a), "hipEventCreate");
+        hip_check(hipEventCreate(&b), "hipEventCreate");
+        ev_pool_.push_back({a, b});
+    }
+    ev_names_.push_back(name);
+    return ev_pool_[ev_used_++];
+}
 void Engine::phases_resolve() {
     phases_.clear();
     if (!profiling_) return;
@@ -935,10 +946,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         int32_t *d_seg_starts = sta.put(seg_starts.data(), seg_starts.size());
         int32_t *d_n_locals = sta.put(n_locals.data(), n_locals.size());
         sta.flush();
-        phase_begin(/*key=*/true);
-        if (!h_chunks.empty())
-            kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s);
-        phase_end("hist_build", /*key=*/true);
+        if (!h_chunks.empty()) {
+            const auto ev = kernel_events("hist_build", /*key=*/true);   // the dispatch's own timestamps: no bubble in the stream
+            kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s,
+                             ev.first, ev.second);
+        }
         phase_begin();
         if (!has_coll_) {
             if (!compute_ids.empty())

@@ -137,7 +137,8 @@ constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [gro
 // ---- split-score histograms (A6) ----
 size_t hist_lds_bytes(int NB, int D, int FG);
 void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
-                const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s);
+                const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s,
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /*the dispatch's own begin / end timestamps*/);
 // hist[slot_map ? slot_map[k] : k] = sum of the partials of chunk-slot k
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
                  int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);

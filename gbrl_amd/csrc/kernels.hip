@@ -5,6 +5,8 @@
 // (deterministic, and bit-identical for 1/2/4/8 row shards).  Scores are evaluated in fp64 from those exact sums and
 // rounded to fp32 once, then compared the way the reference compares them (fitter.cpp:332-341, 435-444).
 #include "kernels.h"
+
+#include <hip/hip_ext.h>
 #include "cat_hash.h"
 
 #include <algorithm>
@@ -1215,7 +1217,8 @@ size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * 
 
 template <int DT, int U>
 static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
-                        int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s) {
+                        int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
+                        hipEvent_t ev_start, hipEvent_t ev_stop) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1223,19 +1226,21 @@ static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, in
         attr_set = true;
     }
     const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
-    hipLaunchKernelGGL((k_hist_build<DT, U>), dim3(grid), dim3(kHistThreads), lds, s, codes, n_rows, qg, D, rows, chunks, n_chunks,
-                       n_groups, FG, shift, NB, partials);
+    // ev_start / ev_stop (nullable): the dispatch's own begin / end timestamps -- no extra packets in the stream, unlike
+    // hipEventRecord around the launch
+    hipExtLaunchKernelGGL((k_hist_build<DT, U>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D, rows,
+                          chunks, n_chunks, n_groups, FG, shift, NB, partials);
 }
 
 void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
-                int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s) {
+                int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
 #ifndef GBRL_HIST_U
 #define GBRL_HIST_U 8
 #endif
-#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s); return;
+#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop); return;
     if (FG == 16) {
         switch (D) {
             GBRL_HIST_CASE(1) GBRL_HIST_CASE(2) GBRL_HIST_CASE(3) GBRL_HIST_CASE(4) GBRL_HIST_CASE(5) GBRL_HIST_CASE(6)
@@ -1244,7 +1249,7 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
         }
     }
 #undef GBRL_HIST_CASE
-    launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s);
+    launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
 }
 
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,

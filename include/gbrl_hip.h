@@ -180,7 +180,7 @@ int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int 
  * names/ms hold up to `cap` entries; returns the number of phases. */
 int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float *ms, int cap);
 /* level 0 (default): no events.  1: only the dominant kernel's launches (histogram build in step(), the traversal kernel in
- * predict()) are bracketed -- two event records per launch, cheap enough for a timed region.  2: every phase is bracketed
+ * predict()) are timed -- step(): the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL events), free for a timed region.  2: every phase is bracketed
  * (diagnostic: each record costs a few microseconds of stream bubble, ~60 records per step). */
 int gbrl_hip_set_profiling(gbrl_hip_model *m, int level);
 
