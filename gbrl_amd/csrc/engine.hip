@@ -874,7 +874,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         int64_t *d_hist = d_hist_lvl[depth & 1];
         const int64_t *d_hist_prev = d_hist_lvl[(depth & 1) ^ 1];
         std::vector<int> compute_ids;
-        std::vector<int32_t> slot_map, sub_entries;
+        std::vector<int32_t> slot_map, sub_par(n_act, -1), sub_sib(n_act, -1);
         if (depth == 0) {
             compute_ids = active;
             for (int k = 0; k < n_act; ++k) slot_map.push_back(k);
@@ -893,9 +893,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                     compute_ids.push_back(id);
                     slot_map.push_back(k);
                 } else {
-                    sub_entries.push_back(k);
-                    sub_entries.push_back(nodes[par].hist_slot);
-                    sub_entries.push_back(sib_active ? slot_of[sib] : -1);
+                    sub_par[k] = nodes[par].hist_slot;
+                    sub_sib[k] = sib_active ? slot_of[sib] : -1;
                 }
             }
         }
@@ -922,7 +921,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         Chunk *d_chunks = sta.put(h_chunks.data(), h_chunks.size());
         int32_t *d_chunk_begin = sta.put(h_chunk_begin.data(), h_chunk_begin.size());
         int32_t *d_slotmap = sta.put(slot_map.data(), slot_map.size());
-        int32_t *d_subent = sta.put(sub_entries.data(), sub_entries.size());
+        int32_t *d_sub_par = sta.put(sub_par.data(), sub_par.size());
+        int32_t *d_sub_sib = sta.put(sub_sib.data(), sub_sib.size());
         int32_t *d_path_len = sta.put(pl.data(), pl.size());
         int32_t *d_path_slot = sta.put(ps.data(), ps.size());
         float *d_path_val = sta.put(pv.data(), pv.size());
@@ -962,12 +962,10 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             exchange(Red::SumI64, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems);
             kern::hist_place(d_hist_coll, d_hist, d_slotmap, nc, hist_node_elems, s);
         }
-        if (!sub_entries.empty())
-            kern::hist_subtract(d_hist_prev, d_hist, d_subent, static_cast<int>(sub_entries.size() / 3), hist_node_elems, s);
         phase_end("hist_reduce");
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
-        kern::score_candidates(d_hist, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
+        kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows

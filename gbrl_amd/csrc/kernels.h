@@ -143,10 +143,11 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
                  int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);
 // cur[dst] = prev[parent] - cur[sibling]  (entries: triples {dst, parent, sibling or -1})
-void hist_subtract(const int64_t *prev, int64_t *cur, const int32_t *entries, int n_entries, size_t node_elems, hipStream_t s);
 
 // ---- scoring / selection (A6, A7, A8) ----
-void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
+// sub_par[node] >= 0: the node's histogram is hist_prev[sub_par] - hist[sub_sib] (sub_sib < 0: no sibling rows) -- computed,
+// scored AND written back by the kernel (fused sibling subtraction); sub_par nullable
+void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *sub_par, const int32_t *sub_sib, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
                       const float *thr /*[F][B]*/, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/, hipStream_t s);

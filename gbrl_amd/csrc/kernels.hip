@@ -414,18 +414,6 @@ __global__ void k_hist_reduce(const int32_t *__restrict__ partials, const int32_
     hist[((static_cast<size_t>(slot) * Fp + g * FG + fl) * NB + cls) * (D + 1) + d] = s;
 }
 
-// Sibling subtraction: the histogram of the larger child is parent - smaller child (exact: integers).  entry =
-// {dst slot, parent slot in the previous level's buffer, slot of the computed sibling or -1 (sibling has no rows)}.
-__global__ void k_hist_subtract(const int64_t *__restrict__ prev, int64_t *__restrict__ cur, const int32_t *__restrict__ entries,
-                                size_t node_elems) {
-    const int32_t dst = entries[blockIdx.y * 3 + 0], par = entries[blockIdx.y * 3 + 1], sib = entries[blockIdx.y * 3 + 2];
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < node_elems;
-         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        const int64_t p = prev[static_cast<size_t>(par) * node_elems + i];
-        cur[static_cast<size_t>(dst) * node_elems + i] = sib >= 0 ? p - cur[static_cast<size_t>(sib) * node_elems + i] : p;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // A6/A7  candidate scores from the exact histograms.  One block per (node, feature slot).
 //   numeric candidate k : right = classes > k (suffix sum), left = total - right
@@ -456,7 +444,8 @@ __device__ __forceinline__ long long dpp_scan_step(long long x) {
     return x + ((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
-__global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist, int Fp, int NB, int D,
+__global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const int64_t *__restrict__ hist_prev,
+                                               const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib, int Fp, int NB, int D,
                                                const FeatureSlot *__restrict__ slots, const float *__restrict__ thr,
                                                int B, int n_cand, int min_data, int cosine, const StepScales *__restrict__ scp,
                                                const int32_t *__restrict__ path_len, const int32_t *__restrict__ path_slot,
@@ -467,8 +456,22 @@ __global__ __launch_bounds__(256) void k_score(const int64_t *__restrict__ hist,
     const int node = blockIdx.y, fs = blockIdx.x;
     const FeatureSlot sl = slots[fs];
     const int W = D + 1;
-    const int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
-    for (int i = threadIdx.x; i < NB * W; i += blockDim.x) sh64[i] = src[i];
+    int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
+    const int par = sub_par ? sub_par[node] : -1;
+    if (par >= 0) {
+        // sibling subtraction fused here: this node was not accumulated from the data; its histogram is parent - sibling (exact
+        // integers).  The slice is written back because the next level subtracts from it and k_resolve_splits reads it.
+        const int sib = sub_sib[node];
+        const int64_t *pp = hist_prev + (static_cast<size_t>(par) * Fp + fs) * NB * W;
+        const int64_t *ss = sib >= 0 ? hist + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
+        for (int i = threadIdx.x; i < NB * W; i += blockDim.x) {
+            const int64_t v = pp[i] - (ss ? ss[i] : 0);
+            sh64[i] = v;
+            src[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < NB * W; i += blockDim.x) sh64[i] = src[i];
+    }
     __syncthreads();
     // totals = sum over all classes; also turn numeric features into suffix sums in place.  Block-wide scan: thread t of a
     // 256-class tile owns class NB-1-(tile*256+t), so an inclusive prefix over t is the suffix sum over classes.  Up to 9
@@ -1259,12 +1262,8 @@ void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const
     hipLaunchKernelGGL(k_hist_reduce, grid, dim3(256), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
 }
 
-void hist_subtract(const int64_t *prev, int64_t *cur, const int32_t *entries, int n_entries, size_t node_elems, hipStream_t s) {
-    dim3 grid(static_cast<unsigned>(std::min<size_t>(256, (node_elems + 255) / 256)), n_entries);
-    hipLaunchKernelGGL(k_hist_subtract, grid, dim3(256), 0, s, prev, cur, entries, node_elems);
-}
-
-void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
+void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *sub_par, const int32_t *sub_sib, int n_nodes, int Fp, int NB,
+                      int D, const FeatureSlot *slots, int n_slots,
                       const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, hipStream_t s) {
@@ -1274,7 +1273,7 @@ void score_candidates(const int64_t *hist, int n_nodes, int Fp, int NB, int D, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, Fp, NB, D, slots, thr, B, n_cand, min_data,
+    hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
                        cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent);
 }
 
