@@ -29,6 +29,7 @@ constexpr int kNone = 0xffff;
 constexpr int kRadixThreads = 1024;
 constexpr int kMaxTargets = 256;
 constexpr int kChunks1 = 8;               // pass 1: small LDS footprint, many blocks
+constexpr int kCopies1 = 4;               // pass 1: lane-interleaved private copies of the 4096-bin histogram (power of two)
 constexpr int kChunksN = 8;               // upper bound of chunks in passes 2..4 (2 at F >= 128: one 128 KB block per CU)
 constexpr int kSlotStride = 128;          // digits per slot in the partials of passes 2..4
 
@@ -58,10 +59,12 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     constexpr int NB = radix_bins(PASS);
     constexpr int SH = radix_shift(PASS);
     const int f = blockIdx.y;
-    const int n_slots = PASS == 1 ? 1 : static_cast<int>(st.n_slots[f * 4 + (PASS - 2)]);
+    // pass 1 keeps kCopies1 private copies of its (small) histogram, chosen by the lane: keys of real data concentrate on a few
+    // first digits, and same-address LDS atomics of one wave serialise
+    const int n_slots = PASS == 1 ? kCopies1 : static_cast<int>(st.n_slots[f * 4 + (PASS - 2)]);
     const int n_cnt = n_slots * NB;
     uint32_t *cnt = rl;                                                        // [n_slots][NB]
-    uint16_t *map1 = reinterpret_cast<uint16_t *>(rl + (PASS == 1 ? kBins1 : kMaxTargets * NB));   // [4096]
+    uint16_t *map1 = reinterpret_cast<uint16_t *>(rl + (PASS == 1 ? kCopies1 * kBins1 : kMaxTargets * NB));   // [4096]
     uint64_t *cbits = reinterpret_cast<uint64_t *>(map1 + kBins1);             // [2][256][2]
     uint16_t *coff = reinterpret_cast<uint16_t *>(cbits + 2 * 512);            // [2][258]
     uint32_t *filt = reinterpret_cast<uint32_t *>(coff + 2 * 260);             // [2048] 65536-bit hashed set of the live prefixes
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
         return coff[level * 258 + slot] + below;
     };
     auto count_one = [&](uint32_t key) {
-        int slot = 0;
+        int slot = PASS == 1 ? static_cast<int>(__lane_id() & (kCopies1 - 1)) : 0;
         if (PASS >= 2) {
             slot = map1[key >> 20];
             if (PASS >= 3 && slot != kNone) slot = child(0, slot, (key >> 13) & 127);
@@ -177,7 +180,12 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     if (PASS == 3 && threadIdx.x == 0) st.list_cnt[f * n_chunks + blockIdx.x] = list_cursor;
     uint32_t *dst = partial + (static_cast<size_t>(f) * n_chunks + blockIdx.x) * (PASS == 1 ? kBins1 : kMaxTargets * kSlotStride);
     if (PASS == 1) {
-        for (int i = threadIdx.x; i < kBins1; i += kRadixThreads) dst[i] = cnt[i];
+        for (int i = threadIdx.x; i < kBins1; i += kRadixThreads) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < kCopies1; ++c) v += cnt[c * kBins1 + i];
+            dst[i] = v;
+        }
     } else {
         for (int i = threadIdx.x; i < n_cnt; i += kRadixThreads) dst[(i / NB) * kSlotStride + (i % NB)] = cnt[i];
     }
@@ -366,7 +374,7 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
     st.list_cnt = reinterpret_cast<uint32_t *>(take(f * kChunksN * 4));
     st.lists = lists;
     const size_t aux = kBins1 * 2 + 2 * 512 * 8 + 2 * 260 * 2 + 2048 * 4;
-    const size_t lds1 = kBins1 * 4 + aux, lds23 = static_cast<size_t>(kMaxTargets) * 128 * 4 + aux,
+    const size_t lds1 = static_cast<size_t>(kCopies1) * kBins1 * 4 + aux, lds23 = static_cast<size_t>(kMaxTargets) * 128 * 4 + aux,
                  lds4 = static_cast<size_t>(kMaxTargets) * 64 * 4 + aux;
     static bool attr = false;
     if (!attr) {
