@@ -134,7 +134,7 @@ class Engine {
     DevBuf d_radix_state_, d_radix_partial_, d_radix_global_, d_scales_;
     DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
     DevBuf d_hist_prev_, d_slotmap_, d_am_v_, d_am_i_, d_stage_const_, d_stage_a_, d_stage_b_, d_results_;
-    PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_, pin_thr_;
+    PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_, pin_thr_, pin_acc_;
     DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
     DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_;

@@ -987,7 +987,12 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved,
                                      d_cursors, s);
             phase_end("partition");
-            hip_check(hipEventSynchronize(ev_level_), "hipEventSynchronize(level results)");
+            // spin on the event (a blocking wait costs a thread wake-up of ~10-20 us per level; the wait itself is a few tens of us)
+            for (;;) {
+                const hipError_t q = hipEventQuery(ev_level_);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) hip_check(q, "hipEventQuery(level results)");
+            }
         }
         hip_check(hipGetLastError(), "growth kernels");
         const int32_t *best_idx_h = reinterpret_cast<const int32_t *>(h_res);
@@ -1107,9 +1112,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     if (has_coll_) {
         exchange(Red::SumI64, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1));
     }
-    acc.assign(nodes.size() * (D + 1), 0);
-    hip_check(hipMemcpyAsync(acc.data(), d_leafacc, sizeof(int64_t) * acc.size(), hipMemcpyDeviceToHost, s), "D2H leaf acc");
+    const size_t n_acc_words = nodes.size() * (D + 1);
+    int64_t *h_acc = static_cast<int64_t *>(pin_acc_.ensure(sizeof(int64_t) * std::max<size_t>(1, n_acc_words)));   // pinned: a true async copy
+    hip_check(hipMemcpyAsync(h_acc, d_leafacc, sizeof(int64_t) * n_acc_words, hipMemcpyDeviceToHost, s), "D2H leaf acc");
     hip_check(hipStreamSynchronize(s), "sync");
+    acc.assign(h_acc, h_acc + n_acc_words);
     // everything enqueued for this tree has completed: scales are in pinned memory
     if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
     leaf_scale = c.h_scales->leaf_scale;
