@@ -129,6 +129,16 @@ def test_depth_limits():
     _check(case, X, Xc, G)
 
 
+@pytest.mark.parametrize("n_bins", [300, 1000])
+def test_more_than_256_bins_use_the_sample_splitter_selection(n_bins):
+    """The radix multi-select handles <= 256 ranks per feature; more bins fall back to the sample-splitter selection (exact as
+    well) and a histogram with more classes."""
+    for policy, gen in (("oblivious", "Quantile"), ("greedy", "Uniform")):
+        case = _case("bins%d" % n_bins, N=6000, F=5, D=2, depth=4, n_bins=n_bins, policy=policy, gen=gen, trees=2)
+        X, Xc, G, y = K.make_inputs(case)
+        _check(case, X, Xc, G)
+
+
 def test_overlapping_optimizer_ranges_fall_back_to_the_general_kernel():
     case = _case("ovl", D=3, policy="oblivious", trees=3,
                  opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=3),
