@@ -263,6 +263,8 @@ struct GrowCtx {
     const float *h_thr;                 // pinned; valid once the stream has passed the copy enqueued behind the binning
     const kern::StepScales *h_scales;   // pinned, same
     const float *d_thr;
+    const uint32_t *d_thrkeys;   // [F][B] ordered keys of the thresholds
+    const uint32_t *d_kt;        // [F][N] feature-major ordered keys of the observations (null when F == 0)
     const uint16_t *d_codes;
     const int32_t *d_qg;
     const float *dgrads;
@@ -970,12 +972,12 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
         kern::resolve_splits(d_am_v, d_am_i, am_parts, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
-                             d_counts4, max_front, d_seg_starts, d_cursors, s);
+                             d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s);
         if (has_coll_) {
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
             hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
             if (!count_chunks.empty())
-                kern::count_right(d_rows[cur], d_codes, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
+                kern::count_right(d_rows[cur], d_codes, c.d_kt, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
             kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);   // global left sizes -> this rank's
         }
         hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
@@ -984,7 +986,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");
             phase_begin();
             if (!part_chunks.empty())
-                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved,
+                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, c.d_kt, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved,
                                      d_cursors, s);
             phase_end("partition");
             // spin on the event (a blocking wait costs a thread wake-up of ~10-20 us per level; the wait itself is a few tens of us)
@@ -1367,7 +1369,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     gc.N = N; gc.F = F; gc.Fc = Fc; gc.D = D; gc.B = B; gc.MD = MD; gc.NB = NB; gc.FG = FG; gc.Fp = Fp; gc.n_groups = n_groups;
     gc.n_slots = n_slots; gc.n_cand = n_cand; gc.chunk_rows = chunk_rows; gc.n_global = n_global; gc.cosine = cosine; gc.oblivious = oblivious;
     gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cat_cands = &cat_cands;
-    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;
     std::vector<int64_t> acc;

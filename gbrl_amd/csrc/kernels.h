@@ -33,7 +33,9 @@ struct NodeSplit {
     int32_t is_cat;
     int32_t seg_start;  // first position of the node's segment
     int32_t n_left;     // rows going left (right child starts at seg_start + n_left)
-    int32_t pad0, pad1;
+    uint32_t thr_key;   // numeric: ordered key of the threshold -- right <=> key(row, feature) > thr_key, read from the
+                        // feature-major keys (4 coalesced bytes per row instead of a 32-byte code record)
+    int32_t pad1;
 };
 
 // Fixed-point scales of one step, derived from the gradient statistics.  They live in device memory so that the whole
@@ -165,16 +167,16 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
                     NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front,
                     const int32_t *seg_start /*nullable: when given, out[] is a complete partition descriptor (do_split from
                     best_score, seg_start, n_left from hist_local) and cursors[2*node..] are zeroed*/,
-                    int32_t *cursors, hipStream_t s);
+                    int32_t *cursors, const uint32_t *thr_keys /*[F][B] ordered threshold keys*/, int B, hipStream_t s);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);
 void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n, size_t node_elems, hipStream_t s);
-void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
+void count_right(const int32_t *rows, const uint16_t *codes, const uint32_t *kt /*nullable: feature-major keys*/, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
                  int64_t *n_right /*[n_nodes], zeroed*/, hipStream_t s);
 
 // ---- partition (A9) ----
-void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows,
+void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, const uint32_t *kt /*nullable*/, int n_rows,
                     const Chunk *chunks, int n_chunks, const NodeSplit *splits, int32_t *cursors /*[n_nodes*2], zeroed*/,
                     hipStream_t s);
 

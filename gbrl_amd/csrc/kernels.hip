@@ -633,7 +633,8 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                                                        const FeatureSlot *__restrict__ slots, const int64_t *__restrict__ hist_local,
                                                        const int64_t *__restrict__ hist_global, int Fp, int NB, int D,
                                                        NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front,
-                                                       const int32_t *__restrict__ seg_start /*nullable*/, int32_t *__restrict__ cursors) {
+                                                       const int32_t *__restrict__ seg_start /*nullable*/, int32_t *__restrict__ cursors,
+                                                       const uint32_t *__restrict__ thr_keys, int B) {
     const int node = blockIdx.x;
     // final stage of the argmax (same total order as stage 1: higher score, then lower reference index): every block
     // reduces the per-block bests of its node (oblivious: of the level); the owner block publishes them for the host
@@ -672,6 +673,7 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     if (threadIdx.x == 0) {
         NodeSplit q{};
         q.fslot = fs; q.bin = bin; q.is_cat = sl.is_cat;
+        q.thr_key = (!sl.is_cat && thr_keys) ? thr_keys[static_cast<size_t>(fs) * B + bin] : 0u;
         if (seg_start) {
             // complete descriptor: the partition of this level is enqueued without waiting for the host's read-back.
             // Same decision rule as the host (fitter.cpp:357 greedy: score >= 0; fitter.cpp:458 oblivious: any finite best)
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
 constexpr int kPartThreads = 1024;
 constexpr int kPartRows = 4096;  // rows per block: 4 per thread, all loads issued before the ballots
 __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__restrict__ rows_in, int32_t *__restrict__ rows_out,
-                                                            const uint16_t *__restrict__ codes, int n_rows,
+                                                            const uint16_t *__restrict__ codes, const uint32_t *__restrict__ kt, int n_rows,
                                                             const Chunk *__restrict__ chunks, const NodeSplit *__restrict__ splits,
                                                             int32_t *__restrict__ cursors) {
     const Chunk ck = chunks[blockIdx.x];
@@ -710,11 +712,19 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__res
         const int p = u * kPartThreads + threadIdx.x;
         row[u] = p < ck.len ? rows_in[ck.start + p] : -1;
     }
-    const uint16_t *cbase = codes + (static_cast<size_t>(sp.fslot >> 4) * n_rows) * kCodeGroup + (sp.fslot & (kCodeGroup - 1));
+    if (!sp.is_cat && kt) {
+        // numeric split: code > bin <=> key > threshold key (the thresholds are sorted); the keys are feature-major, so the rows
+        // of a node cost 4 bytes each instead of a 32-byte code record
+        const uint32_t *kcol = kt + static_cast<size_t>(sp.fslot) * n_rows;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int code = row[u] >= 0 ? cbase[static_cast<size_t>(row[u]) * kCodeGroup] : 0;
-        right[u] = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
+        for (int u = 0; u < U; ++u) right[u] = row[u] >= 0 && kcol[row[u]] > sp.thr_key;
+    } else {
+        const uint16_t *cbase = codes + (static_cast<size_t>(sp.fslot >> 4) * n_rows) * kCodeGroup + (sp.fslot & (kCodeGroup - 1));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int code = row[u] >= 0 ? cbase[static_cast<size_t>(row[u]) * kCodeGroup] : 0;
+            right[u] = sp.is_cat ? (code == sp.bin) : (code > sp.bin);
+        }
     }
     // destination slots: ballots give the rank inside a wave; per-(wave,u) counts are scanned in LDS and the block reserves
     // its range with ONE global atomic per side (at level 0 every wave of the grid would otherwise hit the same two words).
@@ -750,15 +760,20 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__res
 }
 
 __global__ __launch_bounds__(kPartThreads) void k_count_right(const int32_t *__restrict__ rows, const uint16_t *__restrict__ codes,
-                                                              int n_rows, const Chunk *__restrict__ chunks,
+                                                              const uint32_t *__restrict__ kt, int n_rows, const Chunk *__restrict__ chunks,
                                                               const NodeSplit *__restrict__ splits, int64_t *__restrict__ n_right) {
     const Chunk ck = chunks[blockIdx.x];
     const NodeSplit sp = splits[ck.slot];
     const uint16_t *cbase = codes + (static_cast<size_t>(sp.fslot >> 4) * n_rows) * kCodeGroup + (sp.fslot & (kCodeGroup - 1));
     int c = 0;
-    for (int p = threadIdx.x; p < ck.len; p += kPartThreads) {
-        const int code = cbase[static_cast<size_t>(rows[ck.start + p]) * kCodeGroup];
-        c += (sp.is_cat ? (code == sp.bin) : (code > sp.bin)) ? 1 : 0;
+    if (!sp.is_cat && kt) {
+        const uint32_t *kcol = kt + static_cast<size_t>(sp.fslot) * n_rows;
+        for (int p = threadIdx.x; p < ck.len; p += kPartThreads) c += kcol[rows[ck.start + p]] > sp.thr_key ? 1 : 0;
+    } else {
+        for (int p = threadIdx.x; p < ck.len; p += kPartThreads) {
+            const int code = cbase[static_cast<size_t>(rows[ck.start + p]) * kCodeGroup];
+            c += (sp.is_cat ? (code == sp.bin) : (code > sp.bin)) ? 1 : 0;
+        }
     }
     for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
     __shared__ int wsum[kPartThreads / kWave];
@@ -1289,9 +1304,10 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const 
 }
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
-                    NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, hipStream_t s) {
+                    NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, const uint32_t *thr_keys,
+                    int B, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, part_v, part_i, n_parts, best_idx, best_score, oblivious ? 1 : 0,
-                       ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors);
+                       ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors, thr_keys, B);
 }
 
 // Row-sharded runs: k_resolve_splits wrote GLOBAL left sizes; the partition needs this rank's.
@@ -1316,14 +1332,14 @@ void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n
     hipLaunchKernelGGL(k_hist_place, dim3(bx, n), dim3(256), 0, s, src, dst, slot_map, node_elems);
 }
 
-void count_right(const int32_t *rows, const uint16_t *codes, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
-                 int64_t *n_right, hipStream_t s) {
-    hipLaunchKernelGGL(k_count_right, dim3(n_chunks), dim3(kPartThreads), 0, s, rows, codes, n_rows, chunks, splits, n_right);
+void count_right(const int32_t *rows, const uint16_t *codes, const uint32_t *kt, int n_rows, const Chunk *chunks, int n_chunks,
+                 const NodeSplit *splits, int64_t *n_right, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_right, dim3(n_chunks), dim3(kPartThreads), 0, s, rows, codes, kt, n_rows, chunks, splits, n_right);
 }
 
-void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, int n_rows, const Chunk *chunks,
+void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, const uint32_t *kt, int n_rows, const Chunk *chunks,
                     int n_chunks, const NodeSplit *splits, int32_t *cursors, hipStream_t s) {
-    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(kPartThreads), 0, s, rows_in, rows_out, codes, n_rows, chunks, splits,
+    hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(kPartThreads), 0, s, rows_in, rows_out, codes, kt, n_rows, chunks, splits,
                        cursors);
 }
 
