@@ -303,7 +303,9 @@ constexpr int kHistThreads = 1024;
 // Broadcast lane `SRC` of every 16-lane row to the whole row (v_mov_b32_dpp row_newbcast: a VALU move, no LDS traffic).
 template <int SRC>
 __device__ __forceinline__ int row_bcast(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, false);
+    // every lane of the row receives lane SRC's value, so there is no "old" value to keep: mov_dpp leaves the destination
+    // untied (update_dpp(0, ...) made the compiler zero 64 registers per loop iteration)
+    return __builtin_amdgcn_mov_dpp(v, 0x150 + SRC, 0xf, 0xf, true);
 }
 template <int DT, int K>
 struct RowAtomics {   // adds q[K..DT) of this lane's row into dst, one LDS atomic per output dim
