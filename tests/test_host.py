@@ -33,6 +33,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.gbrl_hip_device_count() >= 0
 
 
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/gbrl_hip.h is the drop-in boundary: it must be valid C99 (no C++, no torch types) and a C program must link
+    against libgbrl_hip.so and call an entry point without a GPU."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "gbrl_hip.h"\n#include <stdio.h>\nint main(void) { printf("%d %d\\n", gbrl_hip_abi_version(), '
+                   'gbrl_hip_rccl_available() >= 0); return gbrl_hip_abi_version() > 0 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.dirname(gbrl_amd.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir,
+                    "-lgbrl_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True)
+    assert int(out.stdout.split()[0]) >= 1
+
+
 def test_metadata_struct_is_80_bytes_like_the_reference():
     class Meta(ctypes.Structure):
         _fields_ = [(n, ctypes.c_int32) for n in ("n_leaves", "n_trees", "max_trees", "max_leaves", "max_trees_batch",
