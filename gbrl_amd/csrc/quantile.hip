@@ -15,6 +15,8 @@
 // to the 32-pass bisection of kernels.hip (same results, slower).
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace gbrl {
 namespace kern {
 
@@ -424,9 +426,9 @@ __global__ __launch_bounds__(256) void k_select(const uint32_t *__restrict__ lis
 // 256 rows: reads 16 column segments of 1 KiB (coalesced), searches the 16 threshold rows staged in LDS, and writes the
 // 8 KiB code tile contiguously.
 constexpr int kGroup = 16;
-constexpr int kBinTiles = 16;   // row tiles per block (amortises staging the 16 x 511 threshold tree)
+constexpr int kBinTiles = 16;   // most row tiles per block (amortises staging the 16 x 511 threshold tree); fewer for small batches
 __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ kt, int n, int F, const uint32_t *__restrict__ thr,
-                                                  int B, int levels, uint16_t *__restrict__ codes) {
+                                                  int B, int levels, int tiles_per_block, uint16_t *__restrict__ codes) {
     extern __shared__ uint32_t lds[];
     const int P = (1 << levels) - 1;                      // thresholds padded with the maximal key to a full tree
     uint32_t *t = lds;                                    // [16][P] in BFS order
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ k
     }
     __syncthreads();
     // the threshold tree is staged once and reused for kBinTiles tiles of 256 rows
-    for (int tile = 0; tile < kBinTiles; ++tile) {
-        const int r0 = (blockIdx.x * kBinTiles + tile) * 256;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int r0 = (blockIdx.x * tiles_per_block + tile) * 256;
         if (r0 >= n) break;
         const int r = r0 + threadIdx.x;
         const int rr = r < n ? r : n - 1;
@@ -566,8 +568,12 @@ void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B,
     const size_t lds = static_cast<size_t>(kGroup) * ((1 << levels) - 1) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    dim3 grid((n + 256 * kBinTiles - 1) / (256 * kBinTiles), (F + kGroup - 1) / kGroup);
-    hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, levels, codes);
+    // enough blocks to fill the chip first (small, RL-sized batches), then up to kBinTiles tiles per block to amortise the staging
+    const int groups = (F + kGroup - 1) / kGroup;
+    const long long tiles = (static_cast<long long>(n) + 255) / 256;
+    int tpb = static_cast<int>(std::min<long long>(kBinTiles, std::max<long long>(1, tiles * groups / 1024)));
+    dim3 grid(static_cast<unsigned>((tiles + tpb - 1) / tpb), groups);
+    hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, levels, tpb, codes);
 }
 
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s) {
