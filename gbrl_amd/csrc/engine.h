@@ -114,7 +114,7 @@ class Engine {
 
     // measurement
     int profiling_ = 0;
-    bool force_bisection_ = false, force_sample_select_ = false, force_host_categorical_ = false, last_quantile_fallback_ = false;
+    bool force_bisection_ = false, force_sample_select_ = false, force_host_categorical_ = false, force_radix_ = false, last_quantile_fallback_ = false;
     // fit(): numeric thresholds computed once from the whole data set and reused by every batch's step()
     std::vector<float> fixed_thr_;
     std::vector<detail::CatCandidate> fixed_cat_cands_;

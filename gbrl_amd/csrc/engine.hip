@@ -650,6 +650,12 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             const bool radix_ok = !force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32);
             if (force_bisection_ || (has_coll_ && !coll_fast && !radix_ok)) {
                 bisection_quantiles(cum);
+            } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && N <= kern::sort_quantiles_max_rows()) {
+                // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
+                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, s);
+                last_quantile_fallback_ = false;
             } else if (!force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32)) {
                 // exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip).  Row-sharded
                 // runs sum the digit counts of every pass over ranks (any world size): 4 all-reduces per step.
@@ -1143,6 +1149,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ev_names_.clear();
     if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
     if (const char *e = std::getenv("GBRL_HIP_HOST_CATEGORICAL")) force_host_categorical_ = e[0] == '1';   // test hook: host scan of every cell
+    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_RADIX")) force_radix_ = e[0] == '1';   // test hook: radix multi-select also for small batches
     if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
     hipStream_t s = stream_;
     const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;

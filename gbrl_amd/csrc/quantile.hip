@@ -102,6 +102,33 @@ __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__res
     }
 }
 
+// ---- small batches (RL-sized): the whole column fits in LDS -> sort it, read the ranks ---------------------------------------
+// One block per feature: n <= S keys padded with the maximal key to S (a power of two <= 16384), bitonic sort in LDS,
+// thr_keys[f][k] = sorted[cum[k] - 1].  One launch instead of the eight of the radix multi-select, which are launch-bound at
+// these sizes.  Exact by construction (padding sorts last and no rank points into it).
+__global__ __launch_bounds__(1024) void k_sort_quantiles(const uint32_t *__restrict__ kt, int n, int S, const int64_t *__restrict__ cum, int B,
+                                                         uint32_t *__restrict__ thr_keys) {
+    extern __shared__ uint32_t s[];
+    const int f = blockIdx.x;
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) s[i] = i < n ? col[i] : 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= S; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < S; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = threadIdx.x; k < B; k += blockDim.x) thr_keys[static_cast<size_t>(f) * B + k] = s[cum[k] - 1];
+}
+
 // Sharded runs: sort the union of all ranks' samples ([F][SU] int64 after the exchange, SU a power of two <= 32768) and
 // take every (SU / (n_split+1))-th key: every rank computes the identical splitter set.
 __global__ __launch_bounds__(1024) void k_union_splitters(const int64_t *__restrict__ uni, int SU, int n_split,
@@ -560,6 +587,15 @@ void quantile_extract(const uint32_t *kt, int n, int F, const QuantilePlan &p, c
 void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint32_t *tgt_len, const uint32_t *tgt_rank, int n_targets,
                      uint32_t *thr_keys, hipStream_t s) {
     hipLaunchKernelGGL(k_select, dim3((n_targets + 3) / 4), dim3(256), 0, s, lists, tgt_off, tgt_len, tgt_rank, n_targets, thr_keys);
+}
+
+int sort_quantiles_max_rows() { return 4096; }   // beyond this the bitonic sort (O(n log^2 n) in one block per feature) loses to the radix passes
+void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, hipStream_t s) {
+    int S = 64;
+    while (S < n) S <<= 1;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_quantiles), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_sort_quantiles, dim3(F), dim3(std::min(1024, S / 2 > 64 ? S / 2 : 64)), static_cast<size_t>(S) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys);
 }
 
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s) {

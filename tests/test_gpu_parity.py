@@ -289,12 +289,14 @@ def test_full_size_properties_config3_shape():
     assert np.array_equal(pred, want_pred)
 
 
-def test_fast_quantile_path_equals_bisection_path(monkeypatch):
-    """The MSD radix multi-select (radix_select.hip), the sample-splitter selection (quantile.hip) and the 32-pass bisection
-    (kernels.hip) are all exact: identical trees, also on columns built to stress each of them."""
+@pytest.mark.parametrize("N", [70001, 3001])
+def test_fast_quantile_path_equals_bisection_path(N, monkeypatch):
+    """The exact selections -- LDS sort of the whole column (small batches), MSD radix multi-select (radix_select.hip),
+    sample-splitter selection (quantile.hip) and 32-pass bisection (kernels.hip) -- give identical trees, also on columns built
+    to stress each of them."""
     import gbrl_amd
     rng = np.random.default_rng(11)
-    N, F = 70001, 20
+    F = 20
     X = rng.standard_normal((N, F)).astype(np.float32)
     X[:, 1] = np.round(X[:, 1] * 3) / 3          # heavy duplicates -> equality classes / one radix slot to the last digit
     X[:, 2] = (rng.random(N) < 0.97) * 1.0       # one value holds 97 % of the column
@@ -306,15 +308,16 @@ def test_fast_quantile_path_equals_bisection_path(monkeypatch):
     G = (np.tanh(X[:, :3]) + 0.3 * rng.standard_normal((N, 3))).astype(np.float32)
     case = dict(name="qq", seed=0, N=N, F=F, D=3, depth=6, n_bins=256, score="Cosine", gen="Quantile", policy="greedy", trees=2)
     outs = []
-    for bisect, sample in (("0", "0"), ("0", "1"), ("1", "0")):
-        monkeypatch.setenv("GBRL_HIP_FORCE_BISECTION", bisect)
-        monkeypatch.setenv("GBRL_HIP_QUANTILE_SAMPLE", sample)
+    # (default: sort for N <= 16384, radix above), radix forced, sample splitters, bisection
+    for env in ({}, {"GBRL_HIP_QUANTILE_RADIX": "1"}, {"GBRL_HIP_QUANTILE_SAMPLE": "1"}, {"GBRL_HIP_FORCE_BISECTION": "1"}):
+        for k in ("GBRL_HIP_QUANTILE_RADIX", "GBRL_HIP_QUANTILE_SAMPLE", "GBRL_HIP_FORCE_BISECTION"):
+            monkeypatch.setenv(k, env.get(k, "0"))
         m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
         K.drive(m, case, X, None, G, None)
         outs.append({k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS})
     for k in K.ENSEMBLE_KEYS:
-        assert np.array_equal(outs[0][k], outs[2][k]), ("radix vs bisection", k)
-        assert np.array_equal(outs[1][k], outs[2][k]), ("sample vs bisection", k)
+        for i, what in enumerate(("default", "radix", "sample")):
+            assert np.array_equal(outs[i][k], outs[3][k]), (what + " vs bisection", k)
 
 
 def test_more_rows_than_one_round_of_histogram_chunks():
