@@ -800,8 +800,9 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
     float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
     const int am_parts = kern::argmax_parts(std::max(1, n_cand));
-    float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * static_cast<size_t>(max_front) * am_parts));
-    int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * am_parts));
+    const size_t am_cap = static_cast<size_t>(max_front) * std::max(am_parts, std::max(1, n_slots));   // greedy: one part per feature slot
+    float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * am_cap));
+    int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * am_cap));
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
     hip_check(hipMemsetAsync(d_leafacc, 0, sizeof(int64_t) * max_nodes * (D + 1), s), "memset leaf acc");
@@ -974,10 +975,14 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
         kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
-                               d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, s);
-        kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
+                               d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
+                               oblivious ? nullptr : d_am_v, d_am_i, s);
+        // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
+        // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
+        if (oblivious)
+            kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
-        kern::resolve_splits(d_am_v, d_am_i, am_parts, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+        kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : n_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
                              d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s);
         if (has_coll_) {
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);

@@ -155,7 +155,10 @@ void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_s
 void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *sub_par, const int32_t *sub_sib, int n_nodes, int Fp, int NB, int D, const FeatureSlot *slots, int n_slots,
                       const float *thr /*[F][B]*/, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
-                      float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/, hipStream_t s);
+                      float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/,
+                      const float *cand_w, const int32_t *cand_ref, const int32_t *is_root,
+                      float *part_v /*nullable.  greedy: [n_nodes][n_slots] best gain per feature -- arg-max stage 1 fused, scores not written*/,
+                      int32_t *part_i, hipStream_t s);
 // best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
 // result (sum over nodes); greedy: one per node.  part_v/part_i: scratch of n_nodes * argmax_parts(n_cand).
 int argmax_parts(int n_cand);

@@ -437,6 +437,14 @@ __device__ __forceinline__ double side_term(const int64_t *S, int D, int64_t n, 
     return ss / static_cast<double>(n);
 }
 
+// A8 oblivious: s_j = (sum over nodes, in node order, fp32) * w_j ; lowest index among maxima wins (fitter.cpp:411-457)
+struct Best { float v; int i; };
+__device__ __forceinline__ Best better(Best a, Best b) {
+    // strictly greater wins; on equality the lower reference index wins.  A -inf score never replaces the initial
+    // (-inf, none) state, exactly like "if (score > local_best_score)" with local_best = -inf (fitter.cpp:338, 441).
+    if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
+    return a;
+}
 // Wave-wide inclusive scan step on a 64-bit value with DPP (VALU only; __shfl_up would go through the LDS crossbar, which
 // is what k_score is short of).  ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK>
@@ -452,7 +460,9 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
                                                int B, int n_cand, int min_data, int cosine, const StepScales *__restrict__ scp,
                                                const int32_t *__restrict__ path_len, const int32_t *__restrict__ path_slot,
                                                const float *__restrict__ path_val, const int32_t *__restrict__ path_bin,
-                                               float *__restrict__ scores, float *__restrict__ parent) {
+                                               float *__restrict__ scores, float *__restrict__ parent,
+                                               const float *__restrict__ cand_w, const int32_t *__restrict__ cand_ref,
+                                               const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i) {
     extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
     const double inv_scale = scp->inv_scale;
     const int node = blockIdx.y, fs = blockIdx.x;
@@ -524,10 +534,19 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     }
     __syncthreads();
     const int64_t n_tot = total[D];
-    if (fs == 0 && threadIdx.x == 0) {
-        double x = side_term(total, D, n_tot, inv_scale);
-        parent[node] = static_cast<float>(cosine ? sqrt(x) : x);
+    // parent score of the node (greedy growth): the totals are the same integers for every feature of the node, so every block
+    // derives the identical float
+    float par_score;
+    {
+        const double x = side_term(total, D, n_tot, inv_scale);
+        par_score = static_cast<float>(cosine ? sqrt(x) : x);
     }
+    if (fs == 0 && threadIdx.x == 0) parent[node] = par_score;
+    // greedy growth (part_v != null): the block also reduces its candidates to one best (gain, reference index) -- stage 1 of the
+    // arg-max, fused here so that a greedy level needs no separate arg-max launch (fitter.cpp:318-354: gain = fma(score, w, -parent),
+    // root parent = 0, lowest reference index among maxima)
+    const float par_sub = (part_v && is_root[node]) ? 0.0f : par_score;
+    Best mine{-INFINITY, 0x7fffffff};
     // the node's path conditions on THIS feature slot, staged once per block (a candidate that repeats one of them is rejected,
     // node.cpp:154-166); reading the path arrays from global memory inside the candidate loop costs a memory round trip per
     // path entry and thread at the deep levels
@@ -574,18 +593,31 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
             if (n_r > 0) x += sr / static_cast<double>(n_r);
             out = static_cast<float>(cosine ? sqrt(x) : x);
         }
-        scores[static_cast<size_t>(node) * n_cand + sl.cand_base + k] = out;
+        if (part_v) {
+            const int j = sl.cand_base + k;
+            mine = better(mine, Best{fmaf(out, cand_w[j], -par_sub), cand_ref[j]});
+        } else {
+            scores[static_cast<size_t>(node) * n_cand + sl.cand_base + k] = out;
+        }
+    }
+    if (part_v) {
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const Best other{__shfl_xor(mine.v, o, kWave), __shfl_xor(mine.i, o, kWave)};
+            mine = better(mine, other);
+        }
+        __shared__ float bv[4];
+        __shared__ int bi[4];
+        if (lane == 0) { bv[wave] = mine.v; bi[wave] = mine.i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Best b{bv[0], bi[0]};
+            for (int q = 1; q < 4; ++q) b = better(b, Best{bv[q], bi[q]});
+            part_v[static_cast<size_t>(node) * gridDim.x + fs] = b.v;
+            part_i[static_cast<size_t>(node) * gridDim.x + fs] = b.i;
+        }
     }
 }
 
-// A8 oblivious: s_j = (sum over nodes, in node order, fp32) * w_j ; lowest index among maxima wins (fitter.cpp:411-457)
-struct Best { float v; int i; };
-__device__ __forceinline__ Best better(Best a, Best b) {
-    // strictly greater wins; on equality the lower reference index wins.  A -inf score never replaces the initial
-    // (-inf, none) state, exactly like "if (score > local_best_score)" with local_best = -inf (fitter.cpp:338, 441).
-    if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
-    return a;
-}
 // Two stages: stage 1 (many blocks) reduces a slice of the candidates; the per-block bests are reduced by k_resolve_splits.
 constexpr int kArgmaxThreads = 256;
 __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *__restrict__ scores, int n_nodes, int n_cand,
@@ -1283,7 +1315,8 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       int D, const FeatureSlot *slots, int n_slots,
                       const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
-                      float *scores, float *parent, hipStream_t s) {
+                      float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
+                      int32_t *part_i, hipStream_t s) {
     const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1291,7 +1324,7 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
         attr_set = true;
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
-                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent);
+                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i);
 }
 
 int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }
