@@ -7,8 +7,10 @@
 // Differences that are deliberate:
 //   * every computation runs on the GPU; `device` only selects how predict() delivers its result.
 //   * the DLPack capsule carries kDLROCM (10): torch-ROCm rejects the reference's hard-coded kDLCUDA.
-//   * fit / export / SHAP / print / plot raise RuntimeError: they are outside the accelerated path.
+//   * export / SHAP / print are served from the host copy of the ensemble (csrc/explain.cpp); plot_tree raises the
+//     reference's own no-Graphviz error (this image has no Graphviz).
 #include <pybind11/numpy.h>
+#include <algorithm>
 #include <pybind11/pybind11.h>
 
 #include <cstring>
@@ -342,9 +344,58 @@ float fit_impl(PyGBRL &self, py::object &obs, py::object &cat, py::object &targe
     return loss;
 }
 
-[[noreturn]] void not_on_path(const char *what) {
-    fail(std::string(what) + " is outside the accelerated step/predict path of gbrl_amd (SURVEY.md section 8f); "
-         "use the reference CPU build for it");
+// tree_shap / ensemble_shap (binding.cpp:985-1117): NumPy inputs only, result [n_samples][n_num + n_cat][output_dim]
+struct HostArray {
+    const void *ptr = nullptr;
+    std::vector<py::ssize_t> shape;
+    py::object keep;
+};
+template <typename ArrayT>
+HostArray host_array(py::object &obj) {
+    HostArray a;
+    if (obj.is_none()) return a;
+    ArrayT arr = py::cast<ArrayT>(obj);
+    if (!arr.attr("flags").attr("c_contiguous").template cast<bool>()) fail("Arrays must be C-contiguous");
+    py::buffer_info info = arr.request();
+    a.ptr = info.ptr;
+    a.shape.assign(info.shape.begin(), info.shape.end());
+    a.keep = arr;
+    return a;
+}
+
+py::array_t<float> shap_impl(PyGBRL &self, bool whole_ensemble, int tree_idx, py::object &obs, py::object &categorical_obs,
+                             py::object &norm_values, py::object &base_poly, py::object &offset) {
+    const HostArray o = host_array<py::array_t<float>>(obs);
+    const HostArray c = host_array<py::array>(categorical_obs);
+    const HostArray nv = host_array<py::array_t<float>>(norm_values), bp = host_array<py::array_t<float>>(base_poly),
+                    of = host_array<py::array_t<float>>(offset);
+    // 1-D inputs are ONE sample (binding.cpp:996-1003, 1014-1021)
+    py::ssize_t n = 0, n_num = 0, n_cat = 0;
+    if (o.ptr) { if (o.shape.size() == 1) { n_num = o.shape[0]; n = 1; } else { n_num = o.shape[1]; n = o.shape[0]; } }
+    if (c.ptr) {
+        if (c.shape.size() == 1) { n_cat = c.shape[0]; if (n == 0) n = 1; } else { n_cat = c.shape[1]; if (n == 0) n = c.shape[0]; }
+    }
+    const gbrl_hip_metadata md = self.meta();
+    // the reference trusts the caller here and reads out of bounds on a mismatch; this build checks
+    if (md.n_trees > 0 && (n_num != md.n_num_features || n_cat != md.n_cat_features)) fail("Incompatible dimensions");
+    const size_t depth = static_cast<size_t>(md.max_depth);
+    auto count = [](const HostArray &a) { size_t k = a.ptr ? 1 : 0; for (py::ssize_t d : a.shape) k *= static_cast<size_t>(d); return k; };
+    if (count(nv) < (depth + 1) * depth || count(bp) < depth || count(of) < depth * depth)
+        fail("norm_values, base_poly and offset must be built for the model's max_depth");
+    py::array_t<float> out({n, n_num + n_cat, static_cast<py::ssize_t>(md.output_dim)});
+    float *dst = out.mutable_data();
+    std::fill(dst, dst + out.size(), 0.0f);
+    int rc;
+    {
+        py::gil_scoped_release release;
+        rc = whole_ensemble
+                 ? gbrl_hip_ensemble_shap(self.h, static_cast<const float *>(o.ptr), static_cast<const char *>(c.ptr), static_cast<int>(n),
+                                          static_cast<const float *>(nv.ptr), static_cast<const float *>(bp.ptr), static_cast<const float *>(of.ptr), dst)
+                 : gbrl_hip_tree_shap(self.h, tree_idx, static_cast<const float *>(o.ptr), static_cast<const char *>(c.ptr), static_cast<int>(n),
+                                      static_cast<const float *>(nv.ptr), static_cast<const float *>(bp.ptr), static_cast<const float *>(of.ptr), dst);
+    }
+    check(rc);
+    return out;
 }
 
 }  // namespace
@@ -452,7 +503,16 @@ PYBIND11_MODULE(gbrl_cpp, m) {
         if (rc != GBRL_HIP_OK) { py::gil_scoped_acquire a; fail(gbrl_hip_last_error()); }
         return 0;
     });
-    g.def("export", [](PyGBRL &, py::args, py::kwargs) -> int { not_on_path("export"); });
+    g.def("export", [](PyGBRL &self, const std::string &filename, const std::string &modelname, const std::string &export_format,
+                       const std::string &export_type, const std::string &prefix) -> int {
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = gbrl_hip_export(self.h, filename.c_str(), modelname.c_str(), export_format.c_str(), export_type.c_str(), prefix.c_str());
+        }
+        check(rc);
+        return 0;
+    }, py::arg("filename"), py::arg("modelname") = "", py::arg("export_format") = "float", py::arg("export_type") = "full", py::arg("prefix") = "");
     g.def("get_scheduler_lrs", [](PyGBRL &self) {
         const int n = gbrl_hip_num_optimizers(self.h);
         if (n == 0) fail("No optimizers found");
@@ -495,18 +555,31 @@ PYBIND11_MODULE(gbrl_cpp, m) {
         d["feature_weights"] = fw; d["tree_indices"] = tree_indices; d["depths"] = depths; d["values"] = values;
         d["feature_indices"] = fidx; d["feature_values"] = fval; d["edge_weights"] = ew; d["is_numerics"] = isnum;
         d["inequality_directions"] = ineq; d["mapping_numerics"] = mn; d["categorical_values"] = cats;
-        d["alloc_data_size"] = static_cast<size_t>(0);
+        d["alloc_data_size"] = gbrl_hip_alloc_data_size(self.h);
         return d;
     });
     g.def("get_device", [](PyGBRL &self) { return std::string(self.device ? "cuda" : "cpu"); });
     g.def("get_learner_name", [](PyGBRL &self) { return std::string(gbrl_hip_learner_name(self.h)); });
-    g.def("print_tree", [](PyGBRL &, py::args, py::kwargs) { not_on_path("print_tree"); });
-    g.def("tree_shap", [](PyGBRL &, py::args, py::kwargs) { not_on_path("tree_shap"); });
-    g.def("ensemble_shap", [](PyGBRL &, py::args, py::kwargs) { not_on_path("ensemble_shap"); });
-    g.def("plot_tree", [](PyGBRL &, py::args, py::kwargs) { not_on_path("plot_tree"); });
+    g.def("print_tree", [](PyGBRL &self, int tree_idx) {
+        int rc;
+        { py::gil_scoped_release release; rc = gbrl_hip_print_tree(self.h, tree_idx); }
+        check(rc);
+    }, py::arg("tree_idx") = -1);
+    g.def("tree_shap", [](PyGBRL &self, int tree_idx, py::object &obs, py::object &categorical_obs, py::object &norm_values,
+                          py::object &base_poly, py::object &offset) {
+        return shap_impl(self, false, tree_idx, obs, categorical_obs, norm_values, base_poly, offset);
+    }, py::arg("tree_idx") = 0, py::arg("obs"), py::arg("categorical_obs"), py::arg("norm_values"), py::arg("base_poly"), py::arg("offset"));
+    g.def("ensemble_shap", [](PyGBRL &self, py::object &obs, py::object &categorical_obs, py::object &norm_values, py::object &base_poly,
+                              py::object &offset) {
+        return shap_impl(self, true, 0, obs, categorical_obs, norm_values, base_poly, offset);
+    }, py::arg("obs"), py::arg("categorical_obs"), py::arg("norm_values"), py::arg("base_poly"), py::arg("offset"));
+    g.def("plot_tree", [](PyGBRL &self, int tree_idx, const std::string &filename) {
+        check(gbrl_hip_plot_tree(self.h, tree_idx, filename.c_str()));
+    }, py::arg("tree_idx") = -1, py::arg("filename"));
     g.def("print_ensemble_metadata", [](PyGBRL &self) {
-        const gbrl_hip_metadata md = self.meta();
-        py::print("########", gbrl_hip_learner_name(self.h), "model ######## trees:", md.n_trees, "leaves:", md.n_leaves);
+        int rc;
+        { py::gil_scoped_release release; rc = gbrl_hip_print_ensemble_metadata(self.h, self.device ? "cuda" : "cpu"); }
+        check(rc);
     });
     // GBRL::cuda_available (gbrl.cpp:542-548): here "is a HIP device usable"
     g.def_static("cuda_available", []() { return gbrl_hip_device_count() > 0; });

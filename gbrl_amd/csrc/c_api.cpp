@@ -6,12 +6,15 @@
 #include <utility>
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <new>
 #include <string>
 
 #include "../../include/gbrl_hip.h"
 #include "engine.h"
+#include "explain.h"
 #include "rccl_dyn.h"
 
 struct gbrl_hip_model {
@@ -308,6 +311,65 @@ int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int 
         m->engine.set_rccl(id128, world_size, rank);
     });
 }
+
+// ---- inspection (explain.cpp), served from the host copy of the ensemble ----
+int gbrl_hip_tree_shap(const gbrl_hip_model *m, int tree_idx, const float *obs, const char *cat_obs, int n_samples,
+                       const float *norm_values, const float *base_poly, const float *offset, float *out) {
+    return guarded([&] {
+        if (!m || !out || n_samples < 0) throw gbrl::InvalidArgument("null argument");
+        const gbrl::Model &md = m->engine.model;
+        std::memset(out, 0, sizeof(float) * static_cast<size_t>(n_samples) * (md.meta.n_num_features + md.meta.n_cat_features) * md.meta.output_dim);
+        gbrl::tree_shap(md, tree_idx, obs, cat_obs, n_samples, norm_values, base_poly, offset, out);
+    });
+}
+int gbrl_hip_ensemble_shap(const gbrl_hip_model *m, const float *obs, const char *cat_obs, int n_samples,
+                           const float *norm_values, const float *base_poly, const float *offset, float *out) {
+    return guarded([&] {
+        if (!m || !out || n_samples < 0) throw gbrl::InvalidArgument("null argument");
+        const gbrl::Model &md = m->engine.model;
+        if (md.meta.n_trees == 0) return;   // nothing to explain; the caller's buffer is sized from its inputs (binding zero-fills)
+        std::memset(out, 0, sizeof(float) * static_cast<size_t>(n_samples) * (md.meta.n_num_features + md.meta.n_cat_features) * md.meta.output_dim);
+        gbrl::ensemble_shap(md, obs, cat_obs, n_samples, norm_values, base_poly, offset, out);
+    });
+}
+int gbrl_hip_export(const gbrl_hip_model *m, const char *filename, const char *modelname, const char *export_format,
+                    const char *export_type, const char *prefix) {
+    bool io_error = false;
+    const int rc = guarded([&] {
+        if (!m || !filename) throw gbrl::InvalidArgument("null argument");
+        // the reference opens (and truncates) the file before it validates anything (gbrl.cpp:1107-1118)
+        FILE *f = std::fopen(filename, "wb");
+        if (!f) { io_error = true; throw std::runtime_error("File opening error"); }
+        std::string text;
+        try {
+            gbrl::export_header(m->engine.model, modelname ? modelname : "", export_format ? export_format : "float",
+                                export_type ? export_type : "full", prefix ? prefix : "", text);
+        } catch (...) { std::fclose(f); throw; }
+        const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
+        if (std::fclose(f) != 0 || !ok) { io_error = true; throw std::runtime_error("Writing to file error"); }
+    });
+    return (rc != GBRL_HIP_OK && io_error) ? GBRL_HIP_E_IO : rc;
+}
+int gbrl_hip_print_tree(const gbrl_hip_model *m, int tree_idx) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null argument");
+        const std::string t = gbrl::tree_text(m->engine.model, tree_idx);
+        std::fwrite(t.data(), 1, t.size(), stdout);
+        std::fflush(stdout);
+    });
+}
+int gbrl_hip_print_ensemble_metadata(const gbrl_hip_model *m, const char *device_name) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null argument");
+        const std::string t = gbrl::metadata_text(m->engine.model, device_name ? device_name : "cuda");
+        std::fwrite(t.data(), 1, t.size(), stdout);
+        std::fflush(stdout);
+    });
+}
+int gbrl_hip_plot_tree(const gbrl_hip_model *, int, const char *) {
+    return guarded([&] { throw gbrl::Unsupported("GBRL compiled without Graphviz! Cannot plot model"); });
+}
+size_t gbrl_hip_alloc_data_size(const gbrl_hip_model *m) { return m ? gbrl::reference_alloc_bytes(m->engine.model, true) : 0; }
 
 int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float *ms, int cap) {
     if (!m) return 0;

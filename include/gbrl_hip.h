@@ -176,6 +176,32 @@ int gbrl_hip_rccl_unique_id(void *id128);
 int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int rank);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
+/* ---- inspection, served from the host copy of the ensemble ---------------------- */
+/* Linear TreeSHAP of one tree / of the whole ensemble: GBRL::tree_shap gbrl.cpp:1269-1303, GBRL::ensemble_shap gbrl.cpp:1305-1342,
+ * algorithm shap.cpp:38-364.  HOST pointers only (the reference's binding accepts NumPy arrays only, binding.cpp:985-1117).
+ * obs [n_samples][n_num_features] f32, cat_obs [n_samples][n_cat_features][128] bytes (either may be NULL when the model has no
+ * such features); norm_values [(max_depth+1)][max_depth], base_poly [max_depth], offset [max_depth][max_depth] as built by
+ * gbrl/common/utils.py:317-371.  out [n_samples][n_num_features + n_cat_features][output_dim] is OVERWRITTEN
+ * (left untouched by gbrl_hip_ensemble_shap when the ensemble has no trees: the feature counts are unknown until the first step). */
+int gbrl_hip_tree_shap(const gbrl_hip_model *m, int tree_idx, const float *obs, const char *cat_obs, int n_samples,
+                       const float *norm_values, const float *base_poly, const float *offset, float *out);
+int gbrl_hip_ensemble_shap(const gbrl_hip_model *m, const float *obs, const char *cat_obs, int n_samples,
+                           const float *norm_values, const float *base_poly, const float *offset, float *out);
+/* GBRL::exportModel gbrl.cpp:1106-1128 (text: export_ensemble_data types.cpp:409-679).  export_format "float"|"fxp8"|"fxp16",
+ * export_type "full"|"compact"; NULL strings mean the binding's defaults ("", "float", "full", "").  Oblivious models only. */
+int gbrl_hip_export(const gbrl_hip_model *m, const char *filename, const char *modelname, const char *export_format,
+                    const char *export_type, const char *prefix);
+/* GBRL::print_tree gbrl.cpp:1357-1391 (tree_idx -1 = last tree) and GBRL::print_ensemble_metadata gbrl.cpp:1254-1267: the same
+ * text, written to stdout.  device_name is what get_device() reports ("cpu" | "cuda"). */
+int gbrl_hip_print_tree(const gbrl_hip_model *m, int tree_idx);
+int gbrl_hip_print_ensemble_metadata(const gbrl_hip_model *m, const char *device_name);
+/* GBRL::plot_tree gbrl.cpp:1409-1547 needs Graphviz, which this image does not have: always GBRL_HIP_E_UNSUPPORTED with the
+ * message of the reference's own no-Graphviz build ("GBRL compiled without Graphviz! Cannot plot model"). */
+int gbrl_hip_plot_tree(const gbrl_hip_model *m, int tree_idx, const char *filename);
+/* what get_ensemble_data()["alloc_data_size"] shows in the reference: the size of the exact-size copy it hands out
+ * (copy_ensemble_data types.cpp:322-384, binding.cpp:382) */
+size_t gbrl_hip_alloc_data_size(const gbrl_hip_model *m);
+
 /* Per-phase GPU time of the LAST step()/predict() call, measured with HIP events on the model's stream.
  * names/ms hold up to `cap` entries; returns the number of phases. */
 int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float *ms, int cap);

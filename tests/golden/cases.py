@@ -182,3 +182,33 @@ ENSEMBLE_KEYS = ("tree_indices", "depths", "values", "feature_indices", "feature
                  "is_numerics", "inequality_directions", "categorical_values")
 # cases whose saved .gbrl_model bytes are committed (file-format parity)
 MODEL_FILE_CASES = ("obl_l2_q", "grd_cos_q_ac", "obl_l2_q_cat")
+
+# ---- inspection fixtures (SHAP / export / print), made by make_explain_golden.py ----
+# name -> export variants [(modelname, export_format, export_type, prefix)]; export is oblivious-only in the reference
+EXPLAIN_CASES = {
+    "obl_l2_q": [("", "float", "full", ""), ("policy", "fxp8", "full", "P_"), ("", "fxp16", "compact", "")],
+    "obl_l2_q_d6": [("net", "float", "compact", "M_")],
+    "obl_cos_u_mdl": [("", "float", "full", "")],          # shallow trees next to full-depth ones
+    "obl_l2_q_cat": [("", "float", "full", "")],
+    "obl_cos_q_cat_rmse": [("", "fxp16", "full", "")],     # output_dim 1: scalar form of the header
+    "grd_cos_q_ac": [],
+    "grd_l2_q_mdl": [],
+    "grd_cos_u_cat": [],
+    "grd_l2_q_catonly": [],
+}
+EXPLAIN_ROWS = 40   # SHAP is evaluated on the first rows of the case's inputs
+
+
+def poly_vectors(max_depth):
+    """base_poly, norm_values, offset of Linear TreeSHAP as the reference's Python layer builds them
+    (gbrl/common/utils.py:317-371): Chebyshev points of the second kind mapped to [2, 3], the inverse-Vandermonde
+    normalisation rows and the Vandermonde matrix of base_poly + 1, all float32."""
+    from scipy.special import binom
+    base = np.polynomial.chebyshev.chebpts2(max_depth).astype(np.float32)
+    base = (base + 1) * (3 - 2) / 2 + 2
+    norm = np.zeros((max_depth + 1, max_depth))
+    for i in range(1, max_depth + 1):
+        norm[i, :i] = np.linalg.inv(np.vander(base[:i]).T).dot(1.0 / binom(i - 1, np.arange(i)))
+    offset = np.vander(base + 1).T[::-1]
+    return (np.ascontiguousarray(base, np.float32), np.ascontiguousarray(norm.astype(np.float32)),
+            np.ascontiguousarray(offset.astype(np.float32)))
