@@ -14,6 +14,7 @@ constexpr int UNROLL = 9;
 // MODE 1: random class, layout [(cls*9+d)*16 + f], 16 features x 4 rows per wave (2-way per 32-lane group)
 // MODE 2: random class, layout [f][cls][d] (class-major per feature: random banks)
 // MODE 3: like MODE 1 but 64-bit atomics (8 features)
+// MODE 4/5: MODE 1 with a per-row-slot rotated field order that removes the bank conflicts between the rows of a wave
 template <int MODE>
 __global__ __launch_bounds__(1024) void bench(const uint32_t *__restrict__ codes, uint32_t *__restrict__ out, int nb) {
     extern __shared__ uint32_t h[];
@@ -39,6 +40,27 @@ __global__ __launch_bounds__(1024) void bench(const uint32_t *__restrict__ codes
             const int base = (f * nb + cls) * 9;
 #pragma unroll
             for (int d = 0; d < UNROLL; ++d) atomicAdd(&h[base + d], seed >> 20);
+        } else if (MODE == 4 || MODE == 5) {
+            // design layout, but every 16-lane row slot walks the 8 gradient fields in its own rotated order so that the row
+            // slots of a wave always sit on different (class*9 + field) residues mod 4: field(t) = 4*(t>>2) + ((t + k) & 3),
+            // k = (row slot - class) & 3.  MODE 5 also rotates the values (what the real kernel would have to do).
+            const int f = lane & 15, k = ((lane >> 4) - cls) & 3;
+            const int base = cls * 9 * 16 + f;
+            uint32_t v[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) v[d] = (seed >> 20) + d;
+            if (MODE == 5) {
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    uint32_t a0 = v[4 * hlf], a1 = v[4 * hlf + 1], a2 = v[4 * hlf + 2], a3 = v[4 * hlf + 3];
+                    const bool r1 = k & 1, r2 = k & 2;
+                    uint32_t b0 = r1 ? a1 : a0, b1 = r1 ? a2 : a1, b2 = r1 ? a3 : a2, b3 = r1 ? a0 : a3;
+                    v[4 * hlf] = r2 ? b2 : b0; v[4 * hlf + 1] = r2 ? b3 : b1; v[4 * hlf + 2] = r2 ? b0 : b2; v[4 * hlf + 3] = r2 ? b1 : b3;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) atomicAdd(&h[base + (4 * (t >> 2) + ((t + k) & 3)) * 16], v[t]);
+            atomicAdd(&h[base + 8 * 16], 1u);
         } else {
             const int f = lane & 7;
             unsigned long long *h64 = reinterpret_cast<unsigned long long *>(h);
@@ -83,5 +105,7 @@ int main() {
     if (run<1>("u32 [cls][d][16 feat] x 4 rows/wave (design layout)", nb, nb * 9 * 16 * 4)) return 1;
     if (run<2>("u32 [feat][cls][d] (random banks)", nb, nb * 9 * 16 * 4)) return 1;
     if (run<3>("u64 [cls][d][8 feat] x 8 rows/wave", nb, nb * 9 * 8 * 8)) return 1;
+    if (run<4>("u32 design layout, rotated field order per row slot", nb, nb * 9 * 16 * 4)) return 1;
+    if (run<5>("u32 ... + value rotation (8 v_cndmask per 4 fields)", nb, nb * 9 * 16 * 4)) return 1;
     return 0;
 }

@@ -154,3 +154,48 @@ def test_outputs_without_an_optimizer_keep_the_bias():
     m, r = _check(case, X, Xc, G)
     p = np.asarray(m.predict(X, None, 0, 0))
     assert np.all(p[:, 0] == np.float32(0.5)) and np.all(p[:, 3] == np.float32(0.25))
+
+
+def test_growth_past_the_reference_initial_capacity(tmp_path):
+    """the reference's CPU arena holds 50 000 trees and is re-allocated in steps of 25 000
+    (types.h:49-52, types.cpp:847-855; that re-allocation leaves dangling mappings there, Q3).  Here the model is grow-only
+    storage on both sides of the bus: 50 010 trees, every one equal to the oracle's, the capacity fields booked the way the
+    reference's CPU path books them (they are part of the .gbrl_model bytes), predict over the whole ensemble and over a
+    sub-range straddling the old limit, file round trip, copy."""
+    import gbrl_amd
+    import oracle
+    rng = np.random.default_rng(5)
+    N, F, T = 96, 2, 50010
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    G0 = (np.tanh(X[:, :1]) + 0.3 * rng.standard_normal((N, 1))).astype(np.float32)
+    kw = dict(input_dim=F, output_dim=1, policy_dim=1, max_depth=1, min_data_in_leaf=0, n_bins=16, par_th=10, cv_beta=0.9,
+              split_score_func="L2", generator_type="Quantile", use_control_variates=False, batch_size=5000,
+              grow_policy="oblivious", verbose=0, device="cpu")
+    models = []
+    for mod in (gbrl_amd.GBRL, oracle.OracleGBRL):
+        m = mod(**kw)
+        m.set_feature_weights(np.ones(F, np.float32))
+        m.set_optimizer("SGD", "Const", 0.01, 0, 1)
+        for i in range(T):
+            m.step(X, None, np.ascontiguousarray(np.roll(G0, i, axis=0)))
+        models.append(m)
+    m, r = models
+    assert m.get_num_trees() == T == r.get_num_trees()
+    e, o = m.get_ensemble_data(), r.get_ensemble_data()
+    assert_structure_equal(e, o, what="50010 trees: ")
+    scale = float(np.abs(G0).mean())
+    assert_values_close(e, o, scale, TOL)
+    assert rel_err(np.asarray(m.predict(X, None)), np.asarray(r.predict(X, None)), scale) <= TOL
+    assert rel_err(np.asarray(m.predict(X, None, 49990, 50008)), np.asarray(r.predict(X, None, 49990, 50008)), scale) <= TOL
+    p = tmp_path / "big.gbrl_model"
+    assert m.save(str(p)) == 0
+    # ensembleMetaData follows the 24-byte serialization header: n_leaves, n_trees, max_trees, max_leaves, ... (types.h:218-242).
+    # The reference re-allocates when n_trees reaches max_trees: max = n + batch at that moment (types.cpp:849-853).
+    head = np.frombuffer(p.read_bytes()[24:24 + 16], np.int32)
+    assert head.tolist() == [2 * T, T, 50000 + 25000, 2 * 50000 + 2 * 25000]
+    m2 = gbrl_amd.GBRL.load(str(p))
+    assert m2.get_num_trees() == T
+    assert np.array_equal(np.asarray(m2.predict(X, None)), np.asarray(m.predict(X, None)))
+    m3 = gbrl_amd.GBRL(m)                                   # the copy is independent of the original
+    m3.step(X, None, G0)
+    assert (m3.get_num_trees(), m.get_num_trees()) == (T + 1, T)
