@@ -57,7 +57,7 @@ class PinnedBuf {
 namespace detail {
 struct GrowCtx;
 struct HNode;
-struct CatCandidate;
+struct CatCandidate { int feat; std::string name; int cls; };   // a categorical split candidate: class `cls` of feature `feat` is the category `name`
 }  // namespace detail
 
 class Engine {

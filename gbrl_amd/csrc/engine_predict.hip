@@ -1,0 +1,247 @@
+// engine_predict.hip -- the device mirror of the ensemble (append-only structure-of-arrays + the packed records the fast predict
+// kernels read) and GBRL::predict (see engine.h).
+#include "engine.h"
+
+#include <functional>
+#include "cat_hash.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+
+namespace gbrl {
+
+// ===================================================================================================== predict
+void Engine::sync_model_to_device() {
+    hipStream_t s = stream_;
+    const gbrl_hip_metadata &md = model.meta;
+    const size_t T = md.n_trees, L = md.n_leaves, S = model.split_rows(), MD = md.max_depth, D = md.output_dim;
+    if (mirror_version_ == model.version) return;
+    // dictionary ids for the categorical conditions (strings are compared on the host once; the device compares ids)
+    if (up_splits_ > S || up_trees_ > T || up_leaves_ > L) { up_splits_ = up_trees_ = up_leaves_ = 0; grd_up_nodes_ = 0; cat_dict_.clear(); cat_ids_host_.clear(); cond_pack_host_.clear(); dict_version_ = static_cast<size_t>(-1); }
+    cat_ids_host_.resize(S * MD, 0);
+    for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
+        if (model.is_numerics[c]) continue;
+        const int f = model.feature_indices[c];
+        std::string name(&model.categorical_values[c * kCat], kCat);
+        int id = 0;
+        for (size_t z = 0; z < cat_dict_.size(); ++z)
+            if (cat_dict_[z].first == f && cat_dict_[z].second == name) { id = static_cast<int>(z) + 1; break; }
+        if (id == 0) { cat_dict_.emplace_back(f, name); id = static_cast<int>(cat_dict_.size()); }
+        cat_ids_host_[c] = id;
+    }
+    auto append = [&](DevBuf &buf, const void *host, size_t elem, size_t old_n, size_t new_n) {
+        char *p = static_cast<char *>(buf.ensure_keep(std::max<size_t>(new_n, 1) * elem, old_n * elem, s));
+        if (new_n > old_n)
+            hip_check(hipMemcpyAsync(p + old_n * elem, static_cast<const char *>(host) + old_n * elem, (new_n - old_n) * elem, hipMemcpyHostToDevice, s), "H2D model");
+    };
+    append(m_tree_indices_, model.tree_indices.data(), 4, up_trees_, T);
+    append(m_depths_, model.depths.data(), 4, up_splits_, S);
+    append(m_feature_indices_, model.feature_indices.data(), 4, up_splits_ * MD, S * MD);
+    append(m_feature_values_, model.feature_values.data(), 4, up_splits_ * MD, S * MD);
+    append(m_is_numerics_, model.is_numerics.data(), 1, up_splits_ * MD, S * MD);
+    append(m_cat_ids_, cat_ids_host_.data(), 4, up_splits_ * MD, S * MD);
+    // packed (feature | ~categorical feature, threshold bits | category id) pairs per split row: read through the scalar cache
+    // by the fast oblivious predict kernel
+    cond_pack_host_.resize(S * MD * 2, 0);
+    for (size_t c = up_splits_ * MD; c < S * MD; ++c) {
+        const bool num = model.is_numerics[c] != 0;
+        int32_t tv;
+        std::memcpy(&tv, &model.feature_values[c], sizeof(tv));
+        cond_pack_host_[2 * c] = num ? model.feature_indices[c] : ~model.feature_indices[c];
+        cond_pack_host_[2 * c + 1] = num ? tv : cat_ids_host_[c];
+    }
+    append(m_cond_pack_, cond_pack_host_.data(), 4, up_splits_ * MD * 2, S * MD * 2);
+    append(m_values_, model.values.data(), 4, up_leaves_ * D, L * D);
+    append(m_ineq_, model.inequality_directions.data(), 1, up_leaves_ * MD, L * MD);
+    // Greedy ensembles: rebuild every new tree as a binary tree from its leaves' paths (leaves are stored depth-first, left
+    // first; fitter.cpp:364-365), for the descent of k_predict_grd.  A tree whose leaves do not form a proper binary tree (a
+    // hand-edited model file), or a depth-0 tree (Q7), switches the fast path off for the whole ensemble.
+    if (!model.oblivious()) {
+        if (up_trees_ == 0) { grd_nodes_host_.clear(); grd_off_host_.assign(1, 0); grd_ok_ = true; grd_max_nodes_ = 0; grd_max_leaves_ = 1; }
+        for (size_t t = up_trees_; t < T; ++t) {
+            const int l0 = model.tree_indices[t], l1 = t + 1 < T ? model.tree_indices[t + 1] : static_cast<int>(L);
+            const size_t base = grd_nodes_host_.size() / 4;
+            bool ok = l1 > l0;
+            // same condition (depth d) for two leaves?
+            auto same_cond = [&](int a, int b, int d) {
+                const size_t ca = static_cast<size_t>(a) * MD + d, cb = static_cast<size_t>(b) * MD + d;
+                if (model.is_numerics[ca] != model.is_numerics[cb] || model.feature_indices[ca] != model.feature_indices[cb]) return false;
+                if (model.is_numerics[ca]) return std::memcmp(&model.feature_values[ca], &model.feature_values[cb], 4) == 0;
+                return cat_ids_host_[ca] == cat_ids_host_[cb];
+            };
+            // build(lo, hi, d): leaves [lo, hi) share their first d conditions; returns the child code
+            std::function<int(int, int, int)> build = [&](int lo, int hi, int d) -> int {
+                if (!ok) return -1;
+                if (hi - lo == 1) {
+                    if (model.depths[lo] != d) ok = false;
+                    return ~(lo - l0);
+                }
+                if (d >= static_cast<int>(MD)) { ok = false; return -1; }
+                int mid = lo;
+                for (int q = lo; q < hi; ++q) {
+                    if (model.depths[q] <= d || !same_cond(lo, q, d)) { ok = false; return -1; }
+                    const bool right = model.inequality_directions[static_cast<size_t>(q) * MD + d] != 0;
+                    if (!right) { if (q != mid) { ok = false; return -1; } ++mid; }   // left leaves first, contiguous
+                }
+                if (mid == lo || mid == hi) { ok = false; return -1; }
+                const size_t me = grd_nodes_host_.size() / 4 - base;
+                grd_nodes_host_.insert(grd_nodes_host_.end(), {0, 0, 0, 0});
+                const size_t c = static_cast<size_t>(lo) * MD + d;
+                int32_t tv;
+                std::memcpy(&tv, &model.feature_values[c], sizeof(tv));
+                const bool num = model.is_numerics[c] != 0;
+                const int left = build(lo, mid, d + 1), right = build(mid, hi, d + 1);
+                int32_t *nd = &grd_nodes_host_[(base + me) * 4];
+                nd[0] = num ? model.feature_indices[c] : ~model.feature_indices[c];
+                nd[1] = num ? tv : cat_ids_host_[c];
+                nd[2] = left;
+                nd[3] = right;
+                return static_cast<int>(me);
+            };
+            if (ok && l1 - l0 == 1) ok = false;                 // depth-0 tree: its leaf never passes in the reference (Q7)
+            if (ok) { const int root = build(l0, l1, 0); if (root != 0) ok = false; }
+            if (!ok) { grd_ok_ = false; grd_nodes_host_.resize(base * 4); }
+            grd_off_host_.push_back(static_cast<int32_t>(grd_nodes_host_.size() / 4));
+            grd_max_nodes_ = std::max<int>(grd_max_nodes_, static_cast<int>(grd_nodes_host_.size() / 4 - base));
+            grd_max_leaves_ = std::max(grd_max_leaves_, l1 - l0);
+        }
+        append(m_grd_nodes_, grd_nodes_host_.data(), 4, grd_up_nodes_ * 4, grd_nodes_host_.size());
+        append(m_grd_off_, grd_off_host_.data(), 4, 0, grd_off_host_.size());
+        grd_up_nodes_ = grd_nodes_host_.size() / 4;
+    }
+    up_trees_ = T; up_leaves_ = L; up_splits_ = S;
+    // small, mutable state: always refreshed
+    append(m_bias_, model.bias.data(), 4, 0, D);
+    std::vector<int32_t> os, oe;
+    std::vector<float> olr;
+    for (const auto &o : model.opts) { os.push_back(o.start_idx); oe.push_back(o.stop_idx); olr.push_back(o.init_lr); }  // ConstScheduler::get_lr
+    append(m_opt_start_, os.data(), 4, 0, os.size());
+    append(m_opt_stop_, oe.data(), 4, 0, oe.size());
+    append(m_opt_lr_, olr.data(), 4, 0, olr.size());
+    hip_check(hipStreamSynchronize(s), "sync model upload");
+    mirror_version_ = model.version;
+}
+
+void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
+                     int stop_tree, float *out, bool out_dev) {
+    gbrl_hip_metadata &md = model.meta;
+    // GBRL::predict, gbrl.cpp:378-390
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
+    if (n_num + n_cat != md.input_dim) throw InvalidArgument("Incompatible dataset");
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n <= 0 || out == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (md.output_dim > 128) throw Unsupported("predict: output_dim > 128");
+    ensure_device();
+    ev_used_ = 0;
+    ev_names_.clear();
+    hipStream_t s = stream_;
+    const int D = md.output_dim;
+    // predict_cpu, predictor.cpp:127-141
+    int stop = stop_tree;
+    if (md.n_trees == 0 || stop > md.n_trees || model.opts.empty()) { start_tree = 0; stop = 0; }
+    else if (stop == 0) stop = md.n_trees;
+    sync_model_to_device();
+    phase_begin();
+    const float *dobs = obs;
+    if (n_num > 0 && !obs_dev) {
+        dobs = static_cast<float *>(d_pobs_.ensure(sizeof(float) * static_cast<size_t>(n) * n_num));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * static_cast<size_t>(n) * n_num, hipMemcpyHostToDevice, s), "H2D obs");
+    }
+    int32_t *dcat = nullptr;
+    if (n_cat > 0) {
+        // dictionary encoding on the device: the cells are hashed (strcmp semantics: bytes before the first NUL), looked up in
+        // the per-feature, hash-sorted dictionary of the categories the model's conditions mention, and confirmed word by word
+        const char *dcells = cat;
+        if (!cat_dev) {
+            char *tmp = static_cast<char *>(d_pcells_.ensure(static_cast<size_t>(n) * n_cat * kCat));
+            hip_check(hipMemcpyAsync(tmp, cat, static_cast<size_t>(n) * n_cat * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+            dcells = tmp;
+        }
+        if (dict_version_ != cat_dict_.size() || dict_fc_ != n_cat) {
+            struct E { uint64_t h; int id; uint64_t w[16]; };
+            std::vector<std::vector<E>> per(n_cat);
+            for (size_t z = 0; z < cat_dict_.size(); ++z) {
+                const int f = cat_dict_[z].first;
+                if (f < 0 || f >= n_cat) continue;
+                E e{};
+                uint64_t raw[16];
+                std::memcpy(raw, cat_dict_[z].second.data(), kCat);
+                e.h = cat_cell_hash(raw, e.w);
+                e.id = static_cast<int>(z) + 1;
+                per[f].push_back(e);
+            }
+            std::vector<int32_t> off(n_cat + 1, 0), ids;
+            std::vector<uint64_t> hs, ws;
+            for (int f = 0; f < n_cat; ++f) {
+                std::sort(per[f].begin(), per[f].end(), [](const E &a, const E &b) { return a.h < b.h || (a.h == b.h && a.id < b.id); });
+                for (const E &e : per[f]) { hs.push_back(e.h); ids.push_back(e.id); ws.insert(ws.end(), e.w, e.w + 16); }
+                off[f + 1] = static_cast<int32_t>(hs.size());
+            }
+            hs.push_back(0); ids.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
+            hip_check(hipMemcpyAsync(d_dict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipMemcpyAsync(d_dict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipMemcpyAsync(d_dict_id_.ensure(ids.size() * 4), ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipMemcpyAsync(d_dict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+            hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
+            dict_version_ = cat_dict_.size();
+            dict_fc_ = n_cat;
+        }
+        dcat = static_cast<int32_t *>(d_pcat_.ensure(sizeof(int32_t) * static_cast<size_t>(n) * n_cat));
+        kern::encode_categories(dcells, n, n_cat, d_dict_off_.as<int32_t>(), d_dict_hash_.as<uint64_t>(), d_dict_id_.as<int32_t>(),
+                                d_dict_words_.as<uint64_t>(), dcat, s);
+    }
+    float *dout = out;
+    if (!out_dev) dout = static_cast<float *>(d_pout_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+    phase_end("inputs");
+    phase_begin(/*key=*/true);
+    kern::PredictModel pm{};
+    pm.tree_indices = m_tree_indices_.as<int32_t>();
+    pm.depths = m_depths_.as<int32_t>();
+    pm.feature_indices = m_feature_indices_.as<int32_t>();
+    pm.cat_ids = m_cat_ids_.as<int32_t>();
+    pm.feature_values = m_feature_values_.as<float>();
+    pm.values = m_values_.as<float>();
+    pm.bias = m_bias_.as<float>();
+    pm.is_numerics = m_is_numerics_.as<uint8_t>();
+    pm.inequality_directions = m_ineq_.as<uint8_t>();
+    pm.n_trees = md.n_trees; pm.n_leaves = md.n_leaves; pm.max_depth = md.max_depth; pm.D = D;
+    pm.oblivious = model.oblivious() ? 1 : 0;
+    pm.n_opts = static_cast<int>(model.opts.size());
+    pm.opt_start = m_opt_start_.as<int32_t>();
+    pm.opt_stop = m_opt_stop_.as<int32_t>();
+    pm.opt_lr = m_opt_lr_.as<float>();
+    pm.cond_pack = m_cond_pack_.as<int32_t>();
+    pm.grd_nodes = m_grd_nodes_.as<int32_t>();
+    pm.grd_node_off = m_grd_off_.as<int32_t>();
+    pm.grd_ok = (!model.oblivious() && grd_ok_) ? 1 : 0;
+    pm.grd_max_nodes = grd_max_nodes_;
+    pm.grd_max_leaves = grd_max_leaves_;
+    if (const char *e = std::getenv("GBRL_HIP_PREDICT_GENERIC")) {   // test hook: the general kernels only
+        if (e[0] == '1') { pm.grd_ok = 0; pm.obl_ok = 0; }
+    }
+    pm.obl_ok = model.oblivious() ? 1 : 0;
+    pm.coef_ok = D <= 32 ? 1 : 0;
+    pm.coef_cover = 0;
+    for (int j = 0; j < 32; ++j) pm.coef[j] = 0.0f;
+    for (const auto &o : model.opts) {   // one learning rate per output unless two optimisers share an output
+        for (int j = o.start_idx; j < o.stop_idx && pm.coef_ok; ++j) {
+            if (j < 0 || j >= D || ((pm.coef_cover >> j) & 1u)) { pm.coef_ok = 0; break; }
+            pm.coef_cover |= 1u << j;
+            pm.coef[j] = o.init_lr;
+        }
+    }
+    kern::predict(pm, dobs, n_num, dcat, n_cat, n, start_tree, stop, dout, s);
+    hip_check(hipGetLastError(), "predict launch");
+    phase_end("predict", /*key=*/true);
+    if (!out_dev) hip_check(hipMemcpyAsync(out, dout, sizeof(float) * static_cast<size_t>(n) * D, hipMemcpyDeviceToHost, s), "D2H preds");
+    hip_check(hipStreamSynchronize(s), "sync");
+    phases_resolve();
+}
+
+}  // namespace gbrl

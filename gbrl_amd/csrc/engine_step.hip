@@ -1,0 +1,1308 @@
+// engine_step.hip -- host orchestration of the HIP kernels for GBRL::step and GBRL::fit (see engine.h).
+//
+// step() restates Fitter::step_cpu (gbrl/src/cpp/fitter.cpp:50-115) as a histogram algorithm:
+//   1. gradient statistics + fixed-point quantisation of the build gradients           (A2)
+//   2. split candidates: uniform (min/max) or quantile (exact order statistics)          (A3, A4); categorical on the host (A5)
+//   3. observations -> per-feature class codes (once per step)
+//   4. level-synchronous growth: for every frontier node build (count, sum g[D]) per (feature, class) in LDS, reduce to
+//      exact int64 histograms, score every candidate from suffix sums, pick the split, partition the row list   (A6-A10)
+//   5. leaf values = exact mean of the raw gradients per leaf                              (A11)
+// The reference grows greedy trees depth-first; the split chosen for a node depends only on that node's rows, so growing
+// level by level and emitting the leaves in depth-first (left first) order afterwards gives the identical tree.
+#include "engine.h"
+
+#include <numeric>
+#include <random>
+#include "cat_hash.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+
+namespace gbrl {
+
+using kern::Chunk;
+using kern::FeatureSlot;
+using kern::NodeSplit;
+
+
+namespace detail {
+
+struct HCond {       // splitCondition (types.h:64-70) + what the kernels need
+    int fslot;       // feature slot (numeric f, or F + categorical c)
+    int feat_idx;    // feature index as stored in the model (within its numeric / categorical block)
+    float value;     // numeric threshold, +inf for categorical (split_candidate_generator.cpp:155)
+    int bin;         // numeric: threshold index; categorical: class id
+    bool is_cat;
+    bool dir;
+    float edge_w;
+    int cat_cand;    // index into cat candidate strings, -1 for numeric
+};
+
+struct HNode {
+    int depth = 0;
+    int seg_start = 0;
+    int n_local = 0;        // rows of this rank in the node
+    long long n_global = 0;  // rows over all ranks
+    std::vector<HCond> path;
+    int left = -1, right = -1;
+    int parent = -1;
+    int hist_slot = -1;     // slot of this node's histogram in its level's buffer
+    bool leaf = false;
+};
+
+// Everything Engine::grow_tree needs from the preparation stages of step().
+struct GrowCtx {
+    int N, F, Fc, D, B, MD, NB, FG, Fp, n_groups, n_slots, n_cand, chunk_rows;
+    long long n_global;
+    bool cosine, oblivious;
+    const std::vector<kern::FeatureSlot> *slots;
+    const std::vector<float> *cand_w;
+    const std::vector<int32_t> *cand_ref;
+    const std::vector<int> *ref_to_internal;
+    const std::vector<CatCandidate> *cat_cands;
+    const float *h_thr;                 // pinned; valid once the stream has passed the copy enqueued behind the binning
+    const kern::StepScales *h_scales;   // pinned, same
+    const float *d_thr;
+    const uint32_t *d_thrkeys;   // [F][B] ordered keys of the thresholds
+    const uint32_t *d_kt;        // [F][N] feature-major ordered keys of the observations (null when F == 0)
+    const uint16_t *d_codes;
+    const int32_t *d_qg;
+    const float *dgrads;
+    kern::StepScales *d_scales;
+};
+
+}  // namespace detail
+
+using detail::CatCandidate;
+using detail::GrowCtx;
+using detail::HCond;
+using detail::HNode;
+
+namespace {
+
+// Packs many small host arrays into one pinned block and uploads them with ONE async copy; put() returns the DEVICE
+// address the array will have.  The pinned block must not be refilled before the copy has executed (the caller's
+// per-level synchronisation guarantees it).
+class Stager {
+   public:
+    Stager(PinnedBuf &pin, DevBuf &dev, size_t cap, hipStream_t s) : s_(s) {
+        host_ = static_cast<char *>(pin.ensure(cap));
+        dev_ = static_cast<char *>(dev.ensure(cap));
+        cap_ = cap;
+    }
+    void reset() { used_ = 0; }
+    template <typename T>
+    T *put(const T *src, size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (used_ + bytes + 256 > cap_) throw HipError("internal: staging buffer overflow");
+        if (bytes) std::memcpy(host_ + used_, src, bytes);
+        T *d = reinterpret_cast<T *>(dev_ + used_);
+        used_ += (bytes + 255) & ~static_cast<size_t>(255);
+        return d;
+    }
+    void flush() {
+        if (used_) hip_check(hipMemcpyAsync(dev_, host_, used_, hipMemcpyHostToDevice, s_), "H2D staged descriptors");
+    }
+
+   private:
+    hipStream_t s_;
+    char *host_ = nullptr, *dev_ = nullptr;
+    size_t cap_ = 0, used_ = 0;
+};
+
+
+// ---- A5: categorical candidates on the host, exactly as processCategoricalCandidates (split_candidate_generator.cpp:117-163):
+// same container, same insertion order => same candidate order (Q8).  cat_classes[f] = number of candidate categories of
+// feature f (class ids 1..), h_catcodes[i*Fc+f] = class of the cell (0: not a candidate).
+void categorical_candidates(const char *hcat, const float *hgrads, int N, int Fc, int D, int B, std::vector<CatCandidate> &cat_cands,
+                            std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes) {
+    struct Info { float total = 0.f; int count = 0; int feat = 0; std::string name; };
+    std::vector<float> norms(N, 0.0f);
+    for (int i = 0; i < N; ++i) {  // calculate_squared_norm (math_ops.cpp:726-749), contracted like the reference build
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) { const float g = hgrads[static_cast<size_t>(i) * D + d]; acc = fmaf(g, g, acc); }
+        norms[i] = acc;
+    }
+    std::unordered_map<std::string, Info> uniq;
+    for (int f = 0; f < Fc; ++f)
+        for (int i = 0; i < N; ++i) {
+            std::string name(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+            Info &ci = uniq[name + "_" + std::to_string(f)];
+            ci.total += norms[i];
+            ci.count += 1;
+            ci.feat = f;
+            ci.name = name;
+        }
+    std::vector<std::pair<std::string, float>> vec;
+    for (const auto &kv : uniq) vec.emplace_back(kv.first, kv.second.total / kv.second.count);
+    int n_unique = static_cast<int>(vec.size());
+    if (n_unique > Fc * B) {
+        std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, float> &a, const std::pair<std::string, float> &b) {
+            return a.second > b.second;
+        });
+        n_unique = Fc * B;
+    }
+    std::unordered_map<std::string, int> cls_of;  // key -> class id within its feature
+    for (int i = 0; i < n_unique; ++i) {
+        const Info &ci = uniq[vec[i].first];
+        const int cls = ++cat_classes[ci.feat];
+        if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+        cat_cands.push_back({ci.feat, ci.name, cls});
+        cls_of[vec[i].first] = cls;
+    }
+    h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
+    for (int i = 0; i < N; ++i)
+        for (int f = 0; f < Fc; ++f) {
+            std::string key(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+            key += "_" + std::to_string(f);
+            auto it = cls_of.find(key);
+            if (it != cls_of.end()) h_catcodes[static_cast<size_t>(i) * Fc + f] = static_cast<uint16_t>(it->second);
+        }
+}
+
+// ---- A10/A11: the grown tree joins the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) with exact leaf
+// means of the raw gradients (acc[node] = int64 fixed-point sums | count; fitter.cpp:545-582).
+void append_tree(Model &model, const std::vector<HNode> &nodes, const std::vector<int> &frontier, const std::vector<int64_t> &acc,
+                 double leaf_scale, const std::vector<CatCandidate> &cat_cands) {
+    gbrl_hip_metadata &md = model.meta;
+    const bool oblivious = model.oblivious();
+    const int MD = md.max_depth, D = md.output_dim;
+// leaf order: oblivious = level order of the last level (child slots 2k, 2k+1, fitter.cpp:469-470); greedy = depth-first,
+// left first (fitter.cpp:364-365)
+std::vector<int> leaf_order;
+if (oblivious) {
+    if (nodes.size() == 1) leaf_order.push_back(0);
+    else leaf_order = frontier;
+} else {
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int id = stack.back();
+        stack.pop_back();
+        if (nodes[id].left < 0) { leaf_order.push_back(id); continue; }
+        stack.push_back(nodes[id].right);
+        stack.push_back(nodes[id].left);
+    }
+}
+
+// ---- append to the ensemble (update_ensemble_per_leaf / per_tree, fitter.cpp:493-542) -----------------------------
+model.begin_tree();
+const size_t tree = md.n_trees;
+model.tree_indices.push_back(md.n_leaves);
+auto write_conditions = [&](const HNode &nd, size_t split_row, size_t leaf_row) {
+    for (size_t i = 0; i < nd.path.size(); ++i) {
+        const HCond &c = nd.path[i];
+        if (c.is_cat && c.cat_cand >= 0)
+            std::memcpy(&model.categorical_values[(split_row * MD + i) * kCat], cat_cands[c.cat_cand].name.data(), kCat);
+        model.is_numerics[split_row * MD + i] = c.is_cat ? 0 : 1;
+        model.feature_indices[split_row * MD + i] = c.feat_idx;
+        model.feature_values[split_row * MD + i] = c.value;
+        model.inequality_directions[leaf_row * MD + i] = c.dir ? 1 : 0;
+        model.edge_weights[leaf_row * MD + i] = c.edge_w;
+    }
+};
+const size_t n_new = leaf_order.size();
+const size_t L0 = md.n_leaves;
+const size_t S_new = oblivious ? tree + 1 : L0 + n_new;
+model.depths.resize(S_new, 0);
+model.feature_indices.resize(S_new * MD, 0);
+model.feature_values.resize(S_new * MD, 0.0f);
+model.is_numerics.resize(S_new * MD, 0);
+model.categorical_values.resize(S_new * MD * kCat, 0);
+model.values.resize((L0 + n_new) * D, 0.0f);
+model.edge_weights.resize((L0 + n_new) * MD, 0.0f);
+model.inequality_directions.resize((L0 + n_new) * MD, 0);
+for (size_t q = 0; q < n_new; ++q) {
+    const HNode &nd = nodes[leaf_order[q]];
+    const size_t leaf_row = L0 + q;
+    if (oblivious) {
+        model.depths[tree] = nd.depth;
+        write_conditions(nd, tree, leaf_row);
+    } else {
+        model.depths[leaf_row] = nd.depth;
+        write_conditions(nd, leaf_row, leaf_row);
+    }
+    const int64_t *a = &acc[static_cast<size_t>(leaf_order[q]) * (D + 1)];
+    const int64_t cnt = a[D];
+    for (int d = 0; d < D; ++d) {
+        float v = 0.0f;
+        if (cnt > 0 && nd.depth > 0)  // fitter.cpp:574-578; depth-0 leaf keeps 0 (Q7)
+            v = static_cast<float>((static_cast<double>(a[d]) / leaf_scale) / static_cast<double>(cnt));
+        model.values[leaf_row * D + d] = v;
+    }
+}
+md.n_leaves += static_cast<int32_t>(n_new);
+md.n_trees += 1;
+md.iteration += 1;  // fitter.cpp:114
+++model.version;
+}
+
+}  // namespace
+
+// ---- A5 on the device ------------------------------------------------------------------------------------------------------
+// Finds the distinct (feature, cell) pairs of the batch and their first rows with per-feature hash tables on the device, hands
+// the few distinct cells to the host, which inserts them into the SAME container in the SAME order as the reference's scan
+// (feature-major, first occurrence; split_candidate_generator.cpp:119-129) -- so the candidate order (Q8) is the reference's --
+// and uploads the candidate dictionary for k_cat_step_codes.  Returns false (caller falls back to the host scan) when the
+// batch has more distinct categories than the Fc*B the reference keeps (it then ranks them by mean gradient norm), a table
+// overflowed, or two different cells collided on their 64-bit hash.
+bool Engine::device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
+                                           std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes) {
+    hipStream_t s = stream_;
+    const long long keep = static_cast<long long>(Fc) * B;
+    if (keep > (1 << 20)) return false;
+    int log2_cap = 8;
+    while ((1ll << log2_cap) < 4 * std::min<long long>(N, keep + 1) && log2_cap < 20) ++log2_cap;
+    const size_t slots = static_cast<size_t>(Fc) << log2_cap;
+    const int list_cap = static_cast<int>(keep) + 1;
+    uint64_t *d_keys = static_cast<uint64_t *>(d_cat_keys_.ensure(sizeof(uint64_t) * slots));
+    int32_t *d_first = static_cast<int32_t *>(d_cat_first_.ensure(sizeof(int32_t) * slots));
+    int32_t *d_meta = static_cast<int32_t *>(d_cat_meta_.ensure(sizeof(int32_t) * 4));               // flags[2], counter
+    int32_t *d_lfeat = static_cast<int32_t *>(d_cat_lfeat_.ensure(sizeof(int32_t) * list_cap * 2));   // feat | first
+    int32_t *d_lfirst = d_lfeat + list_cap;
+    uint64_t *d_lhash = static_cast<uint64_t *>(d_cat_lhash_.ensure(sizeof(uint64_t) * list_cap));
+    hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
+    hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
+    hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
+    kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+    kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+    kern::cat_distinct_compact(d_keys, d_first, Fc, log2_cap, d_lfeat, d_lhash, d_lfirst, d_meta + 2, list_cap, d_meta, s);
+    int32_t meta[4];
+    hip_check(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s), "D2H cat meta");
+    hip_check(hipStreamSynchronize(s), "sync");
+    int n_distinct = meta[2];
+    bool declined = meta[0] != 0 || meta[1] != 0 || n_distinct > keep;
+    if (has_coll_) {   // every rank must take the same path
+        int64_t *d_flag = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t)));
+        int64_t hv = declined ? 1 : 0;
+        hip_check(hipMemcpyAsync(d_flag, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D");
+        exchange(Red::SumI64, d_flag, 1);
+        hip_check(hipMemcpyAsync(&hv, d_flag, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        declined = hv != 0;
+    }
+    if (declined) return false;
+    std::vector<int32_t> lfeat(n_distinct), lfirst(n_distinct);
+    std::vector<uint64_t> lhash(n_distinct);
+    if (n_distinct > 0) {
+        hip_check(hipMemcpyAsync(lfeat.data(), d_lfeat, sizeof(int32_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(lfirst.data(), d_lfirst, sizeof(int32_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipMemcpyAsync(lhash.data(), d_lhash, sizeof(uint64_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    // the reference's insertion order: feature-major, then row of first occurrence
+    std::vector<int> order(n_distinct);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return lfeat[a] != lfeat[b] ? lfeat[a] < lfeat[b] : lfirst[a] < lfirst[b]; });
+    // the distinct cells themselves
+    std::vector<char> names(static_cast<size_t>(n_distinct) * kCat);
+    if (hcells) {
+        for (int q = 0; q < n_distinct; ++q)
+            std::memcpy(&names[static_cast<size_t>(q) * kCat], hcells + (static_cast<size_t>(lfirst[q]) * Fc + lfeat[q]) * kCat, kCat);
+    } else if (n_distinct > 0) {
+        char *d_names = static_cast<char *>(d_cat_names_.ensure(names.size()));
+        kern::gather_cells(dcells, Fc, d_lfirst, d_lfeat, n_distinct, d_names, s);
+        hip_check(hipMemcpyAsync(names.data(), d_names, names.size(), hipMemcpyDeviceToHost, s), "D2H names");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    if (has_coll_) {
+        // Row-sharded: every rank needs the distinct cells of ALL ranks, in the order a single process would meet them (rank
+        // after rank = global row order).  All-gather through the sum exchange: counts first, then 18-word records
+        // (feature, first row, the 128 bytes) written into rank-indexed slots of a zeroed buffer.
+        const int world = coll_.world_size, rank = coll_.rank;
+        int64_t *d_cnt = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * (world + 1)));
+        std::vector<int64_t> cnt(world + 1, 0);
+        cnt[rank] = n_distinct;
+        hip_check(hipMemcpyAsync(d_cnt, cnt.data(), sizeof(int64_t) * (world + 1), hipMemcpyHostToDevice, s), "H2D");
+        exchange(Red::SumI64, d_cnt, world + 1);
+        hip_check(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int64_t) * (world + 1), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        long long total = 0, my_off = 0;
+        for (int r = 0; r < world; ++r) { if (r < rank) my_off += cnt[r]; total += cnt[r]; }
+        if (total > (1ll << 20)) throw Unsupported("too many distinct categories for a row-sharded step");
+        std::vector<int64_t> rec(static_cast<size_t>(total) * 18, 0);
+        for (int q = 0; q < n_distinct; ++q) {
+            int64_t *r18 = &rec[(static_cast<size_t>(my_off) + q) * 18];
+            r18[0] = lfeat[order[q]];
+            r18[1] = lfirst[order[q]];
+            std::memcpy(r18 + 2, &names[static_cast<size_t>(order[q]) * kCat], kCat);
+        }
+        if (total > 0) {
+            int64_t *d_rec = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * rec.size()));
+            hip_check(hipMemcpyAsync(d_rec, rec.data(), sizeof(int64_t) * rec.size(), hipMemcpyHostToDevice, s), "H2D");
+            exchange(Red::SumI64, d_rec, rec.size());
+            hip_check(hipMemcpyAsync(rec.data(), d_rec, sizeof(int64_t) * rec.size(), hipMemcpyDeviceToHost, s), "D2H");
+            hip_check(hipStreamSynchronize(s), "sync");
+        }
+        // global list, already rank-major and (feature, first row)-sorted inside a rank: stable sort by feature keeps that order
+        n_distinct = static_cast<int>(total);
+        lfeat.resize(n_distinct); lfirst.resize(n_distinct); lhash.resize(n_distinct);
+        names.resize(static_cast<size_t>(n_distinct) * kCat);
+        for (int q = 0; q < n_distinct; ++q) {
+            const int64_t *r18 = &rec[static_cast<size_t>(q) * 18];
+            lfeat[q] = static_cast<int32_t>(r18[0]);
+            lfirst[q] = q;                                             // position in global order
+            std::memcpy(&names[static_cast<size_t>(q) * kCat], r18 + 2, kCat);
+            uint64_t w[16];
+            std::memcpy(w, r18 + 2, kCat);
+            lhash[q] = cat_cell_hash_raw(w);
+        }
+        order.resize(n_distinct);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lfeat[a] < lfeat[b]; });
+    }
+    struct Info { int feat; int item; };
+    std::unordered_map<std::string, Info> uniq;
+    for (int q : order) {
+        std::string key(&names[static_cast<size_t>(q) * kCat], kCat);
+        key += "_" + std::to_string(lfeat[q]);
+        uniq.emplace(std::move(key), Info{lfeat[q], q});
+    }
+    if (static_cast<long long>(uniq.size()) > keep)
+        throw Unsupported("more distinct categories than Fc * n_bins in a row-sharded step (the reference's mean-gradient ranking is not available sharded)");
+    struct DictE { uint64_t h; int cls; int item; };
+    std::vector<std::vector<DictE>> per(Fc);
+    for (const auto &kv : uniq) {                                  // candidate order = the container's iteration order (Q8)
+        const Info &ci = kv.second;
+        const int cls = ++cat_classes[ci.feat];
+        if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+        cat_cands.push_back({ci.feat, std::string(&names[static_cast<size_t>(ci.item) * kCat], kCat), cls});
+        per[ci.feat].push_back({lhash[ci.item], cls, ci.item});
+    }
+    std::vector<int32_t> off(Fc + 1, 0), clss;
+    std::vector<uint64_t> hs, ws;
+    for (int f = 0; f < Fc; ++f) {
+        std::sort(per[f].begin(), per[f].end(), [](const DictE &a, const DictE &b) { return a.h < b.h || (a.h == b.h && a.cls < b.cls); });
+        for (const DictE &e : per[f]) {
+            hs.push_back(e.h);
+            clss.push_back(e.cls);
+            uint64_t w[16];
+            std::memcpy(w, &names[static_cast<size_t>(e.item) * kCat], kCat);
+            ws.insert(ws.end(), w, w + 16);
+        }
+        off[f + 1] = static_cast<int32_t>(hs.size());
+    }
+    hs.push_back(0); clss.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
+    hip_check(hipMemcpyAsync(d_sdict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipMemcpyAsync(d_sdict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipMemcpyAsync(d_sdict_cls_.ensure(clss.size() * 4), clss.data(), clss.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipMemcpyAsync(d_sdict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+    hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
+    return true;
+}
+
+// ---- A3/A4: numeric split candidates ------------------------------------------------------------------------------------
+// thresholds [F][B] of the rows in dobs (keys already transposed into d_kt): fixed ones (fit()), uniform (min/max + fma), or
+// exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
+// On return d_thr / d_thrkeys hold them on the device (the caller copies them to the host when it needs them there).
+void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
+                                uint32_t *d_thrkeys) {
+    hipStream_t s = stream_;
+    const gbrl_hip_metadata &md = model.meta;
+    uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
+    bool fast_quantile = false;
+    auto bisection_quantiles = [&](const std::vector<int64_t> &cum) {
+        // exact but slow: 32 counting passes (also the multi-GPU path: only integer counts cross ranks)
+        int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+        hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+        uint32_t *d_prefix = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * F * B));
+        uint32_t *d_trial = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * F * B));
+        int64_t *d_counts = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * F * (B + 1)));
+        kern::qsel_init(d_prefix, d_trial, F, B, s);
+        for (int bit = 31; bit >= 0; --bit) {
+            hip_check(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * F * (B + 1), s), "memset");
+            kern::bin_rows(dobs, N, F, d_trial, B, /*strict=*/false, d_counts, nullptr, 0, 0, s);
+            if (has_coll_) exchange(Red::SumI64, d_counts, static_cast<size_t>(F) * (B + 1));
+            kern::qsel_update(d_prefix, d_trial, d_counts, d_cum, F, B, bit, bit - 1, s);
+        }
+        hip_check(hipMemcpyAsync(d_thrkeys, d_trial, sizeof(uint32_t) * F * B, hipMemcpyDeviceToDevice, s), "D2D keys");
+    };
+    std::vector<int64_t> cum;
+    if (F > 0 && !fixed_thr_.empty()) {
+        // fit(): the candidates were generated from the whole data set (fitter.cpp:134-150); this batch only bins against them
+        if (fixed_thr_.size() != static_cast<size_t>(F) * B) throw HipError("internal: fixed thresholds do not match this model");
+        hip_check(hipMemcpyAsync(d_thr, fixed_thr_.data(), sizeof(float) * fixed_thr_.size(), hipMemcpyHostToDevice, s), "H2D thresholds");
+        kern::floats_to_keys(d_thr, d_thrkeys, fixed_thr_.size(), s);
+    } else if (F > 0) {
+        if (md.generator_type == GBRL_HIP_GEN_UNIFORM) {
+            uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
+            hip_check(hipMemsetAsync(d_mm, 0xff, sizeof(uint32_t) * F, s), "memset");
+            hip_check(hipMemsetAsync(d_mm + F, 0x00, sizeof(uint32_t) * F, s), "memset");
+            kern::column_minmax(dobs, N, F, d_mm, d_mm + F, s);
+            if (has_coll_) {
+                // exchange as floats (max / min are exact)
+                float *tmp = static_cast<float *>(d_trial_.ensure(sizeof(float) * 2 * F));
+                kern::keys_to_floats(d_mm, tmp, 2 * static_cast<size_t>(F), s);
+                exchange(Red::MinF32, tmp, F);
+                exchange(Red::MaxF32, tmp + F, F);
+                kern::floats_to_keys(tmp, d_mm, 2 * static_cast<size_t>(F), s);
+            }
+            kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s);
+            kern::floats_to_keys(d_thr, d_thrkeys, static_cast<size_t>(F) * B, s);
+        } else {
+            // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1
+            if (n_global < B + 1) throw InvalidArgument("quantile candidates need n_samples >= n_bins + 1");
+            cum.resize(B);
+            const long long per = n_global / (B + 1), rem = n_global % (B + 1);
+            long long run = 0;
+            for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
+            // sharded fast path needs a power-of-two world (union sample of world*4096 keys sorted in LDS)
+            const bool coll_fast = has_coll_ && (coll_.world_size & (coll_.world_size - 1)) == 0 && coll_.world_size <= 8;
+            const bool radix_ok = !force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32);
+            if (force_bisection_ || (has_coll_ && !coll_fast && !radix_ok)) {
+                bisection_quantiles(cum);
+            } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && N <= kern::sort_quantiles_max_rows()) {
+                // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
+                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, s);
+                last_quantile_fallback_ = false;
+            } else if (!force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32)) {
+                // exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip).  Row-sharded
+                // runs sum the digit counts of every pass over ranks (any world size): 4 all-reduces per step.
+                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                void *d_rs = d_radix_state_.ensure(kern::radix_state_bytes(F, B));
+                uint32_t *d_rp = static_cast<uint32_t *>(d_radix_partial_.ensure(kern::radix_partial_bytes(F)));
+                uint32_t *d_rl = static_cast<uint32_t *>(d_qlists_.ensure(kern::radix_list_bytes(N, F)));
+                kern::RadixComm comm{};
+                if (has_coll_) {
+                    comm.ctx = this;
+                    comm.allreduce_sum_i64 = &Engine::radix_exchange_trampoline;
+                    comm.gbuf = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * kern::radix_exchange_words(F)));
+                    comm.partial_global = static_cast<uint32_t *>(d_radix_global_.ensure(kern::radix_global_partial_bytes(F)));
+                }
+                const int rc = kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s, has_coll_ ? &comm : nullptr);
+                if (rc != 0) throw HipError(rc == 2 ? "allreduce failed" : "radix select failed");
+                last_quantile_fallback_ = false;
+            } else {
+                fast_quantile = true;
+                kern::QuantilePlan plan = kern::quantile_plan(N);
+                if (has_coll_) { plan.sample = 4096; plan.n_split = kern::kQuantileMaxSplit; }   // identical on every rank
+                const uint32_t max_elems = static_cast<uint32_t>(std::min<size_t>(static_cast<size_t>(N) * F, std::max<size_t>(1u << 20, static_cast<size_t>(N) * F / 4)));
+                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * kern::kQuantileMaxSplit));
+                uint32_t *d_split_bfs = d_split + static_cast<size_t>(F) * kern::kQuantileMaxSplit;
+                uint32_t *d_cc = static_cast<uint32_t *>(d_ccounts_.ensure(sizeof(uint32_t) * static_cast<size_t>(plan.n_chunks) * F * kern::kQuantileClasses));
+                uint32_t *d_coff = static_cast<uint32_t *>(d_c2l_.ensure(sizeof(uint32_t) * F * kern::kQuantileClasses));
+                uint32_t *d_toff = static_cast<uint32_t *>(d_tgt_list_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * B));
+                uint32_t *d_tlen = d_toff + static_cast<size_t>(F) * B;
+                uint32_t *d_tr = static_cast<uint32_t *>(d_tgt_rank_.ensure(sizeof(uint32_t) * F * B));
+                uint32_t *d_lists = static_cast<uint32_t *>(d_qlists_.ensure(sizeof(uint32_t) * max_elems));
+                hip_check(hipMemsetAsync(d_coff, 0xff, sizeof(uint32_t) * F * kern::kQuantileClasses, s), "memset");
+                hip_check(hipMemsetAsync(d_qflags, 0, sizeof(uint32_t) * 4, s), "memset");
+                int64_t *d_gcounts = nullptr;
+                if (has_coll_) {
+                    // every rank contributes a 4096-key sample per feature; the union is sorted identically everywhere
+                    const int S = 4096, SU = S * coll_.world_size;
+                    uint32_t *d_samp = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * static_cast<size_t>(F) * S));
+                    int64_t *d_uni = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * std::max<size_t>(static_cast<size_t>(F) * SU, static_cast<size_t>(F) * kern::kQuantileClasses)));
+                    kern::sample_only(d_kt, N, F, S, d_samp, s);
+                    hip_check(hipMemsetAsync(d_uni, 0, sizeof(int64_t) * static_cast<size_t>(F) * SU, s), "memset");
+                    kern::place_sample(d_samp, F, S, coll_.rank, SU, d_uni, s);
+                    exchange(Red::SumI64, d_uni, static_cast<size_t>(F) * SU);
+                    kern::union_splitters(d_uni, F, SU, plan.n_split, d_split, d_split_bfs, s);
+                    kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
+                    d_gcounts = d_uni;   // reuse (the union sample is consumed)
+                    kern::counts_to_i64(d_cc, plan.n_chunks, static_cast<size_t>(F) * kern::kQuantileClasses, d_gcounts, s);
+                    exchange(Red::SumI64, d_gcounts, static_cast<size_t>(F) * kern::kQuantileClasses);
+                } else {
+                    kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
+                    kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
+                }
+                kern::quantile_targets(d_cc, d_gcounts, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
+                                       d_qflags + 2, s);
+                kern::quantile_extract(d_kt, N, F, plan, d_split_bfs, d_coff, d_cc, d_lists, s);
+                if (has_coll_) {
+                    // the lists stay on their ranks; the order statistic of their union is found by 32 counting rounds
+                    uint32_t *d_pref = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * static_cast<size_t>(F) * B));
+                    int64_t *d_scnt = static_cast<int64_t *>(d_selcnt_.ensure(sizeof(int64_t) * (static_cast<size_t>(F) * B + 1)));
+                    hip_check(hipMemsetAsync(d_pref, 0, sizeof(uint32_t) * static_cast<size_t>(F) * B, s), "memset");
+                    for (int bit = 31; bit >= 0; --bit) {
+                        kern::select_count(d_lists, d_toff, d_tlen, d_pref, bit, F * B, d_scnt, s);
+                        exchange(Red::SumI64, d_scnt, static_cast<size_t>(F) * B);
+                        kern::select_update(d_pref, d_scnt, d_toff, d_tr, bit, F * B, d_thrkeys, s);
+                    }
+                } else {
+                    kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
+                }
+            }
+            kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
+        }
+        uint32_t qflags[4] = {0, 0, 0, 0};
+        if (fast_quantile) {
+            hip_check(hipMemcpyAsync(qflags, d_qflags, sizeof(qflags), hipMemcpyDeviceToHost, s), "D2H flags");
+            hip_check(hipStreamSynchronize(s), "sync");
+            if (has_coll_) {   // the fallback decision must be the same on every rank
+                int64_t *d_flag = static_cast<int64_t *>(d_selcnt_.ensure(sizeof(int64_t) * 2));
+                int64_t hv = qflags[2];
+                hip_check(hipMemcpyAsync(d_flag, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D flag");
+                exchange(Red::SumI64, d_flag, 1);
+                hip_check(hipMemcpyAsync(&hv, d_flag, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H flag");
+                hip_check(hipStreamSynchronize(s), "sync");
+                qflags[2] = hv != 0;
+            }
+            if (qflags[2] != 0) {  // a class list outgrew its budget (pathological value distribution): redo exactly, slowly
+                bisection_quantiles(cum);
+                kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
+                last_quantile_fallback_ = true;
+            } else {
+                last_quantile_fallback_ = false;
+            }
+        }
+    }
+}
+
+// ---- A6-A9, A11: level-synchronous growth of one tree from the class codes and the quantised gradients ---------------------
+// Per level the host (1) uploads ONE packed descriptor block (chunk tables, slot maps, paths, partition chunks) from pinned
+// memory, (2) enqueues histogram / reduce / subtract / score / argmax / resolve kernels, the read-back of ONE small result block
+// (best candidate, child sizes) and -- from descriptors the device completes itself -- the partition, (3) waits for the result
+// block only (an event, not the stream) and books the children while the partition runs.  Leaf sums are enqueued when a node
+// becomes a leaf.  On return `nodes` is the tree, `frontier` the unsplit nodes of the last level, acc the per-node int64
+// fixed-point sums of the raw gradients (| count) and leaf_scale their scale.
+void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
+                       double &leaf_scale) {
+    using namespace detail;
+    hipStream_t s = stream_;
+    const gbrl_hip_metadata &md = model.meta;
+    const int N = c.N, F = c.F, D = c.D, B = c.B, MD = c.MD, NB = c.NB, FG = c.FG, Fp = c.Fp, n_groups = c.n_groups, n_slots = c.n_slots,
+              n_cand = c.n_cand, chunk_rows = c.chunk_rows;
+    const long long n_global = c.n_global;
+    const bool cosine = c.cosine, oblivious = c.oblivious;
+    const std::vector<FeatureSlot> &slots = *c.slots;
+    const std::vector<float> &cand_w = *c.cand_w;
+    const std::vector<int32_t> &cand_ref = *c.cand_ref;
+    const std::vector<int> &ref_to_internal = *c.ref_to_internal;
+    const std::vector<CatCandidate> &cat_cands = *c.cat_cands;
+    const float *h_thr = c.h_thr;
+    const float *d_thr = c.d_thr, *dgrads = c.dgrads;
+    const uint16_t *d_codes = c.d_codes;
+    const int32_t *d_qg = c.d_qg;
+    kern::StepScales *d_scales = c.d_scales;
+    // Level-synchronous.  Per level the host (1) uploads ONE packed descriptor block (chunk tables, slot maps, paths) from
+    // pinned memory, (2) enqueues histogram / score / argmax / resolve kernels, (3) reads back ONE small result block (best
+    // candidate, child sizes) -- the only synchronisation of the level -- and (4) uploads the split descriptors and enqueues
+    // leaf sums and the partition without waiting for them.
+    const int max_front = 1 << std::max(0, MD - 1);
+    const int max_nodes = 2 * (1 << MD);
+    const int max_chunks = std::max((N + 1023) / 1024, (N + kern::kPartitionRows - 1) / kern::kPartitionRows) + 2 * (1 << MD) + 2;
+    const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
+    int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
+                          static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
+    // a level needs at most 32 balanced chunks plus one rounding chunk per node
+    const int hist_max_chunks = std::max(32, (N + chunk_rows - 1) / chunk_rows) + 2 * (1 << MD) + 2;
+    int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * static_cast<size_t>(hist_max_chunks) * n_groups * n_acc));
+    const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
+    // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
+    int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems)),
+                              static_cast<int64_t *>(d_hist_prev_.ensure(sizeof(int64_t) * max_front * hist_node_elems))};
+    int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * hist_node_elems)) : nullptr;
+    float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
+    float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
+    const int am_parts = kern::argmax_parts(std::max(1, n_cand));
+    const size_t am_cap = static_cast<size_t>(max_front) * std::max(am_parts, std::max(1, n_slots));   // greedy: one part per feature slot
+    float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * am_cap));
+    int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * am_cap));
+    int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
+    int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
+    hip_check(hipMemsetAsync(d_leafacc, 0, sizeof(int64_t) * max_nodes * (D + 1), s), "memset leaf acc");
+    // per-step constants: slots, candidate weights / reference order / slot lookup
+    std::vector<int32_t> cand_slot(n_cand);
+    for (int fs = 0; fs < n_slots; ++fs)
+        for (int k = 0; k < slots[fs].n_cand; ++k) cand_slot[slots[fs].cand_base + k] = fs;
+    const size_t stage_bytes = 4096 + sizeof(FeatureSlot) * n_slots + static_cast<size_t>(n_cand) * 16 +
+                               sizeof(Chunk) * (static_cast<size_t>(max_chunks) + N / 4096 + 2 * max_nodes + 64) +
+                               static_cast<size_t>(max_front) * (kern::kMaxPath * 12 + 256);
+    Stager stc(pin_const_, d_stage_const_, stage_bytes, s), sta(pin_a_, d_stage_a_, stage_bytes, s), stb(pin_b_, d_stage_b_, stage_bytes, s);
+    FeatureSlot *d_slots = stc.put(slots.data(), slots.size());
+    float *d_cand_w = stc.put(cand_w.data(), cand_w.size());
+    int32_t *d_cand_ref = stc.put(cand_ref.data(), cand_ref.size());
+    int32_t *d_ref_to_internal = stc.put(ref_to_internal.data(), ref_to_internal.size());
+    int32_t *d_cand_slot = stc.put(cand_slot.data(), cand_slot.size());
+    stc.flush();
+    // result block read back once per level: [best_idx i32 x mf][best_score f32 x mf][counts i64 x 4 x mf]
+    const size_t res_bytes = static_cast<size_t>(max_front) * (4 + 4 + 32) + 64;
+    char *d_res = static_cast<char *>(d_results_.ensure(res_bytes));
+    char *h_res = static_cast<char *>(pin_res_.ensure(res_bytes));
+    int32_t *d_best_idx = reinterpret_cast<int32_t *>(d_res);
+    float *d_best_score = reinterpret_cast<float *>(d_res + 4 * static_cast<size_t>(max_front));
+    int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
+    NodeSplit *d_resolved = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
+    kern::iota_rows(d_rows[0], N, s);
+    // No synchronisation here: thresholds and scales are on their way to pinned memory; the first level's event wait (or the
+    // final synchronisation) covers them.  Non-finite gradients are rejected after the loop, before anything joins the model.
+
+    nodes.clear();
+    nodes.reserve(max_nodes);
+    nodes.push_back(HNode{});
+    nodes[0].n_local = N;
+    nodes[0].n_global = n_global;
+    frontier.assign(1, 0);
+    int cur = 0;  // which row list is current
+    std::vector<Chunk> h_chunks;
+    std::vector<int32_t> h_chunk_begin;
+    auto make_chunks = [&](const std::vector<int> &ids, int rows_per_chunk, bool slot_is_node_id) {
+        h_chunks.clear();
+        h_chunk_begin.assign(1, 0);
+        for (size_t k = 0; k < ids.size(); ++k) {
+            const HNode &nd = nodes[ids[k]];
+            if (slot_is_node_id && nd.depth == 0) { h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size())); continue; }  // Q7
+            // equal parts (no short remainder chunk): parts = ceil(n / rows_per_chunk), each ceil(n / parts) rows
+            const int parts = (nd.n_local + rows_per_chunk - 1) / rows_per_chunk;
+            const int each = parts ? (nd.n_local + parts - 1) / parts : 0;
+            for (int off = 0; off < nd.n_local; off += each)
+                h_chunks.push_back({static_cast<int32_t>(slot_is_node_id ? ids[k] : static_cast<int>(k)), nd.seg_start + off,
+                                    std::min(each, nd.n_local - off), 0});
+            h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size()));
+        }
+    };
+    // smallest chunk length t (<= chunk_rows) for which the nodes `ids` need at most `budget` chunks in total
+    auto balanced_chunk_rows = [&](const std::vector<int> &ids, int budget) {
+        int lo = 1024, hi = chunk_rows;
+        auto parts_at = [&](int t) { long long p = 0; for (int id : ids) p += (nodes[id].n_local + t - 1) / t; return p; };
+        if (parts_at(hi) > budget) return hi;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (parts_at(mid) <= budget) hi = mid; else lo = mid + 1;
+        }
+        return hi;
+    };
+
+    for (int depth = 0; depth < MD && n_cand > 0; ++depth) {
+        // nodes that take part at this level: oblivious -> the whole level; greedy -> nodes with rows (fitter.cpp:300)
+        std::vector<int> active;
+        for (int id : frontier)
+            if (oblivious || nodes[id].n_global > 0) active.push_back(id);
+        if (active.empty()) break;
+        const int n_act = static_cast<int>(active.size());
+        // -- histograms.  Level 0: the root.  Deeper levels: of every sibling pair only the child with fewer rows is
+        //    accumulated from the data; the other one is parent - sibling (exact integers), which halves the LDS-atomic work.
+        //    (Row-sharded runs accumulate every node: the "smaller" child differs per rank.)
+        //    The level buffers hold GLOBAL histograms.  Row-sharded runs pick the "smaller" child by its global row count (the
+        //    same on every rank), all-reduce only those children and subtract globally.
+        int64_t *d_hist = d_hist_lvl[depth & 1];
+        const int64_t *d_hist_prev = d_hist_lvl[(depth & 1) ^ 1];
+        std::vector<int> compute_ids;
+        std::vector<int32_t> slot_map, sub_par(n_act, -1), sub_sib(n_act, -1);
+        if (depth == 0) {
+            compute_ids = active;
+            for (int k = 0; k < n_act; ++k) slot_map.push_back(k);
+        } else {
+            std::vector<int> slot_of(nodes.size(), -1);
+            for (int k = 0; k < n_act; ++k) slot_of[active[k]] = k;
+            for (int k = 0; k < n_act; ++k) {
+                const int id = active[k], par = nodes[id].parent;
+                const int sib = nodes[par].left == id ? nodes[par].right : nodes[par].left;
+                const bool sib_active = slot_of[sib] >= 0;
+                // the child that is accumulated: fewer local rows; ties -> the left child
+                const long long mine = has_coll_ ? nodes[id].n_global : nodes[id].n_local;
+                const long long theirs = has_coll_ ? nodes[sib].n_global : nodes[sib].n_local;
+                const bool i_am_small = sib_active && (mine < theirs || (mine == theirs && nodes[par].left == id));
+                if (i_am_small) {
+                    compute_ids.push_back(id);
+                    slot_map.push_back(k);
+                } else {
+                    sub_par[k] = nodes[par].hist_slot;
+                    sub_sib[k] = sib_active ? slot_of[sib] : -1;
+                }
+            }
+        }
+        for (int k = 0; k < n_act; ++k) nodes[active[k]].hist_slot = k;
+        // chunk table of ALL active nodes (row-sharded runs count the local child sizes from the rows themselves)
+        std::vector<Chunk> count_chunks;
+        if (has_coll_) { make_chunks(active, kern::kPartitionRows, false); count_chunks = h_chunks; }
+        make_chunks(compute_ids, balanced_chunk_rows(compute_ids, 32), false);
+        if (h_chunks.size() > static_cast<size_t>(hist_max_chunks)) throw HipError("internal: chunk table overflow");
+        // paths (duplicate-on-path rejection, node.cpp:154-166)
+        std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
+        std::vector<float> pv(static_cast<size_t>(n_act) * kern::kMaxPath, 0.f);
+        for (int k = 0; k < n_act; ++k) {
+            const HNode &nd = nodes[active[k]];
+            pl[k] = static_cast<int32_t>(nd.path.size());
+            root[k] = nd.depth == 0;
+            for (size_t q = 0; q < nd.path.size(); ++q) {
+                ps[k * kern::kMaxPath + q] = nd.path[q].fslot;
+                pv[k * kern::kMaxPath + q] = nd.path[q].value;
+                pb[k * kern::kMaxPath + q] = nd.path[q].bin;
+            }
+        }
+        sta.reset();
+        Chunk *d_chunks = sta.put(h_chunks.data(), h_chunks.size());
+        int32_t *d_chunk_begin = sta.put(h_chunk_begin.data(), h_chunk_begin.size());
+        int32_t *d_slotmap = sta.put(slot_map.data(), slot_map.size());
+        int32_t *d_sub_par = sta.put(sub_par.data(), sub_par.size());
+        int32_t *d_sub_sib = sta.put(sub_sib.data(), sub_sib.size());
+        int32_t *d_path_len = sta.put(pl.data(), pl.size());
+        int32_t *d_path_slot = sta.put(ps.data(), ps.size());
+        float *d_path_val = sta.put(pv.data(), pv.size());
+        int32_t *d_path_bin = sta.put(pb.data(), pb.size());
+        int32_t *d_isroot = sta.put(root.data(), root.size());
+        Chunk *d_count_chunks = sta.put(count_chunks.data(), count_chunks.size());
+        // One GPU: the partition of this level is enqueued right behind the selection kernels, from descriptors the device
+        // completes itself (k_resolve_splits), so that it runs while the host is still waiting for / digesting the read-back.
+        std::vector<Chunk> part_chunks;
+        std::vector<int32_t> seg_starts(n_act), n_locals(n_act);
+        {
+            for (int k = 0; k < n_act; ++k) { seg_starts[k] = nodes[active[k]].seg_start; n_locals[k] = nodes[active[k]].n_local; }
+            std::vector<Chunk> keep = h_chunks;
+            std::vector<int32_t> keep_begin = h_chunk_begin;
+            make_chunks(active, kern::kPartitionRows, false);
+            part_chunks = h_chunks;
+            h_chunks = keep;
+            h_chunk_begin = keep_begin;
+        }
+        Chunk *d_part_chunks = sta.put(part_chunks.data(), part_chunks.size());
+        int32_t *d_seg_starts = sta.put(seg_starts.data(), seg_starts.size());
+        int32_t *d_n_locals = sta.put(n_locals.data(), n_locals.size());
+        sta.flush();
+        if (!h_chunks.empty()) {
+            const auto ev = kernel_events("hist_build", /*key=*/true);   // the dispatch's own timestamps: no bubble in the stream
+            kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s,
+                             ev.first, ev.second);
+        }
+        phase_begin();
+        if (!has_coll_) {
+            if (!compute_ids.empty())
+                kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s);
+        } else if (!compute_ids.empty()) {
+            // local sums of the computed nodes, contiguous -> ONE all-reduce -> placed into their level slots
+            const int nc = static_cast<int>(compute_ids.size());
+            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s);
+            exchange(Red::SumI64, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems);
+            kern::hist_place(d_hist_coll, d_hist, d_slotmap, nc, hist_node_elems, s);
+        }
+        phase_end("hist_reduce");
+        // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
+        phase_begin();
+        kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
+                               d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
+                               oblivious ? nullptr : d_am_v, d_am_i, s);
+        // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
+        // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
+        if (oblivious)
+            kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
+        // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
+        kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : n_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+                             d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s);
+        if (has_coll_) {
+            int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
+            hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
+            if (!count_chunks.empty())
+                kern::count_right(d_rows[cur], d_codes, c.d_kt, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
+            kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);   // global left sizes -> this rank's
+        }
+        hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
+        phase_end("score_select");
+        {
+            hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");
+            phase_begin();
+            if (!part_chunks.empty())
+                kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, c.d_kt, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved,
+                                     d_cursors, s);
+            phase_end("partition");
+            // spin on the event (a blocking wait costs a thread wake-up of ~10-20 us per level; the wait itself is a few tens of us)
+            for (;;) {
+                const hipError_t q = hipEventQuery(ev_level_);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) hip_check(q, "hipEventQuery(level results)");
+            }
+        }
+        hip_check(hipGetLastError(), "growth kernels");
+        const int32_t *best_idx_h = reinterpret_cast<const int32_t *>(h_res);
+        const float *best_score_h = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
+        const int64_t *cnt4 = reinterpret_cast<const int64_t *>(h_res + 8 * static_cast<size_t>(max_front));
+        const int64_t *tot_g = cnt4, *right_g = cnt4 + max_front;
+        const int64_t *right_l = has_coll_ ? cnt4 + 2 * static_cast<size_t>(max_front) : right_g;
+        if (oblivious && best_score_h[0] == -INFINITY) break;  // fitter.cpp:458
+        // -- decisions (best_idx are REFERENCE candidate indices)
+        std::vector<NodeSplit> sp(n_act);
+        std::vector<int> splitting, new_leaves;
+        for (int k = 0; k < n_act; ++k) {
+            HNode &nd = nodes[active[k]];
+            const int bk = oblivious ? 0 : k;
+            const bool do_split = oblivious || best_score_h[bk] >= 0.0f;  // fitter.cpp:357
+            NodeSplit q{};
+            q.seg_start = nd.seg_start;
+            if (do_split) {
+                const int j = ref_to_internal[best_idx_h[bk]];
+                const int fs = cand_slot[j];
+                q.do_split = 1;
+                q.fslot = fs;
+                q.is_cat = slots[fs].is_cat;
+                q.bin = slots[fs].is_cat ? (j - slots[fs].cand_base + 1) : (j - slots[fs].cand_base);
+                splitting.push_back(k);
+            } else {
+                nd.leaf = true;
+                new_leaves.push_back(active[k]);
+            }
+            sp[k] = q;
+        }
+        if (!oblivious)
+            for (int id : frontier)
+                if (nodes[id].n_global == 0 && !nodes[id].leaf) { nodes[id].leaf = true; new_leaves.push_back(id); }
+        std::vector<int> next;
+        for (int k : splitting) {
+            const int id = active[k];
+            if (tot_g[k] != nodes[id].n_global) throw HipError("internal: histogram row count mismatch");
+            const NodeSplit &q = sp[k];
+            HCond c{};
+            c.fslot = q.fslot;
+            c.is_cat = q.is_cat != 0;
+            c.bin = q.bin;
+            if (c.is_cat) {
+                c.feat_idx = q.fslot - F;
+                c.value = INFINITY;
+                c.cat_cand = -1;
+                for (size_t z = 0; z < cat_cands.size(); ++z)
+                    if (cat_cands[z].feat == c.feat_idx && cat_cands[z].cls == q.bin) c.cat_cand = static_cast<int>(z);
+            } else {
+                c.feat_idx = q.fslot;
+                c.value = h_thr[static_cast<size_t>(q.fslot) * B + q.bin];
+                c.cat_cand = -1;
+            }
+            const long long npar = nodes[id].n_global, nr = right_g[k], nl = npar - nr;
+            HNode l, r;
+            l.depth = r.depth = nodes[id].depth + 1;
+            l.parent = r.parent = id;
+            l.path = nodes[id].path;
+            r.path = nodes[id].path;
+            HCond cl = c, cr = c;
+            cl.dir = false;
+            cl.edge_w = npar > 0 ? static_cast<float>(nl) / static_cast<float>(npar) : 0.0f;  // node.cpp:131
+            cr.dir = true;
+            cr.edge_w = npar > 0 ? static_cast<float>(nr) / static_cast<float>(npar) : 0.0f;
+            l.path.push_back(cl);
+            r.path.push_back(cr);
+            const int nl_local = static_cast<int>(nodes[id].n_local - right_l[k]);
+            l.seg_start = nodes[id].seg_start;
+            l.n_local = nl_local;
+            l.n_global = nl;
+            r.seg_start = nodes[id].seg_start + nl_local;
+            r.n_local = static_cast<int>(right_l[k]);
+            r.n_global = nr;
+            sp[k].n_left = nl_local;
+            nodes[id].left = static_cast<int>(nodes.size());
+            nodes.push_back(l);
+            nodes[id].right = static_cast<int>(nodes.size());
+            nodes.push_back(r);
+            next.push_back(nodes[id].left);
+            next.push_back(nodes[id].right);
+        }
+        // -- leaves finalised at this level (their segment is intact in the current list) and the partition: enqueued, not awaited
+        stb.reset();
+        if (!new_leaves.empty()) {
+            make_chunks(new_leaves, 1024, true);
+            if (!h_chunks.empty()) {
+                Chunk *d_lc = stb.put(h_chunks.data(), h_chunks.size());
+                stb.flush();
+                phase_begin();
+                kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), d_scales, d_leafacc, s);
+                phase_end("leaves");
+            }
+        }
+        if (splitting.empty()) { frontier.clear(); break; }
+        cur ^= 1;   // the partition was enqueued from the device-side descriptors (same decisions: best_score rule, n_left)
+        frontier = next;
+    }
+
+    // ---- 5. leaves ---------------------------------------------------------------------------------------------------
+    {
+        std::vector<int> last;
+        for (int id : frontier)
+            if (!nodes[id].leaf) { nodes[id].leaf = true; last.push_back(id); }
+        if (nodes.size() == 1) nodes[0].leaf = true;
+        make_chunks(last, 1024, true);
+        if (!h_chunks.empty()) {
+            // stage B may still be in flight for the partition of the last level: stage A is free (its level is complete)
+            sta.reset();
+            Chunk *d_lc = sta.put(h_chunks.data(), h_chunks.size());
+            sta.flush();
+            phase_begin();
+            kern::leaf_sums(dgrads, D, d_rows[cur], d_lc, static_cast<int>(h_chunks.size()), d_scales, d_leafacc, s);
+            phase_end("leaves");
+        }
+    }
+    if (has_coll_) {
+        exchange(Red::SumI64, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1));
+    }
+    const size_t n_acc_words = nodes.size() * (D + 1);
+    int64_t *h_acc = static_cast<int64_t *>(pin_acc_.ensure(sizeof(int64_t) * std::max<size_t>(1, n_acc_words)));   // pinned: a true async copy
+    hip_check(hipMemcpyAsync(h_acc, d_leafacc, sizeof(int64_t) * n_acc_words, hipMemcpyDeviceToHost, s), "D2H leaf acc");
+    hip_check(hipStreamSynchronize(s), "sync");
+    acc.assign(h_acc, h_acc + n_acc_words);
+    // everything enqueued for this tree has completed: scales are in pinned memory
+    if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
+    leaf_scale = c.h_scales->leaf_scale;
+
+}
+
+// ======================================================================================================== step
+void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *grads, bool grads_dev, int n,
+                  int n_num, int n_cat) {
+    gbrl_hip_metadata &md = model.meta;
+    // GBRL::step, gbrl.cpp:946-958
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n_num + n_cat != md.input_dim) throw InvalidArgument("Total number of features != correct input dim");
+    if (n <= 0 || grads == nullptr) throw InvalidArgument("Cannot call step without grads!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call step without obs!");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call step without cat_obs!");
+    if (md.max_depth > kern::kMaxPath) throw Unsupported("max_depth > 32 is not supported");
+    if (md.n_bins < 1 || md.n_bins > 65534) throw Unsupported("n_bins must be in [1, 65534]");
+    ensure_device();
+    ev_used_ = 0;
+    ev_names_.clear();
+    if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
+    if (const char *e = std::getenv("GBRL_HIP_HOST_CATEGORICAL")) force_host_categorical_ = e[0] == '1';   // test hook: host scan of every cell
+    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_RADIX")) force_radix_ = e[0] == '1';   // test hook: radix multi-select also for small batches
+    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
+    hipStream_t s = stream_;
+    const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
+    const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
+    const bool oblivious = model.oblivious();
+    const int world = has_coll_ ? coll_.world_size : 1;
+
+    // global row count (rows are sharded over ranks)
+    long long n_global = N;
+    if (has_coll_) {
+        int64_t *tmp = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t)));
+        int64_t hv = N;
+        hip_check(hipMemcpyAsync(tmp, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D n");
+        exchange(Red::SumI64, tmp, 1);
+        hip_check(hipMemcpyAsync(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H n");
+        hip_check(hipStreamSynchronize(s), "sync");
+        n_global = hv;
+    }
+
+    // ---- inputs on the device -------------------------------------------------------------------------------------
+    phase_begin();
+    const float *dobs = obs;
+    if (F > 0 && !obs_dev) {
+        dobs = static_cast<float *>(d_obs_.ensure(sizeof(float) * N * F));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * N * F, hipMemcpyHostToDevice, s), "H2D obs");
+    }
+    const float *dgrads = grads;
+    if (!grads_dev) {
+        dgrads = static_cast<float *>(d_grads_.ensure(sizeof(float) * N * D));
+        hip_check(hipMemcpyAsync(const_cast<float *>(dgrads), grads, sizeof(float) * N * D, hipMemcpyHostToDevice, s), "H2D grads");
+    }
+    // categorical cells on the device: the distinct categories of the batch are found there (device_categorical_candidates);
+    // the host-side scan of every cell is only the fallback
+    const char *dcells = cat;
+    if (Fc > 0 && !cat_dev) {
+        char *t = static_cast<char *>(d_pcells_.ensure(static_cast<size_t>(N) * Fc * kCat));
+        hip_check(hipMemcpyAsync(t, cat, static_cast<size_t>(N) * Fc * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+        dcells = t;
+    }
+    phase_end("inputs");
+
+    // ---- 1. gradient statistics and quantisation (A2) -----------------------------------------------------------------
+    phase_begin();
+    const size_t n_el = static_cast<size_t>(N) * D;
+    float *d_meanden = static_cast<float *>(d_meanden_.ensure(sizeof(float) * 2 * D));
+    const float *d_mean = nullptr, *d_den = nullptr;
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 4 * D));
+    const int nblk = kern::column_sums_blocks(N, D);
+    double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
+    if (D > 512) throw Unsupported("output_dim > 512");
+    // LDS accumulators are int32 and one block adds at most `chunk_rows` rows into a cell: the power-of-two scale keeps
+    // chunk_rows * max|q| < 2^31 (exactness of the wrapped int32 sums, kernels.hip k_hist_build).
+    // A histogram block accumulates one chunk of one node's rows.  Chunks are sized per level so that the whole level is ONE
+    // balanced round of <= 32 chunks x (feature groups) blocks (k_hist_build keeps one block per CU); `chunk_rows` is the cap
+    // the fixed-point scale is derived from.  Leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62.
+    // It depends on the GLOBAL row count only (clamped to [4096, 65536]), so the scale -- and with it every integer sum -- is
+    // the same for any sharding of the same rows.
+    const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
+    kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
+    {
+        // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
+        // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
+        // sums (fp64) and take the maxima (fp32, exact) over ranks between the kernels; the arithmetic stays on the device,
+        // so one GPU and N GPUs execute the same instructions on the same global sums.
+        double *d_stat2 = d_stat + 2 * D;
+        float *d_maxf = static_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
+        auto exchange_stats = [&](double *st) {
+            if (!has_coll_) return;
+            kern::f64_to_f32(st + D, d_maxf, D, s);
+            exchange(Red::SumF64, st, D);
+            exchange(Red::MaxF32, d_maxf, D);
+            kern::f32_to_f64(d_maxf, st + D, D, s);
+        };
+        kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
+        exchange_stats(d_stat);
+        if (!cosine) {
+            kern::stats_mean(d_stat, n_global, D, d_meanden, s);
+            kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat2, s);
+            exchange_stats(d_stat2);
+            kern::stats_finish(d_stat, d_stat2, n_global, D, chunk_rows, d_meanden, d_scales, s);
+            d_mean = d_meanden;
+            d_den = d_meanden + D;
+        } else {
+            kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
+        }
+    }
+    int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
+    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
+    phase_end("grad_stats");
+
+    // ---- 2. split candidates ----------------------------------------------------------------------------------------
+    phase_begin();
+    // thresholds and scales reach the host through ONE pinned block, copied behind the binning kernel: nothing waits for them
+    // until the first level's result block has arrived
+    const size_t n_thr = static_cast<size_t>(F) * B;
+    char *pin_ts = static_cast<char *>(pin_thr_.ensure(sizeof(float) * std::max<size_t>(1, n_thr) + sizeof(kern::StepScales) + 64));
+    float *h_thr = reinterpret_cast<float *>(pin_ts);
+    kern::StepScales *h_scales_pin = reinterpret_cast<kern::StepScales *>(pin_ts + ((sizeof(float) * std::max<size_t>(1, n_thr) + 63) & ~static_cast<size_t>(63)));
+    float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, n_thr)));
+    uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, n_thr)));
+    uint32_t *d_kt = nullptr;
+    if (F > 0) {
+        // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
+        d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
+        kern::transpose_keys(dobs, N, F, d_kt, s);
+    }
+    phase_end("transpose");
+    phase_begin();
+    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys);
+    phase_end("candidates");
+
+    // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the
+    // reference's insertion order on the host => same candidate order (Q8).  Falls back to the host scan of every cell when
+    // the batch holds more distinct categories than candidates are kept (the reference then ranks them by mean gradient norm).
+    std::vector<CatCandidate> cat_cands;
+    std::vector<uint16_t> h_catcodes;
+    std::vector<int> cat_classes(Fc, 0);
+    bool cat_codes_on_device = false;
+    if (Fc > 0) {
+        if (fixed_cat_valid_) {   // fit(): candidates of the whole data set (fitter.cpp:152-164); the dictionary is still on the device
+            cat_cands = fixed_cat_cands_;
+            cat_classes = fixed_cat_classes_;
+            cat_codes_on_device = true;
+        } else {
+            cat_codes_on_device = (has_coll_ || !force_host_categorical_) &&
+                                  device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
+        }
+        if (!cat_codes_on_device && has_coll_)
+            throw Unsupported("this batch needs the reference's mean-gradient ranking of categories (more distinct categories than Fc * n_bins), which is not available row-sharded");
+        if (!cat_codes_on_device) {
+            std::vector<char> cat_host_buf;
+            const char *hcat = cat;
+            std::vector<float> grads_host_buf;
+            const float *hgrads = grads;
+            if (cat_dev) {
+                cat_host_buf.resize(static_cast<size_t>(N) * Fc * kCat);
+                hip_check(hipMemcpy(cat_host_buf.data(), cat, cat_host_buf.size(), hipMemcpyDeviceToHost), "D2H cat");
+                hcat = cat_host_buf.data();
+            }
+            if (grads_dev) {
+                grads_host_buf.resize(static_cast<size_t>(N) * D);
+                hip_check(hipMemcpy(grads_host_buf.data(), grads, grads_host_buf.size() * 4, hipMemcpyDeviceToHost), "D2H grads");
+                hgrads = grads_host_buf.data();
+            }
+            cat_cands.clear();
+            std::fill(cat_classes.begin(), cat_classes.end(), 0);
+            categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
+        }
+    }
+
+    if (candidates_only_) {   // fit(): only the candidates of this (whole) data set are wanted
+        if (n_thr) hip_check(hipMemcpyAsync(h_thr, d_thr, sizeof(float) * n_thr, hipMemcpyDeviceToHost, s), "D2H thr");
+        hip_check(hipStreamSynchronize(s), "sync");
+        fixed_thr_.assign(h_thr, h_thr + n_thr);
+        if (Fc > 0) {
+            if (!cat_codes_on_device)
+                throw Unsupported("fit(): the data set holds more distinct categories than Fc * n_bins (mean-gradient ranking of the whole data set is not implemented)");
+            fixed_cat_cands_ = cat_cands;
+            fixed_cat_classes_ = cat_classes;
+            fixed_cat_valid_ = true;
+        }
+        phases_resolve();
+        return;
+    }
+
+    // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
+    const int n_slots = F + Fc;
+    int NB = F > 0 ? B + 1 : 1;
+    for (int c = 0; c < Fc; ++c) NB = std::max(NB, cat_classes[c] + 1);
+    int FG = 16;
+    while (FG > 1 && kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512) FG >>= 1;
+    if (kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512)
+        throw Unsupported("(classes per feature) x (output_dim + 1) does not fit the 160 KiB LDS");
+    if (static_cast<size_t>(NB + 1) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");
+    const int Fp = ((n_slots + FG - 1) / FG) * FG;
+    const int n_groups = Fp / FG;
+    // internal candidate order = slot-grouped; cand_ref maps to the reference's candidate index (numeric f-major, then the
+    // categorical candidates in the hash-map order) which decides ties (lowest reference index wins)
+    std::vector<FeatureSlot> slots(n_slots);
+    int n_cand = 0;
+    for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
+    for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
+    std::vector<int32_t> cand_ref(n_cand);
+    std::vector<float> cand_w(n_cand);
+    std::vector<int> ref_to_internal(n_cand);
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < B; ++k) {
+            const int j = slots[f].cand_base + k;
+            cand_ref[j] = f * B + k;
+            // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
+            const int wi = oblivious ? model.reverse_num[f] : f;
+            cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+        }
+    for (size_t q = 0; q < cat_cands.size(); ++q) {
+        const CatCandidate &cc = cat_cands[q];
+        const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
+        cand_ref[j] = F * B + static_cast<int>(q);
+        const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
+        cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+    }
+    for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
+
+    // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
+    phase_begin();
+    const int n_code_groups = (n_slots + kern::kCodeGroup - 1) / kern::kCodeGroup;
+    const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
+    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
+    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
+    if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
+    if (Fc > 0 && cat_codes_on_device) {
+        kern::cat_step_codes(dcells, N, Fc, F, d_sdict_off_.as<int32_t>(), d_sdict_hash_.as<uint64_t>(), d_sdict_cls_.as<int32_t>(),
+                             d_sdict_words_.as<uint64_t>(), d_codes, s);
+    } else if (Fc > 0) {
+        uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
+        hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
+        kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
+    }
+    phase_end("binning");
+    if (n_thr) hip_check(hipMemcpyAsync(h_thr, d_thr, sizeof(float) * n_thr, hipMemcpyDeviceToHost, s), "D2H thr");
+    hip_check(hipMemcpyAsync(h_scales_pin, d_scales, sizeof(kern::StepScales), hipMemcpyDeviceToHost, s), "D2H scales");
+
+    // ---- 4. growth (level-synchronous; Engine::grow_tree) and 5. leaf sums --------------------------------------------------
+    GrowCtx gc{};
+    gc.N = N; gc.F = F; gc.Fc = Fc; gc.D = D; gc.B = B; gc.MD = MD; gc.NB = NB; gc.FG = FG; gc.Fp = Fp; gc.n_groups = n_groups;
+    gc.n_slots = n_slots; gc.n_cand = n_cand; gc.chunk_rows = chunk_rows; gc.n_global = n_global; gc.cosine = cosine; gc.oblivious = oblivious;
+    gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cat_cands = &cat_cands;
+    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    std::vector<HNode> nodes;
+    std::vector<int> frontier;
+    std::vector<int64_t> acc;
+    double leaf_scale = 1.0;
+    grow_tree(gc, nodes, frontier, acc, leaf_scale);
+    append_tree(model, nodes, frontier, acc, leaf_scale, cat_cands);
+    (void)world;
+    hip_check(hipGetLastError(), "step kernels");
+    phases_resolve();
+}
+
+// ===================================================================================================== fit
+float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *targets, bool targets_dev, int n, int n_num,
+                  int n_cat, int iterations, bool shuffle) {
+    gbrl_hip_metadata &md = model.meta;
+    if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }                      // gbrl.cpp:996-999
+    if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    if (n <= 0 || targets == nullptr) throw InvalidArgument("Cannot call fit without targets!");
+    if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call fit without obs!");
+    if (iterations < 0) throw InvalidArgument("iterations must be >= 0");
+    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call fit without cat_obs!");
+    if (has_coll_) throw Unsupported("fit() is not supported on a row-sharded model");
+    if (md.batch_size <= 0) throw InvalidArgument("batch_size must be positive");
+    ensure_device();
+    hipStream_t s = stream_;
+    const int F = n_num, Fc = n_cat, D = md.output_dim;
+    struct Guard { Engine *e; ~Guard() { e->fixed_thr_.clear(); e->fixed_cat_valid_ = false; e->fixed_cat_cands_.clear(); e->candidates_only_ = false; } } guard{this};
+
+    // the data set on the device, optionally in shuffled order (gbrl.cpp:1016-1024, 1039-1067; the reference seeds
+    // std::mt19937 from std::random_device, i.e. the order differs from run to run there too)
+    const float *dobs = obs, *dtar = targets;
+    const char *dcat = cat;
+    if (Fc > 0 && !cat_dev) {
+        char *t = static_cast<char *>(d_fit_cells_.ensure(static_cast<size_t>(n) * Fc * kCat));
+        hip_check(hipMemcpyAsync(t, cat, static_cast<size_t>(n) * Fc * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+        dcat = t;
+    }
+    if (F > 0 && !obs_dev) {
+        float *t = static_cast<float *>(d_fit_obs_.ensure(sizeof(float) * static_cast<size_t>(n) * F));
+        hip_check(hipMemcpyAsync(t, obs, sizeof(float) * static_cast<size_t>(n) * F, hipMemcpyHostToDevice, s), "H2D obs");
+        dobs = t;
+    }
+    if (!targets_dev) {
+        float *t = static_cast<float *>(d_fit_targets_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+        hip_check(hipMemcpyAsync(t, targets, sizeof(float) * static_cast<size_t>(n) * D, hipMemcpyHostToDevice, s), "H2D targets");
+        dtar = t;
+    }
+    if (shuffle) {
+        std::vector<int32_t> perm(n);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::random_device rd;
+        std::mt19937 gen(rd());
+        std::shuffle(perm.begin(), perm.end(), gen);
+        int32_t *d_perm = static_cast<int32_t *>(d_fit_perm_.ensure(sizeof(int32_t) * n));
+        hip_check(hipMemcpyAsync(d_perm, perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s), "H2D perm");
+        float *o2 = static_cast<float *>(d_fit_obs2_.ensure(sizeof(float) * static_cast<size_t>(n) * F));
+        float *t2 = static_cast<float *>(d_fit_targets2_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+        kern::gather_rows(dobs, d_perm, o2, n, F, s);
+        kern::gather_rows(dtar, d_perm, t2, n, D, s);
+        if (Fc > 0) {   // whole 128-byte cells travel with their row (the reference's shuffled copy keeps only their first byte, Q12)
+            char *c2 = static_cast<char *>(d_fit_cells2_.ensure(static_cast<size_t>(n) * Fc * kCat));
+            kern::gather_rows(reinterpret_cast<const float *>(dcat), d_perm, reinterpret_cast<float *>(c2), n, Fc * (kCat / 4), s);
+            dcat = c2;
+        }
+        hip_check(hipStreamSynchronize(s), "sync");   // perm goes out of scope
+        dobs = o2;
+        dtar = t2;
+    }
+    float *d_zero = static_cast<float *>(d_fit_zero_.ensure(sizeof(float) * D));
+    hip_check(hipMemsetAsync(d_zero, 0, sizeof(float) * D, s), "memset");
+    double *d_stat = static_cast<double *>(d_stat_.ensure(sizeof(double) * 4 * D));
+    std::vector<double> hs(2 * D);
+    auto column_stat = [&](const float *g, int rows, const float *center) {   // column sums (center null) or sums of squares
+        const int nblk = kern::column_sums_blocks(rows, D);
+        double *d_part = static_cast<double *>(d_partials_f64_.ensure(sizeof(double) * nblk * 2 * D));
+        kern::column_sums(g, rows, D, center, d_part, nblk, d_stat, s);
+        hip_check(hipMemcpyAsync(hs.data(), d_stat, sizeof(double) * 2 * D, hipMemcpyDeviceToHost, s), "D2H stat");
+        hip_check(hipStreamSynchronize(s), "sync");
+    };
+    auto rmse = [&](const float *grads_dev, int rows) {                       // MultiRMSE, loss.cpp:42-56: sqrt(0.5 * sum g^2 / rows)
+        column_stat(grads_dev, rows, d_zero);
+        double tot = 0.0;
+        for (int d = 0; d < D; ++d) tot += hs[d];
+        return sqrtf(0.5f * static_cast<float>(tot) * (1.0f / static_cast<float>(rows)));
+    };
+    // bias = column means of the targets (gbrl.cpp:1075-1077)
+    column_stat(dtar, n, nullptr);
+    for (int d = 0; d < D; ++d) model.bias[d] = static_cast<float>(hs[d] / static_cast<double>(n));
+    ++model.version;
+
+    // split candidates from the whole data set, once (fitter.cpp:134-150)
+    {
+        candidates_only_ = true;
+        step(dobs, true, dcat, true, dtar, true, n, F, Fc);   // returns right after the candidates; `dtar` only feeds the (unused) statistics
+        candidates_only_ = false;
+    }
+    const int bs = md.batch_size;
+    float *d_preds = static_cast<float *>(d_fit_preds_.ensure(sizeof(float) * static_cast<size_t>(std::max(n, 1)) * D));
+    float *d_grads = static_cast<float *>(d_fit_grads_.ensure(sizeof(float) * static_cast<size_t>(std::min(n, bs)) * D));
+    int start = 0;
+    int bn = start + bs < n ? bs : n - start;                                   // fitter.cpp:120
+    for (int i = 0; i < iterations; ++i) {
+        const float *ob = dobs + static_cast<size_t>(start) * F;
+        const float *tb = dtar + static_cast<size_t>(start) * D;
+        const char *cb = Fc > 0 ? dcat + static_cast<size_t>(start) * Fc * kCat : nullptr;
+        predict(ob, true, cb, true, bn, F, Fc, 0, i, d_preds, true);           // trees [0, i) -- i == 0 means "all" (fitter.cpp:187)
+        kern::sub_arrays(d_preds, tb, d_grads, static_cast<size_t>(bn) * D, s);
+        step(ob, true, cb, true, d_grads, true, bn, F, Fc);
+        start += bn;                                                            // fitter.cpp:228-231
+        if (start >= n) start = 0;
+        bn = start + bs < n ? bs : n - start;
+    }
+    // loss on the whole data set over trees [0, iterations) (fitter.cpp:246-251)
+    predict(dobs, true, Fc > 0 ? dcat : nullptr, true, n, F, Fc, 0, iterations, d_preds, true);
+    float *d_full_grads = static_cast<float *>(d_fit_grads_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
+    kern::sub_arrays(d_preds, dtar, d_full_grads, static_cast<size_t>(n) * D, s);
+    return rmse(d_full_grads, n);
+}
+
+}  // namespace gbrl
