@@ -222,10 +222,10 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.grd_ok = (!model.oblivious() && grd_ok_) ? 1 : 0;
     pm.grd_max_nodes = grd_max_nodes_;
     pm.grd_max_leaves = grd_max_leaves_;
+    pm.obl_ok = model.oblivious() ? 1 : 0;
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_GENERIC")) {   // test hook: the general kernels only
         if (e[0] == '1') { pm.grd_ok = 0; pm.obl_ok = 0; }
     }
-    pm.obl_ok = model.oblivious() ? 1 : 0;
     pm.coef_ok = D <= 32 ? 1 : 0;
     pm.coef_cover = 0;
     for (int j = 0; j < 32; ++j) pm.coef[j] = 0.0f;
