@@ -79,6 +79,12 @@ class Engine {
     float fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const float *targets, bool targets_dev, int n, int n_num,
               int n_cat, int iterations, bool shuffle);
 
+    // Linear TreeSHAP of tree `tree_idx` (-1: every tree, summed in tree order) on the device; host pointers in and out, `out`
+    // [n][n_num + n_cat][D] is overwritten.  Returns false when it was NOT computed (no HIP device, max_depth / output_dim beyond
+    // the kernel's LDS budget, GBRL_HIP_SHAP_HOST=1): the caller then evaluates on the host (explain.cpp), which gives the same bits.
+    bool shap_on_device(int tree_idx, const float *obs, const char *cat, int n, const float *norm, const float *base_poly,
+                        const float *offset, float *out);
+
     void set_collective(const gbrl_hip_collective *hooks);
     // Native exchange: an RCCL communicator of this engine's own, collectives enqueued on its stream (no host sync).
     // id128 = gbrl_hip_rccl_unique_id() of rank 0, distributed by the caller.  Collective call (all ranks).
@@ -91,6 +97,7 @@ class Engine {
    private:
     void ensure_device();
     void sync_model_to_device();
+    int32_t *encode_categorical_batch(const char *cat, bool cat_dev, int n, int n_cat);
     void grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
                    double &leaf_scale);
     bool device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
@@ -126,6 +133,10 @@ class Engine {
     hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;
+
+    DevBuf d_shap_ops_, d_shap_nodes_, d_shap_values_, d_shap_poly_, d_shap_out_;
+    int shap_n_ops_ = 0;
+    uint64_t shap_prog_version_ = ~0ull;
 
     // ---- per-step workspace (grow-only, reused across steps) ----
     DevBuf d_obs_, d_grads_, d_qg_, d_stat_, d_partials_f64_, d_meanden_, d_maxbits_;

@@ -126,6 +126,53 @@ void Engine::sync_model_to_device() {
     mirror_version_ = model.version;
 }
 
+// Dictionary ids of a batch of categorical cells (0 = a category no condition of the model mentions).  Needs sync_model_to_device().
+int32_t *Engine::encode_categorical_batch(const char *cat, bool cat_dev, int n, int n_cat) {
+    hipStream_t s = stream_;
+    int32_t *dcat = nullptr;
+    // dictionary encoding on the device: the cells are hashed (strcmp semantics: bytes before the first NUL), looked up in
+    // the per-feature, hash-sorted dictionary of the categories the model's conditions mention, and confirmed word by word
+    const char *dcells = cat;
+    if (!cat_dev) {
+        char *tmp = static_cast<char *>(d_pcells_.ensure(static_cast<size_t>(n) * n_cat * kCat));
+        hip_check(hipMemcpyAsync(tmp, cat, static_cast<size_t>(n) * n_cat * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
+        dcells = tmp;
+    }
+    if (dict_version_ != cat_dict_.size() || dict_fc_ != n_cat) {
+        struct E { uint64_t h; int id; uint64_t w[16]; };
+        std::vector<std::vector<E>> per(n_cat);
+        for (size_t z = 0; z < cat_dict_.size(); ++z) {
+            const int f = cat_dict_[z].first;
+            if (f < 0 || f >= n_cat) continue;
+            E e{};
+            uint64_t raw[16];
+            std::memcpy(raw, cat_dict_[z].second.data(), kCat);
+            e.h = cat_cell_hash(raw, e.w);
+            e.id = static_cast<int>(z) + 1;
+            per[f].push_back(e);
+        }
+        std::vector<int32_t> off(n_cat + 1, 0), ids;
+        std::vector<uint64_t> hs, ws;
+        for (int f = 0; f < n_cat; ++f) {
+            std::sort(per[f].begin(), per[f].end(), [](const E &a, const E &b) { return a.h < b.h || (a.h == b.h && a.id < b.id); });
+            for (const E &e : per[f]) { hs.push_back(e.h); ids.push_back(e.id); ws.insert(ws.end(), e.w, e.w + 16); }
+            off[f + 1] = static_cast<int32_t>(hs.size());
+        }
+        hs.push_back(0); ids.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
+        hip_check(hipMemcpyAsync(d_dict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+        hip_check(hipMemcpyAsync(d_dict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+        hip_check(hipMemcpyAsync(d_dict_id_.ensure(ids.size() * 4), ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
+        hip_check(hipMemcpyAsync(d_dict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
+        hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
+        dict_version_ = cat_dict_.size();
+        dict_fc_ = n_cat;
+    }
+    dcat = static_cast<int32_t *>(d_pcat_.ensure(sizeof(int32_t) * static_cast<size_t>(n) * n_cat));
+    kern::encode_categories(dcells, n, n_cat, d_dict_off_.as<int32_t>(), d_dict_hash_.as<uint64_t>(), d_dict_id_.as<int32_t>(),
+                            d_dict_words_.as<uint64_t>(), dcat, s);
+    return dcat;
+}
+
 void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
                      int stop_tree, float *out, bool out_dev) {
     gbrl_hip_metadata &md = model.meta;
@@ -153,49 +200,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
         dobs = static_cast<float *>(d_pobs_.ensure(sizeof(float) * static_cast<size_t>(n) * n_num));
         hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * static_cast<size_t>(n) * n_num, hipMemcpyHostToDevice, s), "H2D obs");
     }
-    int32_t *dcat = nullptr;
-    if (n_cat > 0) {
-        // dictionary encoding on the device: the cells are hashed (strcmp semantics: bytes before the first NUL), looked up in
-        // the per-feature, hash-sorted dictionary of the categories the model's conditions mention, and confirmed word by word
-        const char *dcells = cat;
-        if (!cat_dev) {
-            char *tmp = static_cast<char *>(d_pcells_.ensure(static_cast<size_t>(n) * n_cat * kCat));
-            hip_check(hipMemcpyAsync(tmp, cat, static_cast<size_t>(n) * n_cat * kCat, hipMemcpyHostToDevice, s), "H2D cat cells");
-            dcells = tmp;
-        }
-        if (dict_version_ != cat_dict_.size() || dict_fc_ != n_cat) {
-            struct E { uint64_t h; int id; uint64_t w[16]; };
-            std::vector<std::vector<E>> per(n_cat);
-            for (size_t z = 0; z < cat_dict_.size(); ++z) {
-                const int f = cat_dict_[z].first;
-                if (f < 0 || f >= n_cat) continue;
-                E e{};
-                uint64_t raw[16];
-                std::memcpy(raw, cat_dict_[z].second.data(), kCat);
-                e.h = cat_cell_hash(raw, e.w);
-                e.id = static_cast<int>(z) + 1;
-                per[f].push_back(e);
-            }
-            std::vector<int32_t> off(n_cat + 1, 0), ids;
-            std::vector<uint64_t> hs, ws;
-            for (int f = 0; f < n_cat; ++f) {
-                std::sort(per[f].begin(), per[f].end(), [](const E &a, const E &b) { return a.h < b.h || (a.h == b.h && a.id < b.id); });
-                for (const E &e : per[f]) { hs.push_back(e.h); ids.push_back(e.id); ws.insert(ws.end(), e.w, e.w + 16); }
-                off[f + 1] = static_cast<int32_t>(hs.size());
-            }
-            hs.push_back(0); ids.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
-            hip_check(hipMemcpyAsync(d_dict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
-            hip_check(hipMemcpyAsync(d_dict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
-            hip_check(hipMemcpyAsync(d_dict_id_.ensure(ids.size() * 4), ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
-            hip_check(hipMemcpyAsync(d_dict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
-            hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
-            dict_version_ = cat_dict_.size();
-            dict_fc_ = n_cat;
-        }
-        dcat = static_cast<int32_t *>(d_pcat_.ensure(sizeof(int32_t) * static_cast<size_t>(n) * n_cat));
-        kern::encode_categories(dcells, n, n_cat, d_dict_off_.as<int32_t>(), d_dict_hash_.as<uint64_t>(), d_dict_id_.as<int32_t>(),
-                                d_dict_words_.as<uint64_t>(), dcat, s);
-    }
+    int32_t *dcat = n_cat > 0 ? encode_categorical_batch(cat, cat_dev, n, n_cat) : nullptr;
     float *dout = out;
     if (!out_dev) dout = static_cast<float *>(d_pout_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
     phase_end("inputs");

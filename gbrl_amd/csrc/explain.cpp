@@ -29,21 +29,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 // SHAP: one explicit binary tree per ensemble member, nodes numbered in depth-first (left before right) order
 // ------------------------------------------------------------------------------------------------------------------
-struct XNode {
-    int parent = -1, left = -1, right = -1;
-    int feature = -1;           // raw condition feature index; -1 for a leaf
-    int tied_to = -1;           // parent index when the parent's feature already occurred above it, else -1
-    int n_unique = 0;           // max over the leaves below of the number of distinct feature indices on their path
-    bool numeric = true;
-    float threshold = INFINITY;
-    const char *category = nullptr;   // points into the model (128-byte cell)
-    float weight = 1.0f;        // edge weight from the parent (cumulated with the parent's when tied)
-    int pred = -1;              // leaves: offset of the leaf's [D] cover-weighted value in XTree::leaf_value
-};
-struct XTree {
-    std::vector<XNode> nodes;
-    std::vector<float> leaf_value;
-};
+using XNode = ShapNode;
+using XTree = ShapTree;
 
 int distinct_count(const int32_t *v, int n) {   // utils.cpp:90-110: 1 for an empty path
     int c = 1;
@@ -89,7 +76,7 @@ struct TreeBuilder {
             nd.feature = m.feature_indices[c];
             nd.numeric = m.is_numerics[c] != 0;
             if (nd.numeric) nd.threshold = m.feature_values[c];
-            else nd.category = m.categorical_values.data() + c * kCat;
+            else nd.cond = static_cast<int>(c);
         } else {
             const int leaf = next_leaf++;
             const int uniq = distinct_count(m.feature_indices.data() + static_cast<size_t>(row) * md, tree_depth);
@@ -119,11 +106,7 @@ struct TreeBuilder {
     }
 };
 
-XTree build_tree(const Model &m, int t) {
-    TreeBuilder b(m, t);
-    b.add(-1, 0);
-    return std::move(b.out);
-}
+XTree build_tree(const Model &m, int t) { return build_shap_tree(m, t); }
 
 // per-sample evaluation state: two stacks of [max_depth][D] coefficient tables, one row per tree level
 struct Walker {
@@ -196,7 +179,7 @@ struct Walker {
                 for (int j = 0; j < D; ++j) g[i * D + j] = c[i * D + j] * (pv[j] + 0.0f);
         } else {
             const bool pass = nd.numeric ? x[nd.feature] > nd.threshold
-                                         : std::strcmp(xc + static_cast<size_t>(nd.feature) * kCat, nd.category) == 0;
+                                         : std::strcmp(xc + static_cast<size_t>(nd.feature) * kCat, m.categorical_values.data() + static_cast<size_t>(nd.cond) * kCat) == 0;
             active[nd.right] = pass;
             active[nd.left] = !pass;
             float *g_dn = g + tile;
@@ -298,6 +281,19 @@ void put_number(Text &t, Fmt f, float v) {
 }
 
 }  // namespace
+
+void check_shap_arguments(const Model &m, int tree_idx, const float *obs, const char *cat_obs, const float *norm_values,
+                          const float *base_poly, const float *offset) {
+    check_tree_index(m, tree_idx);
+    check_shap_inputs(m, obs, cat_obs, norm_values, base_poly, offset);
+}
+
+ShapTree build_shap_tree(const Model &m, int t) {
+    if (t < 0 || t >= m.meta.n_trees) throw std::runtime_error("Invalid tree index");
+    TreeBuilder b(m, t);
+    b.add(-1, 0);
+    return std::move(b.out);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 void tree_shap(const Model &m, int tree_idx, const float *obs, const char *cat_obs, int n_samples, const float *norm_values,

@@ -3,11 +3,36 @@
 // unchanged gbrl Python package finds every method of the reference's gbrl_cpp.GBRL class.
 #pragma once
 
+#include <cmath>
 #include <string>
+#include <vector>
 
 #include "model.h"
 
 namespace gbrl {
+
+// One ensemble member as an explicit binary tree, nodes numbered depth-first (left before right), with everything Linear TreeSHAP
+// needs per node (alloc_shap_data shap.cpp:38-168).  Built on the host; evaluated on the host (explain.cpp) or by k_shap (shap.hip).
+struct ShapNode {
+    int parent = -1, left = -1, right = -1;
+    int feature = -1;           // raw condition feature index; -1 for a leaf
+    int tied_to = -1;           // parent index when the parent's feature already occurred above it, else -1
+    int n_unique = 0;           // max over the leaves below of the number of distinct feature indices on their path
+    bool numeric = true;
+    float threshold = INFINITY;
+    int cond = -1;              // categorical condition: index of its 128-byte value in Model::categorical_values (row*max_depth+depth)
+    float weight = 1.0f;        // edge weight from the parent (cumulated with the parent's when tied)
+    int pred = -1;              // leaves: offset of the leaf's [D] cover-weighted value in ShapTree::leaf_value
+};
+struct ShapTree {
+    std::vector<ShapNode> nodes;
+    std::vector<float> leaf_value;
+};
+ShapTree build_shap_tree(const Model &m, int tree_idx);   // throws "Invalid tree index"
+
+// argument checks shared by the host and device evaluations: throws "Invalid tree index" / missing-input errors
+void check_shap_arguments(const Model &m, int tree_idx, const float *obs, const char *cat_obs, const float *norm_values,
+                          const float *base_poly, const float *offset);
 
 // Linear TreeSHAP of ONE tree, accumulated into `out` [n_samples][n_num + n_cat][D] (caller zero-fills).
 // Semantics of GBRL::tree_shap / get_shap_values (gbrl.cpp:1269-1303, shap.cpp:38-364).  Host pointers only, like the

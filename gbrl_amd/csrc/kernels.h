@@ -234,5 +234,19 @@ void encode_categories(const char *cells, int n, int Fc, const int32_t *feat_off
 void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
              int stop_tree, float *out, hipStream_t s);
 
+// ---- Linear TreeSHAP (shap.hip): a uniform program over explicit trees, one thread per (sample, output) ----
+enum { SHAP_ENTER = 0, SHAP_AFTER_LEFT = 1, SHAP_AFTER_RIGHT = 2, SHAP_EXIT = 3 };
+struct ShapOp { int32_t kind, node, level, via; };   // via: feature tested by the parent (-1 at a root)
+struct ShapNodeRec {                                  // explain.h ShapNode, flattened; node indices are global over the program
+    int32_t feature, flags /*1 numeric, 2 tied to parent, 4 leaf, 8 right child*/, cat_id, pred;
+    int32_t n_unique, n_unique_parent, deg_left, deg_right;
+    float threshold, weight, weight_parent, pad;
+};
+int shap_block_threads(int max_depth, int D);   // 0: this (max_depth, D) does not fit the kernel (LDS) -- evaluate on the host
+// out [n_samples][n_num + n_cat][D] is accumulated into (zero it first)
+void shap_values(const ShapOp *ops, int n_ops, const ShapNodeRec *nodes, const float *leaf_value, const float *obs, int n_num,
+                 const int32_t *cat_ids, int n_cat, int n_samples, int D, int max_depth, const float *norm, const float *base,
+                 const float *offset, float *out, hipStream_t s);
+
 }  // namespace kern
 }  // namespace gbrl

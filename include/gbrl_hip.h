@@ -178,7 +178,8 @@ int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* ---- inspection, served from the host copy of the ensemble ---------------------- */
 /* Linear TreeSHAP of one tree / of the whole ensemble: GBRL::tree_shap gbrl.cpp:1269-1303, GBRL::ensemble_shap gbrl.cpp:1305-1342,
- * algorithm shap.cpp:38-364.  HOST pointers only (the reference's binding accepts NumPy arrays only, binding.cpp:985-1117).
+ * algorithm shap.cpp:38-364.  Evaluated on the HIP device when one is usable (same bits as the host evaluation, which serves
+ * machines without a GPU).  HOST pointers only (the reference's binding accepts NumPy arrays only, binding.cpp:985-1117).
  * obs [n_samples][n_num_features] f32, cat_obs [n_samples][n_cat_features][128] bytes (either may be NULL when the model has no
  * such features); norm_values [(max_depth+1)][max_depth], base_poly [max_depth], offset [max_depth][max_depth] as built by
  * gbrl/common/utils.py:317-371.  out [n_samples][n_num_features + n_cat_features][output_dim] is OVERWRITTEN

@@ -565,3 +565,49 @@ def test_inspection_of_a_gpu_grown_model_matches_the_reference(name, tmp_path, c
         h = tmp_path / ("m%d.h" % k)
         assert m.export(str(h), mname, fmt, typ, prefix) == 0
         same_text(h.read_text(), g["export_%d" % k].tobytes().decode(), "export")
+
+
+@pytest.mark.parametrize("name", list(K.EXPLAIN_CASES))
+def test_device_shap_equals_the_host_evaluation_and_the_reference(name, tmp_path, monkeypatch):
+    """k_shap (one thread per (sample, output), the tree walk as a uniform program) makes the host evaluation's roundings, so the
+    two must agree BITWISE; both are within 1e-5 of the reference fixture's scale."""
+    import gbrl_amd
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "explain_" + name + ".npz"))
+    case = K.BY_NAME[name]
+    X, Xc, G, y = K.make_inputs(case)
+    p = tmp_path / "ref.gbrl_model"
+    p.write_bytes(g["model_file"].tobytes())
+    m = gbrl_amd.GBRL.load(str(p))
+    n = K.EXPLAIN_ROWS
+    xs = None if X is None else np.ascontiguousarray(X[:n])
+    xcs = None if Xc is None else np.ascontiguousarray(Xc[:n])
+    args = (g["norm_values"], g["base_poly"], g["offset"])
+    T = int(g["n_trees"])
+    res = {}
+    for host in ("0", "1"):
+        monkeypatch.setenv("GBRL_HIP_SHAP_HOST", host)
+        res[host] = [m.ensemble_shap(xs, xcs, *args)] + [m.tree_shap(t, xs, xcs, *args) for t in sorted({0, T // 2, T - 1})]
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+    want = [g["shap_ensemble"]] + [g["shap_tree_%d" % t] for t in sorted({0, T // 2, T - 1})]
+    for a, w in zip(res["0"], want):
+        assert np.abs(a - w).max() <= 1e-5 * np.abs(w).max()
+
+
+def test_device_shap_at_scale_equals_the_host_evaluation(monkeypatch):
+    """A config-2 shaped model in miniature (oblivious, depth 6, 8 outputs, 24 trees) explained on 20 000 rows: device == host bitwise."""
+    import time
+    import gbrl_amd
+    case = dict(name="shap_scale", seed=5, N=20000, F=24, Fc=0, D=8, depth=6, n_bins=64, score="L2", gen="Quantile", policy="oblivious", trees=24)
+    X, Xc, G, y = K.make_inputs(case)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, Xc, G, y)
+    base, norm, offset = K.poly_vectors(case["depth"])
+    out = {}
+    for host in ("0", "1"):
+        monkeypatch.setenv("GBRL_HIP_SHAP_HOST", host)
+        t0 = time.time()
+        out[host] = m.ensemble_shap(X, None, norm, base, offset)
+        print("ensemble_shap %s: %.3f s" % ("host" if host == "1" else "device", time.time() - t0))
+    assert out["0"].shape == (case["N"], case["F"], case["D"]) and np.abs(out["0"]).max() > 0
+    assert np.array_equal(out["0"], out["1"])
