@@ -525,8 +525,8 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     const int64_t n_tot = total[D];
     // parent score of the node (greedy growth): the totals are the same integers for every feature of the node, so every block
     // derives the identical float
-    float par_score;
-    {
+    float par_score = 0.0f;
+    if (fs == 0 || part_v) {   // oblivious growth needs it from one block only
         const double x = side_term(total, D, n_tot, inv_scale);
         par_score = static_cast<float>(cosine ? sqrt(x) : x);
     }
