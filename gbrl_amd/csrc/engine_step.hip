@@ -1130,6 +1130,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     for (int c = 0; c < Fc; ++c) NB = std::max(NB, cat_classes[c] + 1);
     int FG = 16;
     while (FG > 1 && kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512) FG >>= 1;
+    // more than 16 outputs: k_hist_build_wide spreads the D + 1 fields of a row over the 16 / FG parts of a 16-lane row (<= 16 each)
+    while (D > 16 && FG > 4 && (16 / FG) * 16 < D + 1) FG >>= 1;
     if (kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512)
         throw Unsupported("(classes per feature) x (output_dim + 1) does not fit the 160 KiB LDS");
     if (static_cast<size_t>(NB + 1) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");

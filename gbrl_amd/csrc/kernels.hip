@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace gbrl {
 namespace kern {
@@ -383,6 +384,170 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
             for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
             atomicAdd(dst + D * FG, 1);
         }
+    }
+    __syncthreads();
+    int32_t *out = partials + (static_cast<size_t>(chunk_id) * n_groups + g) * n_acc;
+    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) out[i] = h[i];
+}
+
+// k_hist_build_wide<P, H, U>: output dimensions beyond 16, or class counts that leave room for only 8 or 4 features per block
+// (FG = 16 / P).  A 16-lane DPP row still works on ONE data row, but on FG features x P parts of the D + 1 fields: lane
+// (part p, feature f) adds the fields p*H .. p*H + H - 1 (H = ceil((D + 1) / P) <= 16) of feature f.  Lane l of the row loads the
+// P values (field p*H + l, p = 0..P-1; the count's constant 1 sits at field D) once, and step k hands every part ITS lane-k value
+// with one row_newbcast move per part, written under that part's bank mask (a DPP bank = 4 lanes) -- P moves per atomic instead of
+// D + 1 loads per lane, which is what made the run-time-D path vector-memory bound (3.1 ms per tree at D = 18 against 1.5 ms of
+// atomic-unit time).  Same LDS layout [class][field][FG] and the same partials as the generic path.
+template <int P, int H, int K, int SRC>
+struct WideValue {   // value of step K for this lane's part, assembled from the row's lane K
+    static __device__ __forceinline__ int get(const int (&r)[P]) {
+        constexpr int bank_mask = P == 2 ? (SRC == 0 ? 0x3 : 0xC) : (1 << SRC);
+        const int lower = WideValue<P, H, K, SRC - 1>::get(r);
+        return __builtin_amdgcn_update_dpp(lower, r[SRC], 0x150 + K, 0xf, bank_mask, false);
+    }
+};
+template <int P, int H, int K>
+struct WideValue<P, H, K, 0> {
+    static __device__ __forceinline__ int get(const int (&r)[P]) { return __builtin_amdgcn_mov_dpp(r[0], 0x150 + K, 0xf, 0xf, true); }
+};
+template <int P, int H, int K>
+struct WideAtomics {
+    // n_last (uniform): fields owned by the LAST part; every other part owns H.  Steps below n_last need no per-lane test.
+    static __device__ __forceinline__ void run(int32_t *dst, int FG, const int (&r)[P], int n_last, bool last_part) {
+        const int v = WideValue<P, H, K, P - 1>::get(r);
+        if (K < n_last) atomicAdd(dst + K * FG, v);
+        else if (!last_part) atomicAdd(dst + K * FG, v);
+        WideAtomics<P, H, K + 1>::run(dst, FG, r, n_last, last_part);
+    }
+};
+template <int P, int H>
+struct WideAtomics<P, H, H> {
+    static __device__ __forceinline__ void run(int32_t *, int, const int (&)[P], int, bool) {}
+};
+
+template <int P, int H, int U>
+__global__ __launch_bounds__(kHistThreads) void k_hist_build_wide(const uint16_t *__restrict__ codes, int n_rows,
+                                                                   const int32_t *__restrict__ qg, int D,
+                                                                   const int32_t *__restrict__ rows, const Chunk *__restrict__ chunks,
+                                                                   int n_chunks, int n_groups, int NB, int32_t *__restrict__ partials) {
+    extern __shared__ int32_t h[];
+    constexpr int FG = 16 / P;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int g = jj % n_groups;
+    const int chunk_id = (jj / n_groups) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
+    const int n_acc = NB * (D + 1) * FG;
+    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
+    __syncthreads();
+    const Chunk ck = chunks[chunk_id];
+    const int fl = threadIdx.x & 15;
+    const int part = fl / FG, f = fl & (FG - 1);
+    const int slot = threadIdx.x >> 4;
+    constexpr int n_slots = kHistThreads >> 4;
+    const int row_stride = (D + 1) * FG;
+    const int fslot = g * FG + f;
+    const uint16_t *cbase = codes + (static_cast<size_t>(fslot >> 4) * n_rows) * kCodeGroup + (fslot & (kCodeGroup - 1));
+    const int32_t *rlist = rows + ck.start;
+    const int n_last = D + 1 - (P - 1) * H;          // fields the last part owns (1..H); the others own H
+    const bool last_part = part == P - 1;
+    const int dst_off = f + part * H * FG;
+    // what this lane contributes as a SOURCE: field p*H + fl of the row, for every part p
+    auto load_fields = [&](int row, int (&r)[P]) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int e = p * H + fl;
+            r[p] = (fl < H && e < D) ? qg[static_cast<size_t>(row) * D + e] : (e == D ? 1 : 0);
+        }
+    };
+    int p0 = slot;
+    for (; p0 + (U - 1) * n_slots < ck.len; p0 += n_slots * U) {
+        int row[U], code[U], r[U][P];
+#pragma unroll
+        for (int u = 0; u < U; ++u) row[u] = rlist[p0 + u * n_slots];
+#pragma unroll
+        for (int u = 0; u < U; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * kCodeGroup];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_fields(row[u], r[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) WideAtomics<P, H, 0>::run(h + code[u] * row_stride + dst_off, FG, r[u], n_last, last_part);
+    }
+    for (; p0 < ck.len; p0 += n_slots) {
+        const int row = rlist[p0];
+        const int code = cbase[static_cast<size_t>(row) * kCodeGroup];
+        int r[P];
+        load_fields(row, r);
+        WideAtomics<P, H, 0>::run(h + code * row_stride + dst_off, FG, r, n_last, last_part);
+    }
+    __syncthreads();
+    int32_t *out = partials + (static_cast<size_t>(chunk_id) * n_groups + g) * n_acc;
+    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) out[i] = h[i];
+}
+
+// k_hist_build_quad<R, U>: 4 features per block (FG = 4: many outputs or many classes).  A DPP quad (4 lanes) works on ONE data row:
+// lane j owns feature j and loads the fields j, j + 4, j + 8, ... (R = ceil((D + 1) / 4) registers, 16 contiguous bytes per quad and
+// register); field e is then handed to the quad from lane e % 4, register e / 4, with ONE quad_perm broadcast per atomic.  (Splitting the
+// fields over a 16-lane row as k_hist_build_wide does would need four DPP moves per atomic here, which makes the kernel VALU-bound.)
+template <int R, int E>
+struct QuadAtomics {   // fields E .. 4R-1
+    static __device__ __forceinline__ void run(int32_t *dst, const int (&reg)[R], int D) {
+        if (E <= D) {   // uniform
+            constexpr int j = E & 3;
+            const int v = __builtin_amdgcn_mov_dpp(reg[E >> 2], j * 0x55, 0xf, 0xf, true);   // quad_perm:[j,j,j,j]
+            atomicAdd(dst + E * 4, v);
+        }
+        QuadAtomics<R, E + 1>::run(dst, reg, D);
+    }
+};
+template <int R>
+struct QuadAtomics<R, 4 * R> {
+    static __device__ __forceinline__ void run(int32_t *, const int (&)[R], int) {}
+};
+
+template <int R, int U>
+__global__ __launch_bounds__(kHistThreads) void k_hist_build_quad(const uint16_t *__restrict__ codes, int n_rows,
+                                                                   const int32_t *__restrict__ qg, int D,
+                                                                   const int32_t *__restrict__ rows, const Chunk *__restrict__ chunks,
+                                                                   int n_chunks, int n_groups, int NB, int32_t *__restrict__ partials) {
+    extern __shared__ int32_t h[];
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int g = jj % n_groups;
+    const int chunk_id = (jj / n_groups) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
+    const int n_acc = NB * (D + 1) * 4;
+    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
+    __syncthreads();
+    const Chunk ck = chunks[chunk_id];
+    const int f = threadIdx.x & 3;
+    const int slot = threadIdx.x >> 2;
+    constexpr int n_slots = kHistThreads >> 2;
+    const int row_stride = (D + 1) * 4;
+    const int fslot = g * 4 + f;
+    const uint16_t *cbase = codes + (static_cast<size_t>(fslot >> 4) * n_rows) * kCodeGroup + (fslot & (kCodeGroup - 1));
+    const int32_t *rlist = rows + ck.start;
+    auto load_fields = [&](int row, int (&reg)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = r * 4 + f;
+            reg[r] = e < D ? qg[static_cast<size_t>(row) * D + e] : (e == D ? 1 : 0);
+        }
+    };
+    int p0 = slot;
+    for (; p0 + (U - 1) * n_slots < ck.len; p0 += n_slots * U) {
+        int row[U], code[U], reg[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) row[u] = rlist[p0 + u * n_slots];
+#pragma unroll
+        for (int u = 0; u < U; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * kCodeGroup];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_fields(row[u], reg[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) QuadAtomics<R, 0>::run(h + code[u] * row_stride + f, reg[u], D);
+    }
+    for (; p0 < ck.len; p0 += n_slots) {
+        const int row = rlist[p0];
+        const int code = cbase[static_cast<size_t>(row) * kCodeGroup];
+        int reg[R];
+        load_fields(row, reg);
+        QuadAtomics<R, 0>::run(h + code * row_stride + f, reg, D);
     }
     __syncthreads();
     int32_t *out = partials + (static_cast<size_t>(chunk_id) * n_groups + g) * n_acc;
@@ -980,11 +1145,81 @@ static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, in
                           chunks, n_chunks, n_groups, FG, shift, NB, partials);
 }
 
+template <int P, int H>
+static void launch_hist_wide_one(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                                 int n_chunks, int n_groups, int NB, int32_t *partials, size_t lds, hipStream_t s, hipEvent_t ev_start,
+                                 hipEvent_t ev_stop) {
+    constexpr int U = 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build_wide<P, H, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
+    hipExtLaunchKernelGGL((k_hist_build_wide<P, H, U>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D,
+                          rows, chunks, n_chunks, n_groups, NB, partials);
+}
+template <int P, int H>
+struct WideDispatch {
+    static bool run(int h, const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                    int n_chunks, int n_groups, int NB, int32_t *partials, size_t lds, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+        if (h == H) {
+            launch_hist_wide_one<P, H>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop);
+            return true;
+        }
+        return WideDispatch<P, H - 1>::run(h, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop);
+    }
+};
+template <int P>
+struct WideDispatch<P, 0> {
+    static bool run(int, const uint16_t *, int, const int32_t *, int, const int32_t *, const Chunk *, int, int, int, int32_t *, size_t,
+                    hipStream_t, hipEvent_t, hipEvent_t) { return false; }
+};
+template <int R>
+struct QuadDispatch {
+    static bool run(int r, const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                    int n_chunks, int n_groups, int NB, int32_t *partials, size_t lds, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+        if (r == R) {
+            constexpr int U = R <= 8 ? 4 : 2;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build_quad<R, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024);
+                attr_set = true;
+            }
+            const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
+            hipExtLaunchKernelGGL((k_hist_build_quad<R, U>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg,
+                                  D, rows, chunks, n_chunks, n_groups, NB, partials);
+            return true;
+        }
+        return QuadDispatch<R - 1>::run(r, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop);
+    }
+};
+template <>
+struct QuadDispatch<0> {
+    static bool run(int, const uint16_t *, int, const int32_t *, int, const int32_t *, const Chunk *, int, int, int, int32_t *, size_t,
+                    hipStream_t, hipEvent_t, hipEvent_t) { return false; }
+};
+
+static bool launch_hist_wide(int P, int H, const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
+                             const Chunk *chunks, int n_chunks, int n_groups, int NB, int32_t *partials, size_t lds, hipStream_t s,
+                             hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (H < 1 || H > 16) return false;
+    if (P == 2) return WideDispatch<2, 16>::run(H, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop);
+    return false;
+}
+
 void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                 int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
+    static const bool generic_only = [] { const char *e = std::getenv("GBRL_HIP_HIST_GENERIC"); return e && e[0] == '1'; }();   // test hook
+    if (generic_only) {
+        launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
+        return;
+    }
 #ifndef GBRL_HIST_U
 #define GBRL_HIST_U 8
 #endif
@@ -992,11 +1227,20 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
     if (FG == 16) {
         switch (D) {
             GBRL_HIST_CASE(1) GBRL_HIST_CASE(2) GBRL_HIST_CASE(3) GBRL_HIST_CASE(4) GBRL_HIST_CASE(5) GBRL_HIST_CASE(6)
-            GBRL_HIST_CASE(7) GBRL_HIST_CASE(8) GBRL_HIST_CASE(9) GBRL_HIST_CASE(10) GBRL_HIST_CASE(12) GBRL_HIST_CASE(16)
+            GBRL_HIST_CASE(7) GBRL_HIST_CASE(8) GBRL_HIST_CASE(9) GBRL_HIST_CASE(10) GBRL_HIST_CASE(11) GBRL_HIST_CASE(12)
+            GBRL_HIST_CASE(13) GBRL_HIST_CASE(14) GBRL_HIST_CASE(15) GBRL_HIST_CASE(16)
             default: break;
         }
     }
 #undef GBRL_HIST_CASE
+    // 8 features per block: the fields of a row are split over the two halves of the 16-lane DPP row (k_hist_build_wide);
+    // 4 features per block: one DPP quad per data row (k_hist_build_quad)
+    if (FG == 8 && D + 1 <= 32) {
+        if (launch_hist_wide(2, (D + 2) / 2, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop)) return;
+    }
+    if (FG == 4 && D + 1 <= 64) {
+        if (QuadDispatch<16>::run((D + 4) / 4, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop)) return;
+    }
     launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
 }
 

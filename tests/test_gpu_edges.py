@@ -199,3 +199,37 @@ def test_growth_past_the_reference_initial_capacity(tmp_path):
     m3 = gbrl_amd.GBRL(m)                                   # the copy is independent of the original
     m3.step(X, None, G0)
     assert (m3.get_num_trees(), m.get_num_trees()) == (T + 1, T)
+
+
+@pytest.mark.parametrize("D,n_bins,policy", [(11, 256, "greedy"), (15, 256, "oblivious"),        # 16 features per block, templated D
+                                             (17, 256, "greedy"), (18, 256, "oblivious"),        # 8 features per block, 2 parts of <= 10 fields
+                                             (24, 256, "greedy"), (31, 64, "oblivious"),         # 4 / 8 features per block
+                                             (38, 256, "oblivious"), (40, 64, "greedy"),         # 4 features per block, 4 parts
+                                             (3, 1000, "greedy"), (6, 2000, "oblivious"),        # many classes: 8 / 4 features per block, few fields
+                                             (70, 64, "greedy")])                                # beyond 64 fields: the run-time-D kernel
+def test_histogram_kernel_variants_agree_with_the_oracle(D, n_bins, policy):
+    """k_hist_build<D> (D <= 16), k_hist_build_wide<P, H> (fields of a row split over the 16-lane DPP row) and the run-time-D kernel
+    all feed the same integer histograms: every (output_dim, n_bins) regime must give the oracle's trees."""
+    import neartie
+    case = _case("hist_%d_%d" % (D, n_bins), D=D, F=19, N=4100, depth=4, n_bins=n_bins, policy=policy, trees=1,
+                 score="Cosine" if D % 2 else "L2")
+    X, Xc, G, y = K.make_inputs(case)
+    try:
+        _check(case, X, Xc, G)
+    except AssertionError:
+        # with this many outputs the reference's float32 score sums leave near-ties between candidates (tests/neartie.py: the two
+        # candidates' exact scores differ by less than the float32 noise of the sums); anything else is a real mismatch
+        m, r, _, _ = _both(case, X, Xc, G)
+        info = neartie.explain_first_mismatch(case, X, Xc, G, r.get_ensemble_data(), m.get_ensemble_data())
+        assert info and info.get("explained"), info
+
+
+def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
+    """GBRL_HIP_HIST_GENERIC=1 forces the run-time-D histogram kernel: the templated and the wide kernels must give the same trees
+    bit for bit, values included (the integer histograms are identical).  Separate processes: the hook is read once."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "hist_variants_probe.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if "wide==generic" in ln]
+    assert len(lines) >= 8 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]
