@@ -434,22 +434,24 @@ def test_categorical_cells_are_matched_like_strcmp_on_the_device():
     assert not np.array_equal(pu, pred)
 
 
+@pytest.mark.parametrize("D", [5, 11, 18, 22, 30])
 @pytest.mark.parametrize("policy,Fc", [("greedy", 0), ("greedy", 2), ("oblivious", 0), ("oblivious", 2)])
-def test_fast_predict_kernels_equal_the_general_kernel(policy, Fc, monkeypatch):
+def test_fast_predict_kernels_equal_the_general_kernel(policy, Fc, D, monkeypatch):
     """k_predict_obl (oblivious, numeric) and k_predict_grd (greedy: descent of the tree rebuilt from the leaves' paths,
     numeric and categorical conditions) against the general kernel that walks conditions / leaves like the reference: the same
     fused multiply-adds in the same order, so the outputs must be bitwise equal -- over sub-ranges of trees too."""
     import gbrl_amd
-    case = dict(name="pk", seed=77, N=6000, F=9, Fc=Fc, D=5, depth=5, n_bins=64, score="Cosine", gen="Quantile", policy=policy, trees=9,
-                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=4),
-                      dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=4, stop_idx=5)])
+    case = dict(name="pk", seed=77, N=6000, F=9, Fc=Fc, D=D, depth=5, n_bins=64, score="Cosine", gen="Quantile", policy=policy,
+                trees=9 if D == 5 else 4,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D - 1),
+                      dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=D - 1, stop_idx=D)])
     X, Xc, G, y = K.make_inputs(case)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
     K.drive(m, case, X, Xc, G, y)
     outs = {}
     for generic in ("0", "1"):
         monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", generic)
-        outs[generic] = [np.asarray(m.predict(X, Xc, a, b)) for a, b in ((0, 0), (2, 7), (8, 9), (0, 1))]
+        outs[generic] = [np.asarray(m.predict(X, Xc, a, b)) for a, b in (((0, 0), (2, 7), (8, 9), (0, 1)) if D == 5 else ((0, 0), (1, 3), (3, 4)))]
     for a, b in zip(outs["0"], outs["1"]):
         assert np.array_equal(a, b)
     assert np.abs(outs["0"][0]).max() > 0
