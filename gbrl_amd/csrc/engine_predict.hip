@@ -231,13 +231,13 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_GENERIC")) {   // test hook: the general kernels only
         if (e[0] == '1') { pm.grd_ok = 0; pm.obl_ok = 0; }
     }
-    pm.coef_ok = D <= 32 ? 1 : 0;
+    pm.coef_ok = D <= 64 ? 1 : 0;
     pm.coef_cover = 0;
-    for (int j = 0; j < 32; ++j) pm.coef[j] = 0.0f;
+    for (int j = 0; j < 64; ++j) pm.coef[j] = 0.0f;
     for (const auto &o : model.opts) {   // one learning rate per output unless two optimisers share an output
         for (int j = o.start_idx; j < o.stop_idx && pm.coef_ok; ++j) {
-            if (j < 0 || j >= D || ((pm.coef_cover >> j) & 1u)) { pm.coef_ok = 0; break; }
-            pm.coef_cover |= 1u << j;
+            if (j < 0 || j >= D || ((pm.coef_cover >> j) & 1ull)) { pm.coef_ok = 0; break; }
+            pm.coef_cover |= 1ull << j;
             pm.coef[j] = o.init_lr;
         }
     }

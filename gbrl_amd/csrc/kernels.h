@@ -210,8 +210,8 @@ struct PredictModel {
     const int32_t *grd_node_off;
     int grd_ok, grd_max_nodes, grd_max_leaves;
     int obl_ok, coef_ok;
-    uint32_t coef_cover;
-    float coef[32];
+    uint64_t coef_cover;
+    float coef[64];
 };
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words

@@ -651,18 +651,20 @@ void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat
              int stop_tree, float *out, hipStream_t s) {
     // fast path: oblivious, every output updated by exactly one optimiser.  Outputs are padded to the template's DMAX (zero columns, zero
     // learning rates), so the steps between 8 and 32 are fine-grained: the work per (row, tree) grows with DMAX, not with D
-    const uint32_t all_out = pm.D >= 32 ? 0xffffffffu : ((1u << pm.D) - 1u);
-    if (pm.oblivious && pm.obl_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 32 && stop_tree > start_tree) {
+    const uint64_t all_out = pm.D >= 64 ? ~0ull : ((1ull << pm.D) - 1ull);
+    if (pm.oblivious && pm.obl_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 64 && stop_tree > start_tree) {
         if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 8) { if (launch_predict_obl_d<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 12) { if (launch_predict_obl_d<12>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 16) { if (launch_predict_obl_d<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 20) { if (launch_predict_obl_d<20>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 24) { if (launch_predict_obl_d<24>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else { if (launch_predict_obl_d<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 32) { if (launch_predict_obl_d<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 48) { if (launch_predict_obl_d<48>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else { if (launch_predict_obl_d<64>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     }
     // fast path: greedy ensembles whose trees were rebuilt as binary trees (descent instead of the leaf-by-leaf walk)
-    if (!pm.oblivious && pm.grd_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 32 && stop_tree > start_tree &&
+    if (!pm.oblivious && pm.grd_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 64 && stop_tree > start_tree &&
         pm.grd_max_leaves <= 256) {
         if (pm.D <= 4) { if (launch_predict_grd<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 8) { if (launch_predict_grd<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
@@ -670,7 +672,9 @@ void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat
         else if (pm.D <= 16) { if (launch_predict_grd<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 20) { if (launch_predict_grd<20>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
         else if (pm.D <= 24) { if (launch_predict_grd<24>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else { if (launch_predict_grd<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 32) { if (launch_predict_grd<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else if (pm.D <= 48) { if (launch_predict_grd<48>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        else { if (launch_predict_grd<64>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     }
     if (pm.D <= 8) { if (launch_predict_tiled<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     else if (pm.D <= 32) { if (launch_predict_tiled<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }

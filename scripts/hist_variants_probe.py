@@ -15,7 +15,7 @@ if len(sys.argv) > 1:
     e=m.get_ensemble_data()
     np.savez(sys.argv[4], **{k:np.asarray(e[k]) for k in K.ENSEMBLE_KEYS})
 else:
-    for D,nb,pol in [(11,256,"greedy"),(17,256,"greedy"),(18,256,"oblivious"),(24,256,"greedy"),(31,64,"oblivious"),(38,256,"oblivious"),(40,64,"greedy"),(3,1000,"greedy"),(6,2000,"oblivious")]:
+    for D,nb,pol in [(11,256,"greedy"),(17,256,"greedy"),(18,256,"oblivious"),(24,256,"greedy"),(31,64,"oblivious"),(38,256,"oblivious"),(40,64,"greedy"),(45,256,"oblivious"),(63,256,"greedy"),(10,1500,"oblivious"),(3,1000,"greedy"),(6,2000,"oblivious")]:
         outs=[]
         for gen in ("0","1"):
             f=os.path.join(__import__("tempfile").gettempdir(), "hist_variant_%s.npz" % gen)

@@ -205,6 +205,7 @@ def test_growth_past_the_reference_initial_capacity(tmp_path):
                                              (17, 256, "greedy"), (18, 256, "oblivious"),        # 8 features per block, 2 parts of <= 10 fields
                                              (24, 256, "greedy"), (31, 64, "oblivious"),         # 4 / 8 features per block
                                              (38, 256, "oblivious"), (40, 64, "greedy"),         # 4 features per block, 4 parts
+                                             (45, 256, "oblivious"), (63, 256, "greedy"),        # 2 features per block
                                              (3, 1000, "greedy"), (6, 2000, "oblivious"),        # many classes: 8 / 4 features per block, few fields
                                              (70, 64, "greedy")])                                # beyond 64 fields: the run-time-D kernel
 def test_histogram_kernel_variants_agree_with_the_oracle(D, n_bins, policy):
@@ -232,4 +233,4 @@ def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "hist_variants_probe.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if "wide==generic" in ln]
-    assert len(lines) >= 8 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]
+    assert len(lines) >= 12 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]

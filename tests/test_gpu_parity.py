@@ -434,7 +434,7 @@ def test_categorical_cells_are_matched_like_strcmp_on_the_device():
     assert not np.array_equal(pu, pred)
 
 
-@pytest.mark.parametrize("D", [5, 11, 18, 22, 30])
+@pytest.mark.parametrize("D", [5, 11, 18, 22, 30, 40, 64])
 @pytest.mark.parametrize("policy,Fc", [("greedy", 0), ("greedy", 2), ("oblivious", 0), ("oblivious", 2)])
 def test_fast_predict_kernels_equal_the_general_kernel(policy, Fc, D, monkeypatch):
     """k_predict_obl (oblivious, numeric) and k_predict_grd (greedy: descent of the tree rebuilt from the leaves' paths,
