@@ -593,8 +593,10 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
     int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
                           static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
-    // a level needs at most 32 balanced chunks plus one rounding chunk per node
-    const int hist_max_chunks = std::max(32, (N + chunk_rows - 1) / chunk_rows) + 2 * (1 << MD) + 2;
+    // A level is one balanced round of (chunks x feature groups) histogram blocks, one block per CU: 256 / n_groups chunks, at least
+    // 32 (few features => more, smaller chunks; the chunk length only has an upper bound, `chunk_rows`, from the fixed-point scale).
+    const int hist_chunk_budget = std::max(32, 256 / std::max(1, n_groups));
+    const int hist_max_chunks = std::max(hist_chunk_budget, (N + chunk_rows - 1) / chunk_rows) + 2 * (1 << MD) + 2;
     int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * static_cast<size_t>(hist_max_chunks) * n_groups * n_acc));
     const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
     // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
@@ -715,7 +717,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // chunk table of ALL active nodes (row-sharded runs count the local child sizes from the rows themselves)
         std::vector<Chunk> count_chunks;
         if (has_coll_) { make_chunks(active, kern::kPartitionRows, false); count_chunks = h_chunks; }
-        make_chunks(compute_ids, balanced_chunk_rows(compute_ids, 32), false);
+        make_chunks(compute_ids, balanced_chunk_rows(compute_ids, hist_chunk_budget), false);
         if (h_chunks.size() > static_cast<size_t>(hist_max_chunks)) throw HipError("internal: chunk table overflow");
         // paths (duplicate-on-path rejection, node.cpp:154-166)
         std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
@@ -767,11 +769,12 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         phase_begin();
         if (!has_coll_) {
             if (!compute_ids.empty())
-                kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s);
+                kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s,
+                                  static_cast<int>(h_chunks.size() / compute_ids.size()));
         } else if (!compute_ids.empty()) {
             // local sums of the computed nodes, contiguous -> ONE all-reduce -> placed into their level slots
             const int nc = static_cast<int>(compute_ids.size());
-            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s);
+            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s, static_cast<int>(h_chunks.size() / nc));
             exchange(Red::SumI64, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems);
             kern::hist_place(d_hist_coll, d_hist, d_slotmap, nc, hist_node_elems, s);
         }

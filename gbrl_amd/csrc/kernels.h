@@ -146,7 +146,8 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /*the dispatch's own begin / end timestamps*/);
 // hist[slot_map ? slot_map[k] : k] = sum of the partials of chunk-slot k
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
-                 int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s);
+                 int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s,
+                 int chunks_per_slot = 1 /* average chunks per node: picks the kernel variant */);
 // cur[dst] = prev[parent] - cur[sibling]  (entries: triples {dst, parent, sibling or -1})
 
 // ---- scoring / selection (A6, A7, A8) ----

@@ -555,17 +555,39 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build_quad(const uint16_t
 }
 
 // Sum the int32 chunk partials of every slot (node) into int64, reordering to hist[slot][feature][class][D+1].
-__global__ void k_hist_reduce(const int32_t *__restrict__ partials, const int32_t *__restrict__ slot_chunk_begin,
-                              const int32_t *__restrict__ slot_map, int n_groups, int FG, int NB, int D, int Fp,
-                              int64_t *__restrict__ hist) {
+// kReduceLanes chunk lanes per element: with many chunks per node (few feature groups => up to 256 chunks) a node's chunks are summed
+// by 4 threads with four loads in flight each and combined through LDS; with the usual <= 32 chunks one thread per element is faster.
+template <int kReduceLanes>
+__global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_t *__restrict__ partials,
+                                                                     const int32_t *__restrict__ slot_chunk_begin,
+                                                                     const int32_t *__restrict__ slot_map, int n_groups, int FG, int NB,
+                                                                     int D, int Fp, int64_t *__restrict__ hist) {
+    __shared__ int64_t part[kReduceLanes > 1 ? kReduceLanes - 1 : 1][256];
     const int n_acc = NB * (D + 1) * FG;
     const int k = blockIdx.z, g = blockIdx.y;
     const int slot = slot_map ? slot_map[k] : k;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_acc) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.y;
     const int c0 = slot_chunk_begin[k], c1 = slot_chunk_begin[k + 1];
     int64_t s = 0;
-    for (int c = c0; c < c1; ++c) s += partials[(static_cast<size_t>(c) * n_groups + g) * n_acc + i];
+    if (i < n_acc) {
+        const int32_t *src = partials + static_cast<size_t>(g) * n_acc + i;
+        const size_t stride = static_cast<size_t>(n_groups) * n_acc;
+        int c = c0 + lane;
+        for (; c + 3 * kReduceLanes < c1; c += 4 * kReduceLanes) {   // four independent loads in flight (integer sums: any order)
+            const int32_t a = src[c * stride], b = src[(c + kReduceLanes) * stride], e = src[(c + 2 * kReduceLanes) * stride],
+                          f = src[(c + 3 * kReduceLanes) * stride];
+            s += static_cast<int64_t>(a) + b + e + f;
+        }
+        for (; c < c1; c += kReduceLanes) s += src[c * stride];
+    }
+    if (kReduceLanes > 1) {
+        if (lane > 0) part[lane - 1][threadIdx.x] = s;
+        __syncthreads();
+        if (lane != 0) return;
+#pragma unroll
+        for (int q = 0; q < kReduceLanes - 1; ++q) s += part[q][threadIdx.x];
+    }
+    if (i >= n_acc) return;
     const int fl = i % FG, d = (i / FG) % (D + 1), cls = i / (FG * (D + 1));
     hist[((static_cast<size_t>(slot) * Fp + g * FG + fl) * NB + cls) * (D + 1) + d] = s;
 }
@@ -1245,10 +1267,13 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
 }
 
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,
-                 int NB, int D, int Fp, int64_t *hist, hipStream_t s) {
+                 int NB, int D, int Fp, int64_t *hist, hipStream_t s, int chunks_per_slot) {
     const int n_acc = NB * (D + 1) * FG;
     dim3 grid((n_acc + 255) / 256, n_groups, n_slots);
-    hipLaunchKernelGGL(k_hist_reduce, grid, dim3(256), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
+    if (chunks_per_slot >= 48)
+        hipLaunchKernelGGL(k_hist_reduce<4>, grid, dim3(256, 4), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
+    else
+        hipLaunchKernelGGL(k_hist_reduce<1>, grid, dim3(256, 1), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
 }
 
 void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *sub_par, const int32_t *sub_sib, int n_nodes, int Fp, int NB,
