@@ -431,7 +431,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
             hip_check(hipMemsetAsync(d_mm, 0xff, sizeof(uint32_t) * F, s), "memset");
             hip_check(hipMemsetAsync(d_mm + F, 0x00, sizeof(uint32_t) * F, s), "memset");
-            kern::column_minmax(dobs, N, F, d_mm, d_mm + F, s);
+            kern::column_minmax(d_kt, N, F, d_mm, d_mm + F, s);
             if (has_coll_) {
                 // exchange as floats (max / min are exact)
                 float *tmp = static_cast<float *>(d_trial_.ensure(sizeof(float) * 2 * F));

@@ -141,19 +141,40 @@ __global__ void k_quantize(const float *__restrict__ g, size_t n_el, int D, cons
 // ------------------------------------------------------------------------------------------------------------
 // A4  uniform candidates: per-column min / max (order independent => atomics are deterministic)
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_column_minmax(const float *__restrict__ obs, int n, int F, uint32_t *__restrict__ mn,
-                                uint32_t *__restrict__ mx) {
-    // thread <-> feature (coalesced across a row), grid-stride over rows
-    const int f = blockIdx.y * blockDim.x + threadIdx.x;
-    if (f >= F) return;
+// Column minima / maxima from the feature-major keys (the transpose has already run: every later pass streams columns).  One block
+// per (row chunk, feature): 16-byte loads, eight in flight per thread, wave reduction, one atomic pair per wave.
+__global__ __launch_bounds__(256) void k_column_minmax(const uint32_t *__restrict__ kt, int n, int rows_per_block, uint32_t *__restrict__ mn,
+                                                       uint32_t *__restrict__ mx) {
+    const int f = blockIdx.y;
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
     uint32_t lo = 0xffffffffu, hi = 0u;
-    for (int r = blockIdx.x; r < n; r += gridDim.x) {
-        const uint32_t k = float_to_key(obs[static_cast<size_t>(r) * F + f]);
-        lo = min(lo, k);
-        hi = max(hi, k);
+    // the column start is 4-byte aligned only (n is arbitrary): peel to a 16-byte boundary, then vector loads
+    int r = r0 + threadIdx.x;
+    const uintptr_t mis = (reinterpret_cast<uintptr_t>(col + r0) >> 2) & 3;
+    const int head = min(r1 - r0, static_cast<int>((4 - mis) & 3));
+    if (threadIdx.x < head) { const uint32_t k = col[r]; lo = min(lo, k); hi = max(hi, k); }
+    const int v0 = r0 + head, nvec = (r1 - v0) / 4;
+    const uint4 *vec = reinterpret_cast<const uint4 *>(col + v0);
+    for (int i = threadIdx.x; i < nvec; i += 256 * 4) {
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = vec[min(i + u * 256, nvec - 1)];   // past the end: re-read the last vector (harmless for min / max)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo = min(min(lo, q[u].x), min(q[u].y, min(q[u].z, q[u].w)));
+            hi = max(max(hi, q[u].x), max(q[u].y, max(q[u].z, q[u].w)));
+        }
     }
-    atomicMin(&mn[f], lo);
-    atomicMax(&mx[f], hi);
+    for (r = v0 + nvec * 4 + threadIdx.x; r < r1; r += 256) { const uint32_t k = col[r]; lo = min(lo, k); hi = max(hi, k); }
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        lo = min(lo, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), o, kWave)));
+        hi = max(hi, static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), o, kWave)));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMin(&mn[f], lo);
+        atomicMax(&mx[f], hi);
+    }
 }
 __global__ void k_uniform_thresholds(const uint32_t *__restrict__ mn, const uint32_t *__restrict__ mx, int F, int B,
                                      float *__restrict__ thr) {
@@ -1099,10 +1120,10 @@ void stats_finish(const double *stat_raw, const double *stat_centred, long long 
     hipLaunchKernelGGL(k_stats_finish, dim3(1), dim3(256), 0, s, stat_raw, stat_centred, n, D, chunk_rows, meanden, sc);
 }
 
-void column_minmax(const float *obs, int n, int F, uint32_t *mn, uint32_t *mx, hipStream_t s) {
-    const int bs = 128;
-    dim3 grid(grid_for(n, 1, 1024), (F + bs - 1) / bs);
-    hipLaunchKernelGGL(k_column_minmax, grid, dim3(bs), 0, s, obs, n, F, mn, mx);
+void column_minmax(const uint32_t *kt, int n, int F, uint32_t *mn, uint32_t *mx, hipStream_t s) {
+    const int rows_per_block = 16384;
+    dim3 grid((n + rows_per_block - 1) / rows_per_block, F);
+    hipLaunchKernelGGL(k_column_minmax, grid, dim3(256), 0, s, kt, n, rows_per_block, mn, mx);
 }
 
 void uniform_thresholds(const uint32_t *mn, const uint32_t *mx, int F, int B, float *thr, hipStream_t s) {
