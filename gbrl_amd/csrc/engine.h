@@ -134,6 +134,7 @@ class Engine {
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;
 
+    DevBuf d_pred_partial_;
     DevBuf d_shap_ops_, d_shap_nodes_, d_shap_values_, d_shap_poly_, d_shap_out_;
     int shap_n_ops_ = 0;
     uint64_t shap_prog_version_ = ~0ull;

@@ -241,6 +241,12 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
             pm.coef[j] = o.init_lr;
         }
     }
+    // small batches: scratch for up to 64 partial sums per output (tree ranges spread over blocks, kern::predict)
+    pm.partial = nullptr; pm.partial_floats = 0; pm.tree_chunk = 0;
+    if (n <= 64 * 256 && stop - start_tree >= 128 && stop - start_tree <= 2048) {
+        pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
+        pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
+    }
     kern::predict(pm, dobs, n_num, dcat, n_cat, n, start_tree, stop, dout, s);
     hip_check(hipGetLastError(), "predict launch");
     phase_end("predict", /*key=*/true);

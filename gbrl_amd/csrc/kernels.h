@@ -213,6 +213,9 @@ struct PredictModel {
     int obl_ok, coef_ok;
     uint64_t coef_cover;
     float coef[64];
+    float *partial;          // scratch for tree-split prediction of small batches (nullable), partial_floats elements
+    size_t partial_floats;
+    int tree_chunk;          // set by kern::predict: trees per block column (0 = every block walks the whole range)
 };
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words

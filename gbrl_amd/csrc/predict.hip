@@ -316,8 +316,15 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
                                                      const int32_t *__restrict__ cond_pack, const int32_t *__restrict__ depths,
                                                      const float *__restrict__ bias, OblCoef<DMAX> coef, int D, int md,
                                                      const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc, int n,
-                                                     int start_tree, int stop_tree, float *__restrict__ out, int TT) {
+                                                     int start_tree, int stop_tree, float *__restrict__ out, int TT, int tree_chunk) {
     extern __shared__ float ptile[];
+    // tree_chunk > 0: this block covers the trees [start + y*chunk, ...) only and writes a PARTIAL sum (no bias) into slice y of `out`
+    // (small batches with large ensembles: the trees are spread over blocks; k_predict_combine adds the slices in tree order)
+    if (tree_chunk > 0) {
+        start_tree += blockIdx.y * tree_chunk;
+        stop_tree = min(stop_tree, start_tree + tree_chunk);
+        out += static_cast<size_t>(blockIdx.y) * n * D;
+    }
     const int R = blockDim.x;
     const int xs = F | 1;
     const int LS = 1 << md;
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
     const bool live = static_cast<int>(threadIdx.x) < rows;
     float p[DMAX];
 #pragma unroll
-    for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + bias[j] : 0.0f;
+    for (int j = 0; j < DMAX; ++j) p[j] = (j < D && tree_chunk == 0) ? 0.0f + bias[j] : 0.0f;
     const float *x = xt + threadIdx.x * xs;
     // categorical conditions (feature word < 0) compare the row's dictionary id; the branch is uniform (scalar condition words)
     const int32_t *xc = (CAT && live) ? cat_codes + static_cast<size_t>(r0 + threadIdx.x) * Fc : nullptr;
@@ -455,8 +462,10 @@ static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, 
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
-    hipLaunchKernelGGL((k_predict_obl<DMAX, MAXD, CAT>), dim3((n + R - 1) / R), dim3(R), lds, s, pm.values, pm.tree_indices, pm.cond_pack,
-                       pm.depths, pm.bias, coef, pm.D, pm.max_depth, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, TT);
+    const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
+    hipLaunchKernelGGL((k_predict_obl<DMAX, MAXD, CAT>), dim3((n + R - 1) / R, splits), dim3(R), lds, s, pm.values, pm.tree_indices, pm.cond_pack,
+                       pm.depths, pm.bias, coef, pm.D, pm.max_depth, obs, F, cat_codes, Fc, n, start_tree, stop_tree,
+                       pm.tree_chunk > 0 ? pm.partial : out, TT, pm.tree_chunk);
     return true;
 }
 template <int DMAX, bool CAT>
@@ -489,8 +498,15 @@ __global__ __launch_bounds__(256) void k_predict_grd(const float *__restrict__ v
                                                      const float *__restrict__ bias, OblCoef<DMAX> coef, int D, int n_leaves_total,
                                                      int n_trees_total, int max_nodes, int max_leaves,
                                                      const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc,
-                                                     int n, int start_tree, int stop_tree, float *__restrict__ out, int TT) {
+                                                     int n, int start_tree, int stop_tree, float *__restrict__ out, int TT, int tree_chunk) {
     extern __shared__ float ptile[];
+    // tree_chunk > 0: this block covers the trees [start + y*chunk, ...) only and writes a PARTIAL sum (no bias) into slice y of `out`
+    // (small batches with large ensembles: the trees are spread over blocks; k_predict_combine adds the slices in tree order)
+    if (tree_chunk > 0) {
+        start_tree += blockIdx.y * tree_chunk;
+        stop_tree = min(stop_tree, start_tree + tree_chunk);
+        out += static_cast<size_t>(blockIdx.y) * n * D;
+    }
     const int R = blockDim.x;
     const int xs = F | 1;
     const int LS = max_leaves;
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256) void k_predict_grd(const float *__restrict__ v
     const bool live = static_cast<int>(threadIdx.x) < rows;
     float p[DMAX];
 #pragma unroll
-    for (int j = 0; j < DMAX; ++j) p[j] = j < D ? 0.0f + bias[j] : 0.0f;
+    for (int j = 0; j < DMAX; ++j) p[j] = (j < D && tree_chunk == 0) ? 0.0f + bias[j] : 0.0f;
     const float *x = xt + threadIdx.x * xs;
     const int32_t *xc = (cat_codes && live) ? cat_codes + static_cast<size_t>(r0 + threadIdx.x) * Fc : nullptr;
     const int vtree = DMAX * LS;
@@ -614,9 +630,10 @@ static bool launch_predict_grd(const PredictModel &pm, const float *obs, int F, 
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
-    hipLaunchKernelGGL((k_predict_grd<DMAX>), dim3((n + R - 1) / R), dim3(R), lds, s, pm.values, pm.tree_indices, pm.grd_nodes,
+    const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
+    hipLaunchKernelGGL((k_predict_grd<DMAX>), dim3((n + R - 1) / R, splits), dim3(R), lds, s, pm.values, pm.tree_indices, pm.grd_nodes,
                        pm.grd_node_off, pm.bias, coef, pm.D, pm.n_leaves, pm.n_trees, MN, LS, obs, F, cat_codes, Fc, n, start_tree,
-                       stop_tree, out, TT);
+                       stop_tree, pm.tree_chunk > 0 ? pm.partial : out, TT, pm.tree_chunk);
     return true;
 }
 
@@ -647,35 +664,72 @@ static bool launch_predict_tiled(const PredictModel &pm, const float *obs, int F
     return true;
 }
 
-void predict(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
+// out[r][j] = bias[j] + partial[0][r][j] + partial[1][r][j] + ...  (slices in tree order)
+__global__ void k_predict_combine(const float *__restrict__ partial, int splits, size_t n_el, int D, const float *__restrict__ bias,
+                                  float *__restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_el) return;
+    float p = 0.0f + bias[i % D];
+    for (int q = 0; q < splits; ++q) p += partial[static_cast<size_t>(q) * n_el + i];
+    out[i] = p;
+}
+
+void predict(const PredictModel &pm_in, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
              int stop_tree, float *out, hipStream_t s) {
+    // Small batches with large ensembles (an RL agent acting: tens to thousands of rows, hundreds to thousands of trees) would walk
+    // every tree inside a handful of blocks.  The fast kernels then spread the trees over blocks (partial sums per tree range,
+    // combined in tree order).  The float sums are associated differently from the one-chain-per-row order of large batches (the
+    // reference's CPU path does the same for small batches: per-thread partial buffers, predictor.cpp:144-184); both are within
+    // the 1e-5 parity tolerance, and large batches keep the exact tree-order chain (Q14).
+    PredictModel pm = pm_in;
+    pm.tree_chunk = 0;
+    const int trees = stop_tree - start_tree;
+    const int row_tiles = (n + 255) / 256;
+    // Bounded to 2048 trees: the float32 chain of the reference itself drifts from the exact sum by about 2e-9 per tree (9e-5 at
+    // 50 000 trees, measured), so beyond a few thousand trees a differently associated -- more accurate -- sum would leave the 1e-5
+    // band around the reference's value; larger ensembles keep the reference's chain.
+    if (pm.partial && trees >= 128 && trees <= 2048 && row_tiles <= 64) {
+        int splits = std::min(64, std::min(trees / 32, std::max(1, 512 / row_tiles)));
+        while (splits > 1 && static_cast<size_t>(splits) * n * pm.D > pm.partial_floats) --splits;
+        if (splits > 1) pm.tree_chunk = (trees + splits - 1) / splits;
+    }
+    struct Combine {   // runs after whichever fast kernel took the launch
+        const PredictModel &pm; int n, trees; float *out; hipStream_t s;
+        void operator()() const {
+            const int splits = (trees + pm.tree_chunk - 1) / pm.tree_chunk;
+            const size_t n_el = static_cast<size_t>(n) * pm.D;
+            hipLaunchKernelGGL(k_predict_combine, dim3(static_cast<unsigned>((n_el + 255) / 256)), dim3(256), 0, s, pm.partial, splits, n_el, pm.D,
+                               pm.bias, out);
+        }
+    } combine{pm, n, trees, out, s};
     // fast path: oblivious, every output updated by exactly one optimiser.  Outputs are padded to the template's DMAX (zero columns, zero
     // learning rates), so the steps between 8 and 32 are fine-grained: the work per (row, tree) grows with DMAX, not with D
     const uint64_t all_out = pm.D >= 64 ? ~0ull : ((1ull << pm.D) - 1ull);
     if (pm.oblivious && pm.obl_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 64 && stop_tree > start_tree) {
-        if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 8) { if (launch_predict_obl_d<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 12) { if (launch_predict_obl_d<12>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 16) { if (launch_predict_obl_d<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 20) { if (launch_predict_obl_d<20>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 24) { if (launch_predict_obl_d<24>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 32) { if (launch_predict_obl_d<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 48) { if (launch_predict_obl_d<48>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else { if (launch_predict_obl_d<64>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 8) { if (launch_predict_obl_d<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 12) { if (launch_predict_obl_d<12>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 16) { if (launch_predict_obl_d<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 20) { if (launch_predict_obl_d<20>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 24) { if (launch_predict_obl_d<24>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 32) { if (launch_predict_obl_d<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 48) { if (launch_predict_obl_d<48>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else { if (launch_predict_obl_d<64>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
     }
     // fast path: greedy ensembles whose trees were rebuilt as binary trees (descent instead of the leaf-by-leaf walk)
     if (!pm.oblivious && pm.grd_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 64 && stop_tree > start_tree &&
         pm.grd_max_leaves <= 256) {
-        if (pm.D <= 4) { if (launch_predict_grd<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 8) { if (launch_predict_grd<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 12) { if (launch_predict_grd<12>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 16) { if (launch_predict_grd<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 20) { if (launch_predict_grd<20>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 24) { if (launch_predict_grd<24>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 32) { if (launch_predict_grd<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else if (pm.D <= 48) { if (launch_predict_grd<48>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
-        else { if (launch_predict_grd<64>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
+        if (pm.D <= 4) { if (launch_predict_grd<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 8) { if (launch_predict_grd<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 12) { if (launch_predict_grd<12>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 16) { if (launch_predict_grd<16>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 20) { if (launch_predict_grd<20>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 24) { if (launch_predict_grd<24>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 32) { if (launch_predict_grd<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else if (pm.D <= 48) { if (launch_predict_grd<48>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
+        else { if (launch_predict_grd<64>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
     }
+    pm.tree_chunk = 0;   // the general kernels below always take the whole range
     if (pm.D <= 8) { if (launch_predict_tiled<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     else if (pm.D <= 32) { if (launch_predict_tiled<32>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }
     else { if (launch_predict_tiled<128>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return; }

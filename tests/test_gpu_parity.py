@@ -613,3 +613,27 @@ def test_device_shap_at_scale_equals_the_host_evaluation(monkeypatch):
         print("ensemble_shap %s: %.3f s" % ("host" if host == "1" else "device", time.time() - t0))
     assert out["0"].shape == (case["N"], case["F"], case["D"]) and np.abs(out["0"]).max() > 0
     assert np.array_equal(out["0"], out["1"])
+
+
+@pytest.mark.parametrize("policy,Fc", [("greedy", 0), ("oblivious", 0), ("oblivious", 2), ("greedy", 1)])
+def test_small_batch_prediction_over_a_large_ensemble_spreads_the_trees(policy, Fc, monkeypatch):
+    """An agent acting: a few hundred rows, hundreds of trees.  The fast kernels spread tree ranges over blocks and add the partial
+    sums in tree order (kern::predict), so the result is not bitwise the one-chain-per-row sum of the general kernel (which the
+    other tests pin against the oracle): it must agree with it to float32 rounding of the sum.  Sub-ranges too."""
+    import gbrl_amd
+    case = dict(name="act", seed=91, N=700, F=7, Fc=Fc, D=3, depth=3, n_bins=32, score="L2", gen="Quantile", policy=policy, trees=260,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=0, stop_idx=3)])
+    X, Xc, G, y = K.make_inputs(case)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    rng = np.random.default_rng(3)
+    m.set_feature_weights(np.ones(case["F"] + Fc, np.float32))
+    m.set_optimizer("SGD", "Const", 0.05, 0, 3)
+    for t in range(case["trees"]):
+        m.step(X, Xc, np.ascontiguousarray(np.roll(G, 7 * t, axis=0) + rng.standard_normal(1).astype(np.float32) * 0.1))
+    scale = float(np.abs(G).mean())
+    for a, b in ((0, 0), (3, 250), (100, 260)):
+        monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "0")
+        split = np.asarray(m.predict(X, Xc, a, b))
+        monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "1")
+        chain = np.asarray(m.predict(X, Xc, a, b))
+        assert np.abs(chain).max() > 0 and np.abs(split - chain).max() <= 2e-6 * max(np.abs(chain).max(), scale)
