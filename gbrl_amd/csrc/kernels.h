@@ -82,7 +82,7 @@ void sub_arrays(const float *a, const float *b, float *out, size_t n, hipStream_
 void gather_rows(const float *src, const int32_t *perm, float *dst, int n, int width, hipStream_t s);
 void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
 void f32_to_f64(const float *in, double *out, int n, hipStream_t s);
-void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s);
+void keys_to_floats(uint32_t *keys /*NaN-range keys are raised to -inf's key in place*/, float *out, size_t n, hipStream_t s);
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 

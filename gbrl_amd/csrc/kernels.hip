@@ -149,11 +149,13 @@ __global__ __launch_bounds__(256) void k_column_minmax(const uint32_t *__restric
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
     uint32_t lo = 0xffffffffu, hi = 0u;
+    constexpr uint32_t kMinFinite = 0x007fffffu;   // key of -inf; smaller keys are NaNs, which the reference's `<` / `>` scan never picks up
+    auto upd = [&](uint32_t k) { if (k >= kMinFinite) { lo = min(lo, k); hi = max(hi, k); } };
     // the column start is 4-byte aligned only (n is arbitrary): peel to a 16-byte boundary, then vector loads
     int r = r0 + threadIdx.x;
     const uintptr_t mis = (reinterpret_cast<uintptr_t>(col + r0) >> 2) & 3;
     const int head = min(r1 - r0, static_cast<int>((4 - mis) & 3));
-    if (threadIdx.x < head) { const uint32_t k = col[r]; lo = min(lo, k); hi = max(hi, k); }
+    if (threadIdx.x < head) upd(col[r]);
     const int v0 = r0 + head, nvec = (r1 - v0) / 4;
     const uint4 *vec = reinterpret_cast<const uint4 *>(col + v0);
     for (int i = threadIdx.x; i < nvec; i += 256 * 4) {
@@ -161,12 +163,9 @@ __global__ __launch_bounds__(256) void k_column_minmax(const uint32_t *__restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) q[u] = vec[min(i + u * 256, nvec - 1)];   // past the end: re-read the last vector (harmless for min / max)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            lo = min(min(lo, q[u].x), min(q[u].y, min(q[u].z, q[u].w)));
-            hi = max(max(hi, q[u].x), max(q[u].y, max(q[u].z, q[u].w)));
-        }
+        for (int u = 0; u < 4; ++u) { upd(q[u].x); upd(q[u].y); upd(q[u].z); upd(q[u].w); }
     }
-    for (r = v0 + nvec * 4 + threadIdx.x; r < r1; r += 256) { const uint32_t k = col[r]; lo = min(lo, k); hi = max(hi, k); }
+    for (r = v0 + nvec * 4 + threadIdx.x; r < r1; r += 256) upd(col[r]);
     for (int o = kWave / 2; o > 0; o >>= 1) {
         lo = min(lo, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), o, kWave)));
         hi = max(hi, static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), o, kWave)));
@@ -184,7 +183,11 @@ __global__ void k_uniform_thresholds(const uint32_t *__restrict__ mn, const uint
     const float lo = key_to_float(mn[f]), hi = key_to_float(mx[f]);
     const float step = (hi - lo) / static_cast<float>(B);
     // split_candidate_generator.cpp:67: min + b*step, contracted to ONE fma by the reference's release build (Q5)
-    thr[i] = fmaf(static_cast<float>(b), step, lo);
+    float t = fmaf(static_cast<float>(b), step, lo);
+    // a column with infinite values gives inf - inf = NaN thresholds (in the reference too): a NaN threshold never passes `x > t`;
+    // -inf is stored instead so that the key comparison of step() (NaN has no key above it) and predict()'s float comparison agree
+    if (t != t) t = -INFINITY;
+    thr[i] = t;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -285,9 +288,14 @@ __global__ void k_qsel_update(uint32_t *__restrict__ prefix, uint32_t *__restric
     }
 }
 
-__global__ void k_keys_to_floats(const uint32_t *__restrict__ keys, float *__restrict__ out, size_t n) {
+// Threshold keys -> floats.  A selected key in the NaN range (a column with more NaNs than one quantile step) is raised to -inf's key,
+// in place, so that the key comparison of step() and the float comparison of predict() keep agreeing: `x > -inf`.
+__global__ void k_keys_to_floats(uint32_t *__restrict__ keys, float *__restrict__ out, size_t n) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = key_to_float(keys[i]);
+    if (i >= n) return;
+    uint32_t k = keys[i];
+    if (k < 0x007fffffu) { k = 0x007fffffu; keys[i] = k; }
+    out[i] = key_to_float(k);
 }
 __global__ void k_floats_to_keys(const float *__restrict__ in, uint32_t *__restrict__ keys, size_t n) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1159,7 +1167,7 @@ void qsel_update(uint32_t *prefix, uint32_t *trial, const int64_t *counts, const
     hipLaunchKernelGGL(k_qsel_update, dim3(F), dim3(256), (B + 1) * sizeof(unsigned long long), s, prefix, trial, counts,
                        cum, B, bit, next_bit);
 }
-void keys_to_floats(const uint32_t *keys, float *out, size_t n, hipStream_t s) {
+void keys_to_floats(uint32_t *keys, float *out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_keys_to_floats, dim3((n + 255) / 256), dim3(256), 0, s, keys, out, n);
 }
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s) {

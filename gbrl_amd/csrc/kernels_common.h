@@ -16,6 +16,7 @@ __device__ __forceinline__ uint32_t float_to_key(float x) {
     // order-preserving map float -> uint32; -0.0 and +0.0 map to the same key (they compare equal as floats)
     uint32_t u = __float_as_uint(x);
     if ((u << 1) == 0) u = 0;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0u;   // NaN: below every threshold, like the float comparison `x > t` (false)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float key_to_float(uint32_t k) {

@@ -234,3 +234,32 @@ def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if "wide==generic" in ln]
     assert len(lines) >= 12 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("gen", ["Quantile", "Uniform"])
+@pytest.mark.parametrize("policy", ["greedy", "oblivious"])
+def test_nan_observations_are_routed_the_same_way_by_step_and_predict(gen, policy):
+    """NaN observations are undefined behaviour in the reference (std::sort over NaNs for quantiles).  Here they have one meaning
+    everywhere: `x > t` is false, as in the float comparison of predict -- lowest key in step()'s key comparisons, ignored by the
+    uniform min/max.  Check: with one tree, lr 1 and zero bias, predict(row) = -(mean gradient of the row's training leaf); if
+    training and prediction routed any row differently the per-leaf means would not reproduce."""
+    import gbrl_amd
+    rng = np.random.default_rng(4)
+    N, F, D = 5000, 5, 2
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    X[rng.random((N, F)) < 0.15] = np.nan                       # more NaNs than one quantile step: NaN-range thresholds get selected
+    X[rng.integers(0, N, 40), 0] = -np.inf
+    G = (np.nan_to_num(X[:, :D], nan=2.0, neginf=-3.0) + 0.1 * rng.standard_normal((N, D))).astype(np.float32)
+    m = gbrl_amd.GBRL(input_dim=F, output_dim=D, policy_dim=D, max_depth=4, min_data_in_leaf=0, n_bins=32, par_th=10, cv_beta=0.9,
+                      split_score_func="L2", generator_type=gen, use_control_variates=False, batch_size=5000, grow_policy=policy,
+                      verbose=0, device="cpu")
+    m.set_feature_weights(np.ones(F, np.float32))
+    m.set_optimizer("SGD", "Const", 1.0, 0, D)
+    m.step(X, None, G)
+    p = np.asarray(m.predict(X, None))
+    assert np.isfinite(p).all()
+    leaves, inv = np.unique(p, axis=0, return_inverse=True)
+    assert len(leaves) > 4
+    for k in range(len(leaves)):
+        rows = inv.reshape(-1) == k
+        assert np.allclose(G[rows].mean(axis=0), -leaves[k], rtol=1e-4, atol=1e-5), (k, int(rows.sum()))
