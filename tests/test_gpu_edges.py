@@ -263,3 +263,28 @@ def test_nan_observations_are_routed_the_same_way_by_step_and_predict(gen, polic
     for k in range(len(leaves)):
         rows = inv.reshape(-1) == k
         assert np.allclose(G[rows].mean(axis=0), -leaves[k], rtol=1e-4, atol=1e-5), (k, int(rows.sum()))
+
+
+@pytest.mark.parametrize("name", ["obl_l2_q_cat", "grd_cos_q_ac"])
+def test_training_continues_from_a_loaded_model(name, tmp_path):
+    """tests/test_gbt_single.py::test_continuation_* of the reference: save, load, keep stepping.  A model that grows its last tree
+    after a save / load round trip must equal the model that never left memory, bit for bit (structure, values, predictions) --
+    optimizers, feature mapping, iteration counter and the categorical dictionary all travel through the file."""
+    import gbrl_amd
+    case = dict(K.BY_NAME[name])
+    X, Xc, G, y = K.make_inputs(case)
+    straight = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(straight, case, X, Xc, G, y)
+    first = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(first, dict(case, trees=case["trees"] - 1), X, Xc, G, y)
+    p = tmp_path / "half.gbrl_model"
+    assert first.save(str(p)) == 0
+    resumed = gbrl_amd.GBRL.load(str(p))
+    resumed.to_device("cpu")
+    assert y is None            # these cases step on the same gradients every time
+    resumed.step(X, Xc, np.ascontiguousarray(G))
+    e, o = resumed.get_ensemble_data(), straight.get_ensemble_data()
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(np.asarray(e[k]), np.asarray(o[k])), k
+    assert resumed.get_iteration() == straight.get_iteration()
+    assert np.array_equal(np.asarray(resumed.predict(X, Xc)), np.asarray(straight.predict(X, Xc)))
