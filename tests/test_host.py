@@ -179,3 +179,30 @@ def test_product_does_not_touch_the_oracle():
                 assert "liboracle" not in txt and "import oracle" not in txt and "oracle.h" not in txt, f
     out = os.popen("ldd " + gbrl_amd.LIB_PATH).read()
     assert "oracle" not in out
+
+
+def test_python_signatures_match_the_reference_class():
+    """Every public method of the reference's gbrl_cpp.GBRL exists here with the same argument names, order, defaults and annotated
+    types (pybind11 writes them into the docstrings); only additions are allowed."""
+    import oracle
+    ref_mod = oracle.load_ref()
+    if ref_mod is None:
+        pytest.skip("oracle/_ref not built")
+
+    def signatures(cls):
+        out = {}
+        for n in dir(cls):
+            if n.startswith("__") and n != "__init__":
+                continue
+            doc = getattr(cls, n).__doc__ or ""
+            lines = [ln for ln in doc.split("\n") if re.match(r"\s*(\d+\.\s*)?%s\(" % re.escape(n), ln)]
+            out[n] = [re.sub(r"gbrl_cpp(_ref)?\.GBRL", "GBRL", re.sub(r"^\s*\d+\.\s*", "", ln)).strip() for ln in lines]
+        return out
+
+    ref, mine = signatures(ref_mod.GBRL), signatures(gbrl_amd.GBRL)
+    assert not set(ref) - set(mine), sorted(set(ref) - set(mine))
+    for name, sig in ref.items():
+        if name == "get_feature_mapping":       # same call, the return annotation here is more specific
+            assert [s.split(" -> ")[0] for s in mine[name]] == [s.split(" -> ")[0] for s in sig]
+            continue
+        assert mine[name] == sig, (name, sig, mine[name])
