@@ -31,6 +31,7 @@ constexpr int kMaxTargets = 256;
 constexpr int kChunks1 = 8;               // pass 1: small LDS footprint, many blocks
 constexpr int kCopies1 = 4;               // pass 1: lane-interleaved private copies of the 4096-bin histogram (power of two)
 constexpr int kChunksN = 8;               // upper bound of chunks in passes 2..4 (2 at F >= 128: one 128 KB block per CU)
+constexpr int kFiltWords = 1024, kFiltShift = 17;   // hashed prefix filter of passes 3 / 4: 32768 bits
 constexpr int kSlotStride = 128;          // digits per slot in the partials of passes 2..4
 
 __host__ __device__ constexpr int radix_bins(int pass) { return pass == 1 ? kBins1 : (pass == 4 ? 64 : 128); }
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     uint16_t *map1 = reinterpret_cast<uint16_t *>(rl + (PASS == 1 ? kCopies1 * kBins1 : kMaxTargets * NB));   // [4096]
     uint64_t *cbits = reinterpret_cast<uint64_t *>(map1 + kBins1);             // [2][256][2]
     uint16_t *coff = reinterpret_cast<uint16_t *>(cbits + 2 * 512);            // [2][258]
-    uint32_t *filt = reinterpret_cast<uint32_t *>(coff + 2 * 260);             // [2048] 65536-bit hashed set of the live prefixes
+    uint32_t *filt = reinterpret_cast<uint32_t *>(coff + 2 * 260);             // [1024] 32768-bit hashed set of the live prefixes
+    uint32_t *queue = filt + kFiltWords + (threadIdx.x >> 6) * 128;            // [waves][128] filter hits waiting for the exact chain
     constexpr int PS = PASS == 3 ? 13 : 6;                                     // bits below the prefix a pass-3/4 key must match
     __shared__ uint32_t list_cursor;
     if (threadIdx.x == 0) list_cursor = 0;
@@ -75,11 +77,11 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     for (int i = threadIdx.x; i < n_cnt; i += kRadixThreads) cnt[i] = 0;
     if (PASS >= 3) {
         // Few keys still match a live prefix (a few % in pass 3, ~0.1 % in pass 4): one bit test rejects the rest before the
-        // exact slot chain.  No false negatives; false positives (~B / 65536) fall out of the chain.
-        for (int i = threadIdx.x; i < 2048; i += kRadixThreads) filt[i] = 0;
+        // exact slot chain.  No false negatives; false positives (~B / 32768) fall out of the chain.
+        for (int i = threadIdx.x; i < kFiltWords; i += kRadixThreads) filt[i] = 0;
         __syncthreads();
         if (static_cast<int>(threadIdx.x) < B) {
-            const uint32_t h = ((st.tgt_prefix[static_cast<size_t>(f) * B + threadIdx.x] >> PS) * 0x9E3779B1u) >> 16;
+            const uint32_t h = ((st.tgt_prefix[static_cast<size_t>(f) * B + threadIdx.x] >> PS) * 0x9E3779B1u) >> kFiltShift;
             atomicOr(&filt[h >> 5], 1u << (h & 31));
         }
     }
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     };
     constexpr int U = 8;
     int i0 = lo + threadIdx.x;
+    int qlen = 0;   // wave-uniform
     if (PASS == 4) {
         const uint32_t n_list = st.list_cnt[f * n_chunks + blockIdx.x];
         if (n_list <= st.list_cap) {   // the chunk's survivors of pass 3 fit their list: count those, skip the column
@@ -152,29 +155,33 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
 #pragma unroll
         for (int u = 0; u < U; ++u) key[u] = col[i0 + u * kRadixThreads];
         if (PASS >= 3) {
-            bool hit[U];
+            // The hits (a few % of the keys) are compacted ACROSS the wave into its LDS queue and the exact chain runs on 64 queued
+            // keys at a time: per-lane handling made the whole wave walk the chain for one or two sparse candidates per strip.
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t h = ((key[u] >> PS) * 0x9E3779B1u) >> 16;
-                hit[u] = (filt[h >> 5] >> (h & 31)) & 1;
-            }
-            // per-thread compaction: a lane rarely has more than two candidates among its 8 keys, so the wave runs the exact
-            // chain about twice per strip instead of 8 times
-            uint32_t p0 = 0, p1 = 0;
-            int np = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (hit[u]) {
-                    if (np == 0) p0 = key[u]; else if (np == 1) p1 = key[u]; else count_one(key[u]);
-                    ++np;
+                const uint32_t h = ((key[u] >> PS) * 0x9E3779B1u) >> kFiltShift;
+                const bool hit = (filt[h >> 5] >> (h & 31)) & 1;
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    if (hit) queue[qlen + __popcll(m & ((1ull << __lane_id()) - 1))] = key[u];
+                    qlen += __popcll(m);
+                    __builtin_amdgcn_wave_barrier();   // the queue is exchanged between the lanes of ONE wave: LDS order is program order
+                    if (qlen >= 64) {
+                        const uint32_t k0 = queue[__lane_id()];
+                        const uint32_t k1 = queue[64 + __lane_id()];
+                        count_one(k0);
+                        qlen -= 64;
+                        if (static_cast<int>(__lane_id()) < qlen) queue[__lane_id()] = k1;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
-            if (np > 0) count_one(p0);
-            if (np > 1) count_one(p1);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) count_one(key[u]);
         }
     }
+    if (PASS >= 3 && static_cast<int>(__lane_id()) < qlen) count_one(queue[__lane_id()]);   // what is left in the wave's queue
     for (; i0 < hi; i0 += kRadixThreads) count_one(col[i0]);
     __syncthreads();
     if (PASS == 3 && threadIdx.x == 0) st.list_cnt[f * n_chunks + blockIdx.x] = list_cursor;
@@ -373,7 +380,7 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
     st.tgt_prefix = reinterpret_cast<uint32_t *>(take(f * B * 4));
     st.list_cnt = reinterpret_cast<uint32_t *>(take(f * kChunksN * 4));
     st.lists = lists;
-    const size_t aux = kBins1 * 2 + 2 * 512 * 8 + 2 * 260 * 2 + 2048 * 4;
+    const size_t aux = kBins1 * 2 + 2 * 512 * 8 + 2 * 260 * 2 + kFiltWords * 4 + (kRadixThreads / 64) * 128 * 4;
     const size_t lds1 = static_cast<size_t>(kCopies1) * kBins1 * 4 + aux, lds23 = static_cast<size_t>(kMaxTargets) * 128 * 4 + aux,
                  lds4 = static_cast<size_t>(kMaxTargets) * 64 * 4 + aux;
     static bool attr = false;
