@@ -183,6 +183,8 @@ void Engine::phase_begin(bool key) {
     hip_check(hipEventRecord(ev_pool_[ev_used_].first, stream_), "hipEventRecord");
 }
 void Engine::phase_end(const char *name, bool key) {
+    // a failed launch is sticky and would otherwise surface at the next checked call: attribute it to the phase that made it
+    { const hipError_t e = hipGetLastError(); if (e != hipSuccess) throw HipError(std::string("kernel launch failed in phase '") + name + "': " + hipGetErrorString(e)); }
     if (profiling_ < (key ? 1 : 2)) return;
     hip_check(hipEventRecord(ev_pool_[ev_used_].second, stream_), "hipEventRecord");
     ev_names_.push_back(name);

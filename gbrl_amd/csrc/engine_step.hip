@@ -482,7 +482,10 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 fast_quantile = true;
                 kern::QuantilePlan plan = kern::quantile_plan(N);
                 if (has_coll_) { plan.sample = 4096; plan.n_split = kern::kQuantileMaxSplit; }   // identical on every rank
-                const uint32_t max_elems = static_cast<uint32_t>(std::min<size_t>(static_cast<size_t>(N) * F, std::max<size_t>(1u << 20, static_cast<size_t>(N) * F / 4)));
+                // budget of the extracted class lists: a quarter of the data is ample when the targets are few against the classes
+                // (<= 256 targets, 1024 classes); with more targets nearly every class holds one, so the lists can be the whole data
+                const size_t all_keys = static_cast<size_t>(N) * F;
+                const uint32_t max_elems = static_cast<uint32_t>(B > 256 ? all_keys : std::min<size_t>(all_keys, std::max<size_t>(1u << 20, all_keys / 4)));
                 int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
                 hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
                 uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * kern::kQuantileMaxSplit));
@@ -512,11 +515,14 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                     exchange(Red::SumI64, d_gcounts, static_cast<size_t>(F) * kern::kQuantileClasses);
                 } else {
                     kern::sample_splitters(d_kt, N, F, plan, d_split, d_split_bfs, s);
+                    hip_check(hipGetLastError(), "sample_splitters launch");
                     kern::class_count(d_kt, N, F, plan, d_split_bfs, d_cc, s);
+                    hip_check(hipGetLastError(), "class_count launch");
                 }
                 kern::quantile_targets(d_cc, d_gcounts, d_split, d_cum, F, B, plan, d_coff, d_toff, d_tlen, d_tr, d_thrkeys, d_qflags, max_elems,
                                        d_qflags + 2, s);
                 kern::quantile_extract(d_kt, N, F, plan, d_split_bfs, d_coff, d_cc, d_lists, s);
+                hip_check(hipGetLastError(), "quantile_extract launch");
                 if (has_coll_) {
                     // the lists stay on their ranks; the order statistic of their union is found by 32 counting rounds
                     uint32_t *d_pref = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * static_cast<size_t>(F) * B));
@@ -524,11 +530,14 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                     hip_check(hipMemsetAsync(d_pref, 0, sizeof(uint32_t) * static_cast<size_t>(F) * B, s), "memset");
                     for (int bit = 31; bit >= 0; --bit) {
                         kern::select_count(d_lists, d_toff, d_tlen, d_pref, bit, F * B, d_scnt, s);
+                        hip_check(hipGetLastError(), "select_count launch");
                         exchange(Red::SumI64, d_scnt, static_cast<size_t>(F) * B);
                         kern::select_update(d_pref, d_scnt, d_toff, d_tr, bit, F * B, d_thrkeys, s);
+                        hip_check(hipGetLastError(), "select_update launch");
                     }
                 } else {
                     kern::quantile_select(d_lists, d_toff, d_tlen, d_tr, F * B, d_thrkeys, s);
+                    hip_check(hipGetLastError(), "quantile_select launch");
                 }
             }
             kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);

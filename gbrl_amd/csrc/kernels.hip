@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <stdexcept>
 #include <cstdlib>
 
 namespace gbrl {
@@ -1145,6 +1146,8 @@ void bin_rows(const float *obs, int n, int F, const uint32_t *trial_keys, int B,
     const int rpi = kBinThreads / kBinFT;
     dim3 grid(grid_for(static_cast<size_t>(n), rpi * 64, 1024), tiles);
     const size_t lds = (static_cast<size_t>(B) * kBinFT + static_cast<size_t>(B + 1) * kBinFT) * sizeof(uint32_t);
+    if (lds > 160 * 1024)   // the bisection selection keeps all trial thresholds of 64 features in LDS: n_bins <= 319
+        throw std::runtime_error("the 32-pass bisection selection of quantile candidates supports n_bins <= 319");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -1,5 +1,5 @@
 """Randomised product-vs-oracle sweep on a GPU box (not part of the test suite; prints a summary).
-    python scripts/parity_sweep.py [n_cases] [first_seed]
+    python scripts/parity_sweep.py [n_cases] [first_seed] [wide]      (wide: many outputs / bins / features, the less common kernels)
 Every case: random shape / policy / score / generator / bins / depth / min_data_in_leaf / categorical columns; the product must
 match the oracle restatement bit for bit in structure (or the first mismatch must be an explained near-tie) and within 1e-5
 in leaf values and predictions."""
@@ -15,6 +15,7 @@ import gbrl_amd, oracle
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 rng = np.random.default_rng(seed0)
 exact = near = bad = 0
 t0 = time.time()
@@ -26,11 +27,20 @@ for i in range(n_cases):
                 policy=str(rng.choice(["greedy", "oblivious"])), trees=int(rng.choice([1, 2, 4])),
                 min_data_in_leaf=int(rng.choice([0, 0, 5, 40])))
     if case["policy"] == "greedy" and case["depth"] >= 6: case["depth"] = 5          # reference cannot build those (Q2)
+    if wide:
+        case.update(F=int(rng.choice([5, 33, 64, 130])), D=int(rng.choice([12, 17, 18, 24, 33, 40])), n_bins=int(rng.choice([64, 256, 300, 1000])),
+                    N=int(rng.choice([1200, 5000, 30000])), depth=int(rng.choice([2, 4, 5])))
+        if case["n_bins"] >= 300: case["D"] = min(case["D"], 12)     # score-kernel LDS limit: (classes + 1) x (D + 1) sums
     if rng.random() < 0.3: case["discrete_cols"] = [0]
     if case["N"] < case["n_bins"] + 1: case["n_bins"] = 32
     X, Xc, G, y = K.make_inputs(case)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
-    pred = np.asarray(K.drive(m, case, X, Xc, G, y))
+    try:
+        pred = np.asarray(K.drive(m, case, X, Xc, G, y))
+    except RuntimeError as ex:      # an unsupported configuration is a finding of its own: show it
+        print("PRODUCT-ERROR", case, str(ex)[:200], flush=True)
+        bad += 1
+        continue
     ref = oracle.OracleGBRL(**K.ctor_kwargs(case))
     pref = np.asarray(K.drive(ref, case, X, Xc, G, y))
     e, r = m.get_ensemble_data(), ref.get_ensemble_data()

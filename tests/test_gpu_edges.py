@@ -288,3 +288,12 @@ def test_training_continues_from_a_loaded_model(name, tmp_path):
         assert np.array_equal(np.asarray(e[k]), np.asarray(o[k])), k
     assert resumed.get_iteration() == straight.get_iteration()
     assert np.array_equal(np.asarray(resumed.predict(X, Xc)), np.asarray(straight.predict(X, Xc)))
+
+
+def test_many_bins_many_features_quantile_selection():
+    """n_bins > 256 uses the sample-splitter selection, whose extracted class lists grow to (nearly) the whole data when there are
+    about as many targets as classes: the list budget must follow (found by the wide parity sweep: 30 000 x 130, 700-1000 bins fell
+    into the bisection fallback, which cannot hold that many thresholds in LDS)."""
+    case = _case("manybins", N=30000, F=130, D=6, depth=3, n_bins=700, policy="greedy", trees=1)
+    X, Xc, G, y = K.make_inputs(case)
+    _check(case, X, Xc, G)
