@@ -1,0 +1,45 @@
+"""Randomised fit() sweep on a GPU box: GBRL.fit of the product against the REFERENCE's own CPU fit (oracle/_ref) on random supervised
+problems.  Tree structure must be bit-identical; a mismatch is reported with the first differing tree (the reference's bias is a
+thread-count dependent float32 mean, so values are compared at 1e-4 and a rare near-tie can flip a split -- those show up here as
+mismatches to look at, there is no automatic near-tie analysis for fit()).
+    python scripts/fit_sweep.py [n_cases] [first_seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import numpy as np
+import cases as K
+import gbrl_amd, oracle
+
+ref = oracle.load_ref()
+assert ref is not None, "oracle/_ref is needed"
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
+rng = np.random.default_rng(seed0)
+exact = diff = 0
+t0 = time.time()
+for i in range(n_cases):
+    D = int(rng.choice([1, 1, 2, 3]))
+    bs = int(rng.choice([1200, 2400]))
+    case = dict(name="fit%d" % i, seed=seed0 + i, N=bs * int(rng.choice([1, 2, 3])), F=int(rng.choice([3, 6, 10])), Fc=int(rng.choice([0, 0, 1, 2])),
+                D=D, depth=int(rng.choice([2, 3, 4])), n_bins=int(rng.choice([16, 32, 64])), score=str(rng.choice(["L2", "Cosine"])),
+                gen=str(rng.choice(["Quantile", "Uniform"])), policy=str(rng.choice(["greedy", "oblivious"])), loop="rmse", y_cat_weight=1.0,
+                batch_size=bs, fit_iterations=int(rng.choice([3, 5, 8])),
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=float(rng.choice([0.2, 0.5])), start_idx=0, stop_idx=D)])
+    X, Xc, G, y = K.make_inputs(case)
+    out = []
+    for mod in (gbrl_amd.GBRL, ref.GBRL):
+        m = mod(**K.ctor_kwargs(case))
+        loss, pred = K.drive_fit(m, case, X, y, Xc)
+        out.append((m.get_ensemble_data(), loss, pred))
+    (e, l1, p1), (r, l2, p2) = out
+    same = all(np.array_equal(np.asarray(e[k]), np.asarray(r[k])) for k in ("tree_indices", "depths", "feature_indices", "is_numerics", "inequality_directions", "categorical_values"))
+    same = same and np.array_equal(np.asarray(e["feature_values"]).view(np.uint32) | 0, np.asarray(r["feature_values"]).view(np.uint32) | 0)
+    close = same and np.allclose(np.asarray(e["values"]), np.asarray(r["values"]), rtol=1e-4, atol=1e-5) and abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2))
+    if close:
+        exact += 1
+    else:
+        diff += 1
+        nt = min(len(np.asarray(e["depths"])), len(np.asarray(r["depths"])))
+        print("DIFF", case, "structure equal:", same, "losses", l1, l2, flush=True)
+print("fit cases %d: structure + values agree %d, differ %d  (%.1f s)" % (n_cases, exact, diff, time.time() - t0))

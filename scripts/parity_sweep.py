@@ -16,6 +16,7 @@ import gbrl_amd, oracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+cat = len(sys.argv) > 3 and sys.argv[3] == "cat"     # categorical-heavy: many columns / tokens, few bins (mean-gradient ranking fallback)
 rng = np.random.default_rng(seed0)
 exact = near = bad = 0
 t0 = time.time()
@@ -27,6 +28,10 @@ for i in range(n_cases):
                 policy=str(rng.choice(["greedy", "oblivious"])), trees=int(rng.choice([1, 2, 4])),
                 min_data_in_leaf=int(rng.choice([0, 0, 5, 40])))
     if case["policy"] == "greedy" and case["depth"] >= 6: case["depth"] = 5          # reference cannot build those (Q2)
+    if cat:
+        case.update(Fc=int(rng.choice([2, 5, 12, 30])), F=int(rng.choice([0, 1, 4])), n_tokens=int(rng.choice([3, 8, 20, 32])),
+                    n_bins=int(rng.choice([4, 8, 32, 256])), depth=min(case["depth"], 4))
+        if case["N"] < case["n_bins"] + 1: case["n_bins"] = 32
     if wide:
         case.update(F=int(rng.choice([5, 33, 64, 130])), D=int(rng.choice([12, 17, 18, 24, 33, 40])), n_bins=int(rng.choice([64, 256, 300, 1000])),
                     N=int(rng.choice([1200, 5000, 30000])), depth=int(rng.choice([2, 4, 5])))
@@ -49,6 +54,10 @@ for i in range(n_cases):
         assert_structure_equal(e, r)
         assert_values_close(e, r, scale, 1e-5)
         assert rel_err(pred, pref, scale) <= 1e-5
+        T = m.get_num_trees()
+        if T > 1:            # a random sub-range of trees as well
+            a = int(rng.integers(0, T - 1)); b = int(rng.integers(a + 1, T + 1))
+            assert rel_err(np.asarray(m.predict(X, Xc, a, b)), np.asarray(ref.predict(X, Xc, a, b)), scale) <= 1e-5
         exact += 1
     except AssertionError as ex:
         info = None
