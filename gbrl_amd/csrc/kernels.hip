@@ -198,47 +198,47 @@ __global__ void k_uniform_thresholds(const uint32_t *__restrict__ mn, const uint
 // One block = FT features x (256/FT) rows per iteration; trial keys staged in LDS transposed ([k][f], f fastest)
 // so that the lanes of a wave, which hold consecutive features, always hit distinct banks.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kBinFT = 64;        // features per block tile (256 B of each row: two full 128-B lines)
 constexpr int kBinThreads = 256;
 
-template <bool STRICT>
+// FT = features per block tile: 64 (256 B of each row) while the 2 B + 1 LDS rows of a feature fit, fewer features for more thresholds
+template <bool STRICT, int FT>
 __global__ __launch_bounds__(kBinThreads) void k_bin_rows(const float *__restrict__ obs, int n, int F,
                                                            const uint32_t *__restrict__ trial, int B,
                                                            unsigned long long *__restrict__ counts, uint16_t *__restrict__ codes,
                                                            int code_stride, int code_off) {
     extern __shared__ uint32_t lds[];
     uint32_t *t = lds;                    // [B][FT]
-    uint32_t *cnt = lds + B * kBinFT;     // [B+1][FT]
-    const int f0 = blockIdx.y * kBinFT;
-    const int nf = min(kBinFT, F - f0);
-    for (int i = threadIdx.x; i < B * kBinFT; i += kBinThreads) {
-        const int k = i / kBinFT, fl = i % kBinFT;
+    uint32_t *cnt = lds + B * FT;     // [B+1][FT]
+    const int f0 = blockIdx.y * FT;
+    const int nf = min(FT, F - f0);
+    for (int i = threadIdx.x; i < B * FT; i += kBinThreads) {
+        const int k = i / FT, fl = i % FT;
         t[i] = fl < nf ? trial[static_cast<size_t>(f0 + fl) * B + k] : 0xffffffffu;
     }
     if (counts)
-        for (int i = threadIdx.x; i < (B + 1) * kBinFT; i += kBinThreads) cnt[i] = 0;
+        for (int i = threadIdx.x; i < (B + 1) * FT; i += kBinThreads) cnt[i] = 0;
     __syncthreads();
-    const int fl = threadIdx.x % kBinFT;
-    const int rsub = threadIdx.x / kBinFT;
-    constexpr int RPI = kBinThreads / kBinFT;
+    const int fl = threadIdx.x % FT;
+    const int rsub = threadIdx.x / FT;
+    constexpr int RPI = kBinThreads / FT;
     if (fl < nf) {
         for (int r = blockIdx.x * RPI + rsub; r < n; r += gridDim.x * RPI) {
             const uint32_t key = float_to_key(obs[static_cast<size_t>(r) * F + f0 + fl]);
             int lo = 0, hi = B;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                const uint32_t tv = t[mid * kBinFT + fl];
+                const uint32_t tv = t[mid * FT + fl];
                 const bool below = STRICT ? (tv < key) : (tv <= key);
                 if (below) lo = mid + 1; else hi = mid;
             }
-            if (counts) atomicAdd(&cnt[lo * kBinFT + fl], 1u);
+            if (counts) atomicAdd(&cnt[lo * FT + fl], 1u);
             if (codes) codes[static_cast<size_t>(r) * code_stride + code_off + f0 + fl] = static_cast<uint16_t>(lo);
         }
     }
     if (counts) {
         __syncthreads();
-        for (int i = threadIdx.x; i < (B + 1) * kBinFT; i += kBinThreads) {
-            const int j = i / kBinFT, f = i % kBinFT;
+        for (int i = threadIdx.x; i < (B + 1) * FT; i += kBinThreads) {
+            const int j = i / FT, f = i % FT;
             const uint32_t c = cnt[i];
             if (c != 0 && f < nf) atomicAdd(&counts[static_cast<size_t>(f0 + f) * (B + 1) + j], static_cast<unsigned long long>(c));
         }
@@ -1139,27 +1139,33 @@ void uniform_thresholds(const uint32_t *mn, const uint32_t *mx, int F, int B, fl
     hipLaunchKernelGGL(k_uniform_thresholds, dim3((F * B + 255) / 256), dim3(256), 0, s, mn, mx, F, B, thr);
 }
 
+template <bool STRICT, int FT>
+static void launch_bin_rows(const float *obs, int n, int F, const uint32_t *trial_keys, int B, unsigned long long *counts, uint16_t *codes,
+                            int code_stride, int code_off, hipStream_t s) {
+    const int tiles = (F + FT - 1) / FT;
+    const int rpi = kBinThreads / FT;
+    dim3 grid(grid_for(static_cast<size_t>(n), rpi * 64, 1024), tiles);
+    const size_t lds = (static_cast<size_t>(B) * FT + static_cast<size_t>(B + 1) * FT) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<STRICT, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bin_rows<STRICT, FT>), grid, dim3(kBinThreads), lds, s, obs, n, F, trial_keys, B, counts, codes, code_stride, code_off);
+}
+
 void bin_rows(const float *obs, int n, int F, const uint32_t *trial_keys, int B, bool strict, int64_t *counts_,
               uint16_t *codes, int code_stride, int code_off, hipStream_t s) {
     unsigned long long *counts = reinterpret_cast<unsigned long long *>(counts_);
-    const int tiles = (F + kBinFT - 1) / kBinFT;
-    const int rpi = kBinThreads / kBinFT;
-    dim3 grid(grid_for(static_cast<size_t>(n), rpi * 64, 1024), tiles);
-    const size_t lds = (static_cast<size_t>(B) * kBinFT + static_cast<size_t>(B + 1) * kBinFT) * sizeof(uint32_t);
-    if (lds > 160 * 1024)   // the bisection selection keeps all trial thresholds of 64 features in LDS: n_bins <= 319
-        throw std::runtime_error("the 32-pass bisection selection of quantile candidates supports n_bins <= 319");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    if (strict)
-        hipLaunchKernelGGL(k_bin_rows<true>, grid, dim3(kBinThreads), lds, s, obs, n, F, trial_keys, B, counts, codes,
-                           code_stride, code_off);
-    else
-        hipLaunchKernelGGL(k_bin_rows<false>, grid, dim3(kBinThreads), lds, s, obs, n, F, trial_keys, B, counts, codes,
-                           code_stride, code_off);
+    // thresholds + class counters of one feature take (2 B + 1) LDS words: 64 features per tile up to 319 thresholds, 16 up to 1279, 4 up to 5119
+    auto fits = [&](int ft) { return (static_cast<size_t>(2 * B + 1) * ft) * sizeof(uint32_t) <= 160 * 1024; };
+#define GBRL_BIN_ROWS(FT) do { if (strict) launch_bin_rows<true, FT>(obs, n, F, trial_keys, B, counts, codes, code_stride, code_off, s); \
+                                else launch_bin_rows<false, FT>(obs, n, F, trial_keys, B, counts, codes, code_stride, code_off, s); } while (0)
+    if (fits(64)) GBRL_BIN_ROWS(64);
+    else if (fits(16)) GBRL_BIN_ROWS(16);
+    else if (fits(4)) GBRL_BIN_ROWS(4);
+    else throw std::runtime_error("the 32-pass bisection selection of quantile candidates supports n_bins <= 5119");
+#undef GBRL_BIN_ROWS
 }
 
 void qsel_init(uint32_t *prefix, uint32_t *trial, int F, int B, hipStream_t s) {
