@@ -1,7 +1,7 @@
 """Randomised ROW-SHARDED sweep on one GPU: `world` processes (gloo group, reductions staged through the host, like
 tests/test_gpu_sharded_world2.py) grow random cases on uneven row shards; every rank must produce the tree -- and its shard of the
 predictions -- that ONE process grows from all the rows, bit for bit.
-    python scripts/sharded_sweep.py [n_cases] [first_seed] [world]"""
+    python scripts/sharded_sweep.py [n_cases] [first_seed] [world]      (world 1: the sharded path with the native RCCL exchange)"""
 import json, os, socket, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
@@ -45,13 +45,21 @@ def cuts_of(N, world):
 
 def worker(rank, world, port, cases_json, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = port
+    if world == 1: os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = "1"      # the sharded code path with the NATIVE exchange (own RCCL communicator)
     import torch, torch.distributed as dist
-    from gbrl_amd.dist import install_torch_collective
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gbrl_amd.dist import install_torch_collective, install_rccl
+    dev = torch.device("cuda:0")
+    if world == 1:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        install = lambda m: install_rccl(m, dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        install = lambda m: install_torch_collective(m, dev)
     for case in json.load(open(cases_json)):
         cuts = cuts_of(case["N"], world)
         try:
-            e, pred = grow(case, cuts[rank], cuts[rank + 1], lambda m: install_torch_collective(m, torch.device("cuda:0")))
+            e, pred = grow(case, cuts[rank], cuts[rank + 1], install)
             np.savez(os.path.join(outdir, "%s_r%d.npz" % (case["name"], rank)), pred=pred, **e)
         except RuntimeError as ex:
             open(os.path.join(outdir, "%s_r%d.err" % (case["name"], rank)), "w").write(str(ex))
