@@ -16,6 +16,7 @@ import gbrl_amd, oracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+dev = len(sys.argv) > 3 and sys.argv[3] == "dev"     # torch device tensors in (4-tuples), DLPack capsules out
 cat = len(sys.argv) > 3 and sys.argv[3] == "cat"     # categorical-heavy: many columns / tokens, few bins (mean-gradient ranking fallback)
 rng = np.random.default_rng(seed0)
 exact = near = bad = 0
@@ -41,7 +42,18 @@ for i in range(n_cases):
     X, Xc, G, y = K.make_inputs(case)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
     try:
-        pred = np.asarray(K.drive(m, case, X, Xc, G, y))
+        if dev:
+            import torch
+            keep = []
+            def to_input(a):
+                t = torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0"); keep.append(t)
+                return (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+            to_np = lambda c: c if isinstance(c, np.ndarray) else torch.from_dlpack(c).cpu().numpy()
+            m.to_device("cuda")
+            pred = np.asarray(K.drive(m, case, X, Xc, G, y, to_input=to_input, to_numpy=to_np))
+            m.to_device("cpu")
+        else:
+            pred = np.asarray(K.drive(m, case, X, Xc, G, y))
     except RuntimeError as ex:      # an unsupported configuration is a finding of its own: show it
         print("PRODUCT-ERROR", case, str(ex)[:200], flush=True)
         bad += 1
