@@ -267,8 +267,9 @@ long fixed_point(float v, int frac_bits, float lo, float hi) {   // float_to_int
     scaled = std::max(scaled, lo);
     scaled = std::min(scaled, hi);
     const float r = std::round(scaled);
-    // the reference converts a float that may exceed INT32_MAX after rounding (2147483648.0f); x86 cvttss2si yields INT_MIN there
-    if (r >= 2147483648.0f) return static_cast<long>(INT32_MIN);
+    // the reference converts a float that can be 2147483648.0f after the clamp (static_cast<float>(INT32_MAX) rounds up): out of range
+    // for int32; its build prints INT32_MAX there (seen for the +inf thresholds of categorical conditions)
+    if (r >= 2147483648.0f) return static_cast<long>(INT32_MAX);
     return static_cast<long>(r);
 }
 
