@@ -1,4 +1,5 @@
 """Randomised product-vs-oracle sweep on a GPU box (not part of the test suite; prints a summary).
+    python scripts/parity_sweep.py [n_cases] [first_seed] [wide|cat|dev|weights|ref|refweights]   (ref*: against the REAL reference build, oracle/_ref)
     python scripts/parity_sweep.py [n_cases] [first_seed] [wide]      (wide: many outputs / bins / features, the less common kernels)
 Every case: random shape / policy / score / generator / bins / depth / min_data_in_leaf / categorical columns; the product must
 match the oracle restatement bit for bit in structure (or the first mismatch must be an explained near-tie) and within 1e-5
@@ -38,7 +39,13 @@ for i in range(n_cases):
                     N=int(rng.choice([1200, 5000, 30000])), depth=int(rng.choice([2, 4, 5])))
         if case["n_bins"] >= 300: case["D"] = min(case["D"], 12)     # score-kernel LDS limit: (classes + 1) x (D + 1) sums
     if rng.random() < 0.3: case["discrete_cols"] = [0]
+    weighted = len(sys.argv) > 3 and sys.argv[3] in ("weights", "refweights")     # random feature weights (incl. zeros) and a bias: Q6 indexing, tie-breaking
     if case["N"] < case["n_bins"] + 1: case["n_bins"] = 32
+    if weighted:
+        nin = case["F"] + case["Fc"]
+        case["feature_weights"] = [float(v) for v in rng.choice([0.0, 0.25, 0.5, 1.0, 1.0, 2.0], nin)]
+        if max(case["feature_weights"]) == 0.0: case["feature_weights"][0] = 1.0
+        case["bias"] = [float(v) for v in rng.standard_normal(case["D"]).astype(np.float32)]
     X, Xc, G, y = K.make_inputs(case)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
     try:
@@ -58,7 +65,9 @@ for i in range(n_cases):
         print("PRODUCT-ERROR", case, str(ex)[:200], flush=True)
         bad += 1
         continue
-    ref = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    # "refweights": the REAL reference build (oracle/_ref travels to the GPU box) instead of the restatement -- pins the restatement's
+    # handling of weights on mixed numeric / categorical inputs (Q6) where no committed fixture does
+    ref = (oracle.load_ref().GBRL if len(sys.argv) > 3 and sys.argv[3] in ("refweights", "ref") else oracle.OracleGBRL)(**K.ctor_kwargs(case))
     pref = np.asarray(K.drive(ref, case, X, Xc, G, y))
     e, r = m.get_ensemble_data(), ref.get_ensemble_data()
     scale = float(np.abs(G).mean())
@@ -79,7 +88,7 @@ for i in range(n_cases):
             else:   # re-run with one tree: the first tree is fitted on the given gradients, later ones are not comparable
                 c1 = dict(case, trees=1)
                 m1 = gbrl_amd.GBRL(**K.ctor_kwargs(c1)); K.drive(m1, c1, X, Xc, G, y)
-                r1 = oracle.OracleGBRL(**K.ctor_kwargs(c1)); K.drive(r1, c1, X, Xc, G, y)
+                r1 = type(ref)(**K.ctor_kwargs(c1)); K.drive(r1, c1, X, Xc, G, y)      # the same checker (restatement or real reference)
                 info = neartie.explain_first_mismatch(c1, X, Xc, G, r1.get_ensemble_data(), m1.get_ensemble_data())
                 if info is None:
                     info = dict(explained=False, why="first tree equal; mismatch in a later tree (not analysed)")
