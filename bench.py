@@ -80,6 +80,34 @@ def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows, budget_
             "sample_seconds": dt}
 
 
+def launch_ranks(n):
+    """Start `n` copies of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, the
+    contract torch.distributed.run uses), wait for all of them and return the worst exit code.  Children inherit stdout, so
+    rank 0's JSON line is the launcher's output."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,14 +131,26 @@ def main():
                          "full-size step(), so every k_hist_build launch of the run has the benchmark's shape; 0 disables")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: this process becomes the launcher (it never touches the GPU) and starts one
+    # rank per GPU as child processes; rank 0's JSON line passes through on stdout.  Under torch.distributed.run (the driver's
+    # N>1 command) WORLD_SIZE is already set and this is skipped.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("BENCH_LAUNCH_ONLY") == "1":   # test hook (CPU): show what the launcher handed to this rank, run nothing
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "n_gpus": world, "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+        return
+
     import numpy as np
     import torch
     import torch.distributed as dist
     import gbrl_amd
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available() or not gbrl_amd.cuda_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     # BENCH_SHARE_DEVICE=1 (test hook): every rank uses cuda:0 and the ranks talk through gloo (reductions staged through the

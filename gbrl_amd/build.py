@@ -1,4 +1,4 @@
-"""In-tree build of the HIP library and its Python binding (no cmake: two compiler invocations).
+"""In-tree build of the HIP library and its Python binding (no cmake: one hipcc object per source, compiled in parallel, one link, one g++ for the binding).
 
     python gbrl_amd/build.py [--force]   (run as a script: importing the package needs the built extension)
 
@@ -41,11 +41,32 @@ def _run(cmd):
         sys.stderr.write(out.stderr)
 
 
+def _compile_objects(hipcc, force):
+    """One object per translation unit under gbrl_amd/build/ (git-ignored), compiled in parallel and only when stale."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [d for d in LIB_DEPS if d not in LIB_SRCS]
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in headers)
+    jobs, objs = [], []
+    for src in LIB_SRCS:
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-c", path, "-o", obj])
+    workers = max(1, min(len(jobs), int(os.environ.get("GBRL_BUILD_JOBS", "6"))))
+    if jobs:
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(_run, jobs))
+    return objs, bool(jobs)
+
+
 def build(force: bool = False) -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if force or _stale(LIB, LIB_DEPS):
-        _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-              "-Wno-unused-result", *[os.path.join(CSRC, s) for s in LIB_SRCS], "-o", LIB])
+        objs, _ = _compile_objects(hipcc, force)
+        _run([hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared", *objs, "-o", LIB])
     if force or _stale(EXT, EXT_SRCS + [os.path.join("..", "..", "include", "gbrl_hip.h")]) or \
             os.path.getmtime(EXT) < os.path.getmtime(LIB):
         import pybind11

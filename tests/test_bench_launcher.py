@@ -1,0 +1,52 @@
+"""bench.py --gpus N must start N ranks by itself when no launcher did (the flag was parsed and ignored)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_gpus_flag_spawns_one_rank_per_gpu(n):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         env=_clean_env(BENCH_LAUNCH_ONLY="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == list(range(n))
+    assert all(l["n_gpus"] == n and l["local_rank"] == l["rank"] for l in lines)
+    assert len({l["master"] for l in lines}) == 1 and lines[0]["master"].startswith("127.0.0.1:")
+
+
+def test_under_a_launcher_the_flag_does_not_spawn_again():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                         env=_clean_env(BENCH_LAUNCH_ONLY="1", RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["rank"] == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_mismatched_world_size_is_refused():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                         env=_clean_env(BENCH_LAUNCH_ONLY="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_report_n_gpus_2():
+    """The real N=2 bench path on a single-GPU box: both ranks on cuda:0, reductions staged through gloo (numbers meaningless)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "16384",
+                          "--features", "16", "--no-cpu-baseline", "--large-ensemble", "0"],
+                         env=_clean_env(BENCH_SHARE_DEVICE="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
