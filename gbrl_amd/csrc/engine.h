@@ -153,11 +153,12 @@ class Engine {
     // ---- predict workspace + device mirror of the ensemble ----
     DevBuf d_pobs_, d_pcat_, d_pout_;
     DevBuf m_tree_indices_, m_depths_, m_feature_indices_, m_feature_values_, m_values_, m_is_numerics_, m_ineq_,
-        m_cat_ids_, m_bias_, m_opt_start_, m_opt_stop_, m_opt_lr_, m_cond_pack_, m_grd_nodes_, m_grd_off_;
+        m_cat_ids_, m_bias_, m_opt_start_, m_opt_stop_, m_opt_lr_, m_cond_pack_, m_grd_nodes_, m_grd_off_, m_values_sw_, m_cond_ra_;
     size_t up_trees_ = 0, up_leaves_ = 0, up_splits_ = 0;  // how much of the append-only arrays is already on the device
     uint64_t mirror_version_ = ~0ull;
     // dictionary of the categorical strings that occur in the model's conditions: (cat feature, string) -> id >= 1
-    std::vector<int32_t> cat_ids_host_, cond_pack_host_, grd_nodes_host_, grd_off_host_;
+    std::vector<int32_t> cat_ids_host_, cond_pack_host_, grd_nodes_host_, grd_off_host_, cond_ra_host_;
+    std::vector<float> values_sw_host_;   // second-generation oblivious predict: see kern::PredictModel::values_sw
     bool grd_ok_ = true;
     int grd_max_nodes_ = 0, grd_max_leaves_ = 1;
     size_t grd_up_nodes_ = 0;

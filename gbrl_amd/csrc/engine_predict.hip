@@ -57,6 +57,34 @@ void Engine::sync_model_to_device() {
     append(m_cond_pack_, cond_pack_host_.data(), 4, up_splits_ * MD * 2, S * MD * 2);
     append(m_values_, model.values.data(), 4, up_leaves_ * D, L * D);
     append(m_ineq_, model.inequality_directions.data(), 1, up_leaves_ * MD, L * MD);
+    // Second-generation oblivious kernel (predict_obl2.hip): per tree a right-aligned condition record and the leaf values
+    // pre-swizzled as [worker][leaf][DMAX/4]
+    if (model.oblivious() && kern::obl2_levels(static_cast<int>(MD)) > 0 && kern::obl2_padded_outputs(static_cast<int>(D)) > 0) {
+        const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
+        const size_t LS = size_t(1) << MD, VT = LS * DMAX;
+        if (up_trees_ == 0) { cond_ra_host_.clear(); values_sw_host_.clear(); }
+        cond_ra_host_.resize(T * 2 * MX);
+        values_sw_host_.resize(T * VT);
+        int32_t inf_bits;
+        const float inf = std::numeric_limits<float>::infinity();
+        std::memcpy(&inf_bits, &inf, sizeof(inf_bits));
+        for (size_t t = up_trees_; t < T; ++t) {
+            const size_t depth = static_cast<size_t>(model.depths[t]);
+            int32_t *cr = &cond_ra_host_[t * 2 * MX];
+            for (size_t d = 0; d < MX - depth; ++d) { cr[2 * d] = 0; cr[2 * d + 1] = inf_bits; }
+            for (size_t d = 0; d < depth; ++d) {
+                cr[2 * (MX - depth + d)] = cond_pack_host_[2 * (t * MD + d)];
+                cr[2 * (MX - depth + d) + 1] = cond_pack_host_[2 * (t * MD + d) + 1];
+            }
+            float *vs = &values_sw_host_[t * VT];
+            std::fill(vs, vs + VT, 0.0f);
+            const size_t l0 = static_cast<size_t>(model.tree_indices[t]);
+            for (size_t leaf = 0; leaf < (size_t(1) << depth); ++leaf)
+                for (size_t j = 0; j < D; ++j) vs[((j / DW) * LS + leaf) * DW + (j % DW)] = model.values[(l0 + leaf) * D + j];
+        }
+        append(m_cond_ra_, cond_ra_host_.data(), 4, up_trees_ * 2 * MX, T * 2 * MX);
+        append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * VT, T * VT);
+    }
     // Greedy ensembles: rebuild every new tree as a binary tree from its leaves' paths (leaves are stored depth-first, left
     // first; fitter.cpp:364-365), for the descent of k_predict_grd.  A tree whose leaves do not form a proper binary tree (a
     // hand-edited model file), or a depth-0 tree (Q7), switches the fast path off for the whole ensemble.
@@ -228,6 +256,16 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.grd_max_nodes = grd_max_nodes_;
     pm.grd_max_leaves = grd_max_leaves_;
     pm.obl_ok = model.oblivious() ? 1 : 0;
+    pm.obl2_maxd = 0; pm.values_sw = nullptr; pm.cond_ra = nullptr;
+    pm.cat_dict_size = static_cast<int>(cat_dict_.size());
+    if (model.oblivious() && kern::obl2_levels(md.max_depth) > 0 && kern::obl2_padded_outputs(D) > 0 && md.n_trees > 0) {
+        pm.obl2_maxd = kern::obl2_levels(md.max_depth);
+        pm.values_sw = m_values_sw_.as<float>();
+        pm.cond_ra = m_cond_ra_.as<int32_t>();
+    }
+    if (const char *e = std::getenv("GBRL_HIP_PREDICT_OBL1")) {      // test / measurement hook: the first-generation oblivious kernel
+        if (e[0] == '1') pm.obl2_maxd = 0;
+    }
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_GENERIC")) {   // test hook: the general kernels only
         if (e[0] == '1') { pm.grd_ok = 0; pm.obl_ok = 0; }
     }

@@ -443,8 +443,9 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s);
             kern::floats_to_keys(d_thr, d_thrkeys, static_cast<size_t>(F) * B, s);
         } else {
-            // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1
-            if (n_global < B + 1) throw InvalidArgument("quantile candidates need n_samples >= n_bins + 1");
+            // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1.  With
+            // fewer rows than buckets the remainder loop still gives the first n_samples buckets one row each, so cum_i =
+            // min(i + 1, n_samples) >= 1: the ranks repeat at the column maximum (the reference grows valid trees there).
             cum.resize(B);
             const long long per = n_global / (B + 1), rem = n_global % (B + 1);
             long long run = 0;

@@ -216,7 +216,18 @@ struct PredictModel {
     float *partial;          // scratch for tree-split prediction of small batches (nullable), partial_floats elements
     size_t partial_floats;
     int tree_chunk;          // set by kern::predict: trees per block column (0 = every block walks the whole range)
+    // second-generation oblivious path (predict_obl2.hip): leaf values pre-swizzled per tree as [worker 0..3][leaf < 2^max_depth]
+    // [DMAX/4] (DMAX = obl2_padded_outputs(D), zero padded), and per tree 2*obl2_maxd condition words RIGHT-aligned (a tree of depth
+    // d < obl2_maxd starts with obl2_maxd - d never-true conditions: feature 0, threshold +inf); obl2_maxd = 0: not available
+    const float *values_sw;
+    const int32_t *cond_ra;
+    int obl2_maxd;
+    int cat_dict_size;       // dictionary ids of categorical conditions are 1..cat_dict_size (the kernel packs them in 16 bits)
 };
+int obl2_padded_outputs(int D);     // 4, 8, 16, 32, 64 (0: D > 64)
+int obl2_levels(int max_depth);     // 4, 6, 8 (0: max_depth > 8)
+bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
+                  float *out, hipStream_t s);   // false: shape not covered, nothing was launched
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words
 // (16 uint64 per entry, normalised).  codes[i*Fc+f] = id of the matching entry, 0 when the cell is not in the dictionary.

@@ -180,6 +180,18 @@ def ref_path(native: bool = False):
     return hits[0] if hits else None
 
 
+def load_ref_capacity():
+    """The capacity-only patched reference build (oracle/Makefile target ref-capacity: INITAL_MAX_TREES 50000 -> 16384 in a
+    /tmp copy, so that greedy models with max_depth >= 6 can be constructed).  Returns the module or None."""
+    hits = sorted(glob.glob(os.path.join(_HERE, "_ref", "capacity", "gbrl_cpp_refcap*.so")))
+    if not hits:
+        return None
+    spec = importlib.util.spec_from_file_location("gbrl_cpp_refcap", hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load_ref(native: bool = False):
     """Import the reference's own CPU build (oracle/_ref).  Returns the module or None."""
     path = ref_path(native)

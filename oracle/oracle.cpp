@@ -331,7 +331,7 @@ void quantile_candidates(oracle_model *m, const float *obs, int n) {
                 cum += counts[b];
                 Candidate c;
                 c.feat = f;
-                c.value = col[cum - 1];   // cum==0 (n < n_bins+1) reads index -1 in the reference: UB there, rejected by oracle_step here
+                c.value = col[cum - 1];   // cum >= 1 for every n >= 1: the remainder loop hands the first n % (B+1) buckets one row each
                 out[static_cast<size_t>(f) * B + b] = c;
             }
         }
@@ -641,7 +641,6 @@ int oracle_step(oracle_model *m, const float *obs, const char *cat_obs, const fl
                 int n, int n_num, int n_cat) {
     if (m->iteration == 0) { m->n_num = n_num; m->n_cat = n_cat; }
     if (n_num != m->n_num || n_cat != m->n_cat) return -1;
-    if (m->gen == ORACLE_QUANTILE && n_num > 0 && n < m->n_bins + 1) return -2;
     const int D = m->output_dim;
     omp_set_num_threads(m->max_threads);
     std::vector<float> bg(grads, grads + static_cast<size_t>(n) * D);  // fitter.cpp:57

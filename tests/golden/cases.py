@@ -160,6 +160,21 @@ CASES = [
     _c("grd_cos_u_cat", seed=17, N=1024, F=4, Fc=3, D=2, policy="greedy", score="Cosine", gen="Uniform", trees=2),
     _c("grd_l2_q_catonly", seed=18, N=512, F=0, Fc=3, D=2, policy="greedy", trees=2, n_tokens=6),
     _c("obl_cos_q_cat_rmse", seed=19, N=1024, F=5, Fc=2, D=1, score="Cosine", loop="rmse", trees=5),
+    # fewer rows than n_bins + 1 with quantile candidates (the default constructor's n_bins = 256 against an RL minibatch of a few
+    # dozen transitions): the bucket ranks repeat at the column maximum (split_candidate_generator.cpp:216-249)
+    _c("grd_l2_q_tiny", seed=22, N=100, F=5, D=2, depth=3, policy="greedy", trees=3),
+    _c("obl_cos_q_tiny", seed=23, N=57, F=4, D=2, depth=3, score="Cosine", n_bins=64, trees=3),
+    _c("grd_cos_q_tiny_cat", seed=24, N=41, F=3, Fc=1, D=1, depth=2, policy="greedy", score="Cosine", trees=2, n_tokens=3),
+    # BASELINE configs[4] in miniature: numeric + categorical columns, UNIFORM candidates, oblivious depth 6, a few hundred trees
+    # grown by the rmse loop (every tree sees new gradients), predict over the whole ensemble and over sub-ranges
+    _c("obl_l2_u_cfg5mini", seed=25, N=768, F=24, Fc=8, D=8, depth=6, gen="Uniform", n_bins=32, loop="rmse", y_cat_weight=1.0, trees=320,
+       n_tokens=32, pred_ranges=[[0, 1], [0, 17], [5, 133], [100, 320], [319, 320]]),
+    # BASELINE configs[2] shape in miniature at its real depth: greedy / Cosine / policy + value optimisers, max_depth 6.  The
+    # unpatched reference cannot construct this model (Q2); generated by the capacity-only patched build (oracle/Makefile ref-capacity)
+    _c("grd_cos_q_ac_d6", seed=26, N=3000, F=10, D=8, depth=6, policy="greedy", score="Cosine", trees=2,
+       ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)",
+       opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
+             dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)]),
 ]
 
 # GBRL.fit (gbrl.cpp:983-1104): candidates from the whole data set, one tree per batch of `batch_size` rows, MultiRMSE.
