@@ -219,8 +219,12 @@ py::object predict_impl(PyGBRL &self, py::object &obs, py::object &cat, py::obje
     if (D == 1) shape = {n}; else shape = {n, D};  // binding.cpp:281-286
     const bool dev_out = self.device == 1;
     float *out = nullptr;
+    int dev_id = 0;
     if (dev_out) {
-        out = static_cast<float *>(gbrl_hip_device_alloc(sizeof(float) * static_cast<size_t>(n) * D));
+        // the buffer lives on the MODEL's device (one rank per GPU: not necessarily device 0) and the capsule says so
+        dev_id = gbrl_hip_device_ordinal(self.h);
+        if (dev_id < 0) fail(gbrl_hip_last_error());
+        out = static_cast<float *>(gbrl_hip_device_alloc_on(dev_id, sizeof(float) * static_cast<size_t>(n) * D));
         if (!out) fail(gbrl_hip_last_error());
     } else {
         out = new float[static_cast<size_t>(n) * D];
@@ -235,7 +239,7 @@ py::object predict_impl(PyGBRL &self, py::object &obs, py::object &cat, py::obje
         if (dev_out) gbrl_hip_device_free(out); else delete[] out;
         fail(gbrl_hip_last_error());
     }
-    if (dev_out || return_torch) return make_dlpack(out, shape, dev_out, 0);
+    if (dev_out || return_torch) return make_dlpack(out, shape, dev_out, dev_id);
     py::capsule owner(out, [](void *p) { delete[] static_cast<float *>(p); });
     std::vector<py::ssize_t> shp(shape.begin(), shape.end());
     return py::array_t<float>(shp, out, owner);

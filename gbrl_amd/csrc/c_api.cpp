@@ -53,15 +53,27 @@ int copy_in(void *dst, const void *src, size_t bytes, int on_device) {
 // consumer kernel of its previous life can still be reading it.
 namespace {
 struct DevPool {
+    struct Buf { void *ptr; size_t cap; int device; };
     std::mutex mu;
-    std::unordered_map<void *, size_t> live;            // every buffer handed out -> its capacity
-    std::vector<std::pair<void *, size_t>> idle;
+    std::unordered_map<void *, Buf> live;               // every buffer handed out
+    std::vector<Buf> idle;                              // freed buffers kept for reuse ON THEIR OWN DEVICE
     size_t idle_bytes = 0;
     static constexpr size_t kMaxIdleBytes = size_t(1) << 30;
     static constexpr size_t kMaxIdle = 8;
     ~DevPool() { /* process exit: the runtime reclaims device memory; calling hipFree here can race with its teardown */ }
 };
 DevPool &pool() { static DevPool *p = new DevPool(); return *p; }
+
+// RAII: make `device` current for the calling thread, restore the previous one afterwards
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (device >= 0 && device != prev) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
 }  // namespace
 
 
@@ -77,52 +89,79 @@ int gbrl_hip_device_count(void) {
 
 const char *gbrl_hip_last_error(void) { return g_err.c_str(); }
 
-void *gbrl_hip_device_alloc(size_t bytes) {
+void *gbrl_hip_device_alloc_on(int device, size_t bytes) {
     if (bytes == 0) bytes = 1;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) { g_err = "no HIP device"; return nullptr; }
+    DeviceScope scope(device);
     DevPool &P = pool();
     {
         std::lock_guard<std::mutex> lk(P.mu);
         for (size_t i = 0; i < P.idle.size(); ++i) {
-            if (P.idle[i].second >= bytes && P.idle[i].second <= bytes + bytes / 4 + 4096) {
-                void *p = P.idle[i].first;
-                const size_t cap = P.idle[i].second;
-                P.idle_bytes -= cap;
+            if (P.idle[i].device == device && P.idle[i].cap >= bytes && P.idle[i].cap <= bytes + bytes / 4 + 4096) {
+                const DevPool::Buf b = P.idle[i];
+                P.idle_bytes -= b.cap;
                 P.idle.erase(P.idle.begin() + static_cast<long>(i));
-                P.live[p] = cap;
-                (void)hipDeviceSynchronize();
-                return p;
+                P.live[b.ptr] = b;
+                (void)hipDeviceSynchronize();   // of `device` (current in this scope): no consumer of the buffer's previous life is still reading it
+                return b.ptr;
             }
         }
     }
     void *p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
-        // memory pressure: drop the idle buffers and retry once
-        std::vector<std::pair<void *, size_t>> drop;
-        { std::lock_guard<std::mutex> lk(P.mu); drop.swap(P.idle); P.idle_bytes = 0; }
-        for (auto &d : drop) (void)hipFree(d.first);
+        // memory pressure: drop this device's idle buffers and retry once
+        std::vector<DevPool::Buf> drop;
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            for (size_t i = 0; i < P.idle.size();) {
+                if (P.idle[i].device == device) { drop.push_back(P.idle[i]); P.idle_bytes -= P.idle[i].cap; P.idle.erase(P.idle.begin() + static_cast<long>(i)); }
+                else ++i;
+            }
+        }
+        for (auto &d : drop) (void)hipFree(d.ptr);
         if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
     }
     std::lock_guard<std::mutex> lk(P.mu);
-    P.live[p] = bytes;
+    P.live[p] = DevPool::Buf{p, bytes, device};
     return p;
 }
+void *gbrl_hip_device_alloc(size_t bytes) { return gbrl_hip_device_alloc_on(-1, bytes); }
 void gbrl_hip_device_free(void *ptr) {
     if (!ptr) return;
     DevPool &P = pool();
+    int device = -1;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.live.find(ptr);
         if (it != P.live.end()) {
-            const size_t cap = it->second;
+            const DevPool::Buf b = it->second;
+            device = b.device;
             P.live.erase(it);
-            if (P.idle.size() < DevPool::kMaxIdle && P.idle_bytes + cap <= DevPool::kMaxIdleBytes) {
-                P.idle.emplace_back(ptr, cap);
-                P.idle_bytes += cap;
+            if (P.idle.size() < DevPool::kMaxIdle && P.idle_bytes + b.cap <= DevPool::kMaxIdleBytes) {
+                P.idle.push_back(b);
+                P.idle_bytes += b.cap;
                 return;
             }
         }
     }
+    DeviceScope scope(device);
     (void)hipFree(ptr);
+}
+
+int gbrl_hip_device_ordinal(gbrl_hip_model *m) {
+    int dev = -1;
+    (void)guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        dev = m->engine.device_ordinal();
+    });
+    return dev;
+}
+
+int gbrl_hip_set_stream(gbrl_hip_model *m, void *hip_stream) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.set_stream(static_cast<hipStream_t>(hip_stream));
+    });
 }
 
 gbrl_hip_model *gbrl_hip_create(const gbrl_hip_config *cfg) {

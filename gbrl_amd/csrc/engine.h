@@ -89,6 +89,8 @@ class Engine {
     // Native exchange: an RCCL communicator of this engine's own, collectives enqueued on its stream (no host sync).
     // id128 = gbrl_hip_rccl_unique_id() of rank 0, distributed by the caller.  Collective call (all ranks).
     void set_rccl(const void *id128, int world_size, int rank);
+    int device_ordinal();                 // latches the device like the first step()/predict() would
+    void set_stream(hipStream_t s);       // nullptr: back to the engine's own blocking stream
     void set_profiling(int level) { profiling_ = level; }   // 0 off, 1 histogram build only, 2 every phase
     void set_force_bisection(bool on) { force_bisection_ = on; }   // test hook: exercise the slow exact quantile path
     bool last_quantile_fallback() const { return last_quantile_fallback_; }
@@ -111,7 +113,8 @@ class Engine {
 
     int device_ordinal_ = -1;
     bool device_ready_ = false;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr;        // the stream everything is enqueued on: own_stream_ or the caller's (set_stream)
+    hipStream_t own_stream_ = nullptr;
     gbrl_hip_collective coll_{};
     bool has_coll_ = false;
     void *rccl_comm_ = nullptr;          // non-null: the exchanges below are RCCL calls on stream_

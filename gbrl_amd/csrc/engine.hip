@@ -77,7 +77,7 @@ Engine::~Engine() {
         for (auto &e : ev_pool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (rccl_comm_ && rccl_api().ok) (void)rccl_api().CommDestroy(rccl_comm_);
         if (ev_level_) (void)hipEventDestroy(ev_level_);
-        if (stream_) (void)hipStreamDestroy(stream_);
+        if (own_stream_) (void)hipStreamDestroy(own_stream_);
     }
 }
 
@@ -97,8 +97,20 @@ void Engine::ensure_device() {
     if (device_ordinal_ >= count) throw InvalidArgument("device ordinal out of range");
     hip_check(hipSetDevice(device_ordinal_), "hipSetDevice");
     hip_check(hipEventCreateWithFlags(&ev_level_, hipEventDisableTiming), "hipEventCreate");
-    hip_check(hipStreamCreate(&stream_), "hipStreamCreate");  // blocking stream: ordered with the null stream torch uses by default
+    hip_check(hipStreamCreate(&own_stream_), "hipStreamCreate");  // blocking stream: ordered with the null stream torch uses by default
+    if (stream_ == nullptr) stream_ = own_stream_;
     device_ready_ = true;
+}
+
+int Engine::device_ordinal() {
+    ensure_device();
+    return device_ordinal_;
+}
+
+void Engine::set_stream(hipStream_t s) {
+    ensure_device();
+    if (stream_) hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(set_stream)");   // nothing of ours is left on the old stream
+    stream_ = s ? s : own_stream_;
 }
 
 void Engine::set_collective(const gbrl_hip_collective *hooks) {

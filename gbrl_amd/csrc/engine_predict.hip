@@ -61,9 +61,10 @@ void Engine::sync_model_to_device() {
     // pre-swizzled as [worker][leaf][DMAX/4]
     if (model.oblivious() && kern::obl2_levels(static_cast<int>(MD)) > 0 && kern::obl2_padded_outputs(static_cast<int>(D)) > 0) {
         const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
-        const size_t LS = size_t(1) << MD, VT = LS * DMAX;
+        const size_t LS = size_t(1) << MX, VT = LS * DMAX;   // leaves padded to 2^levels: the kernel's tree stride is a compile-time constant
+        constexpr size_t kPadTrees = 16;                     // the kernel fetches whole groups of records (<= 16 trees) past the last tree
         if (up_trees_ == 0) { cond_ra_host_.clear(); values_sw_host_.clear(); }
-        cond_ra_host_.resize(T * 2 * MX);
+        cond_ra_host_.resize((T + kPadTrees) * 2 * MX);
         values_sw_host_.resize(T * VT);
         int32_t inf_bits;
         const float inf = std::numeric_limits<float>::infinity();
@@ -82,7 +83,10 @@ void Engine::sync_model_to_device() {
             for (size_t leaf = 0; leaf < (size_t(1) << depth); ++leaf)
                 for (size_t j = 0; j < D; ++j) vs[((j / DW) * LS + leaf) * DW + (j % DW)] = model.values[(l0 + leaf) * D + j];
         }
-        append(m_cond_ra_, cond_ra_host_.data(), 4, up_trees_ * 2 * MX, T * 2 * MX);
+        int32_t inf_pad[2] = {0, inf_bits};
+        for (size_t t = T; t < T + kPadTrees; ++t)
+            for (size_t d = 0; d < MX; ++d) { cond_ra_host_[(t * MX + d) * 2] = inf_pad[0]; cond_ra_host_[(t * MX + d) * 2 + 1] = inf_pad[1]; }
+        append(m_cond_ra_, cond_ra_host_.data(), 4, up_trees_ * 2 * MX, (T + kPadTrees) * 2 * MX);
         append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * VT, T * VT);
     }
     // Greedy ensembles: rebuild every new tree as a binary tree from its leaves' paths (leaves are stored depth-first, left

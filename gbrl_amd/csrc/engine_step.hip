@@ -684,7 +684,10 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         return hi;
     };
 
-    for (int depth = 0; depth < MD && n_cand > 0; ++depth) {
+    // L2 with ONE row: the reference's unbiased variance is 0/0 (math_ops.cpp:461-513), every standardised gradient and every
+    // split score is NaN, no comparison succeeds and the tree stays a depth-0 leaf (fitter.cpp:357, :458)
+    const bool l2_degenerate = !c.cosine && n_global < 2;
+    for (int depth = 0; depth < MD && n_cand > 0 && !l2_degenerate; ++depth) {
         // nodes that take part at this level: oblivious -> the whole level; greedy -> nodes with rows (fitter.cpp:300)
         std::vector<int> active;
         for (int id : frontier)

@@ -9,6 +9,20 @@
 namespace gbrl {
 namespace kern {
 
+// hipFuncSetAttribute (and anything else that is per-device state) must run once per DEVICE, not once per process: one process
+// can hold models on several GPUs.  `static PerDeviceOnce once; if (once.first()) hipFuncSetAttribute(...)`.
+struct PerDeviceOnce {
+    uint64_t done = 0;
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if ((done >> d) & 1ull) return false;
+        done |= 1ull << d;
+        return true;
+    }
+};
+
+
 // A contiguous run of positions [start, start+len) of the row list that belongs to one slot (node or leaf).
 struct Chunk {
     int32_t slot;

@@ -1146,10 +1146,9 @@ static void launch_bin_rows(const float *obs, int n, int F, const uint32_t *tria
     const int rpi = kBinThreads / FT;
     dim3 grid(grid_for(static_cast<size_t>(n), rpi * 64, 1024), tiles);
     const size_t lds = (static_cast<size_t>(B) * FT + static_cast<size_t>(B + 1) * FT) * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_rows<STRICT, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL((k_bin_rows<STRICT, FT>), grid, dim3(kBinThreads), lds, s, obs, n, F, trial_keys, B, counts, codes, code_stride, code_off);
 }
@@ -1192,11 +1191,10 @@ template <int DT, int U>
 static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                         int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
-        attr_set = true;
     }
     const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
     // ev_start / ev_stop (nullable): the dispatch's own begin / end timestamps -- no extra packets in the stream, unlike
@@ -1210,11 +1208,10 @@ static void launch_hist_wide_one(const uint16_t *codes, int n_rows, const int32_
                                  int n_chunks, int n_groups, int NB, int32_t *partials, size_t lds, hipStream_t s, hipEvent_t ev_start,
                                  hipEvent_t ev_stop) {
     constexpr int U = 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build_wide<P, H, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
-        attr_set = true;
     }
     const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
     hipExtLaunchKernelGGL((k_hist_build_wide<P, H, U>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D,
@@ -1242,11 +1239,10 @@ struct QuadDispatch {
                     int n_chunks, int n_groups, int NB, int32_t *partials, size_t lds, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
         if (r == R) {
             constexpr int U = R <= 8 ? 4 : 2;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static PerDeviceOnce attr_set;
+            if (attr_set.first()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build_quad<R, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024);
-                attr_set = true;
             }
             const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
             hipExtLaunchKernelGGL((k_hist_build_quad<R, U>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg,
@@ -1321,10 +1317,9 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
                       int32_t *part_i, hipStream_t s) {
     const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
                        cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i);

@@ -455,10 +455,9 @@ static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, 
     int TT = static_cast<int>((budget - meta - static_cast<size_t>(R) * xs * sizeof(float)) / vtree);
     TT = std::max(1, std::min(TT, 64));
     const size_t lds = static_cast<size_t>(R) * xs * sizeof(float) + static_cast<size_t>(TT) * vtree + meta;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl<DMAX, MAXD, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr = true;
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
@@ -623,10 +622,9 @@ static bool launch_predict_grd(const PredictModel &pm, const float *obs, int F, 
     int TT = static_cast<int>((budget - static_cast<size_t>(R) * xs * sizeof(float)) / per_tree);
     TT = std::max(1, std::min(TT, 64));
     const size_t lds = static_cast<size_t>(R) * xs * sizeof(float) + static_cast<size_t>(TT) * per_tree;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_grd<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr = true;
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
@@ -654,10 +652,9 @@ static bool launch_predict_tiled(const PredictModel &pm, const float *obs, int F
         if (TT < 1) return false;
     }
     const size_t lds = static_cast<size_t>(R) * (F + 1) * sizeof(float) + static_cast<size_t>(pm.oblivious ? TT : 0) * vtree;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_tiled<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL(k_predict_tiled<DMAX>, dim3((n + R - 1) / R), dim3(R), lds, s, pm, obs, F, cat_codes, Fc, n, start_tree,
                        stop_tree, out, TT);

@@ -13,7 +13,7 @@
 //     as the reference's loop, so results are bitwise those of the general kernel;
 //   * leaf values come from a pre-swizzled mirror ([tree][worker][leaf][DW], zero padded), so staging a group is a straight
 //     16-byte copy; groups are double-buffered (values of group g+1 are written and those of g+2 are in flight while group g is
-//     consumed) with ONE barrier per group.
+//     consumed) with ONE barrier per group (or single-buffered with two, when that buys a fourth wave per SIMD).
 //   * categorical conditions compare 16-bit dictionary ids packed behind the row's numeric features in the same LDS tile.
 #include "kernels.h"
 #include "kernels_common.h"
@@ -33,14 +33,25 @@ constexpr int kObl2MaxVec = 4;   // float4 registers per thread that carry a gro
 template <int DMAX>
 struct Obl2Coef { float lr[DMAX]; };
 
+// leaf = 2 * leaf + (x > t): the compare writes VCC, the add-with-carry doubles the index and takes the bit (2 VALU per level
+// instead of compare + select + shift/or).  `t` is wave-uniform (scalar register).  x > t is false for NaN, like the reference's.
+__device__ __forceinline__ void push_gt(uint32_t &leaf, float x, float t) {
+    asm("v_cmp_lt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(leaf) : "v"(x), "s"(t) : "vcc");
+}
+__device__ __forceinline__ void push_eq(uint32_t &leaf, uint32_t code, uint32_t id) {
+    asm("v_cmp_eq_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(leaf) : "v"(code), "s"(id) : "vcc");
+}
+
+// LDS map (bytes from 0): leaf values vt[NB][TT][W][LS][DW] f32 (below 64 KiB: their byte offsets travel as 16-bit fields),
+// leaf offsets idx[2][W][NW][R] u32, row tile xt[R][xs] f32.
 template <int DMAX, int MAXD, bool CAT>
-__global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
-                                                       const float *__restrict__ bias, Obl2Coef<DMAX> coef, int D, int md,
+__global__ __launch_bounds__(DMAX >= 64 ? 512 : 1024) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
+                                                       const float *__restrict__ bias, Obl2Coef<DMAX> coef, int D,
                                                        const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc,
-                                                       int n, int start_tree, int stop_tree, float *__restrict__ out, int R, int TT, int xs,
-                                                       int tree_chunk) {
+                                                       int n, int start_tree, int stop_tree, float *__restrict__ out, int R, int TT, int NB,
+                                                       int xs, int tree_chunk) {
     extern __shared__ float lds[];
-    constexpr int W = kObl2Workers, DW = DMAX / W;
+    constexpr int W = kObl2Workers, DW = DMAX / W, LS = 1 << MAXD, VT = LS * DMAX;
     if (tree_chunk > 0) {   // small batches: this block column covers a sub-range of the trees and writes a partial sum (no bias)
         start_tree += blockIdx.y * tree_chunk;
         stop_tree = min(stop_tree, start_tree + tree_chunk);
@@ -49,47 +60,51 @@ __global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__
     const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave / W, q = wave % W;
-    const int LS = 1 << md, VT = LS * DMAX, TPW = TT / W;
-    float *xt = lds;                                                      // [R][xs]
-    float *vt = lds + static_cast<size_t>(R) * xs;                        // [2][TT][W][LS][DW]
-    uint32_t *idx = reinterpret_cast<uint32_t *>(vt + 2 * static_cast<size_t>(TT) * VT);   // [2][W][R]: leaves of worker w's trees, 8 bits each
+    const int TPW = TT / W, NW = TPW > 2 ? 2 : 1;
+    float *vt = lds;
+    uint32_t *idx = reinterpret_cast<uint32_t *>(vt + static_cast<size_t>(NB) * TT * VT);
+    float *xt = reinterpret_cast<float *>(idx + 2 * W * NW * R);
     const int r0 = blockIdx.x * R;
     const int rows = min(R, n - r0);
     const int row_l = rg * 64 + lane;
     const bool live = row_l < rows;
     const int n_groups = (stop_tree - start_tree + TT - 1) / TT;
 
-    float4 vreg[kObl2MaxVec];
+    // A group's values travel global -> registers (kObl2MaxVec = 4 float4 per thread) -> LDS.  The loads are clamped, not predicated
+    // (a predicated load becomes a branch with a wait behind every load): the four must be in flight together, and stay in
+    // flight -- they are consumed one barrier later (store_vals).  Named registers: an array here is demoted to scratch.
+    float4 va, vb, vc, vd;
+    static_assert(kObl2MaxVec == 4, "four named registers below");
     auto load_vals = [&](int g) __attribute__((always_inline)) {
         const int t0 = start_tree + g * TT, tn = min(TT, stop_tree - t0);
         const float4 *src = reinterpret_cast<const float4 *>(vsw + static_cast<size_t>(t0) * VT);
-        const int cnt4 = tn * (VT >> 2);
-#pragma unroll
-        for (int u = 0; u < kObl2MaxVec; ++u) {
-            const int i = u * NT + tid;
-            vreg[u] = i < cnt4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int last = tn * (VT >> 2) - 1;
+        va = src[min(tid, last)];
+        vb = src[min(NT + tid, last)];
+        vc = src[min(2 * NT + tid, last)];
+        vd = src[min(3 * NT + tid, last)];
     };
     auto store_vals = [&](int g) __attribute__((always_inline)) {
         const int t0 = start_tree + g * TT, tn = min(TT, stop_tree - t0);
-        float4 *dst = reinterpret_cast<float4 *>(vt + static_cast<size_t>(g & 1) * TT * VT);
+        float4 *dst = reinterpret_cast<float4 *>(vt + static_cast<size_t>(NB == 2 ? (g & 1) : 0) * TT * VT);
         const int cnt4 = tn * (VT >> 2);
-#pragma unroll
-        for (int u = 0; u < kObl2MaxVec; ++u) {
-            const int i = u * NT + tid;
-            if (i < cnt4) dst[i] = vreg[u];
-        }
+        if (tid < cnt4) dst[tid] = va;
+        if (NT + tid < cnt4) dst[NT + tid] = vb;
+        if (2 * NT + tid < cnt4) dst[2 * NT + tid] = vc;
+        if (3 * NT + tid < cnt4) dst[3 * NT + tid] = vd;
     };
     const float *x = xt + row_l * xs;
-    // phase A: leaves of this worker's trees of group g -> idx[g & 1][q][row].  K = trees per worker (static: the K records are
-    // fetched together through the scalar cache and the K*MAXD feature reads are issued back to back)
+    // phase A: byte offsets (leaf * DW * 4) of this row's leaves in this worker's K trees of group g, 16 bits each ->
+    // idx[g & 1][q][0..NW)[row].  The K records arrive together through the scalar cache (the mirror is padded, so trees past the
+    // end of the range in the last group read valid records; their leaves are never applied).
     auto phase_a_k = [&](int g, auto kc) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
-        // the records of a batch of trees sit in scalar registers together: at most ~36 words (more spills SGPRs into VGPR lanes)
+        constexpr int NWK = K > 2 ? 2 : 1;
+        // records of a batch of trees sit in scalar registers together: at most ~36 words (more spills SGPRs into VGPR lanes)
         constexpr int SBMAX = MAXD <= 4 ? 4 : MAXD <= 6 ? 3 : 2;
         constexpr int SB = K <= SBMAX ? K : (K + 1) / 2;
-        const int t0 = start_tree + g * TT + q * K;
-        uint32_t packed = 0;
+        const int32_t *cp0 = cond + static_cast<size_t>(start_tree + g * TT + q * K) * 2 * MAXD;
+        uint32_t off[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k0 = 0; k0 < K; k0 += SB) {
             int fi[SB][MAXD];
@@ -97,8 +112,7 @@ __global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
                 if (k0 + k < K) {
-                    // trees past the end of the range (last group only) re-read the last tree's record; their leaves are never applied
-                    const int32_t *cp = cond + static_cast<size_t>(min(t0 + k0 + k, stop_tree - 1)) * 2 * MAXD;
+                    const int32_t *cp = cp0 + (k0 + k) * 2 * MAXD;
 #pragma unroll
                     for (int d = 0; d < MAXD; ++d) { fi[k][d] = cp[2 * d]; tv[k][d] = __int_as_float(cp[2 * d + 1]); }
                 }
@@ -119,21 +133,21 @@ __global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__
                     uint32_t leaf = 0;
 #pragma unroll
                     for (int d = 0; d < MAXD; ++d) {
-                        bool pass;
                         if (!CAT || fi[k][d] >= 0) {
-                            pass = xv[k][d] > tv[k][d];
+                            push_gt(leaf, xv[k][d], tv[k][d]);
                         } else {
                             const uint32_t w = __float_as_uint(xv[k][d]);
                             const uint32_t code = ((~fi[k][d]) & 1) ? (w >> 16) : (w & 0xffffu);
-                            pass = code == __float_as_uint(tv[k][d]);
+                            push_eq(leaf, code, __float_as_uint(tv[k][d]));
                         }
-                        leaf = leaf * 2u + (pass ? 1u : 0u);
                     }
-                    packed |= leaf << (8 * (k0 + k));
+                    off[k0 + k] = leaf * (DW * 4);
                 }
             }
         }
-        idx[((g & 1) * W + q) * R + row_l] = packed;
+        uint32_t *ib = idx + (((g & 1) * W + q) * NW) * R + row_l;
+        ib[0] = off[0] | (off[1] << 16);
+        if (NWK == 2) ib[R] = off[2] | (off[3] << 16);
     };
     auto phase_a = [&](int g) __attribute__((always_inline)) {
         switch (TPW) {
@@ -155,51 +169,77 @@ __global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__
         const int j = q * DW + jj;
         p[jj] = (j < D && tree_chunk == 0) ? 0.0f + bias[j] : 0.0f;
     }
-    // phase B: apply the trees of group g in order to this worker's outputs.  K = trees per worker: the K value reads of a
-    // worker's trees are in flight together, the fused multiply-adds follow in tree order.
-    auto phase_b_k = [&](int g, auto kc) __attribute__((always_inline)) {
+    // phase B: apply the trees of group g in order to this worker's outputs.  K = trees per worker.  The 16-bit fields become
+    // complete LDS addresses with one packed add per word (this worker's slice, the buffer); the tree's base is the read's
+    // immediate offset.  The reads of a worker's K trees are in flight together, the fused multiply-adds follow in tree order.
+    auto phase_b_k = [&](int g, auto kc, auto fullc) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
+        constexpr int NWK = K > 2 ? 2 : 1;
+        constexpr bool FULL = decltype(fullc)::value;
         const int t0 = start_tree + g * TT, tn = min(TT, stop_tree - t0);
-        const uint32_t *ib = idx + static_cast<size_t>(g & 1) * W * R + row_l;
-        const float *vb = vt + static_cast<size_t>(g & 1) * TT * VT + q * LS * DW;
-        uint32_t word[W];
+        const uint32_t *ib = idx + static_cast<size_t>(g & 1) * W * NW * R + row_l;
+        const uint32_t qoff = static_cast<uint32_t>(((NB == 2 ? (g & 1) : 0) * TT * VT + q * LS * DW) * 4);
+        const uint32_t qoff2 = qoff | (qoff << 16);
+        uint32_t word[W][NWK];
 #pragma unroll
-        for (int w = 0; w < W; ++w) word[w] = ib[w * R];
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int i = 0; i < NWK; ++i) word[w][i] = ib[(w * NW + i) * R] + qoff2;
+        const char *lb = reinterpret_cast<const char *>(lds);
+        constexpr int KB = DW >= 16 ? 1 : (DW >= 8 && K > 2) ? 2 : K;   // value registers in flight: KB * DW
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            float vv[K][DW];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint32_t leaf = (word[w] >> (8 * k)) & 0xffu;
-                const float *v = vb + (w * K + k) * VT + leaf * DW;   // trees past tn (last group): stale but valid LDS, never applied
-                if (DW == 1) {
-                    vv[k][0] = v[0];
-                } else if (DW == 2) {
-                    const float2 t2 = *reinterpret_cast<const float2 *>(v);
-                    vv[k][0] = t2.x; vv[k][1] = t2.y;
-                } else {
+            for (int k0 = 0; k0 < K; k0 += KB) {
+                float vv[KB][DW];
 #pragma unroll
-                    for (int c = 0; c < DW / 4; ++c) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(v + 4 * c);
-                        vv[k][4 * c] = t4.x; vv[k][4 * c + 1] = t4.y; vv[k][4 * c + 2] = t4.z; vv[k][4 * c + 3] = t4.w;
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int k = k0 + kk;
+                    if (k < K) {
+                        const uint32_t wd = word[w][k >> 1];
+                        const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
+                        const float *v = reinterpret_cast<const float *>(lb + a) + (w * K + k) * VT;
+                        if (DW == 1) {
+                            vv[kk][0] = v[0];
+                        } else if (DW == 2) {
+                            const float2 t2 = *reinterpret_cast<const float2 *>(v);
+                            vv[kk][0] = t2.x; vv[kk][1] = t2.y;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < DW / 4; ++c) {
+                                const float4 t4 = *reinterpret_cast<const float4 *>(v + 4 * c);
+                                vv[kk][4 * c] = t4.x; vv[kk][4 * c + 1] = t4.y; vv[kk][4 * c + 2] = t4.z; vv[kk][4 * c + 3] = t4.w;
+                            }
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (w * K + k < tn) {   // uniform
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int k = k0 + kk;
+                    if (k < K && (FULL || w * K + k < tn)) {   // uniform
 #pragma unroll
-                    for (int jj = 0; jj < DW; ++jj) p[jj] = fmaf(-lr[jj], vv[k][jj], p[jj]);
+                        for (int jj = 0; jj < DW; ++jj) p[jj] = fmaf(-lr[jj], vv[kk][jj], p[jj]);
+                    }
                 }
             }
         }
     };
     auto phase_b = [&](int g) __attribute__((always_inline)) {
-        switch (TPW) {
-            case 1: phase_b_k(g, std::integral_constant<int, 1>{}); break;
-            case 2: phase_b_k(g, std::integral_constant<int, 2>{}); break;
-            case 3: phase_b_k(g, std::integral_constant<int, 3>{}); break;
-            default: phase_b_k(g, std::integral_constant<int, 4>{}); break;
+        const bool full = start_tree + (g + 1) * TT <= stop_tree;
+        if (full) {
+            switch (TPW) {
+                case 1: phase_b_k(g, std::integral_constant<int, 1>{}, std::true_type{}); break;
+                case 2: phase_b_k(g, std::integral_constant<int, 2>{}, std::true_type{}); break;
+                case 3: phase_b_k(g, std::integral_constant<int, 3>{}, std::true_type{}); break;
+                default: phase_b_k(g, std::integral_constant<int, 4>{}, std::true_type{}); break;
+            }
+        } else {
+            switch (TPW) {
+                case 1: phase_b_k(g, std::integral_constant<int, 1>{}, std::false_type{}); break;
+                case 2: phase_b_k(g, std::integral_constant<int, 2>{}, std::false_type{}); break;
+                case 3: phase_b_k(g, std::integral_constant<int, 3>{}, std::false_type{}); break;
+                default: phase_b_k(g, std::integral_constant<int, 4>{}, std::false_type{}); break;
+            }
         }
     };
 
@@ -250,18 +290,26 @@ __global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__
     }
     if (n_groups > 0) {
         store_vals(0);
-        if (n_groups > 1) load_vals(1);
+        load_vals(min(1, n_groups - 1));
     }
     __syncthreads();
     if (n_groups > 0) phase_a(0);
+    // The prefetch loads are unconditional (group index clamped): a load under a condition ends in a register copy behind a
+    // full wait at the join, which would expose the global-memory latency every group.
     for (int g = 0; g < n_groups; ++g) {
-        __syncthreads();   // leaves and values of group g are published; group g-1 is fully consumed
-        if (g + 1 < n_groups) {
-            store_vals(g + 1);
-            if (g + 2 < n_groups) load_vals(g + 2);
-            phase_a(g + 1);
+        __syncthreads();   // offsets and values of group g are published; group g-1 is fully consumed
+        if (NB == 2) {
+            if (g + 1 < n_groups) store_vals(g + 1);
+            load_vals(min(g + 2, n_groups - 1));
+            if (g + 1 < n_groups) phase_a(g + 1);
+            phase_b(g);
+        } else {   // one value buffer: the next group's values replace this group's after everybody has applied them
+            if (g + 1 < n_groups) phase_a(g + 1);
+            phase_b(g);
+            __syncthreads();
+            if (g + 1 < n_groups) store_vals(g + 1);
+            load_vals(min(g + 2, n_groups - 1));
         }
-        phase_b(g);
     }
     if (live) {
         float *o = out + static_cast<size_t>(r0 + row_l) * D + q * DW;
@@ -271,40 +319,45 @@ __global__ __launch_bounds__(1024) void k_predict_obl2(const float *__restrict__
     }
 }
 
-struct Obl2Plan { int RG, TT, xs; size_t lds; };
+struct Obl2Plan { int RG, TT, NB, xs; size_t lds; };
 
-// Rows per block and trees per group: as many waves per CU as the LDS allows while a group still holds >= 8 trees (one barrier
-// per group); small ensembles take 64-row blocks so that several blocks per CU overlap their tile loads with each other's walks.
-static bool obl2_plan(int F, int Fc, bool cat, int md, int DMAX, int trees, Obl2Plan &pl) {
+// Rows per block (64 * RG), trees per group (TT) and value buffers (NB): as many waves per CU as the LDS allows while a group
+// still holds >= 8 trees; small ensembles take 64-row blocks so that several blocks per CU overlap their tile loads with each
+// other's walks.  The value buffers must lie below 64 KiB (16-bit offsets).
+static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, int trees, Obl2Plan &pl) {
+    const int rg_max = DMAX >= 64 ? 2 : 4;   // 16 accumulators + 16 rates per thread: that width is compiled for 512-thread blocks
     const size_t budget = 160 * 1024 - 256;
-    const size_t vtb = (static_cast<size_t>(1) << md) * DMAX * sizeof(float);
+    const size_t vtb = (static_cast<size_t>(1) << maxd) * DMAX * sizeof(float);
     pl.xs = (F + (cat ? (Fc + 1) / 2 : 0)) | 1;
-    auto tt_for = [&](int rg) -> int {
-        const size_t rowb = static_cast<size_t>(64) * rg * pl.xs * 4 + 2 * kObl2Workers * 64 * rg * 4;
-        if (rowb + 2 * 4 * vtb > budget) return 0;
-        int tt = static_cast<int>((budget - rowb) / (2 * vtb));
-        tt = std::min(tt, 16) & ~3;
-        // a group travels through kObl2MaxVec float4 registers per thread
-        while (tt > 0 && static_cast<size_t>(tt) * vtb / 16 > static_cast<size_t>(kObl2MaxVec) * 256 * rg) tt -= 4;
-        return tt;
+    auto lds_for = [&](int rg, int tt, int nb) -> size_t {
+        const int nw = tt / kObl2Workers > 2 ? 2 : 1;
+        return static_cast<size_t>(nb) * tt * vtb + static_cast<size_t>(2) * kObl2Workers * nw * 64 * rg * 4 + static_cast<size_t>(64) * rg * pl.xs * 4;
     };
-    int rg_env = 0, tt_env = 0;
+    auto tt_for = [&](int rg, int nb) -> int {
+        int tt = 16;
+        while (tt >= 4 && (lds_for(rg, tt, nb) > budget || static_cast<size_t>(nb) * tt * vtb > 65536 ||
+                           static_cast<size_t>(tt) * vtb / 16 > static_cast<size_t>(kObl2MaxVec) * 256 * rg)) tt -= 4;
+        return tt >= 4 ? tt : 0;
+    };
+    int rg_env = 0, tt_env = 0, nb_env = 0;
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_RG")) rg_env = std::atoi(e);
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_TT")) tt_env = std::atoi(e);
-    int best_rg = 0, best_tt = 0;
-    if (rg_env >= 1 && rg_env <= 4) {
-        best_rg = rg_env; best_tt = tt_for(rg_env);
+    if (const char *e = std::getenv("GBRL_HIP_PREDICT_NB")) nb_env = std::atoi(e);
+    int best_rg = 0, best_tt = 0, best_nb = 2;
+    if (rg_env >= 1 && rg_env <= rg_max) {
+        best_rg = rg_env; best_nb = nb_env == 1 ? 1 : 2; best_tt = tt_for(rg_env, best_nb);
     } else if (trees <= 48) {
-        for (int rg = 1; rg <= 4 && best_rg == 0; ++rg) { const int tt = tt_for(rg); if (tt >= 4) { best_rg = rg; best_tt = std::min(tt, 8); } }
+        for (int rg = 1; rg <= rg_max && best_rg == 0; ++rg) { const int tt = tt_for(rg, 2); if (tt >= 4) { best_rg = rg; best_tt = std::min(tt, 8); } }
     } else {
-        for (int rg = 4; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg); if (tt >= 8) { best_rg = rg; best_tt = tt; } }
-        for (int rg = 4; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg); if (tt >= 4) { best_rg = rg; best_tt = tt; } }
+        for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, 2); if (tt >= 8) { best_rg = rg; best_tt = tt; } }
+        for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, 2); if (tt >= 4) { best_rg = rg; best_tt = tt; } }
     }
     if (best_rg == 0 || best_tt < 4) return false;
     if (tt_env >= 4 && tt_env <= best_tt) best_tt = tt_env & ~3;
     pl.RG = best_rg;
     pl.TT = best_tt;
-    pl.lds = static_cast<size_t>(64) * best_rg * pl.xs * 4 + 2 * static_cast<size_t>(best_tt) * vtb + 2 * kObl2Workers * 64 * best_rg * 4;
+    pl.NB = best_nb;
+    pl.lds = lds_for(best_rg, best_tt, best_nb);
     return true;
 }
 
@@ -313,7 +366,7 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
                         int stop_tree, float *out, hipStream_t s) {
     const int trees = pm.tree_chunk > 0 ? pm.tree_chunk : stop_tree - start_tree;
     Obl2Plan pl;
-    if (!obl2_plan(F, Fc, CAT, pm.max_depth, DMAX, trees, pl)) return false;
+    if (!obl2_plan(F, Fc, CAT, MAXD, DMAX, trees, pl)) return false;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static uint64_t attr_done = 0;   // per device
@@ -326,8 +379,8 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
     const int R = 64 * pl.RG;
     const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
     hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT>), dim3((n + R - 1) / R, splits), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
-                       pm.bias, coef, pm.D, pm.max_depth, obs, F, cat_codes, Fc, n, start_tree, stop_tree, pm.tree_chunk > 0 ? pm.partial : out, R,
-                       pl.TT, pl.xs, pm.tree_chunk);
+                       pm.bias, coef, pm.D, obs, F, cat_codes, Fc, n, start_tree, stop_tree, pm.tree_chunk > 0 ? pm.partial : out, R,
+                       pl.TT, pl.NB, pl.xs, pm.tree_chunk);
     return true;
 }
 

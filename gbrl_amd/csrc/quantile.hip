@@ -535,15 +535,15 @@ QuantilePlan quantile_plan(int n) {
 }
 
 void sample_splitters(const uint32_t *kt, int n, int F, const QuantilePlan &p, uint32_t *splitters, uint32_t *splitters_bfs, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); }
     hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), p.sample * sizeof(uint32_t), s, kt, n, p.sample, p.n_split, splitters, splitters_bfs,
                        static_cast<uint32_t *>(nullptr));
 }
 
 void sample_only(const uint32_t *kt, int n, int F, int S, uint32_t *sample_out, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 1024); }
     hipLaunchKernelGGL(k_sample_splitters, dim3(F), dim3(1024), S * sizeof(uint32_t), s, kt, n, S, S - 1, static_cast<uint32_t *>(nullptr),
                        static_cast<uint32_t *>(nullptr), sample_out);
 }
@@ -552,8 +552,8 @@ void place_sample(const uint32_t *samp, int F, int S, int rank, int SU, int64_t 
     hipLaunchKernelGGL(k_place_sample, dim3((tot + 255) / 256), dim3(256), 0, s, samp, F, S, rank, SU, uni);
 }
 void union_splitters(const int64_t *uni, int F, int SU, int n_split, uint32_t *splitters, uint32_t *splitters_bfs, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_union_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_union_splitters), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL(k_union_splitters, dim3(F), dim3(1024), SU * sizeof(uint32_t), s, uni, SU, n_split, splitters, splitters_bfs);
 }
 void counts_to_i64(const uint32_t *partial, int n_chunks, size_t fc, int64_t *out, hipStream_t s) {
@@ -594,8 +594,8 @@ int sort_quantiles_max_rows() { return 4096; }   // beyond this the bitonic sort
 void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, hipStream_t s) {
     int S = 64;
     while (S < n) S <<= 1;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_quantiles), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_quantiles), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }
     hipLaunchKernelGGL(k_sort_quantiles, dim3(F), dim3(std::min(1024, S / 2 > 64 ? S / 2 : 64)), static_cast<size_t>(S) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys);
 }
 
@@ -603,8 +603,8 @@ void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B,
     int levels = 1;
     while ((1 << levels) - 1 < B) ++levels;
     const size_t lds = static_cast<size_t>(kGroup) * ((1 << levels) - 1) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     // enough blocks to fill the chip first (small, RL-sized batches), then up to kBinTiles tiles per block to amortise the staging
     const int groups = (F + kGroup - 1) / kGroup;
     const long long tiles = (static_cast<long long>(n) + 255) / 256;

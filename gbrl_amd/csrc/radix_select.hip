@@ -383,13 +383,12 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
     const size_t aux = kBins1 * 2 + 2 * 512 * 8 + 2 * 260 * 2 + kFiltWords * 4 + (kRadixThreads / 64) * 128 * 4;
     const size_t lds1 = static_cast<size_t>(kCopies1) * kBins1 * 4 + aux, lds23 = static_cast<size_t>(kMaxTargets) * 128 * 4 + aux,
                  lds4 = static_cast<size_t>(kMaxTargets) * 64 * 4 + aux;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_count<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds23));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_count<3>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds23));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_count<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds4));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_radix_targets), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxTargets * 128 * 4);
-        attr = true;
     }
     int cn = 1;
     if (n >= (1 << 16)) { cn = 2; while (cn < kChunksN && cn * F < 256) cn *= 2; }

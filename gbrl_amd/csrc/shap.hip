@@ -119,10 +119,9 @@ void shap_values(const ShapOp *ops, int n_ops, const ShapNodeRec *nodes, const f
                  const float *offset, float *out, hipStream_t s) {
     if (n_samples <= 0 || n_ops <= 0) return;
     const int nt = shap_block_threads(md, D);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_shap), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr_set = true;
     }
     const int per_block = nt / D;
     const unsigned blocks = static_cast<unsigned>((n_samples + per_block - 1) / per_block);

@@ -89,7 +89,8 @@ const char *gbrl_hip_last_error(void);
 /* device buffers handed to callers (predict results) -- replaces cudaMalloc/cudaFree in binding.cpp:208-219.
  * Freed buffers are recycled (a few buffers, <= 1 GiB); a recycled buffer is handed out only after a device
  * synchronisation, so a consumer kernel of its previous life cannot still be reading it. */
-void *gbrl_hip_device_alloc(size_t bytes);
+void *gbrl_hip_device_alloc(size_t bytes);              /* on the calling thread's current device */
+void *gbrl_hip_device_alloc_on(int device, size_t bytes); /* on `device` (the buffer pool is keyed by device) */
 void gbrl_hip_device_free(void *ptr);
 
 /* ---- lifetime ----------------------------------------------------------------------------------------- */
@@ -210,6 +211,19 @@ int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float
  * predict()) are timed -- step(): the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL events), free for a timed region.  2: every phase is bracketed
  * (diagnostic: each record costs a few microseconds of stream bubble, ~60 records per step). */
 int gbrl_hip_set_profiling(gbrl_hip_model *m, int level);
+
+/* ---- device / stream contract (new; the reference pins everything to device 0 and the null stream, cuda_types.cu:32-106) -- */
+/* The device the model computes on: the ordinal given at creation, or -- for -1 -- the calling thread's current device at the
+ * first call that needs it (it is latched by this call too).  -1 when no HIP device is usable.  A caller that hands out
+ * predict results as device buffers must allocate them on THIS device (gbrl_hip_device_alloc_on) and label them with it. */
+int gbrl_hip_device_ordinal(gbrl_hip_model *m);
+/* Stream ordering.  By default the model owns a BLOCKING stream: its work is ordered with the legacy null stream only, so a
+ * caller that runs on a non-default (or per-thread default) stream must either synchronise that stream around step()/predict()
+ * or hand it over here: with a non-null `hip_stream` (a hipStream_t of the model's device) every kernel, copy and collective
+ * of this model is enqueued on it -- inputs produced on that stream and outputs consumed on it need no further
+ * synchronisation.  step()/predict() still return after their own work has completed (they read results back).  NULL
+ * restores the model's own stream. */
+int gbrl_hip_set_stream(gbrl_hip_model *m, void *hip_stream);
 
 #ifdef __cplusplus
 }

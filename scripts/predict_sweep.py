@@ -27,7 +27,7 @@ print("grew %d trees in %.1f s" % (T, time.time() - t0), flush=True)
 m.set_profiling(1)
 
 def run(stop, env):
-    for k in ("GBRL_HIP_PREDICT_OBL1", "GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT"):
+    for k in ("GBRL_HIP_PREDICT_OBL1", "GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT", "GBRL_HIP_PREDICT_NB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     p = torch.from_dlpack(m.predict(tup(X), None, 0, stop)); torch.cuda.synchronize()
@@ -41,12 +41,13 @@ for stop in [15, 128, T]:
     ref, t1 = run(stop, {"GBRL_HIP_PREDICT_OBL1": "1"})
     print("trees %5d  gen1            kernel_ms %8.3f  row-trees/s %.3e  rows/s %.3e" % (stop, t1, N * stop / (t1 * 1e-3), N / (t1 * 1e-3)), flush=True)
     for rg in (1, 2, 3, 4):
-        for tt in (4, 8, 12, 16):
-            try:
-                p, t2 = run(stop, {"GBRL_HIP_PREDICT_RG": str(rg), "GBRL_HIP_PREDICT_TT": str(tt)})
-            except Exception as e:
-                print("rg %d tt %d failed: %r" % (rg, tt, e)); continue
-            same = bool(torch.equal(p, ref))
-            print("trees %5d  gen2 rg %d tt %2d  kernel_ms %8.3f  row-trees/s %.3e  rows/s %.3e  bitwise==gen1 %s" % (stop, rg, tt, t2, N * stop / (t2 * 1e-3), N / (t2 * 1e-3), same), flush=True)
+        for nb in (2, 1):
+            for tt in (4, 8, 12, 16):
+                try:
+                    p, t2 = run(stop, {"GBRL_HIP_PREDICT_RG": str(rg), "GBRL_HIP_PREDICT_TT": str(tt), "GBRL_HIP_PREDICT_NB": str(nb)})
+                except Exception as e:
+                    print("rg %d tt %d failed: %r" % (rg, tt, e)); continue
+                same = bool(torch.equal(p, ref))
+                print("trees %5d  gen2 rg %d nb %d tt %2d  kernel_ms %8.3f  row-trees/s %.3e  rows/s %.3e  bitwise==gen1 %s" % (stop, rg, nb, tt, t2, N * stop / (t2 * 1e-3), N / (t2 * 1e-3), same), flush=True)
     p, t2 = run(stop, {})
     print("trees %5d  gen2 default    kernel_ms %8.3f  row-trees/s %.3e  bitwise==gen1 %s" % (stop, t2, N * stop / (t2 * 1e-3), bool(torch.equal(p, ref))), flush=True)

@@ -168,10 +168,17 @@ CASES = [
     # BASELINE configs[4] in miniature: numeric + categorical columns, UNIFORM candidates, oblivious depth 6, a few hundred trees
     # grown by the rmse loop (every tree sees new gradients), predict over the whole ensemble and over sub-ranges
     _c("obl_l2_u_cfg5mini", seed=25, N=768, F=24, Fc=8, D=8, depth=6, gen="Uniform", n_bins=32, loop="rmse", y_cat_weight=1.0, trees=320,
-       n_tokens=32, pred_ranges=[[0, 1], [0, 17], [5, 133], [100, 320], [319, 320]]),
+       n_tokens=32, long_loop=True, pred_ranges=[[0, 1], [0, 17], [5, 133], [100, 320], [319, 320]]),
     # BASELINE configs[2] shape in miniature at its real depth: greedy / Cosine / policy + value optimisers, max_depth 6.  The
     # unpatched reference cannot construct this model (Q2); generated by the capacity-only patched build (oracle/Makefile ref-capacity)
-    _c("grd_cos_q_ac_d6", seed=26, N=3000, F=10, D=8, depth=6, policy="greedy", score="Cosine", trees=2,
+    _c("grd_cos_q_ac_d6", seed=27, N=3000, F=10, D=8, depth=6, policy="greedy", score="Cosine", trees=2,
+       ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)",
+       opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
+             dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)]),
+    # the same with seed 26: the reference (at every thread count) prefers a candidate whose true score is 1.1e-7 relative BELOW the
+    # maximum at a 547-row node of tree 0 -- inside its own float32 summation noise (scripts/d6_seed_probe.py: 27 of 28 seeds are
+    # bit-identical, this is the one that is not).  Kept as a near-tie specimen: exact, or explained with the product at the true max.
+    _c("grd_cos_q_ac_d6_neartie", seed=26, N=3000, F=10, D=8, depth=6, policy="greedy", score="Cosine", trees=2, neartie=True,
        ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)",
        opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
              dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)]),
@@ -196,7 +203,7 @@ BY_NAME = {c["name"]: c for c in CASES + FIT_CASES}
 ENSEMBLE_KEYS = ("tree_indices", "depths", "values", "feature_indices", "feature_values", "edge_weights",
                  "is_numerics", "inequality_directions", "categorical_values")
 # cases whose saved .gbrl_model bytes are committed (file-format parity)
-MODEL_FILE_CASES = ("obl_l2_q", "grd_cos_q_ac", "obl_l2_q_cat")
+MODEL_FILE_CASES = ("obl_l2_q", "grd_cos_q_ac", "obl_l2_q_cat", "obl_l2_u_cfg5mini")
 
 # ---- inspection fixtures (SHAP / export / print), made by make_explain_golden.py ----
 # name -> export variants [(modelname, export_format, export_type, prefix)]; export is oblivious-only in the reference

@@ -83,17 +83,19 @@ def test_tiny_inputs():
             _check(case, X, Xc, G)
 
 
-def test_too_few_rows_for_the_quantile_bins_is_an_error_not_a_crash():
-    import gbrl_amd
-    case = _case("few", N=8, n_bins=16)
+@pytest.mark.parametrize("force", [None, "GBRL_HIP_FORCE_BISECTION", "GBRL_HIP_QUANTILE_RADIX", "GBRL_HIP_QUANTILE_SAMPLE"])
+@pytest.mark.parametrize("N,B,policy", [(8, 16, "greedy"), (100, 256, "oblivious"), (1, 4, "greedy"), (255, 256, "greedy"), (256, 256, "oblivious")])
+def test_fewer_rows_than_quantile_bins_grows_the_reference_tree(N, B, policy, force, monkeypatch):
+    """n_samples < n_bins + 1 with quantile candidates (the default n_bins = 256 against a small RL batch): the reference's
+    remainder loop gives the first n buckets one row each, the ranks repeat at the column maximum and valid trees are grown
+    (split_candidate_generator.cpp:216-249; pinned by the golden fixtures *_tiny).  Every selection path must accept the repeated
+    ranks and give the oracle's tree."""
+    if force:
+        monkeypatch.setenv(force, "1")
+    case = _case("few%d_%d" % (N, B), N=N, n_bins=B, policy=policy, depth=3, trees=2)
     X, Xc, G, y = K.make_inputs(case)
-    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
-    m.set_feature_weights(np.ones(case["F"], np.float32))
-    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=case["D"])
-    m.set_feature_mapping(np.arange(case["F"], dtype=np.int32), np.ones(case["F"], dtype=bool))
-    with pytest.raises(RuntimeError):
-        m.step(X, None, G)
-    assert m.get_num_trees() == 0
+    m, r = _check(case, X, Xc, G)
+    assert m.get_num_trees() == 2
 
 
 @pytest.mark.parametrize("gen", ["Quantile", "Uniform"])

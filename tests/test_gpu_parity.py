@@ -47,7 +47,7 @@ def _run_product(case, X, Xc, G, y, device):
     return m, np.asarray(pred)
 
 
-@pytest.mark.parametrize("name", [c["name"] for c in K.CASES if not c.get("fragile")])
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES if not c.get("fragile") and not c.get("long_loop") and not c.get("neartie")])
 def test_product_matches_reference_golden(name):
     case, g, (X, Xc, G, y) = load_golden(name)
     m, pred = _run_product(case, X, Xc, G, y, "cpu")
@@ -132,6 +132,151 @@ def test_fragile_case_is_exact_or_an_explained_near_tie(name):
     print("near-tie:", info)
     assert info["explained"], info
     assert info["product_is_true_max"], info
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in K.CASES if c.get("neartie")])
+def test_near_tie_specimen_is_exact_or_explained(name):
+    """Inputs on which the reference -- stably, at every thread count -- picks a candidate whose float64 score is below the
+    maximum by less than its own float32 summation noise: the product holds the true maximum; everything before that split
+    must be bit-identical."""
+    import neartie
+    case, g, (X, Xc, G, y) = load_golden(name)
+    m, pred = _run_product(case, X, Xc, G, y, "cpu")
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    if neartie.first_mismatch(g, e, case["policy"]) is None:
+        return
+    info = neartie.explain_first_mismatch(case, X, Xc, G, g, e)
+    print("near-tie:", info)
+    assert info["explained"] and info["product_is_true_max"], info
+    assert info["tree"] == 0, "the gradients of later trees depend on the first difference; only tree 0 can be analysed here"
+
+
+def test_cfg5_miniature_grows_the_reference_ensemble():
+    """BASELINE configs[4] in miniature (24 numeric + 8 categorical columns, UNIFORM candidates, oblivious depth 6, 320 trees grown
+    by the rmse loop): the product must reproduce the reference's ensemble; over a loop this long the first difference, if any,
+    must be an explained near-tie (the reference's float32 summation noise, neartie.py) with the product holding the true maximum,
+    and every tree before it must be bit-identical."""
+    import neartie
+    import oracle
+    case, g, (X, Xc, G, y) = load_golden("obl_l2_u_cfg5mini")
+    m, pred = _run_product(case, X, Xc, G, y, "cpu")
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    assert m.get_num_trees() == int(g["n_trees"]) == 320
+    mm = neartie.first_mismatch(g, e, case["policy"])
+    scale = float(np.abs(y).mean())
+    if mm is None:
+        assert_structure_equal(e, g)
+        assert_values_close(e, g, scale, TOL)
+        assert rel_err(pred.reshape(g["pred"].shape), g["pred"], scale) <= TOL
+        return
+    t = mm[0]
+    print("cfg5mini: first structural difference at tree %d of 320" % t)
+    assert t >= 20, "a near-tie this early would mean a systematic difference"
+    o = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    K.drive(o, dict(case, trees=t), X, Xc, G, y)
+    G_t = np.asarray(o.predict(X, Xc, 0, 0)).astype(np.float32).reshape(y.shape) - y
+    info = neartie.explain_first_mismatch(case, X, Xc, G_t, g, e)
+    print("near-tie:", info)
+    assert info["explained"] and info["product_is_true_max"], info
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_cfg5_miniature_predict_on_the_reference_model(device, generic, tmp_path, monkeypatch):
+    """configs[4] in miniature, predict only: the model FILE the reference wrote (320 oblivious depth-6 trees, numeric and
+    categorical conditions) is loaded by the product; predictions over the whole ensemble and over sub-ranges of it
+    (start_tree_idx / stop_tree_idx) must match the reference's within 1e-5, for host and device inputs, through the fast kernel and
+    through the general one -- and the two kernels must agree bit for bit."""
+    import gbrl_amd
+    case, g, (X, Xc, G, y) = load_golden("obl_l2_u_cfg5mini")
+    path = str(tmp_path / "ref.gbrl_model")
+    open(path, "wb").write(np.asarray(g["model_file"]).tobytes())
+    if generic:
+        monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "1")
+    m = gbrl_amd.GBRL.load(path)
+    assert m.get_num_trees() == 320
+    if device == "cuda":
+        m.to_device("cuda")
+    keep = []
+    xi = _torch_input(keep)(X) if device == "cuda" else X
+    scale = float(np.abs(y).mean())
+    got = {}
+    for a, b in [(0, 0)] + [tuple(r) for r in case["pred_ranges"]]:
+        p = _from_capsule(m.predict(xi, Xc, a, b))
+        want = g["pred"] if (a, b) == (0, 0) else g["pred_%d_%d" % (a, b)]
+        assert rel_err(p.reshape(want.shape), want, scale) <= TOL, (a, b)
+        got[(a, b)] = p
+    if generic:
+        monkeypatch.delenv("GBRL_HIP_PREDICT_GENERIC")
+        for (a, b), p in got.items():
+            q = _from_capsule(m.predict(xi, Xc, a, b))
+            if (b if b else 320) - a < 128:
+                assert np.array_equal(q, p), (a, b)       # one chain per row in tree order: the same bits from both kernels
+            else:
+                # 768 rows x >= 128 trees: the fast path spreads tree ranges over blocks and adds the partial sums in tree order
+                # (kern::predict) -- a different association of the same float32 terms
+                assert rel_err(q, p, scale) <= 2e-6, (a, b)
+
+
+def test_configs4_full_width_properties():
+    """BASELINE configs[4] at its full WIDTH (192 numeric + 64 categorical columns = 8 KiB of S128 cells per row, uniform candidates,
+    oblivious depth 6) on 2^16 rows, through size-independent properties: (1) one step with lr = 1: predict returns minus the
+    value of the leaf the row is routed to by the stored conditions, numeric and categorical, bit for bit; (2) the leaf values are
+    the exact means of the raw gradients; (3) a categorical condition was actually chosen (the target depends on categorical
+    columns); (4) an ensemble of 40 trees grown on 4096-row minibatches predicts the same bits through the fast and the general
+    kernel, over the whole range and over sub-ranges, from host cells and from device-resident inputs."""
+    import gbrl_amd
+    import torch
+    rng = np.random.default_rng(5)
+    N, F, Fc, D = 1 << 16, 192, 64, 8
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    Xc = K.TOKENS[rng.integers(0, 32, size=(N, Fc))]
+    W = rng.standard_normal((8, D)).astype(np.float32)
+    G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    Xc[:, 5] = K.TOKENS[rng.integers(0, 2, size=N)]      # a two-valued categorical column that carries a strong signal
+    G += ((Xc[:, 5] == K.TOKENS[1]).astype(np.float32) * np.float32(3.0))[:, None]
+    case = dict(name="c5", seed=0, N=N, F=F, Fc=Fc, D=D, depth=6, n_bins=256, score="L2", gen="Uniform", policy="oblivious", trees=1,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=1.0, start_idx=0, stop_idx=D)])
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pred = np.asarray(K.drive(m, case, X, Xc, G, None))
+    e = m.get_ensemble_data()
+    depth = int(e["depths"][0])
+    assert depth == 6
+    fi, fv, isn = np.asarray(e["feature_indices"])[0], np.asarray(e["feature_values"])[0], np.asarray(e["is_numerics"])[0]
+    cv = np.asarray(e["categorical_values"])[0]
+    leaf = np.zeros(N, np.int64)
+    for d in range(depth):
+        right = (X[:, fi[d]] > fv[d]) if isn[d] else (Xc[:, fi[d]] == cv[d])
+        leaf |= right.astype(np.int64) << (depth - 1 - d)
+    vals = np.asarray(e["values"])
+    assert np.array_equal(pred, (np.float32(0) - vals[leaf]).astype(np.float32))           # (1)
+    for l in range(64):                                                                     # (2)
+        rows = leaf == l
+        if rows.any():
+            want = G[rows].astype(np.float64).mean(axis=0)
+            assert np.max(np.abs(vals[l] - want) / np.maximum(np.abs(want), 0.5)) < 1e-6
+    assert not isn[:depth].all(), "no categorical condition was chosen"                   # (3)
+    # (4) a small ensemble on minibatches, predicted four ways
+    for i in range(39):
+        o = (i * 4096) % (N - 4096)
+        gi = (G[o:o + 4096] * np.float32(1.0 / (1 + i))).astype(np.float32)
+        m.step(np.ascontiguousarray(X[o:o + 4096]), np.ascontiguousarray(Xc[o:o + 4096]), gi)
+    assert m.get_num_trees() == 40
+    xt = torch.from_numpy(X).to("cuda:0")
+    xin = (xt.data_ptr(), tuple(xt.shape), str(xt.dtype), "cuda")
+    outs = {}
+    for generic in ("0", "1"):
+        os.environ["GBRL_HIP_PREDICT_GENERIC"] = generic
+        try:
+            for rng_ in [(0, 0), (0, 1), (3, 17), (39, 40)]:
+                outs[(generic, "host") + rng_] = np.asarray(m.predict(X, Xc, *rng_))
+                outs[(generic, "dev") + rng_] = np.asarray(m.predict(xin, Xc, *rng_))
+        finally:
+            os.environ.pop("GBRL_HIP_PREDICT_GENERIC", None)
+    for rng_ in [(0, 0), (0, 1), (3, 17), (39, 40)]:
+        ref = outs[("1", "host") + rng_]
+        for k in (("0", "host"), ("0", "dev"), ("1", "dev")):
+            assert np.array_equal(outs[k + rng_], ref), (k, rng_)
 
 
 @pytest.mark.parametrize("name", ["obl_l2_q", "grd_cos_q_ac", "cfg1_rmse_loop"])
