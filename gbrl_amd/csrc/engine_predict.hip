@@ -65,7 +65,10 @@ void Engine::sync_model_to_device() {
         constexpr size_t kPadTrees = 16;                     // the kernel fetches whole groups of records (<= 16 trees) past the last tree
         if (up_trees_ == 0) { cond_ra_host_.clear(); values_sw_host_.clear(); }
         cond_ra_host_.resize((T + kPadTrees) * 2 * MX);
-        values_sw_host_.resize(T * VT);
+        // the kernel loads whole groups (<= 16 trees) and up to 4 x 1024 x 16 bytes per block unconditionally: zero padding behind the last tree
+        const size_t vpad = kPadTrees * VT + (size_t(64) << 10) / sizeof(float);
+        values_sw_host_.resize(T * VT + vpad);
+        std::fill(values_sw_host_.begin() + static_cast<long>(T * VT), values_sw_host_.end(), 0.0f);
         int32_t inf_bits;
         const float inf = std::numeric_limits<float>::infinity();
         std::memcpy(&inf_bits, &inf, sizeof(inf_bits));
@@ -87,7 +90,7 @@ void Engine::sync_model_to_device() {
         for (size_t t = T; t < T + kPadTrees; ++t)
             for (size_t d = 0; d < MX; ++d) { cond_ra_host_[(t * MX + d) * 2] = inf_pad[0]; cond_ra_host_[(t * MX + d) * 2 + 1] = inf_pad[1]; }
         append(m_cond_ra_, cond_ra_host_.data(), 4, up_trees_ * 2 * MX, (T + kPadTrees) * 2 * MX);
-        append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * VT, T * VT);
+        append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * VT, T * VT + vpad);
     }
     // Greedy ensembles: rebuild every new tree as a binary tree from its leaves' paths (leaves are stored depth-first, left
     // first; fitter.cpp:364-365), for the descent of k_predict_grd.  A tree whose leaves do not form a proper binary tree (a

@@ -33,6 +33,8 @@ constexpr int kObl2MaxVec = 4;   // float4 registers per thread that carry a gro
 template <int DMAX>
 struct Obl2Coef { float lr[DMAX]; };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // leaf = 2 * leaf + (x > t): the compare writes VCC, the add-with-carry doubles the index and takes the bit (2 VALU per level
 // instead of compare + select + shift/or).  `t` is wave-uniform (scalar register).  x > t is false for NaN, like the reference's.
 __device__ __forceinline__ void push_gt(uint32_t &leaf, float x, float t) {
@@ -41,11 +43,48 @@ __device__ __forceinline__ void push_gt(uint32_t &leaf, float x, float t) {
 __device__ __forceinline__ void push_eq(uint32_t &leaf, uint32_t code, uint32_t id) {
     asm("v_cmp_eq_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(leaf) : "v"(code), "s"(id) : "vcc");
 }
+// All levels of one all-numeric tree in ONE block: the compiler then waits once for the tree's feature reads instead of once per
+// level (every s_waitcnt is an issue slot of a kernel that is issue bound).
+#define GBRL_LVL(X, T) "v_cmp_lt_f32 vcc, %" #T ", %" #X "\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+template <int MAXD>
+__device__ __forceinline__ uint32_t leaf_of_numeric(const float (&x)[MAXD], const float (&t)[MAXD]) {
+    uint32_t leaf;
+    if constexpr (MAXD == 4) {
+        asm("v_mov_b32 %0, 0\n\t" GBRL_LVL(1, 5) GBRL_LVL(2, 6) GBRL_LVL(3, 7) GBRL_LVL(4, 8)
+            : "=&v"(leaf) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]) : "vcc");
+    } else if constexpr (MAXD == 6) {
+        asm("v_mov_b32 %0, 0\n\t" GBRL_LVL(1, 7) GBRL_LVL(2, 8) GBRL_LVL(3, 9) GBRL_LVL(4, 10) GBRL_LVL(5, 11) GBRL_LVL(6, 12)
+            : "=&v"(leaf) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+              "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]) : "vcc");
+    } else {
+        static_assert(MAXD == 8, "levels: 4, 6 or 8");
+        asm("v_mov_b32 %0, 0\n\t" GBRL_LVL(1, 9) GBRL_LVL(2, 10) GBRL_LVL(3, 11) GBRL_LVL(4, 12) GBRL_LVL(5, 13) GBRL_LVL(6, 14) GBRL_LVL(7, 15) GBRL_LVL(8, 16)
+            : "=&v"(leaf) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+              "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]) : "vcc");
+    }
+    return leaf;
+}
+#undef GBRL_LVL
+// p = fma(nlr, v_k, p) for k = 0..K-1 in order, two outputs at a time (v_pk_fma_f32), in one block: one wait for the K reads
+template <int K>
+__device__ __forceinline__ void apply_pairs(f32x2 &p, f32x2 nlr, const f32x2 (&v)[K]) {
+    if constexpr (K == 1) {
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p) : "v"(nlr), "v"(v[0]));
+    } else if constexpr (K == 2) {
+        asm("v_pk_fma_f32 %0, %1, %2, %0\n\tv_pk_fma_f32 %0, %1, %3, %0" : "+v"(p) : "v"(nlr), "v"(v[0]), "v"(v[1]));
+    } else if constexpr (K == 3) {
+        asm("v_pk_fma_f32 %0, %1, %2, %0\n\tv_pk_fma_f32 %0, %1, %3, %0\n\tv_pk_fma_f32 %0, %1, %4, %0" : "+v"(p) : "v"(nlr), "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    } else {
+        static_assert(K == 4, "1..4 trees per worker");
+        asm("v_pk_fma_f32 %0, %1, %2, %0\n\tv_pk_fma_f32 %0, %1, %3, %0\n\tv_pk_fma_f32 %0, %1, %4, %0\n\tv_pk_fma_f32 %0, %1, %5, %0"
+            : "+v"(p) : "v"(nlr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    }
+}
 
 // LDS map (bytes from 0): leaf values vt[NB][TT][W][LS][DW] f32 (below 64 KiB: their byte offsets travel as 16-bit fields),
-// leaf offsets idx[2][W][NW][R] u32, row tile xt[R][xs] f32.
+// leaf offsets idx[2][W][R][NW] u32, row tile xt[R][xs] f32.
 template <int DMAX, int MAXD, bool CAT>
-__global__ __launch_bounds__(DMAX >= 64 ? 512 : 1024) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
+__global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
                                                        const float *__restrict__ bias, Obl2Coef<DMAX> coef, int D,
                                                        const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc,
                                                        int n, int start_tree, int stop_tree, float *__restrict__ out, int R, int TT, int NB,
@@ -70,182 +109,48 @@ __global__ __launch_bounds__(DMAX >= 64 ? 512 : 1024) void k_predict_obl2(const 
     const bool live = row_l < rows;
     const int n_groups = (stop_tree - start_tree + TT - 1) / TT;
 
-    // A group's values travel global -> registers (kObl2MaxVec = 4 float4 per thread) -> LDS.  The loads are clamped, not predicated
-    // (a predicated load becomes a branch with a wait behind every load): the four must be in flight together, and stay in
-    // flight -- they are consumed one barrier later (store_vals).  Named registers: an array here is demoted to scratch.
+    // A group's values travel global -> registers (kObl2MaxVec = 4 float4 per thread) -> LDS.  The loads are unconditional and
+    // unclamped (the mirror is padded, so a thread beyond the group's size reads valid memory it never stores): a predicated or
+    // clamped load costs address arithmetic and -- worse -- a branch with a wait behind every load; the four must be in flight
+    // together, and stay in flight: they are consumed one barrier later (store_vals).  Named registers: an array here is demoted
+    // to scratch.  Byte offsets of this thread's four pieces are computed once.
     float4 va, vb, vc, vd;
     static_assert(kObl2MaxVec == 4, "four named registers below");
+    const uint32_t o0 = static_cast<uint32_t>(tid) * 16u, o1 = o0 + static_cast<uint32_t>(NT) * 16u, o2 = o1 + static_cast<uint32_t>(NT) * 16u,
+                   o3 = o2 + static_cast<uint32_t>(NT) * 16u;
+    const uint32_t group_bytes = static_cast<uint32_t>(TT) * VT * 4u;
+    const bool st0 = o0 < group_bytes, st1 = o1 < group_bytes, st2 = o2 < group_bytes, st3 = o3 < group_bytes;
     auto load_vals = [&](int g) __attribute__((always_inline)) {
-        const int t0 = start_tree + g * TT, tn = min(TT, stop_tree - t0);
-        const float4 *src = reinterpret_cast<const float4 *>(vsw + static_cast<size_t>(t0) * VT);
-        const int last = tn * (VT >> 2) - 1;
-        va = src[min(tid, last)];
-        vb = src[min(NT + tid, last)];
-        vc = src[min(2 * NT + tid, last)];
-        vd = src[min(3 * NT + tid, last)];
+        const char *src = reinterpret_cast<const char *>(vsw + static_cast<size_t>(start_tree + g * TT) * VT);
+        va = *reinterpret_cast<const float4 *>(src + o0);
+        vb = *reinterpret_cast<const float4 *>(src + o1);
+        vc = *reinterpret_cast<const float4 *>(src + o2);
+        vd = *reinterpret_cast<const float4 *>(src + o3);
     };
+    // whole groups only: the trees past stop_tree in the last group are stored too (they exist in the padded mirror) and never applied
     auto store_vals = [&](int g) __attribute__((always_inline)) {
-        const int t0 = start_tree + g * TT, tn = min(TT, stop_tree - t0);
-        float4 *dst = reinterpret_cast<float4 *>(vt + static_cast<size_t>(NB == 2 ? (g & 1) : 0) * TT * VT);
-        const int cnt4 = tn * (VT >> 2);
-        if (tid < cnt4) dst[tid] = va;
-        if (NT + tid < cnt4) dst[NT + tid] = vb;
-        if (2 * NT + tid < cnt4) dst[2 * NT + tid] = vc;
-        if (3 * NT + tid < cnt4) dst[3 * NT + tid] = vd;
+        char *dst = reinterpret_cast<char *>(vt) + (NB == 2 ? (g & 1) : 0) * group_bytes;
+        if (st0) *reinterpret_cast<float4 *>(dst + o0) = va;
+        if (st1) *reinterpret_cast<float4 *>(dst + o1) = vb;
+        if (st2) *reinterpret_cast<float4 *>(dst + o2) = vc;
+        if (st3) *reinterpret_cast<float4 *>(dst + o3) = vd;
     };
     const float *x = xt + row_l * xs;
-    // phase A: byte offsets (leaf * DW * 4) of this row's leaves in this worker's K trees of group g, 16 bits each ->
-    // idx[g & 1][q][0..NW)[row].  The K records arrive together through the scalar cache (the mirror is padded, so trees past the
-    // end of the range in the last group read valid records; their leaves are never applied).
-    auto phase_a_k = [&](int g, auto kc) __attribute__((always_inline)) {
-        constexpr int K = decltype(kc)::value;
-        constexpr int NWK = K > 2 ? 2 : 1;
-        // records of a batch of trees sit in scalar registers together: at most ~36 words (more spills SGPRs into VGPR lanes)
-        constexpr int SBMAX = MAXD <= 4 ? 4 : MAXD <= 6 ? 3 : 2;
-        constexpr int SB = K <= SBMAX ? K : (K + 1) / 2;
-        const int32_t *cp0 = cond + static_cast<size_t>(start_tree + g * TT + q * K) * 2 * MAXD;
-        uint32_t off[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k0 = 0; k0 < K; k0 += SB) {
-            int fi[SB][MAXD];
-            float tv[SB][MAXD], xv[SB][MAXD];
-#pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                if (k0 + k < K) {
-                    const int32_t *cp = cp0 + (k0 + k) * 2 * MAXD;
-#pragma unroll
-                    for (int d = 0; d < MAXD; ++d) { fi[k][d] = cp[2 * d]; tv[k][d] = __int_as_float(cp[2 * d + 1]); }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                if (k0 + k < K) {
-#pragma unroll
-                    for (int d = 0; d < MAXD; ++d) {
-                        if (!CAT || fi[k][d] >= 0) xv[k][d] = x[fi[k][d]];
-                        else xv[k][d] = x[F + ((~fi[k][d]) >> 1)];
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                if (k0 + k < K) {
-                    uint32_t leaf = 0;
-#pragma unroll
-                    for (int d = 0; d < MAXD; ++d) {
-                        if (!CAT || fi[k][d] >= 0) {
-                            push_gt(leaf, xv[k][d], tv[k][d]);
-                        } else {
-                            const uint32_t w = __float_as_uint(xv[k][d]);
-                            const uint32_t code = ((~fi[k][d]) & 1) ? (w >> 16) : (w & 0xffffu);
-                            push_eq(leaf, code, __float_as_uint(tv[k][d]));
-                        }
-                    }
-                    off[k0 + k] = leaf * (DW * 4);
-                }
-            }
-        }
-        uint32_t *ib = idx + (((g & 1) * W + q) * NW) * R + row_l;
-        ib[0] = off[0] | (off[1] << 16);
-        if (NWK == 2) ib[R] = off[2] | (off[3] << 16);
-    };
-    auto phase_a = [&](int g) __attribute__((always_inline)) {
-        switch (TPW) {
-            case 1: phase_a_k(g, std::integral_constant<int, 1>{}); break;
-            case 2: phase_a_k(g, std::integral_constant<int, 2>{}); break;
-            case 3: phase_a_k(g, std::integral_constant<int, 3>{}); break;
-            default: phase_a_k(g, std::integral_constant<int, 4>{}); break;
-        }
-    };
-    float p[DW], lr[DW];
+    float p[DW], nlr[DW];
 #pragma unroll
     for (int jj = 0; jj < DW; ++jj) {
         // outputs of this worker; the learning rates are selected with scalar compares (a dynamically indexed by-value struct
-        // would be copied to scratch memory)
+        // would be copied to scratch memory).  nlr = -lr exactly, so fma(nlr, v, p) == fma(-lr, v, p) bit for bit.
         float l = coef.lr[jj];
 #pragma unroll
         for (int w = 1; w < W; ++w) l = q == w ? coef.lr[w * DW + jj] : l;
-        lr[jj] = l;
+        nlr[jj] = -l;
         const int j = q * DW + jj;
         p[jj] = (j < D && tree_chunk == 0) ? 0.0f + bias[j] : 0.0f;
     }
-    // phase B: apply the trees of group g in order to this worker's outputs.  K = trees per worker.  The 16-bit fields become
-    // complete LDS addresses with one packed add per word (this worker's slice, the buffer); the tree's base is the read's
-    // immediate offset.  The reads of a worker's K trees are in flight together, the fused multiply-adds follow in tree order.
-    auto phase_b_k = [&](int g, auto kc, auto fullc) __attribute__((always_inline)) {
-        constexpr int K = decltype(kc)::value;
-        constexpr int NWK = K > 2 ? 2 : 1;
-        constexpr bool FULL = decltype(fullc)::value;
-        const int t0 = start_tree + g * TT, tn = min(TT, stop_tree - t0);
-        const uint32_t *ib = idx + static_cast<size_t>(g & 1) * W * NW * R + row_l;
-        const uint32_t qoff = static_cast<uint32_t>(((NB == 2 ? (g & 1) : 0) * TT * VT + q * LS * DW) * 4);
-        const uint32_t qoff2 = qoff | (qoff << 16);
-        uint32_t word[W][NWK];
-#pragma unroll
-        for (int w = 0; w < W; ++w)
-#pragma unroll
-            for (int i = 0; i < NWK; ++i) word[w][i] = ib[(w * NW + i) * R] + qoff2;
-        const char *lb = reinterpret_cast<const char *>(lds);
-        constexpr int KB = DW >= 16 ? 1 : (DW >= 8 && K > 2) ? 2 : K;   // value registers in flight: KB * DW
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-#pragma unroll
-            for (int k0 = 0; k0 < K; k0 += KB) {
-                float vv[KB][DW];
-#pragma unroll
-                for (int kk = 0; kk < KB; ++kk) {
-                    const int k = k0 + kk;
-                    if (k < K) {
-                        const uint32_t wd = word[w][k >> 1];
-                        const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
-                        const float *v = reinterpret_cast<const float *>(lb + a) + (w * K + k) * VT;
-                        if (DW == 1) {
-                            vv[kk][0] = v[0];
-                        } else if (DW == 2) {
-                            const float2 t2 = *reinterpret_cast<const float2 *>(v);
-                            vv[kk][0] = t2.x; vv[kk][1] = t2.y;
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < DW / 4; ++c) {
-                                const float4 t4 = *reinterpret_cast<const float4 *>(v + 4 * c);
-                                vv[kk][4 * c] = t4.x; vv[kk][4 * c + 1] = t4.y; vv[kk][4 * c + 2] = t4.z; vv[kk][4 * c + 3] = t4.w;
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int kk = 0; kk < KB; ++kk) {
-                    const int k = k0 + kk;
-                    if (k < K && (FULL || w * K + k < tn)) {   // uniform
-#pragma unroll
-                        for (int jj = 0; jj < DW; ++jj) p[jj] = fmaf(-lr[jj], vv[kk][jj], p[jj]);
-                    }
-                }
-            }
-        }
-    };
-    auto phase_b = [&](int g) __attribute__((always_inline)) {
-        const bool full = start_tree + (g + 1) * TT <= stop_tree;
-        if (full) {
-            switch (TPW) {
-                case 1: phase_b_k(g, std::integral_constant<int, 1>{}, std::true_type{}); break;
-                case 2: phase_b_k(g, std::integral_constant<int, 2>{}, std::true_type{}); break;
-                case 3: phase_b_k(g, std::integral_constant<int, 3>{}, std::true_type{}); break;
-                default: phase_b_k(g, std::integral_constant<int, 4>{}, std::true_type{}); break;
-            }
-        } else {
-            switch (TPW) {
-                case 1: phase_b_k(g, std::integral_constant<int, 1>{}, std::false_type{}); break;
-                case 2: phase_b_k(g, std::integral_constant<int, 2>{}, std::false_type{}); break;
-                case 3: phase_b_k(g, std::integral_constant<int, 3>{}, std::false_type{}); break;
-                default: phase_b_k(g, std::integral_constant<int, 4>{}, std::false_type{}); break;
-            }
-        }
-    };
 
-    if (n_groups > 0) load_vals(0);
     // row tile: numeric features (coalesced 16-byte reads when F % 4 == 0), then the packed categorical ids
-    {
+    auto stage_rows = [&]() __attribute__((always_inline)) {
         const float *src = obs + static_cast<size_t>(r0) * F;
         if (F > 0 && (F & 3) == 0) {
             const float4 *src4 = reinterpret_cast<const float4 *>(src);
@@ -287,28 +192,210 @@ __global__ __launch_bounds__(DMAX >= 64 ? 512 : 1024) void k_predict_obl2(const 
         }
         // rows beyond the batch (last block): their lanes still walk the trees; give them defined words
         for (int i = rows * xs + tid; i < R * xs; i += NT) xt[i] = 0.0f;
-    }
+    };
+
+    // Everything from here on is compiled once per K = trees per worker and group (static loop bounds and immediate offsets).
+    // idx[2][W][R][NWK]: worker w's K leaf offsets of a row are NWK consecutive words.
+    auto run = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        constexpr int NWK = K > 2 ? 2 : 1;
+        const uint32_t idx_base = static_cast<uint32_t>(reinterpret_cast<const char *>(idx) - reinterpret_cast<const char *>(lds));
+        const uint32_t idx_par = static_cast<uint32_t>(W * R * NWK * 4);          // bytes per parity
+        const uint32_t idx_row = static_cast<uint32_t>(row_l * NWK * 4);
+        const uint32_t idx_wstride = static_cast<uint32_t>(R * NWK * 4);
+        char *lb = reinterpret_cast<char *>(lds);
+        // ---- the pieces of one iteration, ordered so that every memory request is issued as early as its inputs allow ----
+        // (1) phase A, records: the K (feature, threshold) records of this worker's trees of group g through the scalar cache
+        auto a_records = [&](int g, int (&fi)[K][MAXD], float (&tv)[K][MAXD]) __attribute__((always_inline)) {
+            const int32_t *cp0 = cond + static_cast<size_t>(start_tree + g * (4 * K) + q * K) * 2 * MAXD;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int d = 0; d < MAXD; ++d) { fi[k][d] = cp0[(k * MAXD + d) * 2]; tv[k][d] = __int_as_float(cp0[(k * MAXD + d) * 2 + 1]); }
+        };
+        // (2) phase A, feature reads from the row tile
+        auto a_reads = [&](const int (&fi)[K][MAXD], float (&xv)[K][MAXD]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int d = 0; d < MAXD; ++d) {
+                    if (!CAT || fi[k][d] >= 0) xv[k][d] = x[fi[k][d]];
+                    else xv[k][d] = x[F + ((~fi[k][d]) >> 1)];
+                }
+        };
+        // (3) phase A, leaves -> 16-bit byte offsets (leaf * DW * 4) -> idx[g & 1][q][row]
+        auto a_finish = [&](int g, const int (&fi)[K][MAXD], const float (&tv)[K][MAXD], const float (&xv)[K][MAXD]) __attribute__((always_inline)) {
+            uint32_t off[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t leaf;
+                if constexpr (!CAT) {
+                    leaf = leaf_of_numeric<MAXD>(xv[k], tv[k]);
+                } else {
+                    leaf = 0;
+#pragma unroll
+                    for (int d = 0; d < MAXD; ++d) {
+                        if (fi[k][d] >= 0) {
+                            push_gt(leaf, xv[k][d], tv[k][d]);
+                        } else {
+                            const uint32_t w = __float_as_uint(xv[k][d]);
+                            const uint32_t code = ((~fi[k][d]) & 1) ? (w >> 16) : (w & 0xffffu);
+                            push_eq(leaf, code, __float_as_uint(tv[k][d]));
+                        }
+                    }
+                }
+                off[k] = leaf * (DW * 4);
+            }
+            char *ib = lb + idx_base + (g & 1) * idx_par + q * idx_wstride + idx_row;
+            if (NWK == 2) {
+                uint2 w2;
+                w2.x = off[0] | (off[1] << 16);
+                w2.y = K > 3 ? (off[2] | (off[3] << 16)) : off[2];
+                *reinterpret_cast<uint2 *>(ib) = w2;
+            } else {
+                *reinterpret_cast<uint32_t *>(ib) = K > 1 ? (off[0] | (off[1] << 16)) : off[0];
+            }
+        };
+        // (4) phase B, offset words of group g: all W workers' words of this row, made complete LDS addresses with one packed add
+        // per word (this worker's slice of a tree, the value buffer); the tree's base is the read's immediate offset
+        auto b_words = [&](int g, uint32_t (&word)[W][NWK]) __attribute__((always_inline)) {
+            const char *ib = lb + idx_base + (g & 1) * idx_par + idx_row;
+            const uint32_t qoff = (NB == 2 ? (g & 1) : 0) * group_bytes + static_cast<uint32_t>(q * LS * DW * 4);
+            const uint32_t qoff2 = qoff | (qoff << 16);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                if (NWK == 2) {
+                    const uint2 w2 = *reinterpret_cast<const uint2 *>(ib + w * idx_wstride);
+                    word[w][0] = w2.x + qoff2;
+                    word[w][NWK - 1] = w2.y + qoff2;
+                } else {
+                    word[w][0] = *reinterpret_cast<const uint32_t *>(ib + w * idx_wstride) + qoff2;
+                }
+            }
+        };
+        // (5)+(6) phase B, the leaf values of a whole group and their application in tree order (DW == 2: packed, one block per worker word)
+        auto b_apply_full = [&](const uint32_t (&word)[W][NWK]) __attribute__((always_inline)) {
+            if constexpr (DW == 2) {
+                f32x2 acc = {p[0], p[1]};
+                const f32x2 rate = {nlr[0], nlr[1]};
+                f32x2 vv[W][K];
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t wd = word[w][k >> 1];
+                        const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
+                        vv[w][k] = *reinterpret_cast<const f32x2 *>(lb + a + (w * K + k) * (VT * 4));
+                    }
+#pragma unroll
+                for (int w = 0; w < W; ++w) apply_pairs<K>(acc, rate, vv[w]);
+                p[0] = acc.x; p[1] = acc.y;
+            } else {
+                constexpr int KB = DW >= 16 ? 1 : (DW >= 8 && K > 2) ? 2 : K;   // value registers in flight: KB * DW
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+#pragma unroll
+                    for (int k0 = 0; k0 < K; k0 += KB) {
+                        float vv[KB][DW];
+#pragma unroll
+                        for (int kk = 0; kk < KB; ++kk) {
+                            const int k = k0 + kk;
+                            if (k < K) {
+                                const uint32_t wd = word[w][k >> 1];
+                                const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
+                                const float *v = reinterpret_cast<const float *>(lb + a + (w * K + k) * (VT * 4));
+                                if (DW == 1) {
+                                    vv[kk][0] = v[0];
+                                } else {
+#pragma unroll
+                                    for (int c = 0; c < DW / 4; ++c) {
+                                        const float4 t4 = *reinterpret_cast<const float4 *>(v + 4 * c);
+                                        vv[kk][4 * c] = t4.x; vv[kk][4 * c + 1] = t4.y; vv[kk][4 * c + 2] = t4.z; vv[kk][4 * c + 3] = t4.w;
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < KB; ++kk) {
+                            if (k0 + kk < K) {
+#pragma unroll
+                                for (int jj = 0; jj < DW; ++jj) p[jj] = fmaf(nlr[jj], vv[kk][jj], p[jj]);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        // the last group may hold fewer than 4K trees: tree by tree, guarded (uniform)
+        auto b_apply_partial = [&](const uint32_t (&word)[W][NWK], int tn) __attribute__((always_inline)) {
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (w * K + k < tn) {
+                        const uint32_t wd = word[w][k >> 1];
+                        const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
+                        const float *v = reinterpret_cast<const float *>(lb + a + (w * K + k) * (VT * 4));
+#pragma unroll
+                        for (int jj = 0; jj < DW; ++jj) p[jj] = fmaf(nlr[jj], v[jj], p[jj]);
+                    }
+                }
+        };
+
+        {   // leaves of group 0
+            int fi[K][MAXD];
+            float tv[K][MAXD], xv[K][MAXD];
+            a_records(0, fi, tv);
+            a_reads(fi, xv);
+            a_finish(0, fi, tv, xv);
+        }
+        // steady state: groups 0 .. n_groups-2 are whole groups with a successor
+        for (int g = 0; g + 1 < n_groups; ++g) {
+            __syncthreads();   // offsets and values of group g are published; group g-1 is fully consumed
+            int fi[K][MAXD];
+            float tv[K][MAXD], xv[K][MAXD];
+            uint32_t word[W][NWK];
+            a_records(g + 1, fi, tv);
+            b_words(g, word);
+            if (NB == 2) {
+                store_vals(g + 1);
+                load_vals(min(g + 2, n_groups - 1));
+            }
+            a_reads(fi, xv);
+            a_finish(g + 1, fi, tv, xv);
+            b_apply_full(word);
+            if (NB != 2) {   // one value buffer: the next group's values replace this group's after everybody has applied them
+                __syncthreads();
+                store_vals(g + 1);
+                load_vals(min(g + 2, n_groups - 1));
+            }
+        }
+        {   // last group
+            __syncthreads();
+            const int g = n_groups - 1;
+            uint32_t word[W][NWK];
+            b_words(g, word);
+            const int tn = stop_tree - (start_tree + g * (4 * K));
+            if (tn == 4 * K) b_apply_full(word); else b_apply_partial(word, tn);
+        }
+    };
+
+    if (n_groups > 0) load_vals(0);
+    stage_rows();
     if (n_groups > 0) {
         store_vals(0);
         load_vals(min(1, n_groups - 1));
-    }
-    __syncthreads();
-    if (n_groups > 0) phase_a(0);
-    // The prefetch loads are unconditional (group index clamped): a load under a condition ends in a register copy behind a
-    // full wait at the join, which would expose the global-memory latency every group.
-    for (int g = 0; g < n_groups; ++g) {
-        __syncthreads();   // offsets and values of group g are published; group g-1 is fully consumed
-        if (NB == 2) {
-            if (g + 1 < n_groups) store_vals(g + 1);
-            load_vals(min(g + 2, n_groups - 1));
-            if (g + 1 < n_groups) phase_a(g + 1);
-            phase_b(g);
-        } else {   // one value buffer: the next group's values replace this group's after everybody has applied them
-            if (g + 1 < n_groups) phase_a(g + 1);
-            phase_b(g);
-            __syncthreads();
-            if (g + 1 < n_groups) store_vals(g + 1);
-            load_vals(min(g + 2, n_groups - 1));
+        __syncthreads();
+        // wide outputs (DW >= 4 values per worker) keep at most 2 trees per worker in flight (registers); obl2_plan knows
+        if constexpr (DW >= 4) {
+            if (TPW == 1) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 2>{});
+        } else {
+            switch (TPW) {
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                case 2: run(std::integral_constant<int, 2>{}); break;
+                case 3: run(std::integral_constant<int, 3>{}); break;
+                default: run(std::integral_constant<int, 4>{}); break;
+            }
         }
     }
     if (live) {
@@ -325,7 +412,7 @@ struct Obl2Plan { int RG, TT, NB, xs; size_t lds; };
 // still holds >= 8 trees; small ensembles take 64-row blocks so that several blocks per CU overlap their tile loads with each
 // other's walks.  The value buffers must lie below 64 KiB (16-bit offsets).
 static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, int trees, Obl2Plan &pl) {
-    const int rg_max = DMAX >= 64 ? 2 : 4;   // 16 accumulators + 16 rates per thread: that width is compiled for 512-thread blocks
+    const int rg_max = DMAX >= 32 ? 2 : 4;   // 8 or 16 accumulators and rates per thread: those widths are compiled for 512-thread blocks
     const size_t budget = 160 * 1024 - 256;
     const size_t vtb = (static_cast<size_t>(1) << maxd) * DMAX * sizeof(float);
     pl.xs = (F + (cat ? (Fc + 1) / 2 : 0)) | 1;
@@ -334,7 +421,7 @@ static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, int trees, Ob
         return static_cast<size_t>(nb) * tt * vtb + static_cast<size_t>(2) * kObl2Workers * nw * 64 * rg * 4 + static_cast<size_t>(64) * rg * pl.xs * 4;
     };
     auto tt_for = [&](int rg, int nb) -> int {
-        int tt = 16;
+        int tt = DMAX >= 16 ? 8 : 16;   // wide outputs: the kernel is compiled for at most 2 trees per worker
         while (tt >= 4 && (lds_for(rg, tt, nb) > budget || static_cast<size_t>(nb) * tt * vtb > 65536 ||
                            static_cast<size_t>(tt) * vtb / 16 > static_cast<size_t>(kObl2MaxVec) * 256 * rg)) tt -= 4;
         return tt >= 4 ? tt : 0;
