@@ -4,16 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): oblivious tree, L2 split score, quantile
+Timed workload (BASELINE.json configs[1], the configuration the metric is quoted on): oblivious tree, L2 split score, quantile
 candidates, batch = 2^20 rows PER GPU, 128 features, depth 6, output_dim 8, n_bins 256, one SGD optimiser; synthetic
 inputs X ~ N(0,1), G = tanh(X[:, :8] W) + 0.5 N(0,1) generated on the device before the timed region (inputs resident in
 HBM).  One "step" = one GBRL.step() = one tree fitted on the whole batch.  With N > 1 the rows are sharded over the ranks
 (weak scaling: 2^20 rows per GPU, the SAME tree is grown on every rank from all-reduced integer histograms), and `value`
-counts 2^20-row batches: value = steps * n_gpus / seconds.
+counts 2^20-row batches: value = steps * n_gpus / seconds.  `python bench.py --gpus N` without a launcher starts its own N ranks.
 
 Printed JSON (rank 0, one line): the driver contract + "roofline" for the dominant kernel (split-score histogram build,
 HBM-bound, algorithmic bytes from SURVEY.md 8(d)) + "cpu_baseline" (the reference's own CPU path if oracle/_ref is
-loadable, else this repo's restatement) on a bounded sample + predict throughput.
+loadable, else this repo's restatement) on a bounded sample + predict throughput with its own roofline ("predict",
+"predict_large_ensemble") + two further single-GPU legs measured after the timed region: "cfg3" (BASELINE configs[2]: greedy /
+Cosine / policy + value optimisers, full size) and "predict_cfg5" (BASELINE configs[4]: 192 numeric + 64 categorical columns,
+uniform candidates, predict over 10 000 trees).  --workload cfg3 makes configs[2] the timed workload instead.
 """
 import argparse
 import json
@@ -73,7 +76,7 @@ def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows, budget_
     m.predict(X, None, 0, 0)
     dtp = time.perf_counter() - t1
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return {"value": (1.0 / dt) * sample_rows / full_rows, "unit": "trees/s at batch=2^20 (extrapolated linearly in rows)",
+    return {"value": (1.0 / dt) * sample_rows / full_rows, "unit": "trees/s at batch=2^20 (extrapolated x%d linearly in rows from the sample)" % max(1, full_rows // sample_rows),
             "cores": cores, "kind": kind,
             "sample": "1 tree on %d of %d rows (same F=%d, D=%d, depth=%d, n_bins=%d): %.2f s; predict 1 tree %.3f s" % (
                 sample_rows, full_rows, n_feat, out_dim, depth, n_bins, dt, dtp),
@@ -108,6 +111,145 @@ def launch_ranks(n):
     return rc
 
 
+# ---- predict roofline -------------------------------------------------------------------------------------------------
+# Small ensembles are HBM-bound: N*(F + D)*4 bytes + model per call.  Large ensembles are bound by instruction
+# issue: per (64 rows, depth-6 tree, 8 outputs) the traversal needs at least 6 feature reads + 6 compares + 6 index updates and, for
+# the 4 output pairs, 4 offset extractions + 4 value reads + 4 packed FMAs: 30 VALU instructions (4 cycles each on a SIMD-32 for
+# the compare / carry / packed forms, 4 SIMDs per CU) and 10 LDS reads (2 cycles each per CU).  VALU issue: 30 * 4 / 4 = 30 cycles per
+# CU per (64 rows, tree) -> 256 CUs * 2.4e9 / 30 * 64 = 1.31e12 row-trees/s; LDS: 20 cycles -> 1.97e12.  The VALU figure is the bound.
+PREDICT_ISSUE_BOUND = 256 * 2.4e9 / 30.0 * 64.0
+
+
+def predict_roofline(n_rows, n_feat, out_dim, trees, depth, seconds):
+    model_bytes = trees * ((1 << depth) * out_dim * 4 + depth * 9)
+    alg = n_rows * (n_feat + out_dim) * 4 + model_bytes
+    rt = n_rows * trees / seconds
+    return {"hbm": {"bound": "hbm", "achieved": alg / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / seconds / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_call": alg},
+            "issue": {"bound": "valu-issue", "achieved": rt, "peak": PREDICT_ISSUE_BOUND, "unit": "row-trees/s", "frac": rt / PREDICT_ISSUE_BOUND,
+                      "note": "30 VALU (4 clk) + 10 LDS (2 clk) instructions per (64 rows, depth-6 tree, 8 outputs); see bench.py / DESIGN.md section 5"}}
+
+
+def make_model(gbrl_amd, np, kind, F, Fc, D, depth, B, name):
+    """kind: cfg2 = oblivious / L2 / quantile, one optimiser; cfg3 = greedy / Cosine / quantile, policy + value optimisers;
+    cfg5 = oblivious / L2 / uniform, numeric + categorical columns."""
+    kw = dict(input_dim=F + Fc, output_dim=D, policy_dim=D, max_depth=depth, min_data_in_leaf=0, n_bins=B, par_th=10, cv_beta=0.9,
+              use_control_variates=False, batch_size=5000, verbose=0, device="cuda", learner_name=name)
+    if kind == "cfg3":
+        kw.update(split_score_func="Cosine", generator_type="Quantile", grow_policy="greedy")
+    elif kind == "cfg5":
+        kw.update(split_score_func="L2", generator_type="Uniform", grow_policy="oblivious")
+    else:
+        kw.update(split_score_func="L2", generator_type="Quantile", grow_policy="oblivious")
+    m = gbrl_amd.GBRL(**kw)
+    m.set_feature_weights(np.ones(F + Fc, np.float32))
+    if kind == "cfg3":
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D - 1)
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=D - 1, stop_idx=D)
+    else:
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
+    m.set_feature_mapping(np.arange(F + Fc, dtype=np.int32), np.array([True] * F + [False] * Fc, dtype=bool))
+    return m
+
+
+def time_predict(torch, m, xo, co, reps):
+    p = m.predict(xo, co, 0, 0)
+    del p
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        p = m.predict(xo, co, 0, 0)
+        del p
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps
+
+
+def leg_cfg3(torch, np, gbrl_amd, dev, X, G, D, depth, B, steps=6, warmup=2):
+    """BASELINE configs[2] at full size on one GPU: greedy / Cosine / quantile, policy + value optimisers (shared actor-critic)."""
+    N, F = X.shape
+    m = make_model(gbrl_amd, np, "cfg3", F, 0, D, depth, B, "bench_cfg3")
+    tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    xo, go = tup(X), tup(G)
+    m.set_profiling(0)
+    for _ in range(warmup):
+        m.step(xo, None, go)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.step(xo, None, go)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    m.set_profiling(2)
+    acc = {}
+    for _ in range(2):
+        m.step(xo, None, go)
+        for k, v in m.last_phase_times().items():
+            acc[k] = acc.get(k, 0.0) + v / 2
+    m.set_profiling(1)
+    dtp = time_predict(torch, m, xo, None, 5)
+    T = m.get_num_trees()
+    e_leaves = int(np.asarray(m.get_ensemble_data()["values"]).shape[0])
+    return {"workload": "BASELINE configs[2]: greedy tree, Cosine score, quantile candidates, policy [0,%d) lr 0.1 + value [%d,%d) lr 0.01" % (D - 1, D - 1, D),
+            "rows": N, "n_features": F, "output_dim": D, "max_depth": depth, "steps": steps, "ms_per_step": dt * 1e3, "trees_per_s": 1.0 / dt,
+            "leaves_per_tree": e_leaves / float(T), "phases_ms_per_step": {k: v for k, v in sorted(acc.items())},
+            "predict": {"trees": T, "ms_per_call": dtp * 1e3, "rows_per_s": N / dtp, "row_trees_per_s": N * T / dtp,
+                        "kernel_ms": m.last_phase_times().get("predict", 0.0), "roofline": predict_roofline(N, F, D, T, depth, dtp)}}
+
+
+def leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, trees, N=1 << 20, F=192, Fc=64, mini=4096):
+    """BASELINE configs[4]: 192 numeric + 64 categorical columns (32 ASCII tokens, S128 cells), uniform candidates, an ensemble of
+    `trees` oblivious depth-6 trees grown on 4096-row minibatches, predict on 2^20 rows.  The categorical input of predict is the
+    RAW cell matrix (2^20 x 64 x 128 bytes = 8 GiB, resident in HBM): every call hashes and dictionary-encodes it on the device
+    before the traversal -- nothing is pre-encoded."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(55)
+    X = torch.randn((N, F), device=dev, dtype=torch.float32, generator=gen)
+    tok = torch.randint(0, 32, (N, Fc), device=dev, generator=gen, dtype=torch.int64)
+    cells = torch.zeros((N, Fc, 128), device=dev, dtype=torch.uint8)      # "cXX" zero padded to 128 bytes, like numpy S128
+    cells[:, :, 0] = ord("c")
+    cells[:, :, 1] = (ord("0") + tok // 10).to(torch.uint8)
+    cells[:, :, 2] = (ord("0") + tok % 10).to(torch.uint8)
+    wgen = torch.Generator(device=dev)
+    wgen.manual_seed(56)
+    W = torch.randn((8, D), device=dev, dtype=torch.float32, generator=wgen)
+    G = torch.tanh(X[:, :8] @ W) + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)
+    # categorical columns carry signal too: output j is shifted for four tokens of column j and two tokens of column j + D
+    catsig = ((tok[:, :D] % 8) == 3).to(torch.float32) * 2.0 + ((tok[:, D:2 * D] % 16) == 5).to(torch.float32) * 3.0
+    G = (G + catsig).contiguous()
+    del catsig
+    del tok
+    m = make_model(gbrl_amd, np, "cfg5", F, Fc, D, depth, B, "bench_cfg5")
+    tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    ctup = lambda t: (t.data_ptr(), (t.shape[0], t.shape[1]), "S128", "cuda")
+    m.set_profiling(0)
+    t0 = time.perf_counter()
+    n_mb = N // mini
+    for i in range(trees):
+        o = (i % n_mb) * mini
+        scale = 1.0 / (1.0 + 0.01 * i)                                    # later trees see smaller residual-like gradients
+        gi = (G[o:o + mini] * scale).contiguous()
+        m.step(tup(X[o:o + mini]), ctup(cells[o:o + mini]), tup(gi))
+    torch.cuda.synchronize()
+    grow_s = time.perf_counter() - t0
+    e = m.get_ensemble_data()
+    n_cat_conditions = int((np.asarray(e["is_numerics"]) == 0).sum())
+    m.set_profiling(2)
+    xo, co = tup(X), ctup(cells)
+    dtp = time_predict(torch, m, xo, co, 2)
+    ph = m.last_phase_times()
+    T = m.get_num_trees()
+    out = {"workload": "BASELINE configs[4]: %d numeric + %d categorical columns, uniform candidates, oblivious depth %d, predict over %d trees" % (F, Fc, depth, T),
+           "rows": N, "trees": T, "ms_per_call": dtp * 1e3, "rows_per_s": N / dtp, "row_trees_per_s": N * T / dtp,
+           "kernel_ms": ph.get("predict", 0.0), "encode_ms": ph.get("inputs", 0.0),
+           "categorical_input": "raw S128 cells (%.1f GiB in HBM), hashed and dictionary-encoded on the device inside every call" % (N * Fc * 128 / 2.0**30),
+           "categorical_conditions": n_cat_conditions, "conditions": int(np.asarray(e["depths"]).sum()),
+           "grown": "%d steps on %d-row minibatches in %.1f s (%.2f ms/step)" % (trees, mini, grow_s, grow_s * 1e3 / trees),
+           "roofline": predict_roofline(N, F + Fc, D, T, depth, dtp)}
+    del X, cells, G
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +267,11 @@ def main():
     ap.add_argument("--exchange", choices=["rccl", "hooks"], default="rccl",
                     help="multi-GPU exchange: the model's own RCCL communicator (default) or torch.distributed hooks")
     ap.add_argument("--predict-trees", type=int, default=0, help="0: predict over the ensemble grown by the bench")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="timed workload: cfg2 = BASELINE configs[1] (oblivious / L2 / quantile, the metric's configuration); "
+                         "cfg3 = BASELINE configs[2] (greedy / Cosine / policy [0,D-1) lr 0.1 + value [D-1,D) lr 0.01)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the cfg3 and predict_cfg5 legs that follow the timed region (single GPU)")
+    ap.add_argument("--cfg5-trees", type=int, default=10000, help="ensemble size of the predict_cfg5 leg (BASELINE configs[4]: 10 000)")
     ap.add_argument("--large-ensemble", type=int, default=1000,
                     help="also time predict() over an ensemble of this many trees (the row-trees/s rate is flat from ~100 trees on; "
                          "BASELINE configs[4] has 10000).  The extra trees are grown after the timed region with the same "
@@ -181,12 +328,7 @@ def main():
     W = torch.randn((8, D), device=dev, dtype=torch.float32, generator=wgen)
     G = (torch.tanh(X[:, :8] @ W) + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)).contiguous()
 
-    m = gbrl_amd.GBRL(input_dim=F, output_dim=D, policy_dim=D, max_depth=depth, min_data_in_leaf=0, n_bins=B, par_th=10,
-                      cv_beta=0.9, split_score_func="L2", generator_type="Quantile", use_control_variates=False,
-                      batch_size=5000, grow_policy="oblivious", verbose=0, device="cuda", learner_name="bench")
-    m.set_feature_weights(np.ones(F, np.float32))
-    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
-    m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+    m = make_model(gbrl_amd, np, args.workload, F, 0, D, depth, B, "bench")
     # level 1: one HIP event pair per k_hist_build launch, attached to the dispatch itself (hipExtLaunchKernelGGL start/stop
     # events on the engine's own stream: the kernel's begin/end timestamps, no extra packet in the stream), resolved after each
     # call -- no sync inside the step.  The full phase table needs ~60 hipEventRecord calls per step, each a few-microsecond
@@ -278,8 +420,24 @@ def main():
         dtl = (time.perf_counter() - t3) / 2
         T2 = m.get_num_trees()
         large = {"trees": T2, "ms_per_call": dtl * 1e3, "rows_per_s": world * N / dtl, "row_trees_per_s": world * N * T2 / dtl,
-                 "kernel_ms": m.last_phase_times().get("predict", 0.0),
+                 "kernel_ms": m.last_phase_times().get("predict", 0.0), "roofline": predict_roofline(N, F, D, T2, depth, dtl),
                  "grown": "%d extra full-size steps in %.1f s (%.2f ms/step, no profiling events)" % (T2 - n_trees, grow_s, grow_s * 1e3 / max(1, T2 - n_trees))}
+
+    extra = {}
+    if world == 1 and not args.no_extra_legs and not args.force_collective:
+        del m
+        torch.cuda.empty_cache()
+        if args.workload != "cfg3":
+            try:
+                extra["cfg3"] = leg_cfg3(torch, np, gbrl_amd, dev, X, G, D, depth, B)
+            except Exception as e:   # a leg is reporting only; never let it hide the timed measurement
+                extra["cfg3"] = {"error": repr(e)}
+        del X, G
+        torch.cuda.empty_cache()
+        try:
+            extra["predict_cfg5"] = leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, args.cfg5_trees)
+        except Exception as e:
+            extra["predict_cfg5"] = {"error": repr(e)}
 
     if rank == 0:
         steps = args.steps
@@ -303,11 +461,13 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 fixed-point sums / f32 scores",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: oblivious tree, L2 score, quantile candidates", "rows_per_gpu": N,
+            "config": {"workload": ("BASELINE configs[1]: oblivious tree, L2 score, quantile candidates" if args.workload == "cfg2" else
+                                    "BASELINE configs[2]: greedy tree, Cosine score, quantile candidates, policy + value optimisers"), "rows_per_gpu": N,
                        "n_features": F, "output_dim": D, "max_depth": depth, "n_bins": B, "sharding": "rows x%d" % world + (" (collective path forced)" if args.force_collective else ""), "exchange": exchange},
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
-                        "row_trees_per_s": world * N * n_trees / dtp},
+                        "row_trees_per_s": world * N * n_trees / dtp, "roofline": predict_roofline(N, F, D, n_trees, depth, dtp)},
             "predict_large_ensemble": large,
+            "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"),
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
             "collective": ({"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)} if coll is not None else None),
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,

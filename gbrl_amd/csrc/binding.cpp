@@ -106,8 +106,13 @@ Input read_input(py::object &obj, const std::string &name, bool none_allowed, co
         in.ptr = (raw == 0 || raw == static_cast<uintptr_t>(-1)) ? nullptr : reinterpret_cast<const void *>(raw);
         for (py::handle d : t[1].cast<py::tuple>()) in.shape.push_back(d.cast<size_t>());
         const std::string dtype = t[2].cast<std::string>();
-        if (categorical) fail("Unsupported data type: " + dtype);
-        if (dtype != "torch.float32") fail("Expected dtype torch.float32, but got " + dtype);
+        if (categorical) {
+            // extension over the reference (which takes categorical cells as NumPy S128 arrays only): a device-resident cell
+            // matrix, [n, n_cat] cells of 128 bytes each (e.g. a torch.uint8 tensor [n, n_cat, 128]), announced as dtype "S128"
+            if (dtype != "S128" && dtype != "|S128") fail("Unsupported data type: " + dtype);
+        } else if (dtype != "torch.float32") {
+            fail("Expected dtype torch.float32, but got " + dtype);
+        }
         const std::string dev = t[3].cast<std::string>();
         if (dev == "cpu") in.on_device = false;
         else if (dev == "cuda" || dev == "gpu") in.on_device = true;
