@@ -344,7 +344,7 @@ struct RowAtomics<DT, DT> {
 // gradients (32 contiguous bytes per row for D = 8) and the D values are handed to all 16 lanes with row_newbcast moves,
 // instead of every lane loading all D values (which made the vector-memory path, not the LDS atomics, the bottleneck).
 // Every row-slot keeps U rows in flight: all loads of the U rows are issued before the first atomic.
-template <int DT, int U>
+template <int DT, int U, bool PIPE>
 __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
                                                               const int32_t *__restrict__ qg, int D_rt,
                                                               const int32_t *__restrict__ rows,
@@ -373,6 +373,43 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const int32_t *rlist = rows + ck.start;
     const int qlane = fl < (DT ? DT : 1) ? fl : (DT ? DT - 1 : 0);   // lanes >= D re-load the last value (never used)
     int p0 = slot;
+    if (DT && PIPE) {
+        // Software-pipelined main loop (three stages, U rows per slot and stage): while the 9U atomics of iteration i occupy the
+        // LDS atomic unit, the codes / gradients of iteration i+1 (their row ids were loaded one iteration earlier) and the row
+        // ids of iteration i+2 are already in flight.  Without it every wave of the block (one block per CU) waits for the two
+        // dependent global-memory round trips at the same time and the atomic unit idles for a third of the kernel.
+        // Prefetch positions beyond the chunk are clamped to its last row (loaded, never accumulated).
+        const int last = ck.len - 1, step = n_slots * U;
+        int rowB[U], codeA[U], qA[U];
+        {
+            int rowA[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rowA[u] = rlist[min(p0 + u * n_slots, last)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rowB[u] = rlist[min(p0 + step + u * n_slots, last)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) codeA[u] = cbase[static_cast<size_t>(rowA[u]) * kCodeGroup];
+#pragma unroll
+            for (int u = 0; u < U; ++u) qA[u] = qg[static_cast<size_t>(rowA[u]) * DT + qlane];
+        }
+        for (; p0 + (U - 1) * n_slots < ck.len; p0 += step) {
+            int codeB[U], qB[U], rowC[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) codeB[u] = cbase[static_cast<size_t>(rowB[u]) * kCodeGroup];
+#pragma unroll
+            for (int u = 0; u < U; ++u) qB[u] = qg[static_cast<size_t>(rowB[u]) * DT + qlane];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rowC[u] = rlist[min(p0 + 2 * step + u * n_slots, last)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int32_t *dst = h + codeA[u] * row_stride + fl;
+                RowAtomics<DT, 0>::run(dst, 16, qA[u]);
+                atomicAdd(dst + DT * 16, 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { codeA[u] = codeB[u]; qA[u] = qB[u]; rowB[u] = rowC[u]; }
+        }
+    }
     // main loop: U rows per slot, no bounds checks inside => straight-line code: 3U independent loads, then 9U atomics
     for (; p0 + (U - 1) * n_slots < ck.len; p0 += n_slots * U) {
         int row[U], code[U];
@@ -1187,20 +1224,30 @@ void iota_rows(int32_t *rows, int n, hipStream_t s) {
 
 size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * (D + 1) * FG * sizeof(int32_t); }
 
-template <int DT, int U>
-static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
-                        int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
-                        hipEvent_t ev_start, hipEvent_t ev_stop) {
+template <int DT, int U, bool PIPE>
+static void launch_hist_p(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                          int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
+                          hipEvent_t ev_start, hipEvent_t ev_stop) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
     }
     const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
     // ev_start / ev_stop (nullable): the dispatch's own begin / end timestamps -- no extra packets in the stream, unlike
     // hipEventRecord around the launch
-    hipExtLaunchKernelGGL((k_hist_build<DT, U>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D, rows,
+    hipExtLaunchKernelGGL((k_hist_build<DT, U, PIPE>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D, rows,
                           chunks, n_chunks, n_groups, FG, shift, NB, partials);
+}
+template <int DT, int U>
+static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                        int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
+                        hipEvent_t ev_start, hipEvent_t ev_stop) {
+    static const bool pipe = []() { const char *e = std::getenv("GBRL_HIP_HIST_PIPE"); return !(e && e[0] == '0'); }();   // measurement hook
+    if constexpr (DT != 0) {
+        if (pipe) { launch_hist_p<DT, U, true>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop); return; }
+    }
+    launch_hist_p<DT, U, false>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
 }
 
 template <int P, int H>
