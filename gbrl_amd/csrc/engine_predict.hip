@@ -147,6 +147,26 @@ void Engine::sync_model_to_device() {
         append(m_grd_nodes_, grd_nodes_host_.data(), 4, grd_up_nodes_ * 4, grd_nodes_host_.size());
         append(m_grd_off_, grd_off_host_.data(), 4, 0, grd_off_host_.size());
         grd_up_nodes_ = grd_nodes_host_.size() / 4;
+        // Second-generation kernel, greedy mode (predict_obl2.hip): one record per tree = its leaf values pre-swizzled as
+        // [worker][leaf < 2^levels][DMAX/4] followed by its nodes [2^levels] x int4 (zero padded)
+        if (grd_ok_ && kern::obl2_levels(static_cast<int>(MD)) > 0 && kern::obl2_padded_outputs(static_cast<int>(D)) > 0) {
+            const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
+            const size_t LS = size_t(1) << MX, VT = LS * DMAX, RECF = VT + LS * 4;   // floats (= dwords) per record
+            constexpr size_t kPadTrees = 16;
+            const size_t vpad = kPadTrees * RECF + (size_t(64) << 10) / sizeof(float);
+            if (up_trees_ == 0) values_sw_host_.clear();
+            values_sw_host_.resize(T * RECF + vpad);
+            std::fill(values_sw_host_.begin() + static_cast<long>(up_trees_ * RECF), values_sw_host_.end(), 0.0f);
+            for (size_t t = up_trees_; t < T; ++t) {
+                float *rec = &values_sw_host_[t * RECF];
+                const size_t l0 = static_cast<size_t>(model.tree_indices[t]), l1 = t + 1 < T ? static_cast<size_t>(model.tree_indices[t + 1]) : L;
+                for (size_t leaf = 0; leaf < l1 - l0 && leaf < LS; ++leaf)
+                    for (size_t j = 0; j < D; ++j) rec[((j / DW) * LS + leaf) * DW + (j % DW)] = model.values[(l0 + leaf) * D + j];
+                const size_t n0 = static_cast<size_t>(grd_off_host_[t]), n1 = static_cast<size_t>(grd_off_host_[t + 1]);
+                if (n1 - n0 <= LS) std::memcpy(rec + VT, &grd_nodes_host_[n0 * 4], (n1 - n0) * 16);
+            }
+            append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * RECF, T * RECF + vpad);
+        }
     }
     up_trees_ = T; up_leaves_ = L; up_splits_ = S;
     // small, mutable state: always refreshed
@@ -269,6 +289,9 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
         pm.obl2_maxd = kern::obl2_levels(md.max_depth);
         pm.values_sw = m_values_sw_.as<float>();
         pm.cond_ra = m_cond_ra_.as<int32_t>();
+    } else if (!model.oblivious() && grd_ok_ && kern::obl2_levels(md.max_depth) > 0 && kern::obl2_padded_outputs(D) > 0 && md.n_trees > 0) {
+        pm.obl2_maxd = kern::obl2_levels(md.max_depth);   // greedy mode of the same kernel: records = values + nodes
+        pm.values_sw = m_values_sw_.as<float>();
     }
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_OBL1")) {      // test / measurement hook: the first-generation oblivious kernel
         if (e[0] == '1') pm.obl2_maxd = 0;

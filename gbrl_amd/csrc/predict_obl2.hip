@@ -83,7 +83,7 @@ __device__ __forceinline__ void apply_pairs(f32x2 &p, f32x2 nlr, const f32x2 (&v
 
 // LDS map (bytes from 0): leaf values vt[NB][TT][W][LS][DW] f32 (below 64 KiB: their byte offsets travel as 16-bit fields),
 // leaf offsets idx[2][W][R][NW] u32, row tile xt[R][xs] f32.
-template <int DMAX, int MAXD, bool CAT>
+template <int DMAX, int MAXD, bool CAT, bool GREEDY>
 __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
                                                        const float *__restrict__ bias, Obl2Coef<DMAX> coef, int D,
                                                        const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc,
@@ -91,6 +91,9 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                                                        int xs, int tree_chunk) {
     extern __shared__ float lds[];
     constexpr int W = kObl2Workers, DW = DMAX / W, LS = 1 << MAXD, VT = LS * DMAX;
+    // one tree's record in the mirror and in LDS: its leaf values [W][LS][DW] and -- greedy ensembles -- its nodes [LS] x int4
+    // (feature | ~categorical feature, threshold bits | category id, left, right; a child >= 0 is a node, < 0 is ~leaf)
+    constexpr int REC = VT * 4 + (GREEDY ? LS * 16 : 0);   // bytes
     if (tree_chunk > 0) {   // small batches: this block column covers a sub-range of the trees and writes a partial sum (no bias)
         start_tree += blockIdx.y * tree_chunk;
         stop_tree = min(stop_tree, start_tree + tree_chunk);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
     const int rg = wave / W, q = wave % W;
     const int TPW = TT / W, NW = TPW > 2 ? 2 : 1;
     float *vt = lds;
-    uint32_t *idx = reinterpret_cast<uint32_t *>(vt + static_cast<size_t>(NB) * TT * VT);
+    uint32_t *idx = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(vt) + static_cast<size_t>(NB) * TT * REC);
     float *xt = reinterpret_cast<float *>(idx + 2 * W * NW * R);
     const int r0 = blockIdx.x * R;
     const int rows = min(R, n - r0);
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
     static_assert(kObl2MaxVec == 4, "four named registers below");
     const uint32_t o0 = static_cast<uint32_t>(tid) * 16u, o1 = o0 + static_cast<uint32_t>(NT) * 16u, o2 = o1 + static_cast<uint32_t>(NT) * 16u,
                    o3 = o2 + static_cast<uint32_t>(NT) * 16u;
-    const uint32_t group_bytes = static_cast<uint32_t>(TT) * VT * 4u;
+    const uint32_t group_bytes = static_cast<uint32_t>(TT) * REC;
     const bool st0 = o0 < group_bytes, st1 = o1 < group_bytes, st2 = o2 < group_bytes, st3 = o3 < group_bytes;
     auto load_vals = [&](int g) __attribute__((always_inline)) {
-        const char *src = reinterpret_cast<const char *>(vsw + static_cast<size_t>(start_tree + g * TT) * VT);
+        const char *src = reinterpret_cast<const char *>(vsw) + static_cast<size_t>(start_tree + g * TT) * REC;
         va = *reinterpret_cast<const float4 *>(src + o0);
         vb = *reinterpret_cast<const float4 *>(src + o1);
         vc = *reinterpret_cast<const float4 *>(src + o2);
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                     for (int k = 0; k < K; ++k) {
                         const uint32_t wd = word[w][k >> 1];
                         const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
-                        vv[w][k] = *reinterpret_cast<const f32x2 *>(lb + a + (w * K + k) * (VT * 4));
+                        vv[w][k] = *reinterpret_cast<const f32x2 *>(lb + a + (w * K + k) * REC);
                     }
 #pragma unroll
                 for (int w = 0; w < W; ++w) apply_pairs<K>(acc, rate, vv[w]);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                             if (k < K) {
                                 const uint32_t wd = word[w][k >> 1];
                                 const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
-                                const float *v = reinterpret_cast<const float *>(lb + a + (w * K + k) * (VT * 4));
+                                const float *v = reinterpret_cast<const float *>(lb + a + (w * K + k) * REC);
                                 if (DW == 1) {
                                     vv[kk][0] = v[0];
                                 } else {
@@ -335,13 +338,84 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                     if (w * K + k < tn) {
                         const uint32_t wd = word[w][k >> 1];
                         const uint32_t a = (k & 1) ? (wd >> 16) : (wd & 0xffffu);
-                        const float *v = reinterpret_cast<const float *>(lb + a + (w * K + k) * (VT * 4));
+                        const float *v = reinterpret_cast<const float *>(lb + a + (w * K + k) * REC);
 #pragma unroll
                         for (int jj = 0; jj < DW; ++jj) p[jj] = fmaf(nlr[jj], v[jj], p[jj]);
                     }
                 }
         };
 
+        // greedy ensembles, phase A: descend this worker's K trees of group g from their node records in LDS (the group's records
+        // must be visible: a barrier separates store_vals from this).  Branch-free: a lane that has reached a leaf keeps it.
+        auto a_descend = [&](int g) __attribute__((always_inline)) {
+            const char *nb = lb + (NB == 2 ? (g & 1) : 0) * group_bytes + (q * K) * REC + VT * 4;
+            int node[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) node[k] = 0;
+#pragma unroll
+            for (int d = 0; d < MAXD; ++d) {
+                int4 rec[K];
+                float xv[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) rec[k] = *reinterpret_cast<const int4 *>(nb + k * REC + max(node[k], 0) * 16);
+#pragma unroll
+                for (int k = 0; k < K; ++k) xv[k] = (!CAT || rec[k].x >= 0) ? x[rec[k].x] : x[F + ((~rec[k].x) >> 1)];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    bool right;
+                    if (!CAT || rec[k].x >= 0) {
+                        right = xv[k] > __int_as_float(rec[k].y);
+                    } else {
+                        const uint32_t w = __float_as_uint(xv[k]);
+                        const uint32_t code = ((~rec[k].x) & 1) ? (w >> 16) : (w & 0xffffu);
+                        right = code == static_cast<uint32_t>(rec[k].y);
+                    }
+                    const int nxt = right ? rec[k].w : rec[k].z;
+                    node[k] = node[k] >= 0 ? nxt : node[k];
+                }
+            }
+            uint32_t off[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < K; ++k) off[k] = static_cast<uint32_t>(~node[k]) * (DW * 4);   // proper trees: every lane is at a leaf now
+            char *ib = lb + idx_base + (g & 1) * idx_par + q * idx_wstride + idx_row;
+            if (NWK == 2) {
+                uint2 w2;
+                w2.x = off[0] | (off[1] << 16);
+                w2.y = K > 3 ? (off[2] | (off[3] << 16)) : off[2];
+                *reinterpret_cast<uint2 *>(ib) = w2;
+            } else {
+                *reinterpret_cast<uint32_t *>(ib) = K > 1 ? (off[0] | (off[1] << 16)) : off[0];
+            }
+        };
+        if constexpr (GREEDY) {
+            // two barriers per group: [b1] the records of g+1 go to LDS, the values of g are applied; [b2] the trees of g+1 are
+            // descended (they read the records just stored)
+            a_descend(0);
+            for (int g = 0; g + 1 < n_groups; ++g) {
+                __syncthreads();
+                uint32_t word[W][NWK];
+                b_words(g, word);
+                if (NB == 2) {
+                    store_vals(g + 1);
+                    load_vals(min(g + 2, n_groups - 1));
+                }
+                b_apply_full(word);
+                if (NB != 2) {
+                    __syncthreads();
+                    store_vals(g + 1);
+                    load_vals(min(g + 2, n_groups - 1));
+                }
+                __syncthreads();
+                a_descend(g + 1);
+            }
+            __syncthreads();
+            const int g = n_groups - 1;
+            uint32_t word[W][NWK];
+            b_words(g, word);
+            const int tn = stop_tree - (start_tree + g * (4 * K));
+            if (tn == 4 * K) b_apply_full(word); else b_apply_partial(word, tn);
+            return;
+        }
         {   // leaves of group 0
             int fi[K][MAXD];
             float tv[K][MAXD], xv[K][MAXD];
@@ -411,10 +485,10 @@ struct Obl2Plan { int RG, TT, NB, xs; size_t lds; };
 // Rows per block (64 * RG), trees per group (TT) and value buffers (NB): as many waves per CU as the LDS allows while a group
 // still holds >= 8 trees; small ensembles take 64-row blocks so that several blocks per CU overlap their tile loads with each
 // other's walks.  The value buffers must lie below 64 KiB (16-bit offsets).
-static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, int trees, Obl2Plan &pl) {
+static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, bool greedy, int trees, Obl2Plan &pl) {
     const int rg_max = DMAX >= 32 ? 2 : 4;   // 8 or 16 accumulators and rates per thread: those widths are compiled for 512-thread blocks
     const size_t budget = 160 * 1024 - 256;
-    const size_t vtb = (static_cast<size_t>(1) << maxd) * DMAX * sizeof(float);
+    const size_t vtb = (static_cast<size_t>(1) << maxd) * (DMAX * sizeof(float) + (greedy ? 16 : 0));   // one tree's record: leaf values (+ nodes)
     pl.xs = (F + (cat ? (Fc + 1) / 2 : 0)) | 1;
     auto lds_for = [&](int rg, int tt, int nb) -> size_t {
         const int nw = tt / kObl2Workers > 2 ? 2 : 1;
@@ -430,14 +504,15 @@ static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, int trees, Ob
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_RG")) rg_env = std::atoi(e);
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_TT")) tt_env = std::atoi(e);
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_NB")) nb_env = std::atoi(e);
-    int best_rg = 0, best_tt = 0, best_nb = 2;
+    int best_rg = 0, best_tt = 0, best_nb = greedy ? 1 : 2;   // greedy descents read the group's node records from LDS: two barriers per
+                                                                // group either way, so one value buffer (and larger groups) is the better trade
     if (rg_env >= 1 && rg_env <= rg_max) {
-        best_rg = rg_env; best_nb = nb_env == 1 ? 1 : 2; best_tt = tt_for(rg_env, best_nb);
+        best_rg = rg_env; best_nb = nb_env == 1 ? 1 : nb_env == 2 ? 2 : best_nb; best_tt = tt_for(rg_env, best_nb);
     } else if (trees <= 48) {
-        for (int rg = 1; rg <= rg_max && best_rg == 0; ++rg) { const int tt = tt_for(rg, 2); if (tt >= 4) { best_rg = rg; best_tt = std::min(tt, 8); } }
+        for (int rg = 1; rg <= rg_max && best_rg == 0; ++rg) { const int tt = tt_for(rg, best_nb); if (tt >= 4) { best_rg = rg; best_tt = std::min(tt, 8); } }
     } else {
-        for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, 2); if (tt >= 8) { best_rg = rg; best_tt = tt; } }
-        for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, 2); if (tt >= 4) { best_rg = rg; best_tt = tt; } }
+        for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, best_nb); if (tt >= 8) { best_rg = rg; best_tt = tt; } }
+        for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, best_nb); if (tt >= 4) { best_rg = rg; best_tt = tt; } }
     }
     if (best_rg == 0 || best_tt < 4) return false;
     if (tt_env >= 4 && tt_env <= best_tt) best_tt = tt_env & ~3;
@@ -448,24 +523,24 @@ static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, int trees, Ob
     return true;
 }
 
-template <int DMAX, int MAXD, bool CAT>
+template <int DMAX, int MAXD, bool CAT, bool GREEDY>
 static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
                         int stop_tree, float *out, hipStream_t s) {
     const int trees = pm.tree_chunk > 0 ? pm.tree_chunk : stop_tree - start_tree;
     Obl2Plan pl;
-    if (!obl2_plan(F, Fc, CAT, MAXD, DMAX, trees, pl)) return false;
+    if (!obl2_plan(F, Fc, CAT, MAXD, DMAX, GREEDY, trees, pl)) return false;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static uint64_t attr_done = 0;   // per device
     if (dev < 64 && !((attr_done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl2<DMAX, MAXD, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl2<DMAX, MAXD, CAT, GREEDY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done |= 1ull << dev;
     }
     Obl2Coef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
     const int R = 64 * pl.RG;
     const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
-    hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT>), dim3((n + R - 1) / R, splits), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
+    hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT, GREEDY>), dim3((n + R - 1) / R, splits), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
                        pm.bias, coef, pm.D, obs, F, cat_codes, Fc, n, start_tree, stop_tree, pm.tree_chunk > 0 ? pm.partial : out, R,
                        pl.TT, pl.NB, pl.xs, pm.tree_chunk);
     return true;
@@ -474,8 +549,11 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
 template <int DMAX, int MAXD>
 static bool launch_obl2_c(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree,
                           int stop_tree, float *out, hipStream_t s) {
-    return Fc > 0 ? launch_obl2<DMAX, MAXD, true>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)
-                  : launch_obl2<DMAX, MAXD, false>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
+    if (pm.oblivious)
+        return Fc > 0 ? launch_obl2<DMAX, MAXD, true, false>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)
+                      : launch_obl2<DMAX, MAXD, false, false>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
+    return Fc > 0 ? launch_obl2<DMAX, MAXD, true, true>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)
+                  : launch_obl2<DMAX, MAXD, false, true>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);
 }
 
 template <int DMAX>
@@ -502,7 +580,8 @@ int obl2_levels(int max_depth) { return max_depth <= 4 ? 4 : max_depth <= 6 ? 6 
 
 bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
                   float *out, hipStream_t s) {
-    if (pm.values_sw == nullptr || pm.cond_ra == nullptr || pm.obl2_maxd == 0) return false;
+    if (pm.values_sw == nullptr || pm.obl2_maxd == 0) return false;
+    if (pm.oblivious && pm.cond_ra == nullptr) return false;
     if (Fc > 0 && (cat_codes == nullptr || pm.cat_dict_size > 65535)) return false;
     switch (obl2_padded_outputs(pm.D)) {
         case 4: return launch_obl2_d<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s);

@@ -7,14 +7,15 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 depth = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+policy = sys.argv[5] if len(sys.argv) > 5 else "oblivious"
 N = 1 << 20
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 X = torch.randn((N, F), device=dev, generator=g)
 G = torch.randn((N, D), device=dev, generator=g)
 m = gbrl_amd.GBRL(input_dim=F, output_dim=D, policy_dim=D, max_depth=depth, min_data_in_leaf=0, n_bins=256, par_th=10, cv_beta=0.9,
-                  split_score_func="L2", generator_type="Quantile", use_control_variates=False, batch_size=5000,
-                  grow_policy="oblivious", verbose=0, device="cuda", learner_name="probe")
+                  split_score_func="L2" if policy == "oblivious" else "Cosine", generator_type="Quantile", use_control_variates=False, batch_size=5000,
+                  grow_policy=policy, verbose=0, device="cuda", learner_name="probe")
 m.set_feature_weights(np.ones(F, np.float32)); m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
 m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
 tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
