@@ -152,7 +152,8 @@ class Engine {
     PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_, pin_thr_, pin_acc_;
     DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
-    DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_;
+    DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_, d_plan_, d_res_all_;
+    PinnedBuf pin_res_all_;
     // ---- predict workspace + device mirror of the ensemble ----
     DevBuf d_pobs_, d_pcat_, d_pout_;
     DevBuf m_tree_indices_, m_depths_, m_feature_indices_, m_feature_values_, m_values_, m_is_numerics_, m_ineq_,

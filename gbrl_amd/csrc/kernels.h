@@ -196,6 +196,29 @@ void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n
 void count_right(const int32_t *rows, const uint16_t *codes, const uint32_t *kt /*nullable: feature-major keys*/, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
                  int64_t *n_right /*[n_nodes], zeroed*/, hipStream_t s);
 
+// ---- device-side level planning (oblivious trees on one GPU) ----
+// All descriptors of tree level L -- node segments, the histogram chunk table of the smaller child of every pair, slot maps for the
+// sibling subtraction, path arrays, partition chunks -- built on the device from the previous level's resolved splits, so that a
+// whole tree is enqueued without a host round trip per level (the host replays the bookkeeping from the per-level result blocks
+// after ONE synchronisation).  Unused entries of the chunk tables (up to cap_h / cap_p) get len 0: the consumers are launched with
+// those worst-case grids and empty chunks exit at once.  state[0] != 0: growth has stopped (fitter.cpp:458), state[1] = level.
+struct ObliviousPlan {
+    int32_t *node_seg, *node_n;            // [max_depth + 1][mf] segment start / row count of the level's nodes
+    int mf;
+    Chunk *chunks; int cap_h;              // histogram chunks of the level
+    int32_t *chunk_begin;                  // [mf + 1]
+    int32_t *slot_map, *sub_par, *sub_sib; // [mf]
+    int32_t *path_len, *path_slot, *path_bin, *is_root;   // [mf] / [mf][kMaxPath]
+    float *path_val;
+    Chunk *part_chunks; int cap_p;         // partition chunks of the level
+    int32_t *seg_starts;                   // [mf]
+    int32_t *state;                        // [2]
+    int32_t *cond_slot, *cond_bin;         // [kMaxPath] the conditions chosen so far (one per level)
+    float *cond_val;
+};
+void plan_oblivious_level(int level, int n_rows, int chunk_rows, int budget, const NodeSplit *resolved_prev, const float *best_score_prev,
+                          const float *thr, int B, const ObliviousPlan &pl, hipStream_t s);
+
 // ---- partition (A9) ----
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, const uint32_t *kt /*nullable*/, int n_rows,
                     const Chunk *chunks, int n_chunks, const NodeSplit *splits, int32_t *cursors /*[n_nodes*2], zeroed*/,

@@ -360,10 +360,11 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const int g = jj % n_groups;
     const int chunk_id = (jj / n_groups) * 8 + xcd;
     if (chunk_id >= n_chunks) return;
+    const Chunk ck = chunks[chunk_id];
+    if (ck.len <= 0) return;   // block-uniform: an unused entry of a device-planned chunk table
     const int n_acc = NB * (D + 1) * FG;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
     __syncthreads();
-    const Chunk ck = chunks[chunk_id];
     const int fl = threadIdx.x & (FG - 1);
     const int slot = threadIdx.x >> fg_shift;
     const int n_slots = kHistThreads >> fg_shift;
@@ -502,10 +503,11 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build_wide(const uint16_t
     const int g = jj % n_groups;
     const int chunk_id = (jj / n_groups) * 8 + xcd;
     if (chunk_id >= n_chunks) return;
+    const Chunk ck = chunks[chunk_id];
+    if (ck.len <= 0) return;   // unused entry of a device-planned chunk table
     const int n_acc = NB * (D + 1) * FG;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
     __syncthreads();
-    const Chunk ck = chunks[chunk_id];
     const int fl = threadIdx.x & 15;
     const int part = fl / FG, f = fl & (FG - 1);
     const int slot = threadIdx.x >> 4;
@@ -579,10 +581,11 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build_quad(const uint16_t
     const int g = jj % n_groups;
     const int chunk_id = (jj / n_groups) * 8 + xcd;
     if (chunk_id >= n_chunks) return;
+    const Chunk ck = chunks[chunk_id];
+    if (ck.len <= 0) return;   // unused entry of a device-planned chunk table
     const int n_acc = NB * (D + 1) * 4;
     for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
     __syncthreads();
-    const Chunk ck = chunks[chunk_id];
     const int f = threadIdx.x & 3;
     const int slot = threadIdx.x >> 2;
     constexpr int n_slots = kHistThreads >> 2;
@@ -978,6 +981,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(const int32_t *__res
                                                             const Chunk *__restrict__ chunks, const NodeSplit *__restrict__ splits,
                                                             int32_t *__restrict__ cursors) {
     const Chunk ck = chunks[blockIdx.x];
+    if (ck.len <= 0) return;    // unused entry of a device-planned chunk table
     const NodeSplit sp = splits[ck.slot];
     if (!sp.do_split) return;   // the node became a leaf (its segment stays in the input list)
     const int lane = threadIdx.x & (kWave - 1);
@@ -1415,6 +1419,159 @@ void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n
 void count_right(const int32_t *rows, const uint16_t *codes, const uint32_t *kt, int n_rows, const Chunk *chunks, int n_chunks,
                  const NodeSplit *splits, int64_t *n_right, hipStream_t s) {
     hipLaunchKernelGGL(k_count_right, dim3(n_chunks), dim3(kPartThreads), 0, s, rows, codes, kt, n_rows, chunks, splits, n_right);
+}
+
+// One block, compact code (no unrolling: a single wave pays every instruction-cache miss itself).  Node counts live in LDS (a dependent chain of global loads costs ~1 us per link: the first, single-threaded version of
+// this kernel took 70 us per level); thread 0 does the short serial parts (chunk length search, prefix sums over <= 1024 nodes), all
+// threads write the tables.
+constexpr int kPlanThreads = 256;
+constexpr int kPlanMaxNodes = 1024;
+__global__ __launch_bounds__(kPlanThreads) void k_plan_oblivious(int L, int n_rows, int chunk_rows, int budget, const NodeSplit *__restrict__ prev,
+                                                                 const float *__restrict__ best_prev, const float *__restrict__ thr, int B, ObliviousPlan pl) {
+    __shared__ int s_seg[kPlanMaxNodes], s_cnt[kPlanMaxNodes], s_small[kPlanMaxNodes / 2 + 1], s_cb[kPlanMaxNodes / 2 + 2], s_pb[kPlanMaxNodes + 1];
+    __shared__ int s_stopped, s_t, s_cslot[kMaxPath], s_cbin[kMaxPath];
+    __shared__ float s_cval[kMaxPath];
+    const int tid = threadIdx.x;
+    const int n_act = 1 << L, n_comp = L == 0 ? 1 : n_act / 2;
+    if (tid == 0) {
+        int stopped = 0;
+        if (L > 0) {
+            stopped = pl.state[0] != 0;
+            if (!stopped && best_prev[0] == -INFINITY) { stopped = 1; pl.state[0] = 1; pl.state[1] = L - 1; }   // no split at level L-1
+        } else {
+            pl.state[0] = 0; pl.state[1] = -1;
+        }
+        s_stopped = stopped;
+    }
+#pragma unroll 1
+    for (int q = tid; q < L - 1; q += kPlanThreads) { s_cslot[q] = pl.cond_slot[q]; s_cbin[q] = pl.cond_bin[q]; s_cval[q] = pl.cond_val[q]; }
+    __syncthreads();
+    const bool stopped = s_stopped != 0;
+    // nodes of this level from the previous level's resolved splits
+    if (L == 0) {
+        if (tid == 0) { s_seg[0] = 0; s_cnt[0] = n_rows; }
+    } else {
+        const int32_t *pseg = pl.node_seg + static_cast<size_t>(L - 1) * pl.mf, *pcnt = pl.node_n + static_cast<size_t>(L - 1) * pl.mf;
+    #pragma unroll 1
+        for (int k = tid; k < n_act / 2; k += kPlanThreads) {
+            const int nl = stopped ? 0 : prev[k].n_left, ps = stopped ? 0 : pseg[k], pc = stopped ? 0 : pcnt[k];
+            s_seg[2 * k] = ps; s_cnt[2 * k] = nl;
+            s_seg[2 * k + 1] = ps + nl; s_cnt[2 * k + 1] = pc - nl;
+        }
+        if (tid == 0 && !stopped) {   // the condition chosen at level L-1 (one per level)
+            const NodeSplit c = prev[0];
+            s_cslot[L - 1] = c.fslot;
+            s_cbin[L - 1] = c.bin;
+            s_cval[L - 1] = c.is_cat ? INFINITY : thr[static_cast<size_t>(c.fslot) * B + c.bin];
+            pl.cond_slot[L - 1] = s_cslot[L - 1]; pl.cond_bin[L - 1] = s_cbin[L - 1]; pl.cond_val[L - 1] = s_cval[L - 1];
+        }
+    }
+    __syncthreads();
+    int32_t *seg = pl.node_seg + static_cast<size_t>(L) * pl.mf, *cnt = pl.node_n + static_cast<size_t>(L) * pl.mf;
+#pragma unroll 1
+    for (int k = tid; k < n_act; k += kPlanThreads) { seg[k] = s_seg[k]; cnt[k] = s_cnt[k]; pl.seg_starts[k] = s_seg[k]; }
+    // the accumulated child of every pair (fewer rows; ties -> the left child); the other one is parent - sibling
+    if (L == 0) {
+        if (tid == 0) { s_small[0] = 0; pl.slot_map[0] = 0; pl.sub_par[0] = -1; pl.sub_sib[0] = -1; }
+    } else {
+    #pragma unroll 1
+        for (int p = tid; p < n_comp; p += kPlanThreads) {
+            const int l = 2 * p, r = 2 * p + 1;
+            const int small = s_cnt[l] <= s_cnt[r] ? l : r, big = small == l ? r : l;
+            s_small[p] = small;
+            pl.slot_map[p] = small;
+            pl.sub_par[small] = -1; pl.sub_sib[small] = -1;
+            pl.sub_par[big] = stopped ? -1 : p; pl.sub_sib[big] = stopped ? -1 : small;
+        }
+    }
+    __syncthreads();
+    // histogram chunks: the smallest chunk length t in [1024, chunk_rows] for which the accumulated nodes need at most `budget` chunks
+    // (chunk_rows when even that is too many), every node in equal parts (the host's balanced_chunk_rows + make_chunks).  Integer
+    // divisions are slow and a serial bisection costs tens of microseconds on one thread: the threads evaluate 256 candidate lengths
+    // at once, twice (coarse grid, then every integer inside the winning interval) -- the same t as the bisection, parts(t) is monotone.
+    auto parts_at = [&](int t) {
+        int q = 0;
+#pragma unroll 1
+        for (int p = 0; p < n_comp; ++p) q += (s_cnt[s_small[p]] + t - 1) / t;
+        return q;
+    };
+    {
+        const int lo = min(1024, chunk_rows), hi = chunk_rows;
+        const int step = max(1, (hi - lo + kPlanThreads - 1) / kPlanThreads);
+        if (tid == 0) s_t = hi;
+        __syncthreads();
+        const int tc = min(hi, lo + tid * step);                 // coarse grid (the last threads repeat hi)
+        if (parts_at(tc) <= budget) atomicMin(&s_t, tc);
+        __syncthreads();
+        const int coarse = s_t;
+        __syncthreads();
+        if (coarse > lo) {                                        // refine inside (coarse - step, coarse]
+            const int tf = coarse - step + 1 + tid;
+            if (tf >= lo && tf < coarse && parts_at(tf) <= budget) atomicMin(&s_t, tf);
+        }
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int p = tid; p < n_comp; p += kPlanThreads) s_cb[p + 1] = (s_cnt[s_small[p]] + s_t - 1) / s_t;
+#pragma unroll 1
+    for (int k = tid; k < n_act; k += kPlanThreads) s_pb[k + 1] = (s_cnt[k] + kPartitionRows - 1) / kPartitionRows;
+    __syncthreads();
+    if (tid == 0) {   // prefixes (additions only)
+        int nc = 0;
+        s_cb[0] = 0;
+    #pragma unroll 1
+        for (int p = 0; p < n_comp; ++p) { nc = min(pl.cap_h, nc + s_cb[p + 1]); s_cb[p + 1] = nc; }
+        int np = 0;
+        s_pb[0] = 0;
+    #pragma unroll 1
+        for (int k = 0; k < n_act; ++k) { np = min(pl.cap_p, np + s_pb[k + 1]); s_pb[k + 1] = np; }
+    }
+    __syncthreads();
+    const int t = s_t;
+#pragma unroll 1
+    for (int p = tid; p <= n_comp; p += kPlanThreads) pl.chunk_begin[p] = s_cb[p];
+    // one thread per chunk ENTRY (a node of 2^20 rows has 256 partition chunks: written by one thread they cost 25 us): the entry's
+    // node is found by bisection on the prefix, its offset follows from its rank inside the node; entries past the end get len 0
+#pragma unroll 1
+    for (int i = tid; i < pl.cap_h; i += kPlanThreads) {
+        Chunk ck{0, 0, 0, 0};
+        if (i < s_cb[n_comp]) {
+            int lo = 0, hi = n_comp - 1;
+#pragma unroll 1
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_cb[mid] <= i) lo = mid; else hi = mid - 1; }
+            const int p = lo, n = s_cnt[s_small[p]], parts = (n + t - 1) / t, each = parts ? (n + parts - 1) / parts : 0;
+            const int off = (i - s_cb[p]) * each;
+            if (off < n) ck = Chunk{p, s_seg[s_small[p]] + off, min(each, n - off), 0};
+        }
+        pl.chunks[i] = ck;
+    }
+#pragma unroll 1
+    for (int i = tid; i < pl.cap_p; i += kPlanThreads) {
+        Chunk ck{0, 0, 0, 0};
+        if (i < s_pb[n_act]) {
+            int lo = 0, hi = n_act - 1;
+#pragma unroll 1
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pb[mid] <= i) lo = mid; else hi = mid - 1; }
+            const int k = lo, n = s_cnt[k], parts = (n + kPartitionRows - 1) / kPartitionRows, each = parts ? (n + parts - 1) / parts : 0;
+            const int off = (i - s_pb[k]) * each;
+            if (off < n) ck = Chunk{k, s_seg[k] + off, min(each, n - off), 0};
+        }
+        pl.part_chunks[i] = ck;
+    }
+    // paths: every node of an oblivious level has the same conditions behind it
+#pragma unroll 1
+    for (int k = tid; k < n_act; k += kPlanThreads) { pl.path_len[k] = stopped ? 0 : L; pl.is_root[k] = L == 0; }
+#pragma unroll 1
+    for (int i = tid; i < n_act * L; i += kPlanThreads) {
+        const int k = i / L, q = i - k * L;
+        pl.path_slot[k * kMaxPath + q] = s_cslot[q];
+        pl.path_val[k * kMaxPath + q] = s_cval[q];
+        pl.path_bin[k * kMaxPath + q] = s_cbin[q];
+    }
+}
+void plan_oblivious_level(int level, int n_rows, int chunk_rows, int budget, const NodeSplit *resolved_prev, const float *best_score_prev,
+                          const float *thr, int B, const ObliviousPlan &pl, hipStream_t s) {
+    hipLaunchKernelGGL(k_plan_oblivious, dim3(1), dim3(kPlanThreads), 0, s, level, n_rows, chunk_rows, budget, resolved_prev, best_score_prev, thr, B, pl);
 }
 
 void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *codes, const uint32_t *kt, int n_rows, const Chunk *chunks,

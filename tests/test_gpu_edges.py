@@ -299,3 +299,29 @@ def test_many_bins_many_features_quantile_selection():
     case = _case("manybins", N=30000, F=130, D=6, depth=3, n_bins=700, policy="greedy", trees=1)
     X, Xc, G, y = K.make_inputs(case)
     _check(case, X, Xc, G)
+
+
+@pytest.mark.parametrize("name", ["obl_l2_q", "obl_cos_u", "obl_l2_q_d6", "obl_l2_q_dups", "obl_cos_u_mdl", "obl_l2_q_cat", "obl_cos_q_cat_rmse", "obl_cos_q_tiny"])
+def test_device_planned_oblivious_tree_equals_the_host_level_loop(name):
+    """Oblivious trees on one GPU can be enqueued whole (GBRL_HIP_DEVICE_LEVELS=1, read once per process, hence the child process):
+    k_plan_oblivious builds every level's descriptors on the device and the host synchronises once per tree.  The default is the
+    level-synchronous host loop; both must produce the same bytes."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import cases as K, gbrl_amd\n"
+        "from helpers import load_golden\n"
+        "case, g, (X, Xc, G, y) = load_golden(%r)\n"
+        "m = gbrl_amd.GBRL(**K.ctor_kwargs(case)); p = K.drive(m, case, X, Xc, G, y); e = m.get_ensemble_data()\n"
+        "np.savez(sys.argv[1], pred=np.asarray(p), **{k: np.asarray(e[k]) for k in K.ENSEMBLE_KEYS})\n"
+    ) % (os.path.join(HERE, "golden"), HERE, name)
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("0", "1"):
+            path = os.path.join(d, "o%s.npz" % mode)
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, GBRL_HIP_DEVICE_LEVELS=mode), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append(dict(np.load(path)))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
