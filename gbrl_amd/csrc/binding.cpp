@@ -386,7 +386,9 @@ py::array_t<float> shap_impl(PyGBRL &self, bool whole_ensemble, int tree_idx, py
     }
     const gbrl_hip_metadata md = self.meta();
     // the reference trusts the caller here and reads out of bounds on a mismatch; this build checks
-    if (md.n_trees > 0 && (n_num != md.n_num_features || n_cat != md.n_cat_features)) fail("Incompatible dimensions");
+    // (also when the ensemble is empty: predict() may already have latched the feature counts, and the library sizes what it writes from them)
+    if ((md.n_trees > 0 || md.n_num_features + md.n_cat_features > 0) && (n_num != md.n_num_features || n_cat != md.n_cat_features))
+        fail("Incompatible dimensions");
     const size_t depth = static_cast<size_t>(md.max_depth);
     auto count = [](const HostArray &a) { size_t k = a.ptr ? 1 : 0; for (py::ssize_t d : a.shape) k *= static_cast<size_t>(d); return k; };
     if (count(nv) < (depth + 1) * depth || count(bp) < depth || count(of) < depth * depth)
@@ -462,6 +464,7 @@ PYBIND11_MODULE(gbrl_cpp, m) {
     });
     g.def("set_feature_mapping", [](PyGBRL &self, const py::array_t<int> &fm, const py::array_t<bool> &mn) {
         if (!(fm.flags() & py::array::c_style) || !(mn.flags() & py::array::c_style)) fail("Arrays must be C-contiguous");
+        if (fm.size() != mn.size()) fail("feature_mapping and mapping_numerics must have the same length");
         check(gbrl_hip_set_feature_mapping(self.h, fm.data(), reinterpret_cast<const uint8_t *>(mn.data()), static_cast<int>(fm.size())));
     });
     g.def("get_bias", [](PyGBRL &self) {

@@ -357,8 +357,8 @@ int gbrl_hip_tree_shap(const gbrl_hip_model *m, int tree_idx, const float *obs, 
     return guarded([&] {
         if (!m || !out || n_samples < 0) throw gbrl::InvalidArgument("null argument");
         const gbrl::Model &md = m->engine.model;
+        gbrl::check_shap_arguments(md, tree_idx, obs, cat_obs, norm_values, base_poly, offset);   // validate BEFORE anything is written
         std::memset(out, 0, sizeof(float) * static_cast<size_t>(n_samples) * (md.meta.n_num_features + md.meta.n_cat_features) * md.meta.output_dim);
-        gbrl::check_shap_arguments(md, tree_idx, obs, cat_obs, norm_values, base_poly, offset);
         // the device evaluates the same recursion with the same roundings (shap.hip); the host copy serves a machine without a GPU
         if (const_cast<gbrl_hip_model *>(m)->engine.shap_on_device(tree_idx, obs, cat_obs, n_samples, norm_values, base_poly, offset, out)) return;
         gbrl::tree_shap(md, tree_idx, obs, cat_obs, n_samples, norm_values, base_poly, offset, out);
@@ -370,8 +370,8 @@ int gbrl_hip_ensemble_shap(const gbrl_hip_model *m, const float *obs, const char
         if (!m || !out || n_samples < 0) throw gbrl::InvalidArgument("null argument");
         const gbrl::Model &md = m->engine.model;
         if (md.meta.n_trees == 0) return;   // nothing to explain; the caller's buffer is sized from its inputs (binding zero-fills)
-        std::memset(out, 0, sizeof(float) * static_cast<size_t>(n_samples) * (md.meta.n_num_features + md.meta.n_cat_features) * md.meta.output_dim);
         gbrl::check_shap_arguments(md, 0, obs, cat_obs, norm_values, base_poly, offset);
+        std::memset(out, 0, sizeof(float) * static_cast<size_t>(n_samples) * (md.meta.n_num_features + md.meta.n_cat_features) * md.meta.output_dim);
         if (const_cast<gbrl_hip_model *>(m)->engine.shap_on_device(-1, obs, cat_obs, n_samples, norm_values, base_poly, offset, out)) return;
         gbrl::ensemble_shap(md, obs, cat_obs, n_samples, norm_values, base_poly, offset, out);
     });

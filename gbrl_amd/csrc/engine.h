@@ -131,6 +131,7 @@ class Engine {
     std::vector<int> fixed_cat_classes_;
     bool fixed_cat_valid_ = false;
     bool candidates_only_ = false;
+    bool in_fit_ = false;   // predict() called from fit(): keep one accumulation chain per row in tree order (no tree-range split)
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
     hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back

@@ -239,6 +239,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (md.output_dim > 128) throw Unsupported("predict: output_dim > 128");
+    if (start_tree < 0 || stop_tree < 0 || (stop_tree != 0 && start_tree > stop_tree) || start_tree > md.n_trees) throw InvalidArgument("invalid tree range");
     ensure_device();
     ev_used_ = 0;
     ev_names_.clear();
@@ -311,7 +312,8 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     }
     // small batches: scratch for up to 64 partial sums per output (tree ranges spread over blocks, kern::predict)
     pm.partial = nullptr; pm.partial_floats = 0; pm.tree_chunk = 0;
-    if (n <= 64 * 256 && stop - start_tree >= 128 && stop - start_tree <= 2048) {
+    // (not inside fit(): its gradients follow the reference's per-row tree-order chain at every batch size)
+    if (!in_fit_ && n <= 64 * 256 && stop - start_tree >= 128 && stop - start_tree <= 2048) {
         pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
         pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
     }

@@ -1403,7 +1403,9 @@ float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         const float *ob = dobs + static_cast<size_t>(start) * F;
         const float *tb = dtar + static_cast<size_t>(start) * D;
         const char *cb = Fc > 0 ? dcat + static_cast<size_t>(start) * Fc * kCat : nullptr;
-        predict(ob, true, cb, true, bn, F, Fc, 0, i, d_preds, true);           // trees [0, i) -- i == 0 means "all" (fitter.cpp:187)
+        in_fit_ = true;
+        try { predict(ob, true, cb, true, bn, F, Fc, 0, i, d_preds, true); } catch (...) { in_fit_ = false; throw; }   // trees [0, i) -- i == 0 means "all" (fitter.cpp:187)
+        in_fit_ = false;
         kern::sub_arrays(d_preds, tb, d_grads, static_cast<size_t>(bn) * D, s);
         step(ob, true, cb, true, d_grads, true, bn, F, Fc);
         start += bn;                                                            // fitter.cpp:228-231

@@ -38,6 +38,16 @@ template <typename T>
 void get_array(std::ifstream &f, std::vector<T> &v, size_t count) {
     uint8_t check = 0;
     get(f, check);
+    if (check == 1) {
+        // the payload must fit into what is left of the file: a corrupt header must not drive a multi-GB allocation
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streampos end = f.tellg();
+        f.seekg(here);
+        if (!f.good() || static_cast<double>(count) * sizeof(T) > static_cast<double>(end - here)) throw std::runtime_error("Reading file error");
+    } else if (static_cast<double>(count) * sizeof(T) > 4e9) {
+        throw std::runtime_error("Reading file error");
+    }
     v.assign(count, T());
     if (check == 1) f.read(reinterpret_cast<char *>(v.data()), count * sizeof(T));
 }
@@ -185,6 +195,25 @@ Model Model::load(const std::string &filename) {
     get_array(f, m.is_numerics, S * md);
     get_array(f, m.inequality_directions, L * md);
     get_array(f, m.categorical_values, S * md * kCat);
+    // The predict kernels index with these arrays: a corrupt or hand-edited file must fail here, not fault on the device.
+    if (md_.n_num_features < 0 || md_.n_cat_features < 0 || md_.n_num_features + md_.n_cat_features > md_.input_dim) throw std::runtime_error("Reading file error");
+    for (size_t t = 0; t < T; ++t) {
+        const int32_t a = m.tree_indices[t], b = t + 1 < T ? m.tree_indices[t + 1] : static_cast<int32_t>(L);
+        if (a < 0 || a > b || b > static_cast<int32_t>(L) || (t == 0 && a != 0)) throw std::runtime_error("Reading file error");
+    }
+    for (size_t r = 0; r < S; ++r) {
+        if (m.depths[r] < 0 || m.depths[r] > static_cast<int32_t>(md)) throw std::runtime_error("Reading file error");
+        for (int32_t d = 0; d < m.depths[r]; ++d) {
+            const int32_t fi = m.feature_indices[r * md + d];
+            const int32_t lim = m.is_numerics[r * md + d] ? md_.n_num_features : md_.n_cat_features;
+            if (fi < 0 || fi >= lim) throw std::runtime_error("Reading file error");
+        }
+    }
+    if (md_.grow_policy == GBRL_HIP_GROW_OBLIVIOUS)
+        for (size_t t = 0; t < T; ++t) {   // an oblivious tree owns 2^depth leaves
+            const int64_t leaves = (t + 1 < T ? m.tree_indices[t + 1] : static_cast<int32_t>(L)) - m.tree_indices[t];
+            if (leaves != (int64_t(1) << m.depths[t])) throw std::runtime_error("Reading file error");
+        }
     int32_t n_opts = 0;
     get(f, n_opts);
     if (!f.good() || n_opts < 0 || n_opts > md_.output_dim) throw std::runtime_error("Optimizer load error");

@@ -232,7 +232,12 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 uint32_t leaf;
-                if constexpr (!CAT) {
+                int any_cat = 0;   // scalar: the sign bit is set when some level of this tree tests a category
+                if constexpr (CAT) {
+#pragma unroll
+                    for (int d = 0; d < MAXD; ++d) any_cat |= fi[k][d];
+                }
+                if (!CAT || any_cat >= 0) {   // uniform: trees of a mixed model that test numeric features only take the one-block path
                     leaf = leaf_of_numeric<MAXD>(xv[k], tv[k]);
                 } else {
                     leaf = 0;

@@ -206,3 +206,40 @@ def test_python_signatures_match_the_reference_class():
             assert [s.split(" -> ")[0] for s in mine[name]] == [s.split(" -> ")[0] for s in sig]
             continue
         assert mine[name] == sig, (name, sig, mine[name])
+
+
+def test_corrupt_model_files_are_refused_not_loaded(tmp_path):
+    """ADVICE r01: Model::load must not hand the predict kernels out-of-range feature indices, leaf offsets or depths, and a
+    corrupt header must not drive a huge allocation: every such file fails with the reference's load error."""
+    import struct
+    case, g, _ = load_golden("obl_l2_q")
+    ref = bytearray(g["model_file"].tobytes())
+    meta_off = 24                                 # serializationHeader
+    def field(name_idx):                          # int32 fields of ensembleMetaData, types.h:218-242
+        return meta_off + 4 * name_idx
+    def write(path, data):
+        open(path, "wb").write(bytes(data))
+        return str(path)
+    ok = write(tmp_path / "ok.gbrl_model", ref)
+    assert gbrl_amd.GBRL.load(ok).get_num_trees() == int(g["n_trees"])
+    bad = bytearray(ref); struct.pack_into("<i", bad, field(0), 1 << 30)          # n_leaves: payloads larger than the file
+    with pytest.raises(RuntimeError):
+        gbrl_amd.GBRL.load(write(tmp_path / "b1.gbrl_model", bad))
+    bad = bytearray(ref); struct.pack_into("<i", bad, field(9), 31)               # max_depth beyond the supported range
+    with pytest.raises(RuntimeError):
+        gbrl_amd.GBRL.load(write(tmp_path / "b2.gbrl_model", bad))
+    # a feature index beyond n_num_features: locate the feature_indices record (all values < input_dim in the good file)
+    m = gbrl_amd.GBRL.load(ok)
+    fi = np.asarray(m.get_ensemble_data()["feature_indices"], np.int32)
+    pat = fi.tobytes()
+    pos = bytes(ref).find(pat)
+    assert pos > 0
+    bad = bytearray(ref); struct.pack_into("<i", bad, pos, 10 ** 6)
+    with pytest.raises(RuntimeError):
+        gbrl_amd.GBRL.load(write(tmp_path / "b3.gbrl_model", bad))
+    ti = np.asarray(m.get_ensemble_data()["tree_indices"], np.int32)
+    pos = bytes(ref).find(ti.tobytes())
+    assert pos > 0
+    bad = bytearray(ref); struct.pack_into("<i", bad, pos + 4, -5)                # second tree starts at a negative leaf
+    with pytest.raises(RuntimeError):
+        gbrl_amd.GBRL.load(write(tmp_path / "b4.gbrl_model", bad))
