@@ -120,6 +120,10 @@ class Engine {
     void *rccl_comm_ = nullptr;          // non-null: the exchanges below are RCCL calls on stream_
     enum class Red { SumI64, SumF64, MaxF32, MinF32 };
     void exchange(Red op, void *dev_buf, size_t count);   // all-reduce in place; stream-ordered (RCCL) or host-synchronous (hooks)
+    // recv[0 .. count) = sum over ranks of their send[rank * count .. (rank + 1) * count)  (int64).  RCCL: ncclReduceScatter on the
+    // stream (half the bytes of an all-reduce over the xGMI ring); hooks: all-reduce of the whole send buffer, then the own slice.
+    void reduce_scatter_i64(int64_t *send, int64_t *recv, size_t count);
+    size_t exch_bytes_ = 0, exch_calls_ = 0;   // bytes this rank hands to the transport per step() (diagnostic, reported as phases)
     static int radix_exchange_trampoline(void *self, int64_t *dev_buf, size_t count);
 
     // measurement
@@ -151,7 +155,7 @@ class Engine {
     DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
     DevBuf d_hist_prev_, d_slotmap_, d_am_v_, d_am_i_, d_stage_const_, d_stage_a_, d_stage_b_, d_results_;
     PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_, pin_thr_, pin_acc_;
-    DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
+    DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_hist_recv_, d_gather_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
     DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_, d_plan_, d_res_all_;
     PinnedBuf pin_res_all_;

@@ -149,7 +149,24 @@ void Engine::set_rccl(const void *id128, int world_size, int rank) {
 
 // One exchange point: in-place all-reduce of a device buffer.  With an RCCL communicator the call is enqueued on the engine's
 // stream and the host does not wait; with caller-provided hooks the stream is drained first (the hook's contract).
+void Engine::reduce_scatter_i64(int64_t *send, int64_t *recv, size_t count) {
+    const int P = coll_.world_size, r = coll_.rank;
+    ++exch_calls_;
+    if (rccl_comm_ && rccl_api().ReduceScatter) {
+        exch_bytes_ += count * sizeof(int64_t) * static_cast<size_t>(P) / 2;   // a reduce-scatter moves half of what the all-reduce of its send buffer moves
+        const int rc = rccl_api().ReduceScatter(send, recv, count, RcclApi::kInt64, RcclApi::kSum, rccl_comm_, stream_);
+        if (rc != 0) throw HipError(std::string("ncclReduceScatter failed: ") + (rccl_api().GetErrorString ? rccl_api().GetErrorString(rc) : "?"));
+        return;
+    }
+    --exch_calls_;
+    exch_bytes_ -= count * sizeof(int64_t) * static_cast<size_t>(P) / 2;   // hooks: counted as the reduce-scatter it stands for
+    exchange(Red::SumI64, send, count * static_cast<size_t>(P));
+    hip_check(hipMemcpyAsync(recv, send + static_cast<size_t>(r) * count, count * sizeof(int64_t), hipMemcpyDeviceToDevice, stream_), "D2D own slice");
+}
+
 void Engine::exchange(Red op, void *dev_buf, size_t count) {
+    ++exch_calls_;
+    exch_bytes_ += count * (op == Red::MaxF32 || op == Red::MinF32 ? 4 : 8);      // all-reduce payload
     if (rccl_comm_) {
         const RcclApi &api = rccl_api();
         int dt = RcclApi::kInt64, ro = RcclApi::kSum;
@@ -227,5 +244,9 @@ void Engine::phases_resolve() {
     }
     ev_used_ = 0;
     ev_names_.clear();
+    if (has_coll_) {   // not times: what this call handed to the transport (all-reduce payload; a reduce-scatter counts half its send buffer)
+        phases_.emplace_back("exchange_payload_mb", static_cast<float>(exch_bytes_ / 1e6));
+        phases_.emplace_back("exchange_calls", static_cast<float>(exch_calls_));
+    }
 }
 }  // namespace gbrl

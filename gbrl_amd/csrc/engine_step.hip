@@ -612,7 +612,18 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
     int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems)),
                               static_cast<int64_t *>(d_hist_prev_.ensure(sizeof(int64_t) * max_front * hist_node_elems))};
-    int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * hist_node_elems)) : nullptr;
+    // Row-sharded runs exchange the level histograms by FEATURE: the local sums of the accumulated nodes are laid out
+    // [owner rank][node][feature of the rank's slice] and reduce-scattered, so every rank receives the GLOBAL sums of its own
+    // Fs = ceil(Fp / P) features only (half the bytes of an all-reduce on the xGMI ring), scores its own candidates, and the
+    // level's winner is agreed with ONE small all-reduce (kern::winner_pack / winner_adopt).
+    const int coll_P = has_coll_ ? std::max(1, coll_.world_size) : 1;
+    const int coll_Fs = (Fp + coll_P - 1) / coll_P;                          // features per rank slice
+    const int coll_lo = has_coll_ ? coll_.rank * coll_Fs : 0;                // first feature (= feature slot) of this rank
+    const int own_slots = has_coll_ ? std::max(0, std::min(n_slots, coll_lo + coll_Fs) - coll_lo) : n_slots;
+    const size_t feat_elems = static_cast<size_t>(NB) * (D + 1);
+    int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_P) * coll_Fs * feat_elems)) : nullptr;
+    int64_t *d_hist_recv = has_coll_ ? static_cast<int64_t *>(d_hist_recv_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_Fs) * feat_elems)) : nullptr;
+    int64_t *d_gather = has_coll_ ? static_cast<int64_t *>(d_gather_.ensure(sizeof(int64_t) * static_cast<size_t>(coll_P) * 3 * max_front)) : nullptr;
     float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
     float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
     const int am_parts = kern::argmax_parts(std::max(1, n_cand));
@@ -956,26 +967,39 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s,
                                   static_cast<int>(h_chunks.size() / compute_ids.size()));
         } else if (!compute_ids.empty()) {
-            // local sums of the computed nodes, contiguous -> ONE all-reduce -> placed into their level slots
+            // local sums of the computed nodes in the feature-scattered send layout -> ONE reduce-scatter -> this rank's feature
+            // slice of the global sums goes to the nodes' level slots (the other features of d_hist are never read on this rank)
             const int nc = static_cast<int>(compute_ids.size());
-            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s, static_cast<int>(h_chunks.size() / nc));
-            exchange(Red::SumI64, d_hist_coll, static_cast<size_t>(nc) * hist_node_elems);
-            kern::hist_place(d_hist_coll, d_hist, d_slotmap, nc, hist_node_elems, s);
+            if (coll_P * coll_Fs != Fp) hip_check(hipMemsetAsync(d_hist_coll, 0, sizeof(int64_t) * static_cast<size_t>(coll_P) * nc * coll_Fs * feat_elems, s), "memset");
+            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s, static_cast<int>(h_chunks.size() / nc), coll_Fs);
+            reduce_scatter_i64(d_hist_coll, d_hist_recv, static_cast<size_t>(nc) * coll_Fs * feat_elems);
+            kern::hist_place_slice(d_hist_recv, d_hist, d_slotmap, nc, coll_Fs, coll_lo, Fp, feat_elems, s);
         }
         phase_end("hist_reduce");
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
-        kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, n_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
-                               d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
-                               oblivious ? nullptr : d_am_v, d_am_i, s);
+        // (row-sharded: this rank scores its own feature slots only; candidates of the other ranks stay at -inf)
+        if (has_coll_ && oblivious) kern::fill_f32(d_scores, static_cast<size_t>(n_act) * n_cand, -INFINITY, s);
+        if (own_slots > 0)
+            kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
+                                   d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
+                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0);
         // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
         // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
         if (oblivious)
             kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
-        kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : n_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+        kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
                              d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s);
         if (has_coll_) {
+            // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
+            const int n_win = oblivious ? 1 : n_act;
+            const size_t gwords = static_cast<size_t>(coll_P) * (n_win + 2 * n_act);
+            hip_check(hipMemsetAsync(d_gather, 0, sizeof(int64_t) * gwords, s), "memset");
+            kern::winner_pack(d_best_idx, d_best_score, d_counts4, max_front, n_win, n_act, coll_.rank, d_gather, s);
+            exchange(Red::SumI64, d_gather, gwords);
+            kern::winner_adopt(d_gather, coll_P, n_win, n_act, oblivious, d_ref_to_internal, d_cand_slot, d_slots, d_seg_starts, c.d_thrkeys, B, d_best_idx, d_best_score,
+                               d_counts4, max_front, d_resolved, d_cursors, s);
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
             hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
             if (!count_chunks.empty())
@@ -1066,6 +1090,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ensure_device();
     ev_used_ = 0;
     ev_names_.clear();
+    exch_bytes_ = 0;
+    exch_calls_ = 0;
     if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
     if (const char *e = std::getenv("GBRL_HIP_HOST_CATEGORICAL")) force_host_categorical_ = e[0] == '1';   // test hook: host scan of every cell
     if (const char *e = std::getenv("GBRL_HIP_QUANTILE_RADIX")) force_radix_ = e[0] == '1';   // test hook: radix multi-select also for small batches

@@ -161,7 +161,23 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
 // hist[slot_map ? slot_map[k] : k] = sum of the partials of chunk-slot k
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
                  int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s,
-                 int chunks_per_slot = 1 /* average chunks per node: picks the kernel variant */);
+                 int chunks_per_slot = 1 /* average chunks per node: picks the kernel variant */,
+                 int scatter_fs = 0 /* > 0: write the feature-scattered send layout [f / fs][n_slots][f % fs][class][D+1] of a
+                                       reduce-scatter over feature slices of fs features instead of hist[slot][Fp][class][D+1] */);
+// Row-sharded runs, feature-parallel scoring: the reduce-scattered slice [n][fs][class][D+1] of this rank's features goes to its
+// place hist[slot_map[k]][lo + f][class][D+1] (f < min(fs, Fp - lo))
+void hist_place_slice(const int64_t *recv, int64_t *hist, const int32_t *slot_map, int n, int fs, int lo, int Fp, size_t feat_elems, hipStream_t s);
+void fill_f32(float *p, size_t n, float v, hipStream_t s);
+// Winner of a level across ranks with ONE small sum all-reduce: every rank fills its own row of gather[P][n_win + 2 * n_act]
+// (order-preserving key of (local best score, lowest reference index) per winner slot; total | right row counts of ITS best
+// candidate per node) -- the other rows stay zero, so the sum is an all-gather -- and winner_adopt picks the highest key (ties:
+// lowest index, the order of the single-GPU arg-max) and rebuilds best_idx / best_score / counts4 / the NodeSplit descriptors from
+// the owning rank's counts.  n_win = 1 (oblivious: one condition per level) or n_act (greedy).
+void winner_pack(const int32_t *best_idx, const float *best_score, const int64_t *counts4, int max_front, int n_win, int n_act, int rank,
+                 int64_t *gather /*[P][n_win + 2 * n_act], zeroed*/, hipStream_t s);
+void winner_adopt(const int64_t *gather, int P, int n_win, int n_act, bool oblivious, const int32_t *ref_to_internal, const int32_t *cand_slot,
+                  const FeatureSlot *slots, const int32_t *seg_start, const uint32_t *thr_keys, int B, int32_t *best_idx, float *best_score,
+                  int64_t *counts4, int max_front, NodeSplit *out, int32_t *cursors, hipStream_t s);
 // cur[dst] = prev[parent] - cur[sibling]  (entries: triples {dst, parent, sibling or -1})
 
 // ---- scoring / selection (A6, A7, A8) ----
@@ -173,7 +189,7 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/,
                       const float *cand_w, const int32_t *cand_ref, const int32_t *is_root,
                       float *part_v /*nullable.  greedy: [n_nodes][n_slots] best gain per feature -- arg-max stage 1 fused, scores not written*/,
-                      int32_t *part_i, hipStream_t s);
+                      int32_t *part_i, hipStream_t s, int slot0 = 0 /* first feature slot scored (n_slots of them): feature-parallel scoring */);
 // best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
 // result (sum over nodes); greedy: one per node.  part_v/part_i: scratch of n_nodes * argmax_parts(n_cand).
 int argmax_parts(int n_cand);

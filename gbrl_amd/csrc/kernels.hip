@@ -631,7 +631,7 @@ template <int kReduceLanes>
 __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_t *__restrict__ partials,
                                                                      const int32_t *__restrict__ slot_chunk_begin,
                                                                      const int32_t *__restrict__ slot_map, int n_groups, int FG, int NB,
-                                                                     int D, int Fp, int64_t *__restrict__ hist) {
+                                                                     int D, int Fp, int64_t *__restrict__ hist, int scatter_fs) {
     __shared__ int64_t part[kReduceLanes > 1 ? kReduceLanes - 1 : 1][256];
     const int n_acc = NB * (D + 1) * FG;
     const int k = blockIdx.z, g = blockIdx.y;
@@ -659,7 +659,75 @@ __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_
     }
     if (i >= n_acc) return;
     const int fl = i % FG, d = (i / FG) % (D + 1), cls = i / (FG * (D + 1));
-    hist[((static_cast<size_t>(slot) * Fp + g * FG + fl) * NB + cls) * (D + 1) + d] = s;
+    const int f = g * FG + fl;
+    if (scatter_fs > 0) {   // send layout of the feature reduce-scatter: [owner rank][node k][feature inside the slice][class][D+1]
+        if (f < Fp) hist[(((static_cast<size_t>(f / scatter_fs) * gridDim.z + k) * scatter_fs + f % scatter_fs) * NB + cls) * (D + 1) + d] = s;
+        return;
+    }
+    hist[((static_cast<size_t>(slot) * Fp + f) * NB + cls) * (D + 1) + d] = s;
+}
+
+__global__ void k_hist_place_slice(const int64_t *__restrict__ recv, int64_t *__restrict__ hist, const int32_t *__restrict__ slot_map, int fs,
+                                   int lo, int Fp, size_t feat_elems) {
+    const int k = blockIdx.z, f = blockIdx.y;
+    if (lo + f >= Fp) return;
+    const int64_t *src = recv + (static_cast<size_t>(k) * fs + f) * feat_elems;
+    int64_t *dst = hist + (static_cast<size_t>(slot_map[k]) * Fp + lo + f) * feat_elems;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < feat_elems; i += static_cast<size_t>(gridDim.x) * blockDim.x) dst[i] = src[i];
+}
+__global__ void k_fill_f32(float *__restrict__ p, size_t n, float v) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// see kernels.h: winner_pack / winner_adopt
+__global__ void k_winner_pack(const int32_t *__restrict__ best_idx, const float *__restrict__ best_score, const int64_t *__restrict__ counts4,
+                              int max_front, int n_win, int n_act, int rank, int64_t *__restrict__ gather) {
+    int64_t *row = gather + static_cast<size_t>(rank) * (n_win + 2 * n_act);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_win) {
+        const uint64_t key = (static_cast<uint64_t>(float_to_key(best_score[t])) << 32) | (0xffffffffu - static_cast<uint32_t>(best_idx[t]));
+        row[t] = static_cast<int64_t>(key);
+    }
+    if (t < n_act) {
+        row[n_win + 2 * t] = counts4[t];                                           // total rows of node t (global histogram)
+        row[n_win + 2 * t + 1] = counts4[static_cast<size_t>(max_front) + t];      // rows right of this rank's best candidate
+    }
+}
+__global__ void k_winner_adopt(const int64_t *__restrict__ gather, int P, int n_win, int n_act, int oblivious,
+                               const int32_t *__restrict__ ref_to_internal, const int32_t *__restrict__ cand_slot, const FeatureSlot *__restrict__ slots,
+                               const int32_t *__restrict__ seg_start, const uint32_t *__restrict__ thr_keys, int B, int32_t *__restrict__ best_idx,
+                               float *__restrict__ best_score, int64_t *__restrict__ counts4, int max_front, NodeSplit *__restrict__ out,
+                               int32_t *__restrict__ cursors) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_act) return;
+    const int w = oblivious ? 0 : k;
+    const size_t stride = static_cast<size_t>(n_win) + 2 * n_act;
+    uint64_t best_key = 0;
+    int owner = 0;
+    for (int r = 0; r < P; ++r) {
+        const uint64_t key = static_cast<uint64_t>(gather[r * stride + w]);
+        if (r == 0 || key > best_key) { best_key = key; owner = r; }
+    }
+    const float score = key_to_float(static_cast<uint32_t>(best_key >> 32));
+    const int idx = static_cast<int>(0xffffffffu - static_cast<uint32_t>(best_key & 0xffffffffu));
+    const long long tot = gather[owner * stride + n_win + 2 * k], right = gather[owner * stride + n_win + 2 * k + 1];
+    if (k == w || !oblivious) { best_idx[w] = idx; best_score[w] = score; }
+    counts4[k] = tot;
+    counts4[static_cast<size_t>(max_front) + k] = right;
+    const int j = ref_to_internal[idx];
+    const int fs = cand_slot[j];
+    const FeatureSlot sl = slots[fs];
+    NodeSplit q{};
+    q.fslot = fs;
+    q.bin = sl.is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
+    q.is_cat = sl.is_cat;
+    q.thr_key = (!sl.is_cat && thr_keys) ? thr_keys[static_cast<size_t>(fs) * B + q.bin] : 0u;
+    q.do_split = oblivious ? (score != -INFINITY) : (score >= 0.0f);
+    q.seg_start = seg_start[k];
+    q.n_left = static_cast<int>(tot - right);   // global; k_localize_splits replaces it by this rank's
+    cursors[2 * k] = 0;
+    cursors[2 * k + 1] = 0;
+    out[k] = q;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -708,10 +776,10 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
                                                const float *__restrict__ path_val, const int32_t *__restrict__ path_bin,
                                                float *__restrict__ scores, float *__restrict__ parent,
                                                const float *__restrict__ cand_w, const int32_t *__restrict__ cand_ref,
-                                               const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i) {
+                                               const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i, int slot0) {
     extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
     const double inv_scale = scp->inv_scale;
-    const int node = blockIdx.y, fs = blockIdx.x;
+    const int node = blockIdx.y, fs = slot0 + blockIdx.x;
     const FeatureSlot sl = slots[fs];
     const int W = D + 1;
     int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
@@ -783,11 +851,11 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     // parent score of the node (greedy growth): the totals are the same integers for every feature of the node, so every block
     // derives the identical float
     float par_score = 0.0f;
-    if (fs == 0 || part_v) {   // oblivious growth needs it from one block only
+    if (blockIdx.x == 0 || part_v) {   // oblivious growth needs it from one block only
         const double x = side_term(total, D, n_tot, inv_scale);
         par_score = static_cast<float>(cosine ? sqrt(x) : x);
     }
-    if (fs == 0 && threadIdx.x == 0) parent[node] = par_score;
+    if (blockIdx.x == 0 && threadIdx.x == 0) parent[node] = par_score;
     // greedy growth (part_v != null): the block also reduces its candidates to one best (gain, reference index) -- stage 1 of the
     // arg-max, fused here so that a greedy level needs no separate arg-max launch (fitter.cpp:318-354: gain = fma(score, w, -parent),
     // root parent = 0, lowest reference index among maxima)
@@ -858,8 +926,8 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         if (threadIdx.x == 0) {
             Best b{bv[0], bi[0]};
             for (int q = 1; q < 4; ++q) b = better(b, Best{bv[q], bi[q]});
-            part_v[static_cast<size_t>(node) * gridDim.x + fs] = b.v;
-            part_i[static_cast<size_t>(node) * gridDim.x + fs] = b.i;
+            part_v[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.v;
+            part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.i;
         }
     }
 }
@@ -1352,13 +1420,31 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
 }
 
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,
-                 int NB, int D, int Fp, int64_t *hist, hipStream_t s, int chunks_per_slot) {
+                 int NB, int D, int Fp, int64_t *hist, hipStream_t s, int chunks_per_slot, int scatter_fs) {
     const int n_acc = NB * (D + 1) * FG;
     dim3 grid((n_acc + 255) / 256, n_groups, n_slots);
     if (chunks_per_slot >= 48)
-        hipLaunchKernelGGL(k_hist_reduce<4>, grid, dim3(256, 4), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
+        hipLaunchKernelGGL(k_hist_reduce<4>, grid, dim3(256, 4), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist, scatter_fs);
     else
-        hipLaunchKernelGGL(k_hist_reduce<1>, grid, dim3(256, 1), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist);
+        hipLaunchKernelGGL(k_hist_reduce<1>, grid, dim3(256, 1), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist, scatter_fs);
+}
+void hist_place_slice(const int64_t *recv, int64_t *hist, const int32_t *slot_map, int n, int fs, int lo, int Fp, size_t feat_elems, hipStream_t s) {
+    if (n <= 0 || fs <= 0) return;
+    hipLaunchKernelGGL(k_hist_place_slice, dim3(static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(8, (feat_elems + 255) / 256))), fs, n), dim3(256), 0, s, recv, hist,
+                       slot_map, fs, lo, Fp, feat_elems);
+}
+void fill_f32(float *p, size_t n, float v, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fill_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+void winner_pack(const int32_t *best_idx, const float *best_score, const int64_t *counts4, int max_front, int n_win, int n_act, int rank,
+                 int64_t *gather, hipStream_t s) {
+    hipLaunchKernelGGL(k_winner_pack, dim3((n_act + 63) / 64), dim3(64), 0, s, best_idx, best_score, counts4, max_front, n_win, n_act, rank, gather);
+}
+void winner_adopt(const int64_t *gather, int P, int n_win, int n_act, bool oblivious, const int32_t *ref_to_internal, const int32_t *cand_slot,
+                  const FeatureSlot *slots, const int32_t *seg_start, const uint32_t *thr_keys, int B, int32_t *best_idx, float *best_score,
+                  int64_t *counts4, int max_front, NodeSplit *out, int32_t *cursors, hipStream_t s) {
+    hipLaunchKernelGGL(k_winner_adopt, dim3((n_act + 63) / 64), dim3(64), 0, s, gather, P, n_win, n_act, oblivious ? 1 : 0, ref_to_internal, cand_slot,
+                       slots, seg_start, thr_keys, B, best_idx, best_score, counts4, max_front, out, cursors);
 }
 
 void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *sub_par, const int32_t *sub_sib, int n_nodes, int Fp, int NB,
@@ -1366,14 +1452,14 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
-                      int32_t *part_i, hipStream_t s) {
+                      int32_t *part_i, hipStream_t s, int slot0) {
     const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
-                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i);
+                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i, slot0);
 }
 
 int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }

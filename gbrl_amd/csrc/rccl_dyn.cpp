@@ -22,6 +22,7 @@ const RcclApi &rccl_api() {
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(lib, "ncclReduceScatter"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
         a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy;

@@ -8,7 +8,7 @@
 namespace gbrl {
 
 struct RcclApi {
-    // mirrors of the RCCL declarations used (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllReduce, ncclCommDestroy)
+    // mirrors of the RCCL declarations used (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllReduce, ncclReduceScatter, ncclCommDestroy)
     struct UniqueId { char internal[128]; };
     using Comm = void *;
     enum DataType { kInt64 = 4, kFloat32 = 7, kFloat64 = 8 };
@@ -16,6 +16,7 @@ struct RcclApi {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void *, void *, size_t /*recv count*/, int, int, Comm, hipStream_t) = nullptr;   // optional
     int (*CommDestroy)(Comm) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;

@@ -221,10 +221,22 @@ def test_histogram_kernel_variants_agree_with_the_oracle(D, n_bins, policy):
         _check(case, X, Xc, G)
     except AssertionError:
         # with this many outputs the reference's float32 score sums leave near-ties between candidates (tests/neartie.py: the two
-        # candidates' exact scores differ by less than the float32 noise of the sums); anything else is a real mismatch
+        # candidates' exact scores differ by less than the float32 noise of the sums); anything else is a real mismatch.  The
+        # excuses are counted: test_histogram_variant_near_ties_stay_rare bounds them, so a growing near-tie rate fails the suite.
         m, r, _, _ = _both(case, X, Xc, G)
         info = neartie.explain_first_mismatch(case, X, Xc, G, r.get_ensemble_data(), m.get_ensemble_data())
-        assert info and info.get("explained"), info
+        print("NEAR-TIE in variant D=%d n_bins=%d %s: %s" % (D, n_bins, policy, info))
+        _NEAR_TIES.append((D, n_bins, policy))
+        assert info and info.get("explained") and info.get("product_is_true_max"), info
+
+
+_NEAR_TIES = []
+
+
+def test_histogram_variant_near_ties_stay_rare():
+    """Runs after the 13 variants above (file order): at most 2 of them may have needed the near-tie explanation (round 1 and 2: 0-1)."""
+    print("histogram variants that needed the near-tie explanation:", _NEAR_TIES)
+    assert len(_NEAR_TIES) <= 2, _NEAR_TIES
 
 
 def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
