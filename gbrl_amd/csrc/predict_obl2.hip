@@ -440,6 +440,8 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                 store_vals(g + 1);
                 load_vals(min(g + 2, n_groups - 1));
             }
+            // (measured: letting odd row groups apply first and search afterwards, so that the waves do not issue the same burst at the
+            // same time behind the barrier, changes nothing: 2.10 vs 2.06 ms per 1024 trees)
             a_reads(fi, xv);
             a_finish(g + 1, fi, tv, xv);
             b_apply_full(word);

@@ -28,7 +28,7 @@ print("grew %d trees in %.1f s" % (T, time.time() - t0), flush=True)
 m.set_profiling(1)
 
 def run(stop, env):
-    for k in ("GBRL_HIP_PREDICT_OBL1", "GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT", "GBRL_HIP_PREDICT_NB"):
+    for k in ("GBRL_HIP_PREDICT_OBL1", "GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT", "GBRL_HIP_PREDICT_NB", "GBRL_HIP_PREDICT_STAGGER"):
         os.environ.pop(k, None)
     os.environ.update(env)
     p = torch.from_dlpack(m.predict(tup(X), None, 0, stop)); torch.cuda.synchronize()
