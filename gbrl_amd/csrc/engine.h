@@ -158,7 +158,9 @@ class Engine {
     DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_hist_recv_, d_gather_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
     DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_, d_plan_, d_res_all_;
-    PinnedBuf pin_res_all_;
+    PinnedBuf pin_res_all_, pin_cum_;
+    long long cum_cache_n_ = -1;   // (global rows, n_bins) the device copy of the quantile target ranks was built for
+    int cum_cache_b_ = -1;
     // ---- predict workspace + device mirror of the ensemble ----
     DevBuf d_pobs_, d_pcat_, d_pout_;
     DevBuf m_tree_indices_, m_depths_, m_feature_indices_, m_feature_values_, m_values_, m_is_numerics_, m_ineq_,

@@ -404,10 +404,24 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
     const gbrl_hip_metadata &md = model.meta;
     uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
     bool fast_quantile = false;
+    // The target ranks depend on (global row count, n_bins) only: uploaded when they change (an RL loop calls step() with the same
+    // batch size over and over; the upload from pageable memory costs ~70 us of host time per call), through pinned memory.
+    auto upload_cum = [&](const std::vector<int64_t> &cum) -> int64_t * {
+        const bool grown = d_cum_.capacity() < sizeof(int64_t) * static_cast<size_t>(B);
+        int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+        if (grown || cum_cache_n_ != n_global || cum_cache_b_ != B) {
+            int64_t *h = static_cast<int64_t *>(pin_cum_.ensure(sizeof(int64_t) * B));
+            std::memcpy(h, cum.data(), sizeof(int64_t) * B);
+            hip_check(hipMemcpyAsync(d_cum, h, sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+            hip_check(hipStreamSynchronize(s), "sync cum");   // the pinned block may be rewritten by the next call
+            cum_cache_n_ = n_global;
+            cum_cache_b_ = B;
+        }
+        return d_cum;
+    };
     auto bisection_quantiles = [&](const std::vector<int64_t> &cum) {
         // exact but slow: 32 counting passes (also the multi-GPU path: only integer counts cross ranks)
-        int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
-        hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+        int64_t *d_cum = upload_cum(cum);
         uint32_t *d_prefix = static_cast<uint32_t *>(d_prefix_.ensure(sizeof(uint32_t) * F * B));
         uint32_t *d_trial = static_cast<uint32_t *>(d_trial_.ensure(sizeof(uint32_t) * F * B));
         int64_t *d_counts = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * F * (B + 1)));
@@ -457,15 +471,13 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 bisection_quantiles(cum);
             } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && N <= kern::sort_quantiles_max_rows()) {
                 // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
-                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
-                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                int64_t *d_cum = upload_cum(cum);
                 kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, s);
                 last_quantile_fallback_ = false;
             } else if (!force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32)) {
                 // exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip).  Row-sharded
                 // runs sum the digit counts of every pass over ranks (any world size): 4 all-reduces per step.
-                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
-                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                int64_t *d_cum = upload_cum(cum);
                 void *d_rs = d_radix_state_.ensure(kern::radix_state_bytes(F, B));
                 uint32_t *d_rp = static_cast<uint32_t *>(d_radix_partial_.ensure(kern::radix_partial_bytes(F)));
                 uint32_t *d_rl = static_cast<uint32_t *>(d_qlists_.ensure(kern::radix_list_bytes(N, F)));
@@ -487,8 +499,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 // (<= 256 targets, 1024 classes); with more targets nearly every class holds one, so the lists can be the whole data
                 const size_t all_keys = static_cast<size_t>(N) * F;
                 const uint32_t max_elems = static_cast<uint32_t>(B > 256 ? all_keys : std::min<size_t>(all_keys, std::max<size_t>(1u << 20, all_keys / 4)));
-                int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
-                hip_check(hipMemcpyAsync(d_cum, cum.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+                int64_t *d_cum = upload_cum(cum);
                 uint32_t *d_split = static_cast<uint32_t *>(d_splitters_.ensure(sizeof(uint32_t) * 2 * static_cast<size_t>(F) * kern::kQuantileMaxSplit));
                 uint32_t *d_split_bfs = d_split + static_cast<size_t>(F) * kern::kQuantileMaxSplit;
                 uint32_t *d_cc = static_cast<uint32_t *>(d_ccounts_.ensure(sizeof(uint32_t) * static_cast<size_t>(plan.n_chunks) * F * kern::kQuantileClasses));

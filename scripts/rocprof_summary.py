@@ -1,7 +1,9 @@
 """Turn a rocprofv3 results .db (ROCm 7.2 default output) into a small text summary for profiles/.
-    python scripts/rocprof_summary.py gpurun_out/prof_x profiles/r01_x.txt ["title"]
-Kernel table = the `top_kernels` view of the rocpd schema (same numbers as `--stats`), with long names shortened;
-PMC counters (if the run used --pmc) are summed per kernel from `pmc_events`."""
+    python scripts/rocprof_summary.py <rocprof-output-dir> profiles/r02_x.txt ["title"]
+Kernel table = the `top_kernels` view of the rocpd schema (same numbers as `--stats`), with long names shortened.  Below it the
+dispatches of k_hist_build are broken down by grid size: a default bench.py run contains the benchmark's 2^20-row launches AND the
+small launches of the predict_cfg5 leg (10 000 trees grown on 4096-row minibatches) under the same kernel name; the roofline figure in
+bench.py's JSON line is the benchmark-shape group."""
 import glob, os, re, sqlite3, sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -21,17 +23,15 @@ for db in dbs:
     out.append("%-60s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for n, c, t, a, p in rows:
         if p < 0.01: continue
-        out.append("%-60s %8d %14.1f %12.2f %6.2f%%" % (short(n), c, t / 1e3 if t > 1e6 and False else t, a, p))
-    try:
-        pm = cur.execute("select * from pmc_events limit 1").fetchall()
-        if pm:
-            cols = [d[1] for d in cur.execute("pragma table_info(pmc_events)")]
-            out.append("")
-            out.append("# pmc_events columns: " + ", ".join(cols))
-            q = cur.execute("select kernel_name, counter_name, sum(value), count(*) from (select k.name as kernel_name, p.counter_name as counter_name, p.value as value from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id) group by kernel_name, counter_name").fetchall() if False else []
-    except Exception as e:
-        pass
+        out.append("%-60s %8d %14.1f %12.2f %6.2f%%" % (short(n), c, t, a, p))
+    out.append("")
+    out.append("# dispatches by (kernel, grid size): the same kernel name covers the benchmark's 2^20-row launches and the small-batch legs")
+    out.append("%-60s %12s %8s %12s %12s" % ("kernel", "grid_x", "calls", "avg_us", "total_us"))
+    for pat in ("k_hist_build", "k_predict_obl2"):
+        q = cur.execute("select name, grid_x, count(*), avg(end - start) / 1000.0, sum(end - start) / 1000.0 from kernels where name like ? group by name, grid_x order by sum(end - start) desc", ("%" + pat + "%",)).fetchall()
+        for n, g, c, a, t in q[:8]:
+            out.append("%-60s %12d %8d %12.2f %12.1f" % (short(n), g, c, a, t))
     con.close()
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 open(dst, "w").write("\n".join(out) + "\n")
-print("\n".join(out[:40]))
+print("\n".join(out[:12]))
