@@ -1,9 +1,9 @@
 """Turn a rocprofv3 results .db (ROCm 7.2 default output) into a small text summary for profiles/.
     python scripts/rocprof_summary.py <rocprof-output-dir> profiles/r02_x.txt ["title"]
 Kernel table = the `top_kernels` view of the rocpd schema (same numbers as `--stats`), with long names shortened.  Below it the
-dispatches of k_hist_build are broken down by grid size: a default bench.py run contains the benchmark's 2^20-row launches AND the
-small launches of the predict_cfg5 leg (10 000 trees grown on 4096-row minibatches) under the same kernel name; the roofline figure in
-bench.py's JSON line is the benchmark-shape group."""
+dispatches of k_hist_build are split in time: a default bench.py run contains the benchmark's 2^20-row launches AND the small launches
+of the predict_cfg5 leg (10 000 trees grown on 4096-row minibatches) under the same kernel name; the roofline figure in bench.py's
+JSON line is the benchmark-shape group."""
 import glob, os, re, sqlite3, sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -25,12 +25,17 @@ for db in dbs:
         if p < 0.01: continue
         out.append("%-60s %8d %14.1f %12.2f %6.2f%%" % (short(n), c, t, a, p))
     out.append("")
-    out.append("# dispatches by (kernel, grid size): the same kernel name covers the benchmark's 2^20-row launches and the small-batch legs")
-    out.append("%-60s %12s %8s %12s %12s" % ("kernel", "grid_x", "calls", "avg_us", "total_us"))
-    for pat in ("k_hist_build", "k_predict_obl2"):
-        q = cur.execute("select name, grid_x, count(*), avg(end - start) / 1000.0, sum(end - start) / 1000.0 from kernels where name like ? group by name, grid_x order by sum(end - start) desc", ("%" + pat + "%",)).fetchall()
-        for n, g, c, a, t in q[:8]:
-            out.append("%-60s %12d %8d %12.2f %12.1f" % (short(n), g, c, a, t))
+    # The predict_cfg5 leg (10 000 trees grown on 4096-row minibatches, categorical columns) launches the same k_hist_build template
+    # on small inputs.  Everything before its first categorical kernel ran on 2^20 x 128 rows (timed workload, ensemble growth, cfg3 leg).
+    t_split = cur.execute("select min(start) from kernels where name like '%k_cat_distinct_insert%'").fetchone()[0]
+    if t_split is not None:
+        out.append("# k_hist_build split at the start of the predict_cfg5 leg (first k_cat_distinct_insert dispatch):")
+        out.append("%-60s %8s %12s %14s" % ("group", "calls", "avg_us", "total_us"))
+        for label, cond in (("k_hist_build on 2^20 x 128 rows (bench shape: timed steps, ensemble growth, cfg3 leg)", "start < ?"),
+                            ("k_hist_build on 4096-row minibatches (predict_cfg5 leg)", "start >= ?")):
+            c, a, t = cur.execute("select count(*), avg(end - start) / 1000.0, sum(end - start) / 1000.0 from kernels where name like '%k_hist_build%' and " + cond, (t_split,)).fetchone()
+            out.append("%-60s %8d %12.2f %14.1f" % (label[:60], c or 0, a or 0.0, t or 0.0))
+            out.append("#   ^ " + label)
     con.close()
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 open(dst, "w").write("\n".join(out) + "\n")
