@@ -158,7 +158,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
         if (F > 0 && (F & 3) == 0) {
             const float4 *src4 = reinterpret_cast<const float4 *>(src);
             const int F4 = F >> 2, tot4 = rows * F4;
-            constexpr int UL = 4;
+            constexpr int UL = 8;   // 16-byte loads in flight per thread: the whole tile of a 64-row block in one batch
             for (int i0 = tid; i0 < tot4; i0 += NT * UL) {
                 float4 v[UL];
 #pragma unroll
@@ -516,6 +516,9 @@ static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, bool greedy, 
     if (rg_env >= 1 && rg_env <= rg_max) {
         best_rg = rg_env; best_nb = nb_env == 1 ? 1 : nb_env == 2 ? 2 : best_nb; best_tt = tt_for(rg_env, best_nb);
     } else if (trees <= 48) {
+        // HBM-bound regime: 64-row blocks with ONE value buffer (53 KB of LDS at 128 features: three blocks per CU, whose tile loads
+        // overlap each other's walks): 0.145 ms against 0.17 ms with two buffers at 2^20 x 128, 15 trees
+        best_nb = 1;
         for (int rg = 1; rg <= rg_max && best_rg == 0; ++rg) { const int tt = tt_for(rg, best_nb); if (tt >= 4) { best_rg = rg; best_tt = std::min(tt, 8); } }
     } else {
         for (int rg = rg_max; rg >= 1 && best_rg == 0; --rg) { const int tt = tt_for(rg, best_nb); if (tt >= 8) { best_rg = rg; best_tt = tt; } }
