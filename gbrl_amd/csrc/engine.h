@@ -104,6 +104,8 @@ class Engine {
                    double &leaf_scale);
     bool device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
                                        std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes);
+    void sharded_categorical_ranking(const char *hcat, const float *hgrads, int N, int Fc, int D, int B, std::vector<detail::CatCandidate> &cat_cands,
+                                     std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes);
     void numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
                             uint32_t *d_thrkeys);
     void phase_begin(bool key = false);

@@ -249,6 +249,145 @@ md.iteration += 1;  // fitter.cpp:114
 // and uploads the candidate dictionary for k_cat_step_codes.  Returns false (caller falls back to the host scan) when the
 // batch has more distinct categories than the Fc*B the reference keeps (it then ranks them by mean gradient norm), a table
 // overflowed, or two different cells collided on their 64-bit hash.
+// ---- A5, row-sharded, more distinct categories than Fc * n_bins: the reference keeps the Fc * n_bins categories with the largest mean
+// gradient norm (split_candidate_generator.cpp:141-149).  Its per-category total is a float32 sum in ROW order and its candidate order
+// is the iteration order of its hash map followed by std::sort -- both reproduced here exactly: (1) every rank scans its own cells on
+// the host in the reference's loop order (feature-major, row-minor); (2) the ranks' distinct (feature, category) pairs are all-gathered
+// in rank order, which is global first-occurrence order; (3) the totals are accumulated by ONE rank at a time in rank order, each
+// starting from the running totals of the ranks before it (P small broadcasts), so every addition happens in global row order;
+// (4) every rank builds the reference's container from the global list and ranks it.  Slow (host scan, P rounds) and rare.
+void Engine::sharded_categorical_ranking(const char *hcat, const float *hgrads, int N, int Fc, int D, int B,
+                                         std::vector<detail::CatCandidate> &cat_cands, std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes) {
+    hipStream_t s = stream_;
+    const int world = coll_.world_size, rank = coll_.rank;
+    std::vector<float> norms(N, 0.0f);
+    for (int i = 0; i < N; ++i) {   // calculate_squared_norm (math_ops.cpp:726-749), contracted like the reference build
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) { const float g = hgrads[static_cast<size_t>(i) * D + d]; acc = fmaf(g, g, acc); }
+        norms[i] = acc;
+    }
+    // (1) local scan: local id of every cell, distinct pairs in local first-occurrence order (feature-major)
+    std::unordered_map<std::string, int> local_id;
+    std::vector<int> l_feat;
+    std::vector<std::string> l_name;
+    std::vector<int32_t> cell_lid(static_cast<size_t>(N) * Fc);
+    for (int f = 0; f < Fc; ++f)
+        for (int i = 0; i < N; ++i) {
+            std::string name(hcat + (static_cast<size_t>(i) * Fc + f) * kCat, kCat);
+            auto it = local_id.emplace(name + "_" + std::to_string(f), static_cast<int>(l_feat.size()));
+            if (it.second) { l_feat.push_back(f); l_name.push_back(std::move(name)); }
+            cell_lid[static_cast<size_t>(i) * Fc + f] = it.first->second;
+        }
+    // all-gather helper through the sum exchange: every rank writes its block into a zeroed buffer
+    auto all_gather_i64 = [&](const std::vector<int64_t> &mine, std::vector<long long> &counts) -> std::vector<int64_t> {
+        int64_t *d_cnt = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * (world + 1)));
+        std::vector<int64_t> cnt(world + 1, 0);
+        cnt[rank] = static_cast<int64_t>(mine.size());
+        hip_check(hipMemcpyAsync(d_cnt, cnt.data(), sizeof(int64_t) * (world + 1), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipStreamSynchronize(s), "sync");
+        exchange(Red::SumI64, d_cnt, world + 1);
+        hip_check(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int64_t) * (world + 1), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        counts.assign(cnt.begin(), cnt.begin() + world);
+        size_t total = 0, off = 0;
+        for (int r = 0; r < world; ++r) { if (r < rank) off += static_cast<size_t>(cnt[r]); total += static_cast<size_t>(cnt[r]); }
+        if (total > (size_t(1) << 24)) throw Unsupported("too many distinct categories for a row-sharded step");
+        std::vector<int64_t> all(std::max<size_t>(total, 1), 0);
+        std::copy(mine.begin(), mine.end(), all.begin() + static_cast<long>(off));
+        int64_t *d_all = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * all.size()));
+        hip_check(hipMemcpyAsync(d_all, all.data(), sizeof(int64_t) * all.size(), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipStreamSynchronize(s), "sync");
+        exchange(Red::SumI64, d_all, all.size());
+        hip_check(hipMemcpyAsync(all.data(), d_all, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+        all.resize(total);
+        return all;
+    };
+    // (2) global list of distinct pairs: 17-word records (feature, the 128 bytes) in rank order
+    std::vector<int64_t> mine(l_feat.size() * 17, 0);
+    for (size_t q = 0; q < l_feat.size(); ++q) {
+        mine[q * 17] = l_feat[q];
+        std::memcpy(&mine[q * 17 + 1], l_name[q].data(), kCat);
+    }
+    std::vector<long long> rec_counts;
+    const std::vector<int64_t> all = all_gather_i64(mine, rec_counts);
+    const size_t n_rec = all.size() / 17;
+    // the reference inserts feature-major, then in row order: stable sort of the rank-major list by feature
+    std::vector<int> order(n_rec);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return all[static_cast<size_t>(a) * 17] < all[static_cast<size_t>(b) * 17]; });
+    struct Info { float total = 0.f; long long count = 0; int feat = 0; std::string name; int gid = -1; };
+    std::unordered_map<std::string, Info> uniq;   // same container, same insertion sequence as the reference => same iteration order (Q8)
+    std::vector<std::string> gkey;                // global id -> key
+    for (int q : order) {
+        const int f = static_cast<int>(all[static_cast<size_t>(q) * 17]);
+        std::string name(reinterpret_cast<const char *>(&all[static_cast<size_t>(q) * 17 + 1]), kCat);
+        std::string key = name + "_" + std::to_string(f);
+        auto it = uniq.find(key);
+        if (it == uniq.end()) {
+            Info ci;
+            ci.feat = f; ci.name = std::move(name); ci.gid = static_cast<int>(gkey.size());
+            gkey.push_back(key);
+            uniq.emplace(std::move(key), std::move(ci));
+        }
+    }
+    const size_t G = gkey.size();
+    std::vector<int> lid_to_gid(l_feat.size());
+    for (size_t q = 0; q < l_feat.size(); ++q) lid_to_gid[q] = uniq[l_name[q] + "_" + std::to_string(l_feat[q])].gid;
+    // counts: exact integer all-reduce
+    std::vector<int64_t> cnts(std::max<size_t>(G, 1), 0);
+    for (size_t c = 0; c < cell_lid.size(); ++c) ++cnts[lid_to_gid[cell_lid[c]]];
+    {
+        int64_t *d = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * cnts.size()));
+        hip_check(hipMemcpyAsync(d, cnts.data(), sizeof(int64_t) * cnts.size(), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipStreamSynchronize(s), "sync");
+        exchange(Red::SumI64, d, cnts.size());
+        hip_check(hipMemcpyAsync(cnts.data(), d, sizeof(int64_t) * cnts.size(), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    // (3) totals: float32 sums in GLOBAL row order, one rank at a time.  The reference's loop is feature-major over ALL rows, but a key
+    // belongs to one feature, so per key the order of its additions is simply the global row order.
+    std::vector<double> tot(std::max<size_t>(G, 1), 0.0);   // transported as doubles (exact for float32 values), summed with zeros
+    for (int r = 0; r < world; ++r) {
+        std::vector<double> send(tot.size(), 0.0);
+        if (r == rank) {
+            std::vector<float> t32(tot.size());
+            for (size_t k = 0; k < tot.size(); ++k) t32[k] = static_cast<float>(tot[k]);
+            for (int f = 0; f < Fc; ++f)
+                for (int i = 0; i < N; ++i) {
+                    float &t = t32[lid_to_gid[cell_lid[static_cast<size_t>(i) * Fc + f]]];
+                    t += norms[i];
+                }
+            for (size_t k = 0; k < tot.size(); ++k) send[k] = static_cast<double>(t32[k]);
+        }
+        double *d = static_cast<double *>(d_cat_xchg_.ensure(sizeof(double) * send.size()));
+        hip_check(hipMemcpyAsync(d, send.data(), sizeof(double) * send.size(), hipMemcpyHostToDevice, s), "H2D");
+        hip_check(hipStreamSynchronize(s), "sync");
+        exchange(Red::SumF64, d, send.size());
+        hip_check(hipMemcpyAsync(tot.data(), d, sizeof(double) * send.size(), hipMemcpyDeviceToHost, s), "D2H");
+        hip_check(hipStreamSynchronize(s), "sync");
+    }
+    for (auto &kv : uniq) { kv.second.total = static_cast<float>(tot[kv.second.gid]); kv.second.count = cnts[kv.second.gid]; }
+    // (4) the reference's ranking (split_candidate_generator.cpp:131-161)
+    std::vector<std::pair<std::string, float>> vec;
+    for (const auto &kv : uniq) vec.emplace_back(kv.first, kv.second.total / static_cast<float>(static_cast<int>(kv.second.count)));
+    int n_unique = static_cast<int>(vec.size());
+    if (n_unique > Fc * B) {
+        std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, float> &a, const std::pair<std::string, float> &b) { return a.second > b.second; });
+        n_unique = Fc * B;
+    }
+    std::vector<int> cls_of_gid(std::max<size_t>(G, 1), 0);
+    for (int i = 0; i < n_unique; ++i) {
+        const Info &ci = uniq[vec[i].first];
+        const int cls = ++cat_classes[ci.feat];
+        if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+        cat_cands.push_back({ci.feat, ci.name, cls});
+        cls_of_gid[ci.gid] = cls;
+    }
+    h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
+    for (size_t c = 0; c < cell_lid.size(); ++c) h_catcodes[c] = static_cast<uint16_t>(cls_of_gid[lid_to_gid[cell_lid[c]]]);
+}
+
 bool Engine::device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
                                            std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes) {
     hipStream_t s = stream_;
@@ -1233,8 +1372,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             cat_codes_on_device = (has_coll_ || !force_host_categorical_) &&
                                   device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, cat_cands, cat_classes);
         }
-        if (!cat_codes_on_device && has_coll_)
-            throw Unsupported("this batch needs the reference's mean-gradient ranking of categories (more distinct categories than Fc * n_bins), which is not available row-sharded");
         if (!cat_codes_on_device) {
             std::vector<char> cat_host_buf;
             const char *hcat = cat;
@@ -1252,7 +1389,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             }
             cat_cands.clear();
             std::fill(cat_classes.begin(), cat_classes.end(), 0);
-            categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
+            if (has_coll_) sharded_categorical_ranking(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
+            else categorical_candidates(hcat, hgrads, N, Fc, D, B, cat_cands, h_catcodes, cat_classes);
         }
     }
 

@@ -165,6 +165,10 @@ CASES = [
     _c("grd_l2_q_tiny", seed=22, N=100, F=5, D=2, depth=3, policy="greedy", trees=3),
     _c("obl_cos_q_tiny", seed=23, N=57, F=4, D=2, depth=3, score="Cosine", n_bins=64, trees=3),
     _c("grd_cos_q_tiny_cat", seed=24, N=41, F=3, Fc=1, D=1, depth=2, policy="greedy", score="Cosine", trees=2, n_tokens=3),
+    # more distinct categories than Fc * n_bins: the reference keeps the Fc * n_bins categories with the largest mean gradient norm
+    # (split_candidate_generator.cpp:141-149; float32 totals in row order, std::sort on the hash map's iteration order)
+    _c("grd_l2_q_catrank", seed=27, N=600, F=3, Fc=2, D=2, depth=3, policy="greedy", n_bins=4, n_tokens=12, trees=2),
+    _c("obl_cos_u_catrank", seed=28, N=500, F=2, Fc=3, D=1, depth=3, score="Cosine", gen="Uniform", n_bins=5, n_tokens=20, trees=2),
     # BASELINE configs[4] in miniature: numeric + categorical columns, UNIFORM candidates, oblivious depth 6, a few hundred trees
     # grown by the rmse loop (every tree sees new gradients), predict over the whole ensemble and over sub-ranges
     _c("obl_l2_u_cfg5mini", seed=25, N=768, F=24, Fc=8, D=8, depth=6, gen="Uniform", n_bins=32, loop="rmse", y_cat_weight=1.0, trees=320,

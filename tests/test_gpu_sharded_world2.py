@@ -54,7 +54,8 @@ def _run_world(name, world, tmp_path, extra_env=None):
 
 @pytest.mark.parametrize("name,world", [("obl_l2_q_d6", 2), ("obl_l2_q_d6", 3), ("grd_cos_q_ac", 2), ("obl_cos_u", 2),
                                         ("cfg1_rmse_loop", 2), ("obl_l2_q_dups", 3), ("grd_l2_q_mdl", 2),
-                                        ("obl_l2_q_cat", 2), ("grd_cos_u_cat", 3), ("grd_l2_q_catonly", 2), ("obl_cos_q_cat_rmse", 2)])
+                                        ("obl_l2_q_cat", 2), ("grd_cos_u_cat", 3), ("grd_l2_q_catonly", 2), ("obl_cos_q_cat_rmse", 2),
+                                        ("grd_l2_q_catrank", 2), ("grd_l2_q_catrank", 3), ("obl_cos_u_catrank", 3)])
 def test_sharded_ranks_grow_the_single_process_tree(name, world, tmp_path):
     import gbrl_amd
     case, g, (X, Xc, G, y) = load_golden(name)
