@@ -4,6 +4,7 @@ thread-count dependent float32 mean, so values are compared at 1e-4 and a rare n
 mismatches to look at, there is no automatic near-tie analysis for fit()).
     python scripts/fit_sweep.py [n_cases] [first_seed]"""
 import os, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", "8")   # the reference's fit() bias is a thread-count dependent float32 mean: pin it (256 threads on the GPU box disagree with 1 / 3 / 8)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
@@ -41,5 +42,8 @@ for i in range(n_cases):
     else:
         diff += 1
         nt = min(len(np.asarray(e["depths"])), len(np.asarray(r["depths"])))
-        print("DIFF", case, "structure equal:", same, "losses", l1, l2, flush=True)
+        bad_keys = [k for k in ("tree_indices", "depths", "feature_indices", "feature_values", "is_numerics", "inequality_directions", "categorical_values")
+                    if not np.array_equal(np.asarray(e[k]), np.asarray(r[k]))]
+        vdiff = float(np.max(np.abs(np.asarray(e["values"]) - np.asarray(r["values"])))) if np.asarray(e["values"]).shape == np.asarray(r["values"]).shape else -1.0
+        print("DIFF", case, "structure equal:", same, "differing keys:", bad_keys, "max |value diff|", vdiff, "losses", l1, l2, flush=True)
 print("fit cases %d: structure + values agree %d, differ %d  (%.1f s)" % (n_cases, exact, diff, time.time() - t0))
