@@ -602,6 +602,37 @@ def test_fast_predict_kernels_equal_the_general_kernel(policy, Fc, D, monkeypatc
     assert np.abs(outs["0"][0]).max() > 0
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("policy,Fc,F", [("oblivious", 0, 12), ("greedy", 0, 7), ("oblivious", 2, 5), ("greedy", 1, 13)])
+def test_second_generation_predict_kernel_at_every_depth(policy, Fc, F, depth, monkeypatch):
+    """k_predict_obl2 is compiled for 4, 6 and 8 levels (shallower trees are padded in front with a never-true condition; a
+    `max_depth` in between pads the leaf tables to the next size) and for trees-per-worker 1..4: every max_depth from 1 to 8, both
+    policies, with and without categorical columns, feature counts that are and are not multiples of 4, ensembles that end inside
+    a group, sub-ranges that start and stop inside groups -- against the general kernel, bit for bit, and against the
+    first-generation fast kernels."""
+    import gbrl_amd
+    n_trees = 27
+    case = dict(name="pd", seed=300 + depth, N=1500, F=F, Fc=Fc, D=3, depth=depth, n_bins=32, score="L2", gen="Uniform", policy=policy, trees=n_trees,
+                loop="rmse", y_cat_weight=0.5)
+    X, Xc, G, y = K.make_inputs(case)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, Xc, G, y)
+    assert m.get_num_trees() == n_trees
+    ranges = ((0, 0), (0, 1), (3, 20), (11, 12), (16, 27), (26, 27))
+    outs = {}
+    for mode, env in (("gen2", {}), ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"}), ("gen1", {"GBRL_HIP_PREDICT_OBL1": "1"}),
+                      ("gen2_k1", {"GBRL_HIP_PREDICT_RG": "1", "GBRL_HIP_PREDICT_TT": "4"}), ("gen2_nb1", {"GBRL_HIP_PREDICT_RG": "2", "GBRL_HIP_PREDICT_NB": "1"})):
+        for k in ("GBRL_HIP_PREDICT_GENERIC", "GBRL_HIP_PREDICT_OBL1", "GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT", "GBRL_HIP_PREDICT_NB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[mode] = [np.asarray(m.predict(X, Xc, a, b)) for a, b in ranges]
+    for mode in ("gen2", "gen1", "gen2_k1", "gen2_nb1"):
+        for r, a, b in zip(ranges, outs[mode], outs["generic"]):
+            assert np.array_equal(a, b), (mode, r)
+    assert np.abs(outs["gen2"][0]).max() > 0
+
+
 def test_random_sweep_against_the_oracle_has_no_unexplained_mismatch():
     """60 random configurations (shape, policy, score, generator, bins, depth, min_data_in_leaf, categorical columns, discrete
     columns): bit-identical structure or an explained near-tie (tests/neartie.py), values / predictions within 1e-5."""
