@@ -313,7 +313,9 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     // small batches: scratch for up to 64 partial sums per output (tree ranges spread over blocks, kern::predict)
     pm.partial = nullptr; pm.partial_floats = 0; pm.tree_chunk = 0;
     // (not inside fit(): its gradients follow the reference's per-row tree-order chain at every batch size)
-    if (!in_fit_ && n <= 64 * 256 && stop - start_tree >= 128 && stop - start_tree <= 2048) {
+    pm.par_th = md.par_th;
+    // (nor for a model whose file cleared parallel_predict: the reference then runs the chain for every batch, predictor.cpp:144)
+    if (!in_fit_ && model.parallel_predict && n <= 64 * 256 && stop - start_tree >= 128) {
         pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
         pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
     }

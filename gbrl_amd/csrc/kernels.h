@@ -269,6 +269,8 @@ struct PredictModel {
     float *partial;          // scratch for tree-split prediction of small batches (nullable), partial_floats elements
     size_t partial_floats;
     int tree_chunk;          // set by kern::predict: trees per block column (0 = every block walks the whole range)
+    int tree_splits;         // set by kern::predict: block columns (the last one takes the remainder of the range)
+    int par_th;              // the model's par_th (the reference's rows / trees per host thread, utils.h:64-80)
     // second-generation oblivious path (predict_obl2.hip): leaf values pre-swizzled per tree as [worker 0..3][leaf < 2^max_depth]
     // [DMAX/4] (DMAX = obl2_padded_outputs(D), zero padded), and per tree 2*obl2_maxd condition words RIGHT-aligned (a tree of depth
     // d < obl2_maxd starts with obl2_maxd - d never-true conditions: feature 0, threshold +inf); obl2_maxd = 0: not available

@@ -25,7 +25,7 @@ static_assert(sizeof(gbrl_hip_metadata) == 80, "ensembleMetaData must be 80 byte
 struct Model {
     gbrl_hip_metadata meta{};
     std::string learner_name = "GBRL";
-    bool parallel_predict = false;
+    bool parallel_predict = true;   // gbrl.h:511 (the reference clears it for Adam only, which this build refuses); saved and loaded with the file
 
     // ensembleData (types.h:279-304).  S = trees (oblivious) | leaves (greedy)
     std::vector<float> bias, feature_weights;                 // [D], [in]

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_predict_obl(const float *__restrict__ v
     // (small batches with large ensembles: the trees are spread over blocks; k_predict_combine adds the slices in tree order)
     if (tree_chunk > 0) {
         start_tree += blockIdx.y * tree_chunk;
-        stop_tree = min(stop_tree, start_tree + tree_chunk);
+        if (blockIdx.y + 1 < gridDim.y) stop_tree = min(stop_tree, start_tree + tree_chunk);   // the last slice takes the remainder
         out += static_cast<size_t>(blockIdx.y) * n * D;
     }
     const int R = blockDim.x;
@@ -461,7 +461,7 @@ static bool launch_predict_obl(const PredictModel &pm, const float *obs, int F, 
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
-    const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
+    const int splits = pm.tree_chunk > 0 ? pm.tree_splits : 1;
     hipLaunchKernelGGL((k_predict_obl<DMAX, MAXD, CAT>), dim3((n + R - 1) / R, splits), dim3(R), lds, s, pm.values, pm.tree_indices, pm.cond_pack,
                        pm.depths, pm.bias, coef, pm.D, pm.max_depth, obs, F, cat_codes, Fc, n, start_tree, stop_tree,
                        pm.tree_chunk > 0 ? pm.partial : out, TT, pm.tree_chunk);
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_predict_grd(const float *__restrict__ v
     // (small batches with large ensembles: the trees are spread over blocks; k_predict_combine adds the slices in tree order)
     if (tree_chunk > 0) {
         start_tree += blockIdx.y * tree_chunk;
-        stop_tree = min(stop_tree, start_tree + tree_chunk);
+        if (blockIdx.y + 1 < gridDim.y) stop_tree = min(stop_tree, start_tree + tree_chunk);   // the last slice takes the remainder
         out += static_cast<size_t>(blockIdx.y) * n * D;
     }
     const int R = blockDim.x;
@@ -628,7 +628,7 @@ static bool launch_predict_grd(const PredictModel &pm, const float *obs, int F, 
     }
     OblCoef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
-    const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
+    const int splits = pm.tree_chunk > 0 ? pm.tree_splits : 1;
     hipLaunchKernelGGL((k_predict_grd<DMAX>), dim3((n + R - 1) / R, splits), dim3(R), lds, s, pm.values, pm.tree_indices, pm.grd_nodes,
                        pm.grd_node_off, pm.bias, coef, pm.D, pm.n_leaves, pm.n_trees, MN, LS, obs, F, cat_codes, Fc, n, start_tree,
                        stop_tree, pm.tree_chunk > 0 ? pm.partial : out, TT, pm.tree_chunk);
@@ -682,18 +682,35 @@ void predict(const PredictModel &pm_in, const float *obs, int F, const int32_t *
     pm.tree_chunk = 0;
     const int trees = stop_tree - start_tree;
     const int row_tiles = (n + 255) / 256;
-    // Bounded to 2048 trees: the float32 chain of the reference itself drifts from the exact sum by about 2e-9 per tree (9e-5 at
+    // Window 128..2048 trees: the float32 chain of the reference itself drifts from the exact sum by about 2e-9 per tree (9e-5 at
     // 50 000 trees, measured), so beyond a few thousand trees a differently associated -- more accurate -- sum would leave the 1e-5
-    // band around the reference's value; larger ensembles keep the reference's chain.
+    // band around the reference's chain; larger ensembles keep the chain wherever the reference runs it.
+    pm.tree_splits = 1;
     if (pm.partial && trees >= 128 && trees <= 2048 && row_tiles <= 64) {
         int splits = std::min(64, std::min(trees / 32, std::max(1, 512 / row_tiles)));
         while (splits > 1 && static_cast<size_t>(splits) * n * pm.D > pm.partial_floats) --splits;
-        if (splits > 1) pm.tree_chunk = (trees + splits - 1) / splits;
+        if (splits > 1) {
+            pm.tree_chunk = (trees + splits - 1) / splits;
+            pm.tree_splits = (trees + pm.tree_chunk - 1) / pm.tree_chunk;
+        }
+    } else if (pm.partial && trees > 2048) {
+        // Larger ensembles, a handful of rows (an agent acting in a few environments): the reference does NOT run the chain there.
+        // predict_cpu (predictor.cpp:142-163) gives every OpenMP thread trees/n_tree_threads consecutive trees (the last thread the
+        // remainder) and adds the per-thread buffers to bias in thread order whenever n_tree_threads > n_sample_threads, with
+        // n_x_threads = clamp(count / par_th, 1, host threads) (utils.h:64-80).  The same slices, for a nominal host of 64 threads:
+        // the result is the one the reference produces on such a host, and the trees spread over 64 block columns instead of one.
+        const int par = pm.par_th > 0 ? pm.par_th : 1;
+        const int n_tree_thr = std::max(1, std::min(64, trees / par));
+        const int n_row_thr = std::max(1, std::min(64, n / par));
+        if (n_tree_thr > 1 && n_tree_thr > n_row_thr && static_cast<size_t>(n_tree_thr) * n * pm.D <= pm.partial_floats) {
+            pm.tree_splits = n_tree_thr;
+            pm.tree_chunk = trees / n_tree_thr;
+        }
     }
     struct Combine {   // runs after whichever fast kernel took the launch
         const PredictModel &pm; int n, trees; float *out; hipStream_t s;
         void operator()() const {
-            const int splits = (trees + pm.tree_chunk - 1) / pm.tree_chunk;
+            const int splits = pm.tree_splits;
             const size_t n_el = static_cast<size_t>(n) * pm.D;
             hipLaunchKernelGGL(k_predict_combine, dim3(static_cast<unsigned>((n_el + 255) / 256)), dim3(256), 0, s, pm.partial, splits, n_el, pm.D,
                                pm.bias, out);

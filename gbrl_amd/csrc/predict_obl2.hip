@@ -96,7 +96,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
     constexpr int REC = VT * 4 + (GREEDY ? LS * 16 : 0);   // bytes
     if (tree_chunk > 0) {   // small batches: this block column covers a sub-range of the trees and writes a partial sum (no bias)
         start_tree += blockIdx.y * tree_chunk;
-        stop_tree = min(stop_tree, start_tree + tree_chunk);
+        if (blockIdx.y + 1 < gridDim.y) stop_tree = min(stop_tree, start_tree + tree_chunk);   // the last slice takes the remainder
         out += static_cast<size_t>(blockIdx.y) * n * D;
     }
     const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63;
@@ -549,7 +549,7 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
     Obl2Coef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
     const int R = 64 * pl.RG;
-    const int splits = pm.tree_chunk > 0 ? (stop_tree - start_tree + pm.tree_chunk - 1) / pm.tree_chunk : 1;
+    const int splits = pm.tree_chunk > 0 ? pm.tree_splits : 1;
     hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT, GREEDY>), dim3((n + R - 1) / R, splits), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
                        pm.bias, coef, pm.D, obs, F, cat_codes, Fc, n, start_tree, stop_tree, pm.tree_chunk > 0 ? pm.partial : out, R,
                        pl.TT, pl.NB, pl.xs, pm.tree_chunk);

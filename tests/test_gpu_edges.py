@@ -337,3 +337,89 @@ def test_device_planned_oblivious_tree_equals_the_host_level_loop(name):
             outs.append(dict(np.load(path)))
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+_REF_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+ref = oracle.load_ref()
+m = ref.GBRL.load(sys.argv[2])
+X = np.load(sys.argv[3])
+out = {}
+for n in [int(v) for v in sys.argv[5].split(",")]:
+    out["p%d" % n] = np.asarray(m.predict(np.ascontiguousarray(X[:n]), None, 0, 0))
+np.savez(sys.argv[4], **out)
+"""
+
+
+@pytest.mark.parametrize("policy", ["oblivious", "greedy"])
+def test_few_rows_against_a_large_ensemble_follow_the_reference_thread_slices(policy, tmp_path, monkeypatch):
+    """An agent acting: a handful of rows, thousands of trees.  The reference does not run one chain per row there: whenever
+    n_tree_threads > n_sample_threads each OpenMP thread sums trees/n_tree_threads consecutive trees into its own buffer and the
+    buffers are added to bias in thread order (predictor.cpp:142-163).  The product takes the same slices for a nominal 64-thread
+    host and spreads them over block columns: bit for bit (1) the sum bias + slice_0 + slice_1 + ... of its own chain over every slice,
+    (2) the general kernel's single chain wherever the reference runs the chain (rows / par_th >= the tree threads), and (3) the
+    reference's own build run with 64 OpenMP threads: bit for bit on the first call of its process, within 1e-5 afterwards."""
+    import subprocess
+    import gbrl_amd
+    import oracle
+    T, par_th, F, D = 2500, 10, 8, 3
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((1024, F), dtype=np.float32)
+    W = rng.standard_normal((F, D)).astype(np.float32)
+    case = dict(name="act", seed=0, N=256, F=F, Fc=0, D=D, depth=3, n_bins=32, score="Cosine", gen="Quantile", policy=policy, trees=0,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=0, stop_idx=D)])
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    bias = np.array([0.25, -1.5, 3.0], np.float32)
+    m.set_bias(bias); m.set_feature_weights(np.ones(F, np.float32))
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=0, stop_idx=D)
+    m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+    for t in range(T):
+        rows = rng.integers(0, 1024, size=256)
+        G = (np.tanh(X[rows] @ W * np.float32(0.2 + 0.01 * (t % 40))) + 0.3 * rng.standard_normal((256, D), dtype=np.float32)).astype(np.float32)
+        m.step(np.ascontiguousarray(X[rows]), None, G)
+    assert m.get_num_trees() == T
+    sizes = [1, 7, 19, 64, 300, 639, 640, 1000]
+    full = {n: np.asarray(m.predict(np.ascontiguousarray(X[:n]), None, 0, 0)).reshape(n, D) for n in sizes}
+    # (2) where the reference runs the chain
+    monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "1")
+    chain = {n: np.asarray(m.predict(np.ascontiguousarray(X[:n]), None, 0, 0)).reshape(n, D) for n in sizes}
+    monkeypatch.delenv("GBRL_HIP_PREDICT_GENERIC")
+    n_tree_thr = min(64, T // par_th)
+    sliced = [n for n in sizes if n_tree_thr > max(1, min(64, n // par_th))]
+    assert sliced == [1, 7, 19, 64, 300, 639]
+    for n in sizes:
+        if n not in sliced:
+            assert np.array_equal(full[n], chain[n]), n
+        else:
+            assert rel_err(full[n], chain[n], 1.0) <= 1e-5, n                    # a different association of the same terms
+    # (1) the slices of the reference's tree-parallel branch, each one a chain of < 128 trees (never spread over blocks)
+    m.set_bias(np.zeros(D, np.float32))
+    chunk = T // n_tree_thr
+    for n in sliced:
+        x = np.ascontiguousarray(X[:n])
+        acc = np.broadcast_to(bias, (n, D)).astype(np.float32).copy()
+        for y in range(n_tree_thr):
+            a, b = y * chunk, (T if y == n_tree_thr - 1 else (y + 1) * chunk)
+            acc = (acc + np.asarray(m.predict(x, None, a, b)).reshape(n, D)).astype(np.float32)
+        assert np.array_equal(full[n], acc), n
+    m.set_bias(bias)
+    # (3) the reference's own build on 64 OpenMP threads
+    if oracle.ref_path() is None:
+        pytest.skip("oracle/_ref not built")
+    path, xs, outp = str(tmp_path / "act.gbrl_model"), str(tmp_path / "x.npy"), str(tmp_path / "ref.npz")
+    assert m.save(path) == 0
+    np.save(xs, X)
+    env = dict(os.environ, OMP_NUM_THREADS="64")
+    subprocess.run([sys.executable, "-c", _REF_CHILD, os.path.dirname(HERE), path, xs, outp, ",".join(str(n) for n in sizes)], check=True, env=env,
+                   timeout=600)
+    ref = np.load(outp)
+    # The reference's thread count only ever shrinks inside a process: calculate_num_threads (utils.h:64-80) caps at
+    # omp_get_max_threads(), which every omp_set_num_threads(n) of an earlier, smaller loop has lowered (the bias add of a 7-row batch
+    # leaves 2).  Its slices therefore depend on the call history; only the first call of a fresh process -- 1 row here -- is the
+    # full 64-thread split, and that one must be the product's result bit for bit.  The others agree within the tolerance.
+    assert np.array_equal(full[1], ref["p1"].reshape(1, D))
+    for n in sizes:
+        want = ref["p%d" % n].reshape(n, D)
+        assert rel_err(full[n], want, 1.0) <= TOL, n

@@ -87,6 +87,32 @@ def test_model_file_roundtrip_is_byte_compatible(name, tmp_path):
     assert np.array_equal(np.asarray(m2.get_ensemble_data()["values"]), g["values"])
 
 
+def test_model_file_of_a_fresh_model_is_the_file_the_reference_writes(tmp_path):
+    """A model constructed HERE (not loaded) and saved before any tree: byte for byte the file the reference writes for the same
+    constructor and optimizer calls -- header, the 80-byte metadata, the parallel_predict flag (true unless Adam, gbrl.h:511: the
+    reference's small-batch tree-parallel predict depends on it after a load), use_cv, learner name, optimizer records."""
+    import oracle
+    kw = dict(input_dim=4, output_dim=2, policy_dim=2, max_depth=3, min_data_in_leaf=0, n_bins=256, par_th=10, cv_beta=0.9, split_score_func="L2",
+              generator_type="Quantile", use_control_variates=False, batch_size=5000, grow_policy="oblivious", verbose=0, device="cpu",
+              learner_name="fresh")
+    m = gbrl_amd.GBRL(**kw)
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=1)
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=1, stop_idx=2)
+    p = tmp_path / "fresh.gbrl_model"
+    assert m.save(str(p)) == 0
+    ours = p.read_bytes()
+    assert ours[24 + 80] == 1 and ours[24 + 81] == 0          # parallel_predict, use_cv
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    r = ref.GBRL(**kw)
+    r.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=1)
+    r.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=1, stop_idx=2)
+    q = tmp_path / "fresh_ref.gbrl_model"
+    assert r.save(str(q)) == 0
+    assert _mask_header_padding(ours) == _mask_header_padding(q.read_bytes())
+
+
 def test_model_file_written_here_loads_in_the_reference(tmp_path):
     import oracle
     ref = oracle.load_ref()
