@@ -145,6 +145,7 @@ class Engine {
     size_t ev_used_ = 0;
 
     DevBuf d_pred_partial_;
+    DevBuf d_pred_slots_;     // leaf slots of the two-launch chain path (kern::predict_chain)
     DevBuf d_shap_ops_, d_shap_nodes_, d_shap_values_, d_shap_poly_, d_shap_out_;
     int shap_n_ops_ = 0;
     uint64_t shap_prog_version_ = ~0ull;

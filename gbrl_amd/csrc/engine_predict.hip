@@ -14,6 +14,9 @@
 
 namespace gbrl {
 
+constexpr int kChainMinTrees = 512;   // below: the tiled kernels are as fast (measured, scripts/predict_latency.py)
+constexpr int kChainMaxRows = 4096;
+
 // ===================================================================================================== predict
 void Engine::sync_model_to_device() {
     hipStream_t s = stream_;
@@ -318,6 +321,23 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     if (!in_fit_ && model.parallel_predict && n <= 64 * 256 && stop - start_tree >= 128) {
         pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
         pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
+    }
+    // Up to 4096 rows against a large tree range: leaf search spread over the chip + one multiply-add chain per (row, output)
+    // (kern::predict_chain: the bits of the one-chain-per-row kernels, so fit() uses it too).  Measured against the tiled kernels'
+    // 80 ns per tree: 1024 rows x 20 000 trees 1.59 -> 0.25 ms, 3000 rows 1.59 -> 0.54 ms; beyond ~4096 rows the leaf search
+    // alone costs what the tiled kernel does.  GBRL_HIP_PREDICT_CHAIN=0 / 1: never / whenever the shape is covered (tests).
+    pm.slots = nullptr; pm.slot_ints = 0;
+    {
+        const int trees = stop - start_tree;
+        bool want = n <= kChainMaxRows && trees >= kChainMinTrees;
+        if (const char *e = std::getenv("GBRL_HIP_PREDICT_CHAIN")) want = e[0] == '1' ? (n <= 64 * 256 && trees >= 1) : false;
+        if (want) {
+            const size_t ints = kern::predict_chain_slot_ints(n, trees);
+            if (ints <= (size_t(1) << 27)) {
+                pm.slot_ints = ints;
+                pm.slots = static_cast<int32_t *>(d_pred_slots_.ensure(ints * sizeof(int32_t)));
+            }
+        }
     }
     kern::predict(pm, dobs, n_num, dcat, n_cat, n, start_tree, stop, dout, s);
     hip_check(hipGetLastError(), "predict launch");

@@ -271,6 +271,8 @@ struct PredictModel {
     int tree_chunk;          // set by kern::predict: trees per block column (0 = every block walks the whole range)
     int tree_splits;         // set by kern::predict: block columns (the last one takes the remainder of the range)
     int par_th;              // the model's par_th (the reference's rows / trees per host thread, utils.h:64-80)
+    int32_t *slots;          // scratch of the two-launch chain path (predict_chain.hip), slot_ints elements; nullptr: path not offered
+    size_t slot_ints;
     // second-generation oblivious path (predict_obl2.hip): leaf values pre-swizzled per tree as [worker 0..3][leaf < 2^max_depth]
     // [DMAX/4] (DMAX = obl2_padded_outputs(D), zero padded), and per tree 2*obl2_maxd condition words RIGHT-aligned (a tree of depth
     // d < obl2_maxd starts with obl2_maxd - d never-true conditions: feature 0, threshold +inf); obl2_maxd = 0: not available
@@ -281,6 +283,11 @@ struct PredictModel {
 };
 int obl2_padded_outputs(int D);     // 4, 8, 16, 32, 64 (0: D > 64)
 int obl2_levels(int max_depth);     // 4, 6, 8 (0: max_depth > 8)
+// Small / medium batches against large ensembles: leaf search spread over the chip, then one fused multiply-add chain per (row,
+// output) in tree order -- the bits of the one-chain-per-row kernels (predict_chain.hip).  false: not covered, nothing was launched.
+size_t predict_chain_slot_ints(int n, int trees);
+bool predict_chain(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
+                   float *out, hipStream_t s);
 bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
                   float *out, hipStream_t s);   // false: shape not covered, nothing was launched
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per

@@ -694,19 +694,22 @@ void predict(const PredictModel &pm_in, const float *obs, int F, const int32_t *
             pm.tree_splits = (trees + pm.tree_chunk - 1) / pm.tree_chunk;
         }
     } else if (pm.partial && trees > 2048) {
-        // Larger ensembles, a handful of rows (an agent acting in a few environments): the reference does NOT run the chain there.
-        // predict_cpu (predictor.cpp:142-163) gives every OpenMP thread trees/n_tree_threads consecutive trees (the last thread the
-        // remainder) and adds the per-thread buffers to bias in thread order whenever n_tree_threads > n_sample_threads, with
-        // n_x_threads = clamp(count / par_th, 1, host threads) (utils.h:64-80).  The same slices, for a nominal host of 64 threads:
-        // the result is the one the reference produces on such a host, and the trees spread over 64 block columns instead of one.
+        // Larger ensembles, fewer than 2 * par_th rows (an agent acting in a few environments): the reference does NOT run the chain
+        // there on any multi-threaded host.  predict_cpu (predictor.cpp:142-163) gives every OpenMP thread trees/n_tree_threads
+        // consecutive trees (the last thread the remainder) and adds the per-thread buffers to bias in thread order whenever
+        // n_tree_threads > n_sample_threads, with n_x_threads = clamp(count / par_th, 1, host threads) (utils.h:64-80) -- and
+        // rows / par_th <= 1 makes n_sample_threads 1.  The same slices, for a nominal host of 64 threads: the result is the one the
+        // reference produces on such a host (bit for bit, tests/test_gpu_edges.py), and the trees spread over 64 block columns
+        // instead of one.  With more rows the reference's choice depends on the host (8 threads: the chain from 80 rows on), so
+        // those batches keep the exact chain (kern::predict_chain below).
         const int par = pm.par_th > 0 ? pm.par_th : 1;
         const int n_tree_thr = std::max(1, std::min(64, trees / par));
-        const int n_row_thr = std::max(1, std::min(64, n / par));
-        if (n_tree_thr > 1 && n_tree_thr > n_row_thr && static_cast<size_t>(n_tree_thr) * n * pm.D <= pm.partial_floats) {
+        if (n / par <= 1 && n_tree_thr > 1 && static_cast<size_t>(n_tree_thr) * n * pm.D <= pm.partial_floats) {
             pm.tree_splits = n_tree_thr;
             pm.tree_chunk = trees / n_tree_thr;
         }
     }
+    if (pm.tree_chunk == 0 && pm.slots && predict_chain(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return;
     struct Combine {   // runs after whichever fast kernel took the launch
         const PredictModel &pm; int n, trees; float *out; hipStream_t s;
         void operator()() const {

@@ -813,3 +813,43 @@ def test_small_batch_prediction_over_a_large_ensemble_spreads_the_trees(policy, 
         monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "1")
         chain = np.asarray(m.predict(X, Xc, a, b))
         assert np.abs(chain).max() > 0 and np.abs(split - chain).max() <= 2e-6 * max(np.abs(chain).max(), scale)
+
+
+@pytest.mark.parametrize("policy,Fc,D", [("oblivious", 0, 5), ("greedy", 0, 5), ("oblivious", 2, 8), ("greedy", 2, 3)])
+def test_two_launch_chain_predict_has_the_bits_of_the_general_kernel(policy, Fc, D, monkeypatch):
+    """Up to 4096 rows against >= 512 trees go through kern::predict_chain (leaf search spread over the chip, then one fused
+    multiply-add chain per (row, output) relayed between the waves of a block).  Same operands, same order, same fused operation as
+    the one-thread-per-row general kernel: the same bits -- for both policies, numeric and categorical conditions, outputs without an
+    optimizer, batches of 1 .. 3000 rows, the whole range and sub-ranges that start / end inside a 64-tree batch; forced
+    (GBRL_HIP_PREDICT_CHAIN=1) for the short ranges the dispatcher would not give it."""
+    import gbrl_amd
+    rng = np.random.default_rng(3)
+    F, N, T = 7, 3000, 700
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    Xc = K.TOKENS[rng.integers(0, 6, size=(N, Fc))] if Fc else None
+    m = gbrl_amd.GBRL(input_dim=F + Fc, output_dim=D, policy_dim=D, max_depth=5, min_data_in_leaf=0, n_bins=64, par_th=10, cv_beta=0.9,
+                      split_score_func="cosine", generator_type="Quantile", use_control_variates=False, batch_size=5000, grow_policy=policy,
+                      verbose=0, device="cpu", learner_name="chain")
+    m.set_bias(rng.standard_normal(D).astype(np.float32)); m.set_feature_weights(np.ones(F + Fc, np.float32))
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=0, stop_idx=D - 2)
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=D - 2, stop_idx=D - 1)     # the last output has no optimizer
+    m.set_feature_mapping(np.arange(F + Fc, dtype=np.int32), np.array([True] * F + [False] * Fc))
+    for t in range(T):
+        rows = rng.integers(0, N, size=512)
+        G = rng.standard_normal((512, D), dtype=np.float32) + np.float32(0.5) * X[rows][:, :1]
+        if Fc:
+            G[:, 0] += (Xc[rows][:, 0] == K.TOKENS[1]).astype(np.float32) * 2
+        m.step(np.ascontiguousarray(X[rows]), None if Xc is None else np.ascontiguousarray(Xc[rows]), G)
+    assert m.get_num_trees() == T
+    for n in (1, 5, 64, 257, 3000):
+        xa, xc = np.ascontiguousarray(X[:n]), (None if Xc is None else np.ascontiguousarray(Xc[:n]))
+        for a, b in ((0, 0), (0, 1), (3, 40), (100, 700), (0, 63), (0, 64), (0, 65), (5, 133), (60, 700), (0, 512)):
+            monkeypatch.setenv("GBRL_HIP_PREDICT_CHAIN", "0"); monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "1")
+            want = np.asarray(m.predict(xa, xc, a, b))
+            monkeypatch.delenv("GBRL_HIP_PREDICT_GENERIC")
+            monkeypatch.setenv("GBRL_HIP_PREDICT_CHAIN", "1")
+            got = np.asarray(m.predict(xa, xc, a, b))
+            assert np.array_equal(got, want), (n, a, b)
+            monkeypatch.delenv("GBRL_HIP_PREDICT_CHAIN")
+            if (b if b else T) - a >= 512 and n >= 640:      # the dispatcher's own choice for these shapes (fewer rows: thread slices)
+                assert np.array_equal(np.asarray(m.predict(xa, xc, a, b)), want), (n, a, b)
