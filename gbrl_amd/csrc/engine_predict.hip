@@ -15,7 +15,7 @@
 namespace gbrl {
 
 constexpr int kChainMinTrees = 512;   // below: the tiled kernels are as fast (measured, scripts/predict_latency.py)
-constexpr int kChainMaxRows = 4096;
+constexpr int kChainMaxRows = 8192;   // 5000 rows x 20 000 trees: 1.58 -> 0.88 ms, 8192 x 5000: 0.39 -> 0.32 ms; beyond, the leaf search alone costs as much
 
 // ===================================================================================================== predict
 void Engine::sync_model_to_device() {
@@ -322,9 +322,9 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
         pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
         pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
     }
-    // Up to 4096 rows against a large tree range: leaf search spread over the chip + one multiply-add chain per (row, output)
+    // Up to 8192 rows against a large tree range: leaf search spread over the chip + one multiply-add chain per (row, output)
     // (kern::predict_chain: the bits of the one-chain-per-row kernels, so fit() uses it too).  Measured against the tiled kernels'
-    // 80 ns per tree: 1024 rows x 20 000 trees 1.59 -> 0.25 ms, 3000 rows 1.59 -> 0.54 ms; beyond ~4096 rows the leaf search
+    // 80 ns per tree: 1024 rows x 20 000 trees 1.59 -> 0.27 ms, 4096 rows 1.58 -> 0.64 ms; beyond ~8192 rows the leaf search
     // alone costs what the tiled kernel does.  GBRL_HIP_PREDICT_CHAIN=0 / 1: never / whenever the shape is covered (tests).
     pm.slots = nullptr; pm.slot_ints = 0;
     {

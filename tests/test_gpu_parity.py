@@ -817,7 +817,7 @@ def test_small_batch_prediction_over_a_large_ensemble_spreads_the_trees(policy, 
 
 @pytest.mark.parametrize("policy,Fc,D", [("oblivious", 0, 5), ("greedy", 0, 5), ("oblivious", 2, 8), ("greedy", 2, 3)])
 def test_two_launch_chain_predict_has_the_bits_of_the_general_kernel(policy, Fc, D, monkeypatch):
-    """Up to 4096 rows against >= 512 trees go through kern::predict_chain (leaf search spread over the chip, then one fused
+    """Up to 8192 rows against >= 512 trees go through kern::predict_chain (leaf search spread over the chip, then one fused
     multiply-add chain per (row, output) relayed between the waves of a block).  Same operands, same order, same fused operation as
     the one-thread-per-row general kernel: the same bits -- for both policies, numeric and categorical conditions, outputs without an
     optimizer, batches of 1 .. 3000 rows, the whole range and sub-ranges that start / end inside a 64-tree batch; forced
