@@ -853,3 +853,30 @@ def test_two_launch_chain_predict_has_the_bits_of_the_general_kernel(policy, Fc,
             monkeypatch.delenv("GBRL_HIP_PREDICT_CHAIN")
             if (b if b else T) - a >= 512 and n >= 640:      # the dispatcher's own choice for these shapes (fewer rows: thread slices)
                 assert np.array_equal(np.asarray(m.predict(xa, xc, a, b)), want), (n, a, b)
+
+
+def test_fit_past_512_trees_uses_the_chain_path_and_grows_the_same_model(monkeypatch):
+    """fit() predicts trees [0, i) for every batch; from 512 trees on those predictions go through kern::predict_chain, which has
+    the bits of the one-chain-per-row kernel: the 560-tree model and the returned loss are identical with the path switched off."""
+    import gbrl_amd
+    rng = np.random.default_rng(21)
+    N, F, D = 700, 5, 2
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    y = (np.tanh(X[:, :D]) + 0.2 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    out = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("GBRL_HIP_PREDICT_CHAIN", chain) if chain == "0" else monkeypatch.delenv("GBRL_HIP_PREDICT_CHAIN", raising=False)
+        m = gbrl_amd.GBRL(input_dim=F, output_dim=D, policy_dim=D, max_depth=3, min_data_in_leaf=0, n_bins=32, par_th=10, cv_beta=0.9,
+                          split_score_func="L2", generator_type="Quantile", use_control_variates=False, batch_size=256, grow_policy="oblivious",
+                          verbose=0, device="cpu", learner_name="fitchain")
+        m.set_feature_weights(np.ones(F, np.float32))
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=0, stop_idx=D)
+        m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+        loss = m.fit(X, None, y, 560, False, "MultiRMSE")
+        out.append((loss, m.get_ensemble_data(), np.asarray(m.predict(X, None, 0, 0))))
+    (l1, e1, p1), (l0, e0, p0) = out
+    assert int(np.asarray(e1["depths"]).size) == 560
+    assert l1 == l0
+    for k in K.ENSEMBLE_KEYS:
+        assert np.array_equal(np.asarray(e1[k]), np.asarray(e0[k])), k
+    assert np.array_equal(p1, p0)
