@@ -34,7 +34,7 @@ struct ChainCoef {
     uint64_t cover;     // outputs owned by an optimiser (the others keep the bias, like the general kernel)
 };
 
-template <bool GREEDY>
+template <bool GREEDY, int LV>
 __global__ __launch_bounds__(256) void k_leaf_slots(const int32_t *__restrict__ tree_indices, const int32_t *__restrict__ depths,
                                                     const int32_t *__restrict__ cond_pack, int md, const int32_t *__restrict__ nodes,
                                                     const int32_t *__restrict__ node_off, int D, const float *__restrict__ obs, int F,
@@ -45,9 +45,28 @@ __global__ __launch_bounds__(256) void k_leaf_slots(const int32_t *__restrict__ 
     const int r0 = blockIdx.y * rows_per_block;
     const int rows = min(rows_per_block, n - r0);
     const float *src = obs + static_cast<size_t>(r0) * F;
-    for (int i = threadIdx.x; i < rows * F; i += 256) {
-        const int r = i / F, f = i - r * F;
-        xt[r * xs + f] = src[i];
+    if ((F & 3) == 0) {   // 16-byte reads, four in flight per thread: a block pays one memory round trip for its tile, not one per element
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        const int F4 = F >> 2, tot4 = rows * F4;
+        for (int i0 = threadIdx.x; i0 < tot4; i0 += 256 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; v[u] = i < tot4 ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < tot4) {
+                    const int r = i / F4, f = (i - r * F4) << 2;
+                    float *dst4 = xt + r * xs + f;
+                    dst4[0] = v[u].x; dst4[1] = v[u].y; dst4[2] = v[u].z; dst4[3] = v[u].w;
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < rows * F; i += 256) {
+            const int r = i / F, f = i - r * F;
+            xt[r * xs + f] = src[i];
+        }
     }
     __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;     // tree of the range, or padding behind it
@@ -62,13 +81,13 @@ __global__ __launch_bounds__(256) void k_leaf_slots(const int32_t *__restrict__ 
     if (!GREEDY) {
         const int depth = depths[t];
         const int32_t *cp = cond_pack + static_cast<size_t>(t) * 2 * md;
-        if (depth <= 8) {
+        if (depth <= LV) {
             // the tree's conditions in registers for all rows of the tile, padded at the FRONT with never-true ones (feature 0 >
-            // +inf) so that level k always carries bit 7 - k of an 8-level index whose top 8 - depth bits are zero
-            int fi[8], tv[8];
+            // +inf) so that level k always carries bit LV - 1 - k of an LV-level index whose top LV - depth bits are zero
+            int fi[LV], tv[LV];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int dd = k - (8 - depth);
+            for (int k = 0; k < LV; ++k) {
+                const int dd = k - (LV - depth);
                 fi[k] = dd >= 0 ? cp[2 * dd] : 0;
                 tv[k] = dd >= 0 ? cp[2 * dd + 1] : 0x7f800000;
             }
@@ -76,10 +95,10 @@ __global__ __launch_bounds__(256) void k_leaf_slots(const int32_t *__restrict__ 
                 const float *x = xt + r * xs;
                 int leaf = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < LV; ++k) {
                     const bool pass = fi[k] >= 0 ? (x[fi[k]] > __int_as_float(tv[k]))
                                                  : (cat_codes != nullptr && cat_codes[static_cast<size_t>(r0 + r) * Fc + ~fi[k]] == tv[k]);
-                    leaf |= pass ? (128 >> k) : 0;
+                    leaf |= pass ? ((1 << (LV - 1)) >> k) : 0;
                 }
                 dst[static_cast<size_t>(r) * Ts] = (first + leaf) * D * 4;
             }
@@ -241,12 +260,12 @@ bool predict_chain(const PredictModel &pm, const float *obs, int F, const int32_
     while (rows > 8 && static_cast<long long>(tree_blocks) * ((n + rows - 1) / rows) < 1024) rows >>= 1;
     const size_t lds = static_cast<size_t>(rows) * xs * sizeof(float);
     dim3 grid(tree_blocks, (n + rows - 1) / rows);
-    if (pm.oblivious)
-        hipLaunchKernelGGL(k_leaf_slots<false>, grid, dim3(256), lds, s, pm.tree_indices, pm.depths, pm.cond_pack, pm.max_depth, nullptr, nullptr,
-                           pm.D, obs, F, cat_codes, Fc, n, start_tree, Tn, Ts, rows, pm.slots);
-    else
-        hipLaunchKernelGGL(k_leaf_slots<true>, grid, dim3(256), lds, s, pm.tree_indices, nullptr, nullptr, pm.max_depth, pm.grd_nodes,
-                           pm.grd_node_off, pm.D, obs, F, cat_codes, Fc, n, start_tree, Tn, Ts, rows, pm.slots);
+#define GBRL_SLOTS(G_, LV_) hipLaunchKernelGGL((k_leaf_slots<G_, LV_>), grid, dim3(256), lds, s, pm.tree_indices, pm.depths, pm.cond_pack, pm.max_depth, pm.grd_nodes, pm.grd_node_off, pm.D, obs, F, cat_codes, Fc, n, start_tree, Tn, Ts, rows, pm.slots)
+    if (!pm.oblivious) GBRL_SLOTS(true, 8);
+    else if (pm.max_depth <= 4) GBRL_SLOTS(false, 4);
+    else if (pm.max_depth <= 6) GBRL_SLOTS(false, 6);
+    else GBRL_SLOTS(false, 8);
+#undef GBRL_SLOTS
     ChainCoef coef;
     for (int j = 0; j < 64; ++j) coef.c[j] = j < pm.D ? -pm.coef[j] : 0.0f;
     coef.cover = pm.coef_cover;
