@@ -422,6 +422,15 @@ def main():
         large = {"trees": T2, "ms_per_call": dtl * 1e3, "rows_per_s": world * N / dtl, "row_trees_per_s": world * N * T2 / dtl,
                  "kernel_ms": m.last_phase_times().get("predict", 0.0), "roofline": predict_roofline(N, F, D, T2, depth, dtl),
                  "grown": "%d extra full-size steps in %.1f s (%.2f ms/step, no profiling events)" % (T2 - n_trees, grow_s, grow_s * 1e3 / max(1, T2 - n_trees))}
+        # the same ensemble asked for an RL-sized batch (an agent's minibatch): the latency path (exact chain in two launches up to 8192 rows,
+        # the reference's thread slices below 2 * par_th rows -- DESIGN.md section 5, profiles/r02_predict_latency.txt)
+        small = {}
+        for rows in (16, 1024, 4096):
+            xs_ = X[:rows]
+            xr = (xs_.data_ptr(), tuple(xs_.shape), str(xs_.dtype), "cuda")
+            dts = time_predict(torch, m, xr, None, 20)
+            small[str(rows)] = {"ms_per_call": dts * 1e3, "kernel_ms": m.last_phase_times().get("predict", 0.0), "row_trees_per_s": rows * T2 / dts}
+        large["small_batches"] = small
 
     extra = {}
     if world == 1 and not args.no_extra_legs and not args.force_collective:
