@@ -318,7 +318,8 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     // (not inside fit(): its gradients follow the reference's per-row tree-order chain at every batch size)
     pm.par_th = md.par_th;
     // (nor for a model whose file cleared parallel_predict: the reference then runs the chain for every batch, predictor.cpp:144)
-    if (!in_fit_ && model.parallel_predict && n <= 64 * 256 && stop - start_tree >= 128) {
+    const char *nosplit = std::getenv("GBRL_HIP_PREDICT_NOSPLIT");   // measurement hook: no partial sums over tree ranges
+    if (!in_fit_ && model.parallel_predict && n <= 64 * 256 && stop - start_tree >= 128 && !(nosplit && nosplit[0] == '1')) {
         pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
         pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
     }
@@ -329,7 +330,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.slots = nullptr; pm.slot_ints = 0;
     {
         const int trees = stop - start_tree;
-        bool want = n <= kChainMaxRows && trees >= kChainMinTrees;
+        bool want = (n <= kChainMaxRows && trees >= kChainMinTrees) || (n <= 1024 && trees >= 128);
         if (const char *e = std::getenv("GBRL_HIP_PREDICT_CHAIN")) want = e[0] == '1' ? (n <= 64 * 256 && trees >= 1) : false;
         if (want) {
             const size_t ints = kern::predict_chain_slot_ints(n, trees);

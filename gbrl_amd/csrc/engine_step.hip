@@ -1588,7 +1588,9 @@ float Engine::fit(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         bn = start + bs < n ? bs : n - start;
     }
     // loss on the whole data set over trees [0, iterations) (fitter.cpp:246-251)
-    predict(dobs, true, Fc > 0 ? dcat : nullptr, true, n, F, Fc, 0, iterations, d_preds, true);
+    in_fit_ = true;   // the chain here too: the returned loss does not depend on how a stand-alone predict() would split the trees
+    try { predict(dobs, true, Fc > 0 ? dcat : nullptr, true, n, F, Fc, 0, iterations, d_preds, true); } catch (...) { in_fit_ = false; throw; }
+    in_fit_ = false;
     float *d_full_grads = static_cast<float *>(d_fit_grads_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
     kern::sub_arrays(d_preds, dtar, d_full_grads, static_cast<size_t>(n) * D, s);
     return rmse(d_full_grads, n);

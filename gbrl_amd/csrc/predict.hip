@@ -686,7 +686,10 @@ void predict(const PredictModel &pm_in, const float *obs, int F, const int32_t *
     // 50 000 trees, measured), so beyond a few thousand trees a differently associated -- more accurate -- sum would leave the 1e-5
     // band around the reference's chain; larger ensembles keep the chain wherever the reference runs it.
     pm.tree_splits = 1;
-    if (pm.partial && trees >= 128 && trees <= 2048 && row_tiles <= 64) {
+    // (up to 1024 rows the exact chain of kern::predict_chain costs the same -- 17 vs 14 us at 600 trees, 36 vs 32 us at 2000 -- and is taken
+    // instead: those batches get the same bits whatever their size)
+    const bool chain_first = pm.slots != nullptr && n <= 1024;
+    if (pm.partial && trees >= 128 && trees <= 2048 && row_tiles <= 64 && !chain_first) {
         int splits = std::min(64, std::min(trees / 32, std::max(1, 512 / row_tiles)));
         while (splits > 1 && static_cast<size_t>(splits) * n * pm.D > pm.partial_floats) --splits;
         if (splits > 1) {

@@ -873,7 +873,10 @@ def test_fit_past_512_trees_uses_the_chain_path_and_grows_the_same_model(monkeyp
         m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.05, start_idx=0, stop_idx=D)
         m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
         loss = m.fit(X, None, y, 560, False, "MultiRMSE")
+        if chain == "0":
+            monkeypatch.setenv("GBRL_HIP_PREDICT_GENERIC", "1")      # the one-thread-per-row chain
         out.append((loss, m.get_ensemble_data(), np.asarray(m.predict(X, None, 0, 0))))
+        monkeypatch.delenv("GBRL_HIP_PREDICT_GENERIC", raising=False)
     (l1, e1, p1), (l0, e0, p0) = out
     assert int(np.asarray(e1["depths"]).size) == 560
     assert l1 == l0
