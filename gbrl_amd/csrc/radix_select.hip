@@ -17,6 +17,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace gbrl {
@@ -55,7 +56,7 @@ struct RadixState {
 // ---- counting pass --------------------------------------------------------------------------------------------------
 template <int PASS>
 __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *__restrict__ kt, int n, int n_chunks, int B,
-                                                               RadixState st, uint32_t *__restrict__ partial) {
+                                                               RadixState st, uint32_t *__restrict__ partial, bool plain_loads) {
     extern __shared__ uint32_t rl[];
     constexpr int NB = radix_bins(PASS);
     constexpr int SH = radix_shift(PASS);
@@ -150,10 +151,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
             i0 = hi;
         }
     }
-    for (; i0 + (U - 1) * kRadixThreads < hi; i0 += kRadixThreads * U) {   // full strips: straight-line loads
-        uint32_t key[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) key[u] = col[i0 + u * kRadixThreads];
+    auto strip = [&](const uint32_t (&key)[U]) __attribute__((always_inline)) {
         if (PASS >= 3) {
             // The hits (a few % of the keys) are compacted ACROSS the wave into its LDS queue and the exact chain runs on 64 queued
             // keys at a time: per-lane handling made the whole wave walk the chain for one or two sparse candidates per strip.
@@ -180,6 +178,28 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
 #pragma unroll
             for (int u = 0; u < U; ++u) count_one(key[u]);
         }
+    };
+    if (i0 < hi && (n & 3) == 0 && !plain_loads) {
+        // 16-byte loads (the column starts 16-byte aligned when n % 4 == 0, the chunk bounds are multiples of 4): a thread takes four
+        // consecutive keys per load, two loads per iteration.  Counting does not depend on the order of the keys.
+        const int iters = (hi - i0 + static_cast<int>(threadIdx.x)) / (kRadixThreads * U);      // (hi - chunk start) / keys per iteration
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(col + (i0 - static_cast<int>(threadIdx.x)));
+        for (int it = 0; it < iters; ++it) {
+            uint32_t key[U];
+#pragma unroll
+            for (int v = 0; v < U / 4; ++v) {
+                const uint4 x = c4[(it * (U / 4) + v) * kRadixThreads + threadIdx.x];
+                key[4 * v] = x.x; key[4 * v + 1] = x.y; key[4 * v + 2] = x.z; key[4 * v + 3] = x.w;
+            }
+            strip(key);
+        }
+        i0 += iters * kRadixThreads * U;
+    }
+    for (; i0 + (U - 1) * kRadixThreads < hi; i0 += kRadixThreads * U) {   // full strips: straight-line loads
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) key[u] = col[i0 + u * kRadixThreads];
+        strip(key);
     }
     if (PASS >= 3 && static_cast<int>(__lane_id()) < qlen) count_one(queue[__lane_id()]);   // what is left in the wave's queue
     for (; i0 < hi; i0 += kRadixThreads) count_one(col[i0]);
@@ -424,13 +444,14 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
         return 0;
     };
     int rc = 0;
-    hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial);
+    static const bool plain_loads = [] { const char *e = std::getenv("GBRL_HIP_RADIX_PLAIN_LOADS"); return e && e[0] == '1'; }();   // measurement hook
+    hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial, plain_loads);
     if ((rc = finish_pass(1, c1)) != 0) return rc;
-    hipLaunchKernelGGL(k_radix_count<2>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
+    hipLaunchKernelGGL(k_radix_count<2>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial, plain_loads);
     if ((rc = finish_pass(2, cn)) != 0) return rc;
-    hipLaunchKernelGGL(k_radix_count<3>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial);
+    hipLaunchKernelGGL(k_radix_count<3>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial, plain_loads);
     if ((rc = finish_pass(3, cn)) != 0) return rc;
-    hipLaunchKernelGGL(k_radix_count<4>, dim3(cn, F), dim3(kRadixThreads), lds4, s, kt, n, cn, B, st, partial);
+    hipLaunchKernelGGL(k_radix_count<4>, dim3(cn, F), dim3(kRadixThreads), lds4, s, kt, n, cn, B, st, partial, plain_loads);
     return finish_pass(4, cn);
 }
 
