@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
             atomicAdd(&cnt[idx], 1u);
         }
     };
-    constexpr int U = 8;
+    constexpr int U = 16;   // keys per thread in flight (8: 0.441 ms, 16: 0.406 ms, 32: 0.432 ms for the four passes at 2^20 x 128)
     int i0 = lo + threadIdx.x;
     int qlen = 0;   // wave-uniform
     if (PASS == 4) {
