@@ -790,13 +790,31 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         const int sib = sub_sib[node];
         const int64_t *pp = hist_prev + (static_cast<size_t>(par) * Fp + fs) * NB * W;
         const int64_t *ss = sib >= 0 ? hist + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
-        for (int i = threadIdx.x; i < NB * W; i += blockDim.x) {
-            const int64_t v = pp[i] - (ss ? ss[i] : 0);
-            sh64[i] = v;
-            src[i] = v;
+        // four elements per thread in flight (the slice is ~2300 words: nine dependent round trips per thread otherwise)
+        const int tot = NB * W, step = static_cast<int>(blockDim.x);
+        for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * step) {
+            int64_t a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * step;
+                a[u] = i < tot ? pp[i] : 0;
+                b[u] = (ss && i < tot) ? ss[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * step;
+                if (i < tot) { const int64_t v = a[u] - b[u]; sh64[i] = v; src[i] = v; }
+            }
         }
     } else {
-        for (int i = threadIdx.x; i < NB * W; i += blockDim.x) sh64[i] = src[i];
+        const int tot = NB * W, step = static_cast<int>(blockDim.x);
+        for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * step) {
+            int64_t a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * step; a[u] = i < tot ? src[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * step; if (i < tot) sh64[i] = a[u]; }
+        }
     }
     __syncthreads();
     // totals = sum over all classes; also turn numeric features into suffix sums in place.  Block-wide scan: thread t of a
@@ -810,7 +828,10 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         long long run_base[WCH];
 #pragma unroll
         for (int j = 0; j < WCH; ++j) run_base[j] = 0;
-        for (int tile = 0; tile * 256 < NB; ++tile) {
+        // (a last tile of at most 4 classes -- 257 classes = 256 + 1 is the usual shape -- is added serially below instead of
+        // paying a block-wide scan and two barriers for it)
+        const int n_tiles = (NB + 255) / 256 - ((NB % 256) != 0 && (NB % 256) <= 4 && NB > 256 ? 1 : 0);
+        for (int tile = 0; tile < n_tiles; ++tile) {
             const int c = NB - 1 - (tile * 256 + static_cast<int>(threadIdx.x));
             long long v[WCH];
 #pragma unroll
@@ -841,9 +862,17 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
+        const int rem = NB - n_tiles * 256;       // classes 0 .. rem-1 not covered by a tile (0 or 1..4): suffix sums by one thread per field
+        if (static_cast<int>(threadIdx.x) < WCH && w0 + static_cast<int>(threadIdx.x) < W) {
+            const int j = threadIdx.x;
+            long long run = 0;
 #pragma unroll
-            for (int j = 0; j < WCH; ++j) if (w0 + j < W) total[w0 + j] = run_base[j];
+            for (int jj = 0; jj < WCH; ++jj) if (jj == j) run = run_base[jj];
+            for (int c = rem - 1; c >= 0; --c) {
+                run += sh64[c * W + w0 + j];
+                if (!sl.is_cat) sh64[c * W + w0 + j] = run;
+            }
+            total[w0 + j] = run;
         }
     }
     __syncthreads();
