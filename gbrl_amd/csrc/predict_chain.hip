@@ -13,7 +13,7 @@
 //                  take turns on the same chains and gather while the others apply (see the kernel).
 //
 // The result has the bits of the one-chain-per-row kernels (same operands, same order, same fused operation), so it also serves
-// fit()'s internal predictions.  Scratch: n * (trees + 1600) int32.
+// fit()'s internal predictions.  Scratch: n * (trees + 704) int32.
 #include "kernels.h"
 #include "kernels_common.h"
 
@@ -27,7 +27,7 @@ namespace kern {
 namespace {
 
 constexpr int kChainU = 64;          // slot rows are padded in multiples of this many trees
-constexpr int kSlotPad = 24 * kChainU;   // >= 2 * U * K of every variant below: the ring reads up to 2 K - 1 batches behind the last whole round
+constexpr int kSlotPad = 10 * kChainU;   // the relay requests up to 3 W - 2 batches behind the range (k_chain_relay asserts it)
 
 struct ChainCoef {
     float c[64];        // -lr of the optimiser that owns the output
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_leaf_slots(const int32_t *__restrict__ 
     const int j = blockIdx.x * 256 + threadIdx.x;     // tree of the range, or padding behind it
     if (j >= Ts) return;
     int32_t *dst = slots + static_cast<size_t>(r0) * Ts + j;
-    if (j >= Tn) {   // padding: the chain kernel loads (never applies) up to four batches behind the range
+    if (j >= Tn) {   // padding: the chain kernel loads (never applies) up to ten batches behind the range
         for (int r = 0; r < rows; ++r) dst[static_cast<size_t>(r) * Ts] = 0;
         return;
     }
