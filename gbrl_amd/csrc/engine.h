@@ -140,7 +140,8 @@ class Engine {
     bool in_fit_ = false;   // predict() called from fit(): keep one accumulation chain per row in tree order (no tree-range split)
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
-    hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back
+    hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back (GBRL_HIP_EVENT_RESULTS=1: the copy-engine path)
+    uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;
 

@@ -16,6 +16,7 @@
 #include "cat_hash.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -800,7 +801,14 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // result block read back once per level: [best_idx i32 x mf][best_score f32 x mf][counts i64 x 4 x mf]
     const size_t res_bytes = static_cast<size_t>(max_front) * (4 + 4 + 32) + 64;
     char *d_res = static_cast<char *>(d_results_.ensure(res_bytes));
-    char *h_res = static_cast<char *>(pin_res_.ensure(res_bytes));
+    // The block lives in pinned host memory that the device can write: a one-block kernel publishes it (k_publish_block) and the host
+    // polls a sequence word behind it -- no copy-engine launch, no event, and the partition kernel starts right behind the selection.
+    char *h_res = static_cast<char *>(pin_res_.ensure(res_bytes + 64));
+    volatile uint32_t *h_flag = reinterpret_cast<volatile uint32_t *>(h_res + res_bytes);
+    void *h_res_dev = nullptr;
+    hip_check(hipHostGetDevicePointer(&h_res_dev, h_res, 0), "hipHostGetDevicePointer");
+    uint32_t *d_flag = reinterpret_cast<uint32_t *>(static_cast<char *>(h_res_dev) + res_bytes);
+    const bool event_results = [] { const char *e = std::getenv("GBRL_HIP_EVENT_RESULTS"); return e && e[0] == '1'; }();   // measurement hook
     int32_t *d_best_idx = reinterpret_cast<int32_t *>(d_res);
     float *d_best_score = reinterpret_cast<float *>(d_res + 4 * static_cast<size_t>(max_front));
     int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
@@ -1156,20 +1164,39 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 kern::count_right(d_rows[cur], d_codes, c.d_kt, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
             kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);   // global left sizes -> this rank's
         }
-        hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
+        uint32_t seq = 0;
+        if (event_results) hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
+        else {
+            seq = ++level_seq_;
+            if (seq == 0) seq = ++level_seq_;
+            kern::publish_block(d_res, h_res_dev, res_bytes, d_flag, seq, s);
+        }
         phase_end("score_select");
         {
-            hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");
+            if (event_results) hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");
             phase_begin();
             if (!part_chunks.empty())
                 kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, c.d_kt, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved,
                                      d_cursors, s);
             phase_end("partition");
             // spin on the event (a blocking wait costs a thread wake-up of ~10-20 us per level; the wait itself is a few tens of us)
-            for (;;) {
-                const hipError_t q = hipEventQuery(ev_level_);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) hip_check(q, "hipEventQuery(level results)");
+            if (event_results) {
+                for (;;) {
+                    const hipError_t q = hipEventQuery(ev_level_);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) hip_check(q, "hipEventQuery(level results)");
+                }
+            } else {
+                // poll the sequence word; now and then ask the stream for errors (a faulted kernel would never publish)
+                int idle = 0;
+                for (unsigned spins = 1; *h_flag != seq; ++spins) {
+                    if ((spins & 0x3fff) == 0) {
+                        const hipError_t q = hipStreamQuery(s);
+                        if (q == hipSuccess) { if (++idle > 64) throw HipError("internal: level results were not published"); }
+                        else if (q != hipErrorNotReady) hip_check(q, "hipStreamQuery(level results)");
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
             }
         }
         hip_check(hipGetLastError(), "growth kernels");

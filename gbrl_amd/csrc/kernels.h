@@ -98,6 +98,10 @@ void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
 void f32_to_f64(const float *in, double *out, int n, hipStream_t s);
 void keys_to_floats(uint32_t *keys /*NaN-range keys are raised to -inf's key in place*/, float *out, size_t n, hipStream_t s);
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
+// The level's result block handed to the host without a copy engine: one block copies `bytes` (a multiple of 4) from device memory to
+// pinned, device-mapped host memory and then stores `seq` to `flag` (system scope).  The host polls the flag; what it then reads is
+// complete (the stores are fenced before the flag) and every earlier operation of the stream has finished.
+void publish_block(const void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 
 // ---- exact quantile selection and binning on transposed keys (quantile.hip) ----

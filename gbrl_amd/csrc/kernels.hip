@@ -694,6 +694,13 @@ __global__ void k_hist_place_slice(const int64_t *__restrict__ recv, int64_t *__
     int64_t *dst = hist + (static_cast<size_t>(slot_map[k]) * Fp + lo + f) * feat_elems;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < feat_elems; i += static_cast<size_t>(gridDim.x) * blockDim.x) dst[i] = src[i];
 }
+__global__ __launch_bounds__(256) void k_publish_block(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int words, uint32_t *flag,
+                                                       uint32_t seq) {
+    for (int i = threadIdx.x; i < words; i += 256) __builtin_nontemporal_store(src[i], &dst[i]);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_fill_f32(float *__restrict__ p, size_t n, float v) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1480,6 +1487,10 @@ void hist_place_slice(const int64_t *recv, int64_t *hist, const int32_t *slot_ma
     if (n <= 0 || fs <= 0) return;
     hipLaunchKernelGGL(k_hist_place_slice, dim3(static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(8, (feat_elems + 255) / 256))), fs, n), dim3(256), 0, s, recv, hist,
                        slot_map, fs, lo, Fp, feat_elems);
+}
+void publish_block(const void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_publish_block, dim3(1), dim3(256), 0, s, static_cast<const uint32_t *>(d_src), static_cast<uint32_t *>(h_dst_mapped),
+                       static_cast<int>(bytes / 4), flag_mapped, seq);
 }
 void fill_f32(float *p, size_t n, float v, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p, n, v);
