@@ -141,6 +141,21 @@ class Engine {
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
     hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back (GBRL_HIP_EVENT_RESULTS=1: the copy-engine path)
+    // Per-step constants of numeric-only steps (feature slots, candidate weights / reference order / slot lookup): they depend on
+    // (F, n_bins, growth policy, feature weights, feature mapping) only, so they are built and uploaded once and reused while those
+    // stay the same and the device staging block is still the one they were uploaded to.
+    struct StepConstCache {
+        bool valid = false;
+        int F = 0, B = 0, oblivious = 0;
+        std::vector<float> fw;
+        std::vector<int32_t> rev;
+        std::vector<kern::FeatureSlot> slots;
+        std::vector<int32_t> cand_ref, cand_slot;
+        std::vector<float> cand_w;
+        std::vector<int> ref_to_internal;
+        const void *dev_base = nullptr;   // device staging block that holds the uploaded copy (nullptr: not uploaded yet)
+        size_t stage_bytes = 0;
+    } step_const_;
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;

@@ -64,6 +64,8 @@ struct GrowCtx {
     const std::vector<float> *cand_w;
     const std::vector<int32_t> *cand_ref;
     const std::vector<int> *ref_to_internal;
+    const std::vector<int32_t> *cand_slot;
+    bool const_cacheable;               // numeric-only step: the constants above live in Engine::step_const_
     const std::vector<CatCandidate> *cat_cands;
     const float *h_thr;                 // pinned; valid once the stream has passed the copy enqueued behind the binning
     const kern::StepScales *h_scales;   // pinned, same
@@ -105,9 +107,18 @@ class Stager {
         used_ += (bytes + 255) & ~static_cast<size_t>(255);
         return d;
     }
+    template <typename T>
+    T *reserve(size_t n) {     // the device address put() would return, without touching the host copy (the block is already uploaded)
+        const size_t bytes = n * sizeof(T);
+        if (used_ + bytes + 256 > cap_) throw HipError("internal: staging buffer overflow");
+        T *d = reinterpret_cast<T *>(dev_ + used_);
+        used_ += (bytes + 255) & ~static_cast<size_t>(255);
+        return d;
+    }
     void flush() {
         if (used_) hip_check(hipMemcpyAsync(dev_, host_, used_, hipMemcpyHostToDevice, s_), "H2D staged descriptors");
     }
+    const void *device_base() const { return dev_; }
 
    private:
     hipStream_t s_;
@@ -785,19 +796,30 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
     hip_check(hipMemsetAsync(d_leafacc, 0, sizeof(int64_t) * max_nodes * (D + 1), s), "memset leaf acc");
     // per-step constants: slots, candidate weights / reference order / slot lookup
-    std::vector<int32_t> cand_slot(n_cand);
-    for (int fs = 0; fs < n_slots; ++fs)
-        for (int k = 0; k < slots[fs].n_cand; ++k) cand_slot[slots[fs].cand_base + k] = fs;
+    const std::vector<int32_t> &cand_slot = *c.cand_slot;
     const size_t stage_bytes = 4096 + sizeof(FeatureSlot) * n_slots + static_cast<size_t>(n_cand) * 16 +
                                sizeof(Chunk) * (static_cast<size_t>(max_chunks) + N / 4096 + 2 * max_nodes + 64) +
                                static_cast<size_t>(max_front) * (kern::kMaxPath * 12 + 256);
     Stager stc(pin_const_, d_stage_const_, stage_bytes, s), sta(pin_a_, d_stage_a_, stage_bytes, s), stb(pin_b_, d_stage_b_, stage_bytes, s);
-    FeatureSlot *d_slots = stc.put(slots.data(), slots.size());
-    float *d_cand_w = stc.put(cand_w.data(), cand_w.size());
-    int32_t *d_cand_ref = stc.put(cand_ref.data(), cand_ref.size());
-    int32_t *d_ref_to_internal = stc.put(ref_to_internal.data(), ref_to_internal.size());
-    int32_t *d_cand_slot = stc.put(cand_slot.data(), cand_slot.size());
-    stc.flush();
+    FeatureSlot *d_slots;
+    float *d_cand_w;
+    int32_t *d_cand_ref, *d_ref_to_internal, *d_cand_slot;
+    static_assert(sizeof(int) == sizeof(int32_t), "ref_to_internal is uploaded as int32");
+    if (c.const_cacheable && step_const_.dev_base == stc.device_base() && step_const_.stage_bytes == stage_bytes) {
+        d_slots = stc.reserve<FeatureSlot>(slots.size());          // uploaded by an earlier step, same layout
+        d_cand_w = stc.reserve<float>(cand_w.size());
+        d_cand_ref = stc.reserve<int32_t>(cand_ref.size());
+        d_ref_to_internal = reinterpret_cast<int32_t *>(stc.reserve<int>(ref_to_internal.size()));
+        d_cand_slot = stc.reserve<int32_t>(cand_slot.size());
+    } else {
+        d_slots = stc.put(slots.data(), slots.size());
+        d_cand_w = stc.put(cand_w.data(), cand_w.size());
+        d_cand_ref = stc.put(cand_ref.data(), cand_ref.size());
+        d_ref_to_internal = reinterpret_cast<int32_t *>(stc.put(ref_to_internal.data(), ref_to_internal.size()));
+        d_cand_slot = stc.put(cand_slot.data(), cand_slot.size());
+        stc.flush();
+        if (c.const_cacheable) { step_const_.dev_base = stc.device_base(); step_const_.stage_bytes = stage_bytes; }
+    }
     // result block read back once per level: [best_idx i32 x mf][best_score f32 x mf][counts i64 x 4 x mf]
     const size_t res_bytes = static_cast<size_t>(max_front) * (4 + 4 + 32) + 64;
     char *d_res = static_cast<char *>(d_results_.ensure(res_bytes));
@@ -1451,29 +1473,61 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const int n_groups = Fp / FG;
     // internal candidate order = slot-grouped; cand_ref maps to the reference's candidate index (numeric f-major, then the
     // categorical candidates in the hash-map order) which decides ties (lowest reference index wins)
-    std::vector<FeatureSlot> slots(n_slots);
+    std::vector<FeatureSlot> slots_local;
+    std::vector<int32_t> cand_ref_local, cand_slot_local;
+    std::vector<float> cand_w_local;
+    std::vector<int> ref_to_internal_local;
+    // numeric-only steps: these constants depend on (F, n_bins, policy, feature weights, feature mapping) only -- built once, kept in
+    // Engine::step_const_ together with their uploaded copy (grow_tree)
+    const bool const_cacheable = Fc == 0 && F > 0;
+    bool reuse = false;
+    if (const_cacheable) {
+        StepConstCache &cc = step_const_;
+        reuse = cc.valid && cc.F == F && cc.B == B && cc.oblivious == (oblivious ? 1 : 0) && cc.fw == model.feature_weights && cc.rev == model.reverse_num;
+        if (!reuse) {
+            cc.valid = false;
+            cc.dev_base = nullptr;
+            cc.F = F; cc.B = B; cc.oblivious = oblivious ? 1 : 0;
+            cc.fw = model.feature_weights;
+            cc.rev = model.reverse_num;
+        }
+    }
+    std::vector<FeatureSlot> &slots = const_cacheable ? step_const_.slots : slots_local;
+    std::vector<int32_t> &cand_ref = const_cacheable ? step_const_.cand_ref : cand_ref_local;
+    std::vector<int32_t> &cand_slot = const_cacheable ? step_const_.cand_slot : cand_slot_local;
+    std::vector<float> &cand_w = const_cacheable ? step_const_.cand_w : cand_w_local;
+    std::vector<int> &ref_to_internal = const_cacheable ? step_const_.ref_to_internal : ref_to_internal_local;
     int n_cand = 0;
-    for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
-    for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
-    std::vector<int32_t> cand_ref(n_cand);
-    std::vector<float> cand_w(n_cand);
-    std::vector<int> ref_to_internal(n_cand);
-    for (int f = 0; f < F; ++f)
-        for (int k = 0; k < B; ++k) {
-            const int j = slots[f].cand_base + k;
-            cand_ref[j] = f * B + k;
-            // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
-            const int wi = oblivious ? model.reverse_num[f] : f;
+    if (reuse) {
+        n_cand = static_cast<int>(cand_ref.size());
+    } else {
+        slots.assign(n_slots, FeatureSlot{});
+        for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
+        for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
+        cand_ref.assign(n_cand, 0);
+        cand_w.assign(n_cand, 0.0f);
+        ref_to_internal.assign(n_cand, 0);
+        cand_slot.assign(n_cand, 0);
+        for (int f = 0; f < F; ++f)
+            for (int k = 0; k < B; ++k) {
+                const int j = slots[f].cand_base + k;
+                cand_ref[j] = f * B + k;
+                // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
+                const int wi = oblivious ? model.reverse_num[f] : f;
+                cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+            }
+        for (size_t q = 0; q < cat_cands.size(); ++q) {
+            const CatCandidate &cc = cat_cands[q];
+            const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
+            cand_ref[j] = F * B + static_cast<int>(q);
+            const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
             cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
         }
-    for (size_t q = 0; q < cat_cands.size(); ++q) {
-        const CatCandidate &cc = cat_cands[q];
-        const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
-        cand_ref[j] = F * B + static_cast<int>(q);
-        const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
-        cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+        for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
+        for (int fs = 0; fs < n_slots; ++fs)
+            for (int k = 0; k < slots[fs].n_cand; ++k) cand_slot[slots[fs].cand_base + k] = fs;
+        if (const_cacheable) step_const_.valid = true;
     }
-    for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
 
     // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
     phase_begin();
@@ -1498,7 +1552,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     GrowCtx gc{};
     gc.N = N; gc.F = F; gc.Fc = Fc; gc.D = D; gc.B = B; gc.MD = MD; gc.NB = NB; gc.FG = FG; gc.Fp = Fp; gc.n_groups = n_groups;
     gc.n_slots = n_slots; gc.n_cand = n_cand; gc.chunk_rows = chunk_rows; gc.n_global = n_global; gc.cosine = cosine; gc.oblivious = oblivious;
-    gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cat_cands = &cat_cands;
+    gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cand_slot = &cand_slot;
+    gc.const_cacheable = const_cacheable; gc.cat_cands = &cat_cands;
     gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;

@@ -424,3 +424,30 @@ def test_few_rows_against_a_large_ensemble_follow_the_reference_thread_slices(po
     for n in sizes:
         want = ref["p%d" % n].reshape(n, D)
         assert rel_err(full[n], want, 1.0) <= TOL, n
+
+
+@pytest.mark.parametrize("policy", ["greedy", "oblivious"])
+def test_feature_weights_changed_between_steps_are_picked_up(policy):
+    """Numeric-only steps keep their per-step constants (candidate weights, reference order) on the device between calls; a
+    set_feature_weights / another batch size between two steps must rebuild them: every tree equals the oracle's."""
+    import gbrl_amd
+    import oracle
+    case = _case("fw", policy=policy, score="Cosine", N=600, F=5, D=2, depth=3, n_bins=16, trees=0)
+    X, Xc, G, y = K.make_inputs(case)
+    rng = np.random.default_rng(4)
+    models = [gbrl_amd.GBRL(**K.ctor_kwargs(case)), oracle.OracleGBRL(**K.ctor_kwargs(case))]
+    for m in models:
+        K.drive(m, case, X, Xc, G, y)        # optimizers, mapping, unit weights; no trees
+    w1 = np.array([1.0, 0.2, 3.0, 0.0, 1.5], np.float32)
+    w2 = np.array([0.1, 2.0, 1.0, 1.0, 0.0], np.float32)
+    steps = [("step", X, G), ("step", X, (G * np.float32(0.7)).astype(np.float32)), ("w", w1), ("step", X, G), ("step", X[:333], G[:333]),
+             ("w", w2), ("step", X[:333], G[:333]), ("step", X, G), ("w", np.ones(5, np.float32)), ("step", X, G)]
+    for m in models:
+        for op in steps:
+            if op[0] == "w":
+                m.set_feature_weights(op[1])
+            else:
+                m.step(np.ascontiguousarray(op[1]), None, np.ascontiguousarray(op[2]))
+    e, o = models[0].get_ensemble_data(), models[1].get_ensemble_data()
+    assert_structure_equal(e, o, what="weights changed between steps: ")
+    assert_values_close(e, o, float(np.abs(G).mean()), TOL)
