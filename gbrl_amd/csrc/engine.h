@@ -156,6 +156,9 @@ class Engine {
         const void *dev_base = nullptr;   // device staging block that holds the uploaded copy (nullptr: not uploaded yet)
         size_t stage_bytes = 0;
     } step_const_;
+    DevBuf d_rows_iota_;              // 0, 1, 2, ...: the root's row list, generated when it grows and read-only afterwards
+    const void *iota_ptr_ = nullptr;
+    int iota_n_ = 0;
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;

@@ -835,7 +835,27 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     float *d_best_score = reinterpret_cast<float *>(d_res + 4 * static_cast<size_t>(max_front));
     int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
     NodeSplit *d_resolved = static_cast<NodeSplit *>(d_splits_.ensure(sizeof(NodeSplit) * max_front));
-    kern::iota_rows(d_rows[0], N, s);
+    // The root's row list 0 .. N-1 is kept between steps (generated again only when N outgrows it): level 0 reads it in place of
+    // d_rows[0] and, after the first partition, d_rows[0] becomes the second scratch list again.  (The device-planned loop indexes the
+    // two lists by depth parity and keeps generating its own.)
+    int32_t *const d_rows_b = d_rows[0];
+    bool iota_root = false;
+    {
+        const char *e = std::getenv("GBRL_HIP_DEVICE_LEVELS");
+        const char *e2 = std::getenv("GBRL_HIP_NO_IOTA_CACHE");   // measurement hook
+        if (!(oblivious && e && e[0] == '1') && !(e2 && e2[0] == '1')) {
+            int32_t *d_iota = static_cast<int32_t *>(d_rows_iota_.ensure(sizeof(int32_t) * N));
+            if (d_iota != iota_ptr_ || iota_n_ < N) {
+                kern::iota_rows(d_iota, N, s);
+                iota_ptr_ = d_iota;
+                iota_n_ = N;
+            }
+            d_rows[0] = d_iota;
+            iota_root = true;
+        } else {
+            kern::iota_rows(d_rows[0], N, s);
+        }
+    }
     // No synchronisation here: thresholds and scales are on their way to pinned memory; the first level's event wait (or the
     // final synchronisation) covers them.  Non-finite gradients are rejected after the loop, before anything joins the model.
 
@@ -1239,6 +1259,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         }
         if (splitting.empty()) { frontier.clear(); break; }
         cur ^= 1;   // the partition was enqueued from the device-side descriptors (same decisions: best_score rule, n_left)
+        if (iota_root) { d_rows[0] = d_rows_b; iota_root = false; }   // the root list is read-only: the next partition writes the scratch list
         frontier = next;
     }
 
