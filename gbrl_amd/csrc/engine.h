@@ -159,6 +159,8 @@ class Engine {
     DevBuf d_rows_iota_;              // 0, 1, 2, ...: the root's row list, generated when it grows and read-only afterwards
     const void *iota_ptr_ = nullptr;
     int iota_n_ = 0;
+    DevBuf d_pub_done_;               // block counter of k_resolve_splits' in-kernel publication (zero between launches)
+    const void *pub_done_ptr_ = nullptr;
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;

@@ -830,6 +830,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     void *h_res_dev = nullptr;
     hip_check(hipHostGetDevicePointer(&h_res_dev, h_res, 0), "hipHostGetDevicePointer");
     uint32_t *d_flag = reinterpret_cast<uint32_t *>(static_cast<char *>(h_res_dev) + res_bytes);
+    unsigned *d_pub_done = static_cast<unsigned *>(d_pub_done_.ensure(256));
+    if (d_pub_done != pub_done_ptr_) {
+        hip_check(hipMemsetAsync(d_pub_done, 0, 256, s), "memset publication counter");
+        pub_done_ptr_ = d_pub_done;
+    }
     const bool event_results = [] { const char *e = std::getenv("GBRL_HIP_EVENT_RESULTS"); return e && e[0] == '1'; }();   // measurement hook
     int32_t *d_best_idx = reinterpret_cast<int32_t *>(d_res);
     float *d_best_score = reinterpret_cast<float *>(d_res + 4 * static_cast<size_t>(max_front));
@@ -1189,8 +1194,15 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         if (oblivious)
             kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
+        // (one GPU: the kernel itself mirrors the result block into the pinned host copy and its last block publishes the sequence word)
+        uint32_t seq = 0;
+        const bool publish_in_resolve = !has_coll_ && !event_results;
+        if (!event_results) {
+            seq = ++level_seq_;
+            if (seq == 0) seq = ++level_seq_;
+        }
         kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
-                             d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s);
+                             d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, publish_in_resolve ? h_res_dev : nullptr, d_flag, seq, d_pub_done);
         if (has_coll_) {
             // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
             const int n_win = oblivious ? 1 : n_act;
@@ -1206,13 +1218,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 kern::count_right(d_rows[cur], d_codes, c.d_kt, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
             kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);   // global left sizes -> this rank's
         }
-        uint32_t seq = 0;
         if (event_results) hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
-        else {
-            seq = ++level_seq_;
-            if (seq == 0) seq = ++level_seq_;
-            kern::publish_block(d_res, h_res_dev, res_bytes, d_flag, seq, s);
-        }
+        else if (!publish_in_resolve) kern::publish_block(d_res, h_res_dev, res_bytes, d_flag, seq, s);   // row-sharded: later kernels complete the block
         phase_end("score_select");
         {
             if (event_results) hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");

@@ -208,7 +208,10 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
                     NodeSplit *out, int64_t *counts4 /*[4][max_front]*/, int max_front,
                     const int32_t *seg_start /*nullable: when given, out[] is a complete partition descriptor (do_split from
                     best_score, seg_start, n_left from hist_local) and cursors[2*node..] are zeroed*/,
-                    int32_t *cursors, const uint32_t *thr_keys /*[F][B] ordered threshold keys*/, int B, hipStream_t s);
+                    int32_t *cursors, const uint32_t *thr_keys /*[F][B] ordered threshold keys*/, int B, hipStream_t s,
+                    void *pub = nullptr /*pinned, device-mapped copy of the result block [best_idx | best_score | counts4]: mirrored, then ...*/,
+                    uint32_t *pub_flag = nullptr /*... the last block stores pub_seq here (system scope)*/, uint32_t pub_seq = 0,
+                    unsigned *pub_done = nullptr /*device counter, zero between launches*/);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);

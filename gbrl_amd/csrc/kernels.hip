@@ -1037,8 +1037,14 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                                                        const int64_t *__restrict__ hist_global, int Fp, int NB, int D,
                                                        NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front,
                                                        const int32_t *__restrict__ seg_start /*nullable*/, int32_t *__restrict__ cursors,
-                                                       const uint32_t *__restrict__ thr_keys, int B) {
+                                                       const uint32_t *__restrict__ thr_keys, int B, char *pub, uint32_t *pub_flag,
+                                                       uint32_t pub_seq, unsigned *pub_done) {
     const int node = blockIdx.x;
+    // pub != nullptr: the result block [best_idx | best_score | counts4] is mirrored into pinned, device-mapped host memory of the same
+    // layout and the LAST block to finish stores pub_seq to pub_flag (system scope) -- the host polls it (no publishing launch)
+    int32_t *pub_idx = reinterpret_cast<int32_t *>(pub);
+    float *pub_score = reinterpret_cast<float *>(pub + 4 * static_cast<size_t>(max_front));
+    int64_t *pub_counts = reinterpret_cast<int64_t *>(pub + 8 * static_cast<size_t>(max_front));
     // final stage of the argmax (same total order as stage 1: higher score, then lower reference index): every block
     // reduces the per-block bests of its node (oblivious: of the level); the owner block publishes them for the host
     const int src_node = oblivious ? 0 : node;
@@ -1051,7 +1057,10 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     }
     const int best = mine.i == 0x7fffffff ? 0 : mine.i;
     const float best_v = mine.v;
-    if (threadIdx.x == 0 && node == src_node) { best_idx[node] = best; best_score[node] = best_v; }
+    if (threadIdx.x == 0 && node == src_node) {
+        best_idx[node] = best; best_score[node] = best_v;
+        if (pub) { pub_idx[node] = best; pub_score[node] = best_v; }
+    }
     const int j = ref_to_internal[best];
     const int fs = cand_slot[j];
     const FeatureSlot sl = slots[fs];
@@ -1070,6 +1079,10 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
         if (threadIdx.x == 0) {
             counts4[(2 * pass + 0) * static_cast<size_t>(max_front) + node] = tot;
             counts4[(2 * pass + 1) * static_cast<size_t>(max_front) + node] = right;
+            if (pub) {
+                pub_counts[(2 * pass + 0) * static_cast<size_t>(max_front) + node] = tot;
+                pub_counts[(2 * pass + 1) * static_cast<size_t>(max_front) + node] = right;
+            }
             if (pass == 0) n_left = static_cast<int>(tot - right);
         }
     }
@@ -1088,6 +1101,13 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
             cursors[2 * node + 1] = 0;
         }
         out[node] = q;
+        if (pub) {
+            __threadfence_system();
+            if (atomicAdd(pub_done, 1u) == gridDim.x - 1) {
+                *pub_done = 0;     // ready for the next launch (launches on one stream do not overlap)
+                __hip_atomic_store(pub_flag, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -1534,9 +1554,10 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const 
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
                     NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, const uint32_t *thr_keys,
-                    int B, hipStream_t s) {
+                    int B, hipStream_t s, void *pub, uint32_t *pub_flag, uint32_t pub_seq, unsigned *pub_done) {
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, part_v, part_i, n_parts, best_idx, best_score, oblivious ? 1 : 0,
-                       ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors, thr_keys, B);
+                       ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors, thr_keys, B,
+                       static_cast<char *>(pub), pub_flag, pub_seq, pub_done);
 }
 
 // Row-sharded runs: k_resolve_splits wrote GLOBAL left sizes; the partition needs this rank's.
