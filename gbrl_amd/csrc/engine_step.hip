@@ -1291,9 +1291,33 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         exchange(Red::SumI64, d_leafacc, static_cast<size_t>(nodes.size()) * (D + 1));
     }
     const size_t n_acc_words = nodes.size() * (D + 1);
-    int64_t *h_acc = static_cast<int64_t *>(pin_acc_.ensure(sizeof(int64_t) * std::max<size_t>(1, n_acc_words)));   // pinned: a true async copy
-    hip_check(hipMemcpyAsync(h_acc, d_leafacc, sizeof(int64_t) * n_acc_words, hipMemcpyDeviceToHost, s), "D2H leaf acc");
-    hip_check(hipStreamSynchronize(s), "sync");
+    // The leaf sums reach the host the way the level results do: a one-block kernel stores them into pinned, device-mapped memory and
+    // then a sequence word; the host polls it instead of a copy-engine transfer + hipStreamSynchronize (a blocking wait costs a thread
+    // wake-up).  Seeing the word means every earlier operation of the stream -- all kernels that read the caller's inputs, the
+    // copies of thresholds and scales -- has completed.
+    const size_t acc_bytes = sizeof(int64_t) * std::max<size_t>(1, n_acc_words);
+    char *h_acc_raw = static_cast<char *>(pin_acc_.ensure(acc_bytes + 64));
+    int64_t *h_acc = reinterpret_cast<int64_t *>(h_acc_raw);
+    if (event_results) {
+        hip_check(hipMemcpyAsync(h_acc, d_leafacc, sizeof(int64_t) * n_acc_words, hipMemcpyDeviceToHost, s), "D2H leaf acc");
+        hip_check(hipStreamSynchronize(s), "sync");
+    } else {
+        void *h_acc_dev = nullptr;
+        hip_check(hipHostGetDevicePointer(&h_acc_dev, h_acc_raw, 0), "hipHostGetDevicePointer");
+        volatile uint32_t *h_aflag = reinterpret_cast<volatile uint32_t *>(h_acc_raw + acc_bytes);
+        uint32_t seq = ++level_seq_;
+        if (seq == 0) seq = ++level_seq_;
+        kern::publish_block(d_leafacc, h_acc_dev, sizeof(int64_t) * n_acc_words, reinterpret_cast<uint32_t *>(static_cast<char *>(h_acc_dev) + acc_bytes), seq, s);
+        int idle = 0;
+        for (unsigned spins = 1; *h_aflag != seq; ++spins) {
+            if ((spins & 0x3fff) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) { if (++idle > 64) throw HipError("internal: leaf sums were not published"); }
+                else if (q != hipErrorNotReady) hip_check(q, "hipStreamQuery(leaf sums)");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     acc.assign(h_acc, h_acc + n_acc_words);
     // everything enqueued for this tree has completed: scales are in pinned memory
     if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
