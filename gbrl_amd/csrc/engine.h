@@ -161,6 +161,8 @@ class Engine {
     int iota_n_ = 0;
     DevBuf d_pub_done_;               // block counter of k_resolve_splits' in-kernel publication (zero between launches)
     const void *pub_done_ptr_ = nullptr;
+    const void *leafacc_clean_ptr_ = nullptr;   // leaf accumulators known to be zero (handed back clean by the last publication)
+    size_t leafacc_clean_bytes_ = 0;
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;

@@ -794,7 +794,13 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * am_cap));
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
-    hip_check(hipMemsetAsync(d_leafacc, 0, sizeof(int64_t) * max_nodes * (D + 1), s), "memset leaf acc");
+    {   // zero unless the last tree's publication handed these words back clean
+        const size_t need = sizeof(int64_t) * max_nodes * (D + 1);
+        if (!(leafacc_clean_ptr_ == d_leafacc && need <= leafacc_clean_bytes_))
+            hip_check(hipMemsetAsync(d_leafacc, 0, need, s), "memset leaf acc");
+        leafacc_clean_ptr_ = nullptr;     // dirty until the end of this tree
+        leafacc_clean_bytes_ = need;
+    }
     // per-step constants: slots, candidate weights / reference order / slot lookup
     const std::vector<int32_t> &cand_slot = *c.cand_slot;
     const size_t stage_bytes = 4096 + sizeof(FeatureSlot) * n_slots + static_cast<size_t>(n_cand) * 16 +
@@ -1307,7 +1313,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         volatile uint32_t *h_aflag = reinterpret_cast<volatile uint32_t *>(h_acc_raw + acc_bytes);
         uint32_t seq = ++level_seq_;
         if (seq == 0) seq = ++level_seq_;
-        kern::publish_block(d_leafacc, h_acc_dev, sizeof(int64_t) * n_acc_words, reinterpret_cast<uint32_t *>(static_cast<char *>(h_acc_dev) + acc_bytes), seq, s);
+        kern::publish_block(d_leafacc, h_acc_dev, sizeof(int64_t) * n_acc_words, reinterpret_cast<uint32_t *>(static_cast<char *>(h_acc_dev) + acc_bytes), seq, s,
+                            /*zero_src=*/true);
         int idle = 0;
         for (unsigned spins = 1; *h_aflag != seq; ++spins) {
             if ((spins & 0x3fff) == 0) {
@@ -1317,6 +1324,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        leafacc_clean_ptr_ = d_leafacc;   // only the copied words were ever written, and the kernel cleared them
     }
     acc.assign(h_acc, h_acc + n_acc_words);
     // everything enqueued for this tree has completed: scales are in pinned memory
@@ -1597,8 +1605,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
     }
     phase_end("binning");
-    if (n_thr) hip_check(hipMemcpyAsync(h_thr, d_thr, sizeof(float) * n_thr, hipMemcpyDeviceToHost, s), "D2H thr");
-    hip_check(hipMemcpyAsync(h_scales_pin, d_scales, sizeof(kern::StepScales), hipMemcpyDeviceToHost, s), "D2H scales");
+    {   // thresholds and scales into the pinned block with ONE launch (device-written host memory) instead of two copy-engine transfers
+        static_assert(sizeof(kern::StepScales) % 4 == 0, "copied as 32-bit words");
+        void *pin_dev = nullptr;
+        hip_check(hipHostGetDevicePointer(&pin_dev, pin_ts, 0), "hipHostGetDevicePointer");
+        char *pd = static_cast<char *>(pin_dev);
+        kern::publish_pair(d_thr, pd, sizeof(float) * n_thr, d_scales, pd + (reinterpret_cast<char *>(h_scales_pin) - pin_ts), sizeof(kern::StepScales), s);
+    }
 
     // ---- 4. growth (level-synchronous; Engine::grow_tree) and 5. leaf sums --------------------------------------------------
     GrowCtx gc{};

@@ -101,7 +101,9 @@ void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
 // The level's result block handed to the host without a copy engine: one block copies `bytes` (a multiple of 4) from device memory to
 // pinned, device-mapped host memory and then stores `seq` to `flag` (system scope).  The host polls the flag; what it then reads is
 // complete (the stores are fenced before the flag) and every earlier operation of the stream has finished.
-void publish_block(const void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s);
+void publish_block(void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s, bool zero_src = false /*clear the source words after copying them*/);
+// Two device arrays (sizes multiples of 4 bytes) into pinned, device-mapped host memory with one launch, no flag.
+void publish_pair(const void *d_a, void *h_a_mapped, size_t a_bytes, const void *d_b, void *h_b_mapped, size_t b_bytes, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 
 // ---- exact quantile selection and binning on transposed keys (quantile.hip) ----

@@ -694,12 +694,23 @@ __global__ void k_hist_place_slice(const int64_t *__restrict__ recv, int64_t *__
     int64_t *dst = hist + (static_cast<size_t>(slot_map[k]) * Fp + lo + f) * feat_elems;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < feat_elems; i += static_cast<size_t>(gridDim.x) * blockDim.x) dst[i] = src[i];
 }
-__global__ __launch_bounds__(256) void k_publish_block(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int words, uint32_t *flag,
-                                                       uint32_t seq) {
-    for (int i = threadIdx.x; i < words; i += 256) __builtin_nontemporal_store(src[i], &dst[i]);
+__global__ __launch_bounds__(256) void k_publish_block(uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int words, uint32_t *flag,
+                                                       uint32_t seq, int zero_src) {
+    for (int i = threadIdx.x; i < words; i += 256) {
+        __builtin_nontemporal_store(src[i], &dst[i]);
+        if (zero_src) src[i] = 0;      // accumulators handed back clean: the next tree needs no memset
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Two device arrays copied into pinned, device-mapped host memory by one launch (no flag: whoever reads them has polled a later
+// publication of the same stream).
+__global__ __launch_bounds__(256) void k_publish_pair(const uint32_t *__restrict__ a, uint32_t *__restrict__ ha, int a_words,
+                                                      const uint32_t *__restrict__ b, uint32_t *__restrict__ hb, int b_words) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a_words) __builtin_nontemporal_store(a[i], &ha[i]);
+    if (i < b_words) __builtin_nontemporal_store(b[i], &hb[i]);
 }
 __global__ void k_fill_f32(float *__restrict__ p, size_t n, float v) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1508,9 +1519,14 @@ void hist_place_slice(const int64_t *recv, int64_t *hist, const int32_t *slot_ma
     hipLaunchKernelGGL(k_hist_place_slice, dim3(static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(8, (feat_elems + 255) / 256))), fs, n), dim3(256), 0, s, recv, hist,
                        slot_map, fs, lo, Fp, feat_elems);
 }
-void publish_block(const void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s) {
-    hipLaunchKernelGGL(k_publish_block, dim3(1), dim3(256), 0, s, static_cast<const uint32_t *>(d_src), static_cast<uint32_t *>(h_dst_mapped),
-                       static_cast<int>(bytes / 4), flag_mapped, seq);
+void publish_block(void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s, bool zero_src) {
+    hipLaunchKernelGGL(k_publish_block, dim3(1), dim3(256), 0, s, static_cast<uint32_t *>(d_src), static_cast<uint32_t *>(h_dst_mapped),
+                       static_cast<int>(bytes / 4), flag_mapped, seq, zero_src ? 1 : 0);
+}
+void publish_pair(const void *d_a, void *h_a_mapped, size_t a_bytes, const void *d_b, void *h_b_mapped, size_t b_bytes, hipStream_t s) {
+    const int aw = static_cast<int>(a_bytes / 4), bw = static_cast<int>(b_bytes / 4);
+    hipLaunchKernelGGL(k_publish_pair, dim3((std::max(aw, bw) + 255) / 256), dim3(256), 0, s, static_cast<const uint32_t *>(d_a),
+                       static_cast<uint32_t *>(h_a_mapped), aw, static_cast<const uint32_t *>(d_b), static_cast<uint32_t *>(h_b_mapped), bw);
 }
 void fill_f32(float *p, size_t n, float v, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p, n, v);
