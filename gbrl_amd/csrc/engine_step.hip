@@ -615,6 +615,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             const long long per = n_global / (B + 1), rem = n_global % (B + 1);
             long long run = 0;
             for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
+            bool floats_done = false;
             // sharded fast path needs a power-of-two world (union sample of world*4096 keys sorted in LDS)
             const bool coll_fast = has_coll_ && (coll_.world_size & (coll_.world_size - 1)) == 0 && coll_.world_size <= 8;
             const bool radix_ok = !force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32);
@@ -623,7 +624,8 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && N <= kern::sort_quantiles_max_rows()) {
                 // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
                 int64_t *d_cum = upload_cum(cum);
-                kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, s);
+                kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, d_thr, s);
+                floats_done = true;
                 last_quantile_fallback_ = false;
             } else if (!force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32)) {
                 // exact MSD radix multi-select, four counting passes over the transposed keys (radix_select.hip).  Row-sharded
@@ -703,7 +705,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                     hip_check(hipGetLastError(), "quantile_select launch");
                 }
             }
-            kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);
+            if (!floats_done) kern::keys_to_floats(d_thrkeys, d_thr, static_cast<size_t>(F) * B, s);   // (the LDS sort writes the floats itself)
         }
         uint32_t qflags[4] = {0, 0, 0, 0};
         if (fast_quantile) {

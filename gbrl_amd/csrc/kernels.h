@@ -137,7 +137,7 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 // codes[(slot/16)*n*16 + row*16 + slot%16] (u16) = #{k : thr_key[f][k] < key(row, f)}
 // small batches: one LDS sort per column (n <= sort_quantiles_max_rows()); thr_keys[f][k] = key of 1-based rank cum[k]
 int sort_quantiles_max_rows();
-void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, hipStream_t s);
+void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats /*the same thresholds as floats*/, hipStream_t s);
 // radix_select.hip: exact order statistics by MSD radix counting (one GPU)
 size_t radix_state_bytes(int F, int B);
 size_t radix_partial_bytes(int F);

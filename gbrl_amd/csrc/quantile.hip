@@ -137,8 +137,12 @@ __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__res
 // One block per feature: n <= S keys padded with the maximal key to S (a power of two <= 16384), bitonic sort in LDS,
 // thr_keys[f][k] = sorted[cum[k] - 1].  One launch instead of the eight of the radix multi-select, which are launch-bound at
 // these sizes.  Exact by construction (padding sorts last and no rank points into it).
+__device__ __forceinline__ float key_to_float_q(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
 __global__ __launch_bounds__(1024) void k_sort_quantiles(const uint32_t *__restrict__ kt, int n, int S, const int64_t *__restrict__ cum, int B,
-                                                         uint32_t *__restrict__ thr_keys) {
+                                                         uint32_t *__restrict__ thr_keys, float *__restrict__ thr_floats) {
     extern __shared__ uint32_t s[];
     const int f = blockIdx.x;
     const uint32_t *col = kt + static_cast<size_t>(f) * n;
@@ -176,7 +180,13 @@ __global__ __launch_bounds__(1024) void k_sort_quantiles(const uint32_t *__restr
         }
         __syncthreads();                             // the next k starts with pairs across chunks (or the ranks are read)
     }
-    for (int k = threadIdx.x; k < B; k += blockDim.x) thr_keys[static_cast<size_t>(f) * B + k] = s[cum[k] - 1];
+    // keys and floats at once (what k_keys_to_floats does for the other selections: a key in the NaN range is raised to -inf's key)
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        uint32_t key = s[cum[k] - 1];
+        if (key < 0x007fffffu) key = 0x007fffffu;
+        thr_keys[static_cast<size_t>(f) * B + k] = key;
+        thr_floats[static_cast<size_t>(f) * B + k] = key_to_float_q(key);
+    }
 }
 
 // Sharded runs: sort the union of all ranks' samples ([F][SU] int64 after the exchange, SU a power of two <= 32768) and
@@ -644,12 +654,12 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 }
 
 int sort_quantiles_max_rows() { return 4096; }   // beyond this the bitonic sort (O(n log^2 n) in one block per feature) loses to the radix passes
-void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, hipStream_t s) {
+void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats, hipStream_t s) {
     int S = 64;
     while (S < n) S <<= 1;
     static PerDeviceOnce attr;
     if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_quantiles), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }
-    hipLaunchKernelGGL(k_sort_quantiles, dim3(F), dim3(std::min(1024, S / 2 > 64 ? S / 2 : 64)), static_cast<size_t>(S) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys);
+    hipLaunchKernelGGL(k_sort_quantiles, dim3(F), dim3(std::min(1024, S / 2 > 64 ? S / 2 : 64)), static_cast<size_t>(S) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys, thr_floats);
 }
 
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s) {
