@@ -838,6 +838,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     void *h_res_dev = nullptr;
     hip_check(hipHostGetDevicePointer(&h_res_dev, h_res, 0), "hipHostGetDevicePointer");
     uint32_t *d_flag = reinterpret_cast<uint32_t *>(static_cast<char *>(h_res_dev) + res_bytes);
+    *h_flag = 0;   // nothing is in flight here; a freshly allocated block must not hold a stale sequence number
     unsigned *d_pub_done = static_cast<unsigned *>(d_pub_done_.ensure(256));
     if (d_pub_done != pub_done_ptr_) {
         hip_check(hipMemsetAsync(d_pub_done, 0, 256, s), "memset publication counter");
@@ -1315,6 +1316,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         volatile uint32_t *h_aflag = reinterpret_cast<volatile uint32_t *>(h_acc_raw + acc_bytes);
         uint32_t seq = ++level_seq_;
         if (seq == 0) seq = ++level_seq_;
+        *h_aflag = 0;
         kern::publish_block(d_leafacc, h_acc_dev, sizeof(int64_t) * n_acc_words, reinterpret_cast<uint32_t *>(static_cast<char *>(h_acc_dev) + acc_bytes), seq, s,
                             /*zero_src=*/true);
         int idle = 0;
