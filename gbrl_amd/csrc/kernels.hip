@@ -933,16 +933,18 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     __shared__ float s_pval[kMaxPath];
     __shared__ int s_pbin[kMaxPath];
     __shared__ int s_np;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < kWave) {   // the first wave, one path entry per lane (kMaxPath <= 64): all loads in flight together, not one round trip per entry
+        static_assert(kMaxPath <= kWave, "one lane per path entry");
         const int plen = path_len[node];
-        int np = 0;
-        for (int p = 0; p < plen; ++p)
-            if (path_slot[node * kMaxPath + p] == fs) {
-                s_pval[np] = path_val[node * kMaxPath + p];
-                s_pbin[np] = path_bin[node * kMaxPath + p];
-                ++np;
-            }
-        s_np = np;
+        const int p = threadIdx.x;
+        const bool hit = p < plen && path_slot[node * kMaxPath + p] == fs;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int pos = __popcll(m & ((1ull << p) - 1));
+            s_pval[pos] = path_val[node * kMaxPath + p];
+            s_pbin[pos] = path_bin[node * kMaxPath + p];
+        }
+        if (p == 0) s_np = __popcll(m);
     }
     __syncthreads();
     const int np = s_np;
