@@ -34,8 +34,7 @@ __global__ void k_column_sums(const float *__restrict__ g, size_t n_el, int D, c
     const float c = center ? center[col] : 0.0f;
     double acc = 0.0;
     float mx = 0.0f;
-    for (size_t e = static_cast<size_t>(blockIdx.x) * bs + threadIdx.x; e < n_el; e += static_cast<size_t>(gridDim.x) * bs) {
-        const float v = g[e];
+    auto take = [&](float v) {
         if (center) {
             const float dv = v - c;  // fp32 subtraction like the reference (math_ops.cpp:498)
             acc += static_cast<double>(dv) * static_cast<double>(dv);
@@ -44,7 +43,18 @@ __global__ void k_column_sums(const float *__restrict__ g, size_t n_el, int D, c
             acc += static_cast<double>(v);
             mx = fmaxf(mx, fabsf(v));
         }
+    };
+    // eight loads in flight per thread, accumulated in the order of the plain grid-stride loop (the sums keep their bits)
+    const size_t stride = static_cast<size_t>(gridDim.x) * bs;
+    size_t e = static_cast<size_t>(blockIdx.x) * bs + threadIdx.x;
+    for (; e + 7 * stride < n_el; e += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = g[e + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) take(v[u]);
     }
+    for (; e < n_el; e += stride) take(g[e]);
     sh[threadIdx.x] = acc;
     sh[bs + threadIdx.x] = static_cast<double>(mx);
     __syncthreads();
