@@ -1023,7 +1023,15 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *_
         float sc;
         if (oblivious) {   // sum over nodes in node order, fp32, then * w (fitter.cpp:426-435)
             sc = 0.0f;
-            for (int nd = 0; nd < n_nodes; ++nd) sc += scores[static_cast<size_t>(nd) * n_cand + j];
+            int nd = 0;
+            for (; nd + 8 <= n_nodes; nd += 8) {      // eight loads in flight, added in node order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = scores[static_cast<size_t>(nd + u) * n_cand + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sc += v[u];
+            }
+            for (; nd < n_nodes; ++nd) sc += scores[static_cast<size_t>(nd) * n_cand + j];
             sc = sc * w[j];
         } else {           // fma(score, w, -parent): the reference's "score*w - parent" is contracted (fitter.cpp:332)
             const float par = is_root[node] ? 0.0f : parent[node];
