@@ -1101,10 +1101,16 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     for (int pass = 0; pass < (hist_global ? 2 : 1); ++pass) {
         const int64_t *src = (pass ? hist_global : hist_local) + (static_cast<size_t>(node) * Fp + fs) * NB * W;
         long long tot = 0, right = 0;
-        for (int c = threadIdx.x; c < NB; c += kWave) {
-            const long long n = src[c * W + D];
-            tot += n;
-            if (sl.is_cat ? (c == bin) : (c > bin)) right += n;
+        for (int c0 = threadIdx.x; c0 < NB; c0 += 8 * kWave) {     // the class counts of the winner's slice: eight loads in flight per lane
+            long long n[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] = c < NB ? src[c * W + D] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * kWave;
+                tot += n[u];
+                if (c < NB && (sl.is_cat ? (c == bin) : (c > bin))) right += n[u];
+            }
         }
         for (int o = kWave / 2; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, kWave); right += __shfl_xor(right, o, kWave); }
         if (threadIdx.x == 0) {
