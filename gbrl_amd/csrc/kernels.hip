@@ -653,7 +653,14 @@ __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_
         const int32_t *src = partials + static_cast<size_t>(g) * n_acc + i;
         const size_t stride = static_cast<size_t>(n_groups) * n_acc;
         int c = c0 + lane;
-        for (; c + 3 * kReduceLanes < c1; c += 4 * kReduceLanes) {   // four independent loads in flight (integer sums: any order)
+        for (; c + 7 * kReduceLanes < c1; c += 8 * kReduceLanes) {   // eight independent loads in flight (integer sums: any order)
+            int32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(c + u * kReduceLanes) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c + 3 * kReduceLanes < c1; c += 4 * kReduceLanes) {
             const int32_t a = src[c * stride], b = src[(c + kReduceLanes) * stride], e = src[(c + 2 * kReduceLanes) * stride],
                           f = src[(c + 3 * kReduceLanes) * stride];
             s += static_cast<int64_t>(a) + b + e + f;
@@ -1263,17 +1270,17 @@ __global__ __launch_bounds__(256) void k_leaf_sums(const float *__restrict__ gra
     const int d = threadIdx.x % D, sub = threadIdx.x / D;
     long long s = 0;
     if (sub < per) {
-        // four independent (row id -> gradient) load chains in flight per thread
+        // eight independent (row id -> gradient) load chains in flight per thread
         int p = sub;
-        for (; p + 3 * per < ck.len; p += 4 * per) {
-            int r[4];
-            float g[4];
+        for (; p + 7 * per < ck.len; p += 8 * per) {
+            int r[8];
+            float g[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r[u] = rows[ck.start + p + u * per];
+            for (int u = 0; u < 8; ++u) r[u] = rows[ck.start + p + u * per];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = grads[static_cast<size_t>(r[u]) * D + d];
+            for (int u = 0; u < 8; ++u) g[u] = grads[static_cast<size_t>(r[u]) * D + d];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s += __double2ll_rn(static_cast<double>(g[u]) * scale);
+            for (int u = 0; u < 8; ++u) s += __double2ll_rn(static_cast<double>(g[u]) * scale);
         }
         for (; p < ck.len; p += per) {
             const int row = rows[ck.start + p];
