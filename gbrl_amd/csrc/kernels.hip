@@ -373,7 +373,12 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const Chunk ck = chunks[chunk_id];
     if (ck.len <= 0) return;   // block-uniform: an unused entry of a device-planned chunk table
     const int n_acc = NB * (D + 1) * FG;
-    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
+    if ((n_acc & 3) == 0) {   // 16-byte LDS writes (FG = 16: always)
+        int4 *h4 = reinterpret_cast<int4 *>(h);
+        for (int i = threadIdx.x; i < n_acc / 4; i += kHistThreads) h4[i] = make_int4(0, 0, 0, 0);
+    } else {
+        for (int i = threadIdx.x; i < n_acc; i += kHistThreads) h[i] = 0;
+    }
     __syncthreads();
     const int fl = threadIdx.x & (FG - 1);
     const int slot = threadIdx.x >> fg_shift;
@@ -465,7 +470,13 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     }
     __syncthreads();
     int32_t *out = partials + (static_cast<size_t>(chunk_id) * n_groups + g) * n_acc;
-    for (int i = threadIdx.x; i < n_acc; i += kHistThreads) out[i] = h[i];
+    if ((n_acc & 3) == 0) {   // the block's 148 KB of partial sums leave in 16-byte pieces
+        const int4 *h4 = reinterpret_cast<const int4 *>(h);
+        int4 *o4 = reinterpret_cast<int4 *>(out);
+        for (int i = threadIdx.x; i < n_acc / 4; i += kHistThreads) o4[i] = h4[i];
+    } else {
+        for (int i = threadIdx.x; i < n_acc; i += kHistThreads) out[i] = h[i];
+    }
 }
 
 // k_hist_build_wide<P, H, U>: output dimensions beyond 16, or class counts that leave room for only 8 or 4 features per block
