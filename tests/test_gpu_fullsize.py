@@ -1,0 +1,85 @@
+"""Split CHOICE at the BASELINE sizes ("what's missing" 2): at 2^20 x 128 the brute-force oracle cannot follow
+(~10^3 s per tree), and the size-independent properties of test_gpu_parity.py (routing, exact leaf means, edge weights) would
+also hold for a tree grown from a WRONG histogram, because leaf sums come from a separate kernel.  Here every stored
+(feature, threshold) is compared with an independent float64 evaluation (tests/fullsize.py: NumPy sort -> rank-exact thresholds ->
+searchsorted class codes -> bincount histograms per (node, feature, class) -> suffix sums -> L2 / Cosine score -> lowest-index
+arg-max), which is itself pinned against the reference build at sizes the reference handles (tests/test_oracle.py).
+
+A dropped chunk, an int32 wrap in one LDS cell, a wrong slot in the sibling subtraction or a wrong fixed-point scale moves sums by
+far more than the 1e-6 relative gap these tests tolerate.
+"""
+import numpy as np
+import pytest
+
+import cases as K
+import fullsize
+
+pytestmark = pytest.mark.gpu
+
+
+def _grow(case, X, G):
+    import gbrl_amd
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(m, case, X, None, G, None)
+    return {k: np.asarray(v) for k, v in m.get_ensemble_data().items()}
+
+
+def test_config2_full_size_split_choice_is_the_float64_argmax():
+    """BASELINE configs[1]: oblivious / L2 / quantile, N = 2^20, F = 128, D = 8, depth 6, bench.py's synthetic inputs."""
+    rng = np.random.default_rng(0)
+    N, F, D = 1 << 20, 128, 8
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    W = rng.standard_normal((8, D)).astype(np.float32)
+    G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((N, D))).astype(np.float32)
+    case = dict(name="c2", seed=0, N=N, F=F, D=D, depth=6, n_bins=256, score="L2", gen="Quantile", policy="oblivious", trees=1)
+    e = _grow(case, X, G)
+    assert int(e["depths"][0]) == 6
+    recs = fullsize.check_oblivious_tree(X, G, e, 256, "L2")
+    assert len(recs) == 6 and all(r["threshold_is_rank_exact"] for r in recs)
+    print("config 2 levels:", [(r["stored"], r["exact"], "%.1e" % r["gap_rel"]) for r in recs])
+
+
+def test_config2_pure_noise_gradients_full_size_split_choice():
+    """The same shape with NO signal in the gradients: all 32 768 candidates of a level score within a fraction of a percent of
+    each other, so a small error anywhere in the histograms picks another candidate."""
+    rng = np.random.default_rng(3)
+    N, F, D = 1 << 20, 128, 8
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    G = rng.standard_normal((N, D), dtype=np.float32)
+    case = dict(name="c2n", seed=0, N=N, F=F, D=D, depth=6, n_bins=256, score="L2", gen="Quantile", policy="oblivious", trees=1)
+    e = _grow(case, X, G)
+    recs = fullsize.check_oblivious_tree(X, G, e, 256, "L2", rel_tol=2e-4)   # fixed-point step 2^-12 per value: ~5e-5 relative on a pure-noise score
+    print("config 2 noise levels:", [(r["stored"], r["exact"], "%.1e" % r["gap_rel"]) for r in recs])
+
+
+def test_config3_full_size_root_and_deep_nodes():
+    """BASELINE configs[2]: greedy / Cosine / quantile / shared actor-critic at 2^20 x 128: the root and the deepest split on the
+    paths of the first, a middle and the last leaf."""
+    rng = np.random.default_rng(1)
+    N, F, D = 1 << 20, 128, 8
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    W = rng.standard_normal((8, D)).astype(np.float32)
+    G = (np.tanh(X[:, :8] @ W) + 0.5 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    case = dict(name="c3", seed=0, N=N, F=F, D=D, depth=6, n_bins=256, score="Cosine", gen="Quantile", policy="greedy", trees=1,
+                opts=[dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
+                      dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)])
+    e = _grow(case, X, G)
+    L = len(e["values"])
+    leaves = [0, 0, L // 2, L - 1]
+    levels = [0] + [int(e["depths"][l]) - 1 for l in leaves[1:]]
+    recs = fullsize.check_greedy_nodes(X, G, e, 256, "Cosine", leaves, levels)
+    assert all(r["gain"] >= 0 for r in recs)                    # greedy splits only when the gain is non-negative (fitter.cpp:357)
+    print("config 3 nodes:", [(r["leaf"], r["level"], r["n_rows"], r["stored"], r["exact"], "%.1e" % r["gap_rel"]) for r in recs])
+
+
+def test_multi_round_chunks_split_choice():
+    """N = 3 * 2^20 + 17 (> 32 x 65 536 rows: several rounds of histogram chunks per level, ragged tail)."""
+    rng = np.random.default_rng(5)
+    N, F, D = 3 * (1 << 20) + 17, 16, 2
+    X = rng.standard_normal((N, F), dtype=np.float32)
+    G = (np.sign(X[:, :D]) + 0.25 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    case = dict(name="big", seed=0, N=N, F=F, D=D, depth=4, n_bins=256, score="L2", gen="Quantile", policy="oblivious", trees=1)
+    e = _grow(case, X, G)
+    recs = fullsize.check_oblivious_tree(X, G, e, 256, "L2")
+    assert len(recs) == 4
+    print("multi-round levels:", [(r["stored"], r["exact"], "%.1e" % r["gap_rel"]) for r in recs])

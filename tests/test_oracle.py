@@ -87,3 +87,30 @@ def test_restatement_agrees_with_the_reference_build_beyond_the_fixtures():
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "oracle_vs_ref_sweep.py"), "16", "977"], capture_output=True, text=True,
                          timeout=900, env=dict(os.environ, OMP_NUM_THREADS="8"))
     assert out.returncode == 0 and "unexplained 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("policy,score", [("oblivious", "L2"), ("oblivious", "Cosine"), ("greedy", "Cosine"), ("greedy", "L2")])
+def test_fullsize_checker_agrees_with_the_reference_build(policy, score):
+    """tests/fullsize.py (the float64 histogram re-evaluation the full-size GPU tests use as their third opinion) is itself pinned:
+    on a batch the reference's brute force still handles, the reference's own tree must pass it level by level."""
+    import fullsize
+    ref = oracle.load_ref()
+    impl = ref.GBRL if ref is not None else oracle.OracleGBRL
+    rng = np.random.default_rng(31)
+    N, F, D, B, depth = 6000, 6, 3, 40, 3
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    X[:, 4] = np.round(X[:, 4] * 2) / 2                       # duplicates: candidates with equal thresholds
+    W = rng.standard_normal((3, D)).astype(np.float32)
+    G = (np.tanh(X[:, :3] @ W) + 0.3 * rng.standard_normal((N, D))).astype(np.float32)
+    case = dict(name="fs", seed=0, N=N, F=F, D=D, depth=depth, n_bins=B, score=score, gen="Quantile", policy=policy, trees=1)
+    m = impl(**K.ctor_kwargs(case))
+    K.drive(m, case, X, None, G, None)
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items()}
+    tol = 4.0 * np.finfo(np.float32).eps * np.sqrt(N)          # the reference's own float32 summation noise (tests/neartie.py)
+    if policy == "oblivious":
+        recs = fullsize.check_oblivious_tree(X, G, e, B, score, rel_tol=tol)
+        assert len(recs) == depth
+    else:
+        leaves = [0, len(e["values"]) - 1]
+        recs = fullsize.check_greedy_nodes(X, G, e, B, score, leaves, [0, int(e["depths"][leaves[1]]) - 1], rel_tol=tol)
+    assert all(r["exact"] for r in recs), recs
