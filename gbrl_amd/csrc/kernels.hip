@@ -388,6 +388,26 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const uint16_t *cbase = codes + (static_cast<size_t>(fslot >> 4) * n_rows) * kCodeGroup + (fslot & (kCodeGroup - 1));
     const int32_t *rlist = rows + ck.start;
     const int qlane = fl < (DT ? DT : 1) ? fl : (DT ? DT - 1 : 0);   // lanes >= D re-load the last value (never used)
+    // DT path: block-uniform base pointers (SGPR pair) + 32-bit per-lane byte offsets, so that every load carries ONE address
+    // VGPR to the memory pipeline instead of two (`global_load v, v_off, s[base]`).  The VGPR -> LDS / TA transfer path is shared
+    // with the LDS atomics' address + data (2 clk per source dword per wave-instruction): with 64-bit VGPR addresses the two
+    // gathered loads per row cost 8 clk of that path per wave-iteration on top of the 40 clk of the 9 atomics (52.5 measured);
+    // the launcher takes this kernel only when n_rows * 64 fits 32 bits.
+    const char *cgroup = reinterpret_cast<const char *>(codes + static_cast<size_t>(g) * n_rows * kCodeGroup);   // FG == 16: group g
+    const char *qbase = reinterpret_cast<const char *>(qg);
+    const uint32_t coff = static_cast<uint32_t>(fl) * 2u, qoff = static_cast<uint32_t>(qlane) * 4u;
+    auto ld_code = [&](int row) -> int {
+#ifdef GBRL_HIST_EXP_NOLOAD
+        return static_cast<int>((static_cast<uint32_t>(row) * 2654435761u + coff * 40503u) >> 24);
+#endif
+        return *reinterpret_cast<const uint16_t *>(cgroup + (static_cast<uint32_t>(row) * (kCodeGroup * 2u) + coff));
+    };
+    auto ld_q = [&](int row) -> int {
+#ifdef GBRL_HIST_EXP_NOLOAD
+        return row + static_cast<int>(qoff);
+#endif
+        return *reinterpret_cast<const int32_t *>(qbase + (static_cast<uint32_t>(row) * static_cast<uint32_t>(DT * 4) + qoff));
+    };
     int p0 = slot;
     if (DT && PIPE) {
         // Software-pipelined main loop (three stages, U rows per slot and stage): while the 9U atomics of iteration i occupy the
@@ -404,16 +424,16 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
 #pragma unroll
             for (int u = 0; u < U; ++u) rowB[u] = rlist[min(p0 + step + u * n_slots, last)];
 #pragma unroll
-            for (int u = 0; u < U; ++u) codeA[u] = cbase[static_cast<size_t>(rowA[u]) * kCodeGroup];
+            for (int u = 0; u < U; ++u) codeA[u] = ld_code(rowA[u]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) qA[u] = qg[static_cast<size_t>(rowA[u]) * DT + qlane];
+            for (int u = 0; u < U; ++u) qA[u] = ld_q(rowA[u]);
         }
         for (; p0 + (U - 1) * n_slots < ck.len; p0 += step) {
             int codeB[U], qB[U], rowC[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) codeB[u] = cbase[static_cast<size_t>(rowB[u]) * kCodeGroup];
+            for (int u = 0; u < U; ++u) codeB[u] = ld_code(rowB[u]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) qB[u] = qg[static_cast<size_t>(rowB[u]) * DT + qlane];
+            for (int u = 0; u < U; ++u) qB[u] = ld_q(rowB[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) rowC[u] = rlist[min(p0 + 2 * step + u * n_slots, last)];
 #pragma unroll
@@ -431,12 +451,12 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
         int row[U], code[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) row[u] = rlist[p0 + u * n_slots];
-#pragma unroll
-        for (int u = 0; u < U; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * kCodeGroup];
         if (DT) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) code[u] = ld_code(row[u]);
             int myq[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) myq[u] = qg[static_cast<size_t>(row[u]) * DT + qlane];
+            for (int u = 0; u < U; ++u) myq[u] = ld_q(row[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int32_t *dst = h + code[u] * row_stride + fl;
@@ -444,6 +464,8 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
                 atomicAdd(dst + DT * 16, 1);
             }
         } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * kCodeGroup];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int32_t *q = qg + static_cast<size_t>(row[u]) * D;
@@ -456,13 +478,14 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     // tail: one row per slot (p0 is uniform across the 16 lanes of a DPP row, so whole rows take the branch)
     for (; p0 < ck.len; p0 += n_slots) {
         const int row = rlist[p0];
-        const int code = cbase[static_cast<size_t>(row) * kCodeGroup];
-        int32_t *dst = h + code * row_stride + fl;
         if (DT) {
-            const int myq = qg[static_cast<size_t>(row) * DT + qlane];
+            int32_t *dst = h + ld_code(row) * row_stride + fl;
+            const int myq = ld_q(row);
             RowAtomics<DT, 0>::run(dst, 16, myq);
             atomicAdd(dst + DT * 16, 1);
         } else {
+            const int code = cbase[static_cast<size_t>(row) * kCodeGroup];
+            int32_t *dst = h + code * row_stride + fl;
             const int32_t *q = qg + static_cast<size_t>(row) * D;
             for (int d = 0; d < D; ++d) atomicAdd(dst + d * FG, q[d]);
             atomicAdd(dst + D * FG, 1);
@@ -1521,7 +1544,8 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
     static const bool generic_only = [] { const char *e = std::getenv("GBRL_HIP_HIST_GENERIC"); return e && e[0] == '1'; }();   // test hook
-    if (generic_only) {
+    // the compile-time-D kernels address codes and gradients with 32-bit byte offsets from block-uniform bases (64 bytes per row at D = 16)
+    if (generic_only || n_rows > (1 << 26)) {
         launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
         return;
     }
