@@ -100,13 +100,33 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # Poll all ranks: the first one to fail takes the others down (they may be blocked inside an RCCL collective waiting for it),
+    # and the whole launch has a wall-clock limit -- the launcher must exit non-zero, not hang (torch.distributed.run does the same).
+    limit = float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3600"))
+    t0 = time.monotonic()
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                r = p.poll()
+                if r is None:
+                    continue
+                live.remove(p)
+                if r != 0:
+                    rc = abs(r) or 1
+            if time.monotonic() - t0 > limit:
+                rc = 124
+            if live and rc == 0:
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
                 p.kill()
     return rc
 
@@ -291,6 +311,11 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if os.environ.get("BENCH_LAUNCH_ONLY") == "1":   # test hook (CPU): show what the launcher handed to this rank, run nothing
         print(json.dumps({"rank": rank, "local_rank": local_rank, "n_gpus": world, "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+        fail = os.environ.get("BENCH_LAUNCH_FAIL_RANK")   # test hook: this rank dies, the others "hang in a collective"
+        if fail is not None:
+            if int(fail) == rank:
+                raise SystemExit(3)
+            time.sleep(600)
         return
 
     import numpy as np

@@ -48,7 +48,8 @@ void *PinnedBuf::ensure(size_t bytes) {
     if (ptr_) (void)hipHostFree(ptr_);
     ptr_ = nullptr;
     const size_t want = std::max<size_t>(4096, bytes + bytes / 4);
-    hip_check(hipHostMalloc(&ptr_, want, hipHostMallocDefault), "hipHostMalloc");
+    // polled by the host while kernels store into it (level results, leaf sums): fine-grained coherent + device-mapped, stated explicitly
+    hip_check(hipHostMalloc(&ptr_, want, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc");
     cap_ = want;
     return ptr_;
 }

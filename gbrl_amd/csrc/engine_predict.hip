@@ -62,7 +62,7 @@ void Engine::sync_model_to_device() {
     append(m_ineq_, model.inequality_directions.data(), 1, up_leaves_ * MD, L * MD);
     // Second-generation oblivious kernel (predict_obl2.hip): per tree a right-aligned condition record and the leaf values
     // pre-swizzled as [worker][leaf][DMAX/4]
-    if (model.oblivious() && kern::obl2_levels(static_cast<int>(MD)) > 0 && kern::obl2_padded_outputs(static_cast<int>(D)) > 0) {
+    if (model.oblivious() && kern::obl2_feasible(static_cast<int>(MD), static_cast<int>(D), false)) {
         const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
         const size_t LS = size_t(1) << MX, VT = LS * DMAX;   // leaves padded to 2^levels: the kernel's tree stride is a compile-time constant
         constexpr size_t kPadTrees = 16;                     // the kernel fetches whole groups of records (<= 16 trees) past the last tree
@@ -152,7 +152,7 @@ void Engine::sync_model_to_device() {
         grd_up_nodes_ = grd_nodes_host_.size() / 4;
         // Second-generation kernel, greedy mode (predict_obl2.hip): one record per tree = its leaf values pre-swizzled as
         // [worker][leaf < 2^levels][DMAX/4] followed by its nodes [2^levels] x int4 (zero padded)
-        if (grd_ok_ && kern::obl2_levels(static_cast<int>(MD)) > 0 && kern::obl2_padded_outputs(static_cast<int>(D)) > 0) {
+        if (grd_ok_ && kern::obl2_feasible(static_cast<int>(MD), static_cast<int>(D), true)) {
             const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
             const size_t LS = size_t(1) << MX, VT = LS * DMAX, RECF = VT + LS * 4;   // floats (= dwords) per record
             constexpr size_t kPadTrees = 16;
@@ -242,7 +242,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (md.output_dim > 128) throw Unsupported("predict: output_dim > 128");
-    if (start_tree < 0 || stop_tree < 0 || (stop_tree != 0 && start_tree > stop_tree) || start_tree > md.n_trees) throw InvalidArgument("invalid tree range");
+    if (start_tree < 0 || stop_tree < 0) throw InvalidArgument("invalid tree range");   // the reference would index out of bounds
     ensure_device();
     ev_used_ = 0;
     ev_names_.clear();
@@ -252,6 +252,8 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     int stop = stop_tree;
     if (md.n_trees == 0 || stop > md.n_trees || model.opts.empty()) { start_tree = 0; stop = 0; }
     else if (stop == 0) stop = md.n_trees;
+    // an empty or inverted range walks no tree: predict_cpu's loops run from start to stop (predictor.cpp:139-163), the result is the bias
+    if (start_tree >= stop) { start_tree = 0; stop = 0; }
     sync_model_to_device();
     phase_begin();
     const float *dobs = obs;
@@ -289,11 +291,11 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     pm.obl_ok = model.oblivious() ? 1 : 0;
     pm.obl2_maxd = 0; pm.values_sw = nullptr; pm.cond_ra = nullptr;
     pm.cat_dict_size = static_cast<int>(cat_dict_.size());
-    if (model.oblivious() && kern::obl2_levels(md.max_depth) > 0 && kern::obl2_padded_outputs(D) > 0 && md.n_trees > 0) {
+    if (model.oblivious() && kern::obl2_feasible(md.max_depth, D, false) && md.n_trees > 0) {
         pm.obl2_maxd = kern::obl2_levels(md.max_depth);
         pm.values_sw = m_values_sw_.as<float>();
         pm.cond_ra = m_cond_ra_.as<int32_t>();
-    } else if (!model.oblivious() && grd_ok_ && kern::obl2_levels(md.max_depth) > 0 && kern::obl2_padded_outputs(D) > 0 && md.n_trees > 0) {
+    } else if (!model.oblivious() && grd_ok_ && kern::obl2_feasible(md.max_depth, D, true) && md.n_trees > 0) {
         pm.obl2_maxd = kern::obl2_levels(md.max_depth);   // greedy mode of the same kernel: records = values + nodes
         pm.values_sw = m_values_sw_.as<float>();
     }

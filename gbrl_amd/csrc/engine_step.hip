@@ -19,6 +19,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <unordered_map>
@@ -268,6 +269,32 @@ md.iteration += 1;  // fitter.cpp:114
 // in rank order, which is global first-occurrence order; (3) the totals are accumulated by ONE rank at a time in rank order, each
 // starting from the running totals of the ranks before it (P small broadcasts), so every addition happens in global row order;
 // (4) every rank builds the reference's container from the global list and ranks it.  Slow (host scan, P rounds) and rare.
+// GBRL_HIP_DEVICE_LEVELS=1 (opt-in device-planned level loop), latched at the first use: the cached root row list and the choice of
+// the loop must see the same value for the whole process.
+static bool device_levels_requested() {
+    static const bool v = [] { const char *e = std::getenv("GBRL_HIP_DEVICE_LEVELS"); return e && e[0] == '1'; }();
+    return v;
+}
+// Host side of the copy-free hand-overs: poll a sequence word in coherent pinned memory; every 16384 polls ask the stream for errors
+// (a faulted kernel never publishes) and give up after `kSpinSeconds` of wall clock (a hung kernel must not spin a core forever).
+static void spin_until_published(volatile uint32_t *flag, uint32_t seq, hipStream_t s, const char *what) {
+    constexpr double kSpinSeconds = 30.0;
+    int idle = 0;
+    std::chrono::steady_clock::time_point t0;
+    bool timed = false;
+    for (unsigned spins = 1; *flag != seq; ++spins) {
+        if ((spins & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) { if (++idle > 64) throw HipError(std::string("internal: ") + what + " were not published"); }
+            else if (q != hipErrorNotReady) hip_check(q, what);
+            if (!timed) { t0 = std::chrono::steady_clock::now(); timed = true; }
+            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kSpinSeconds)
+                throw HipError(std::string("timeout: ") + what + " did not arrive within 30 s");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 void Engine::sharded_categorical_ranking(const char *hcat, const float *hgrads, int N, int Fc, int D, int B,
                                          std::vector<detail::CatCandidate> &cat_cands, std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes) {
     hipStream_t s = stream_;
@@ -855,9 +882,9 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     int32_t *const d_rows_b = d_rows[0];
     bool iota_root = false;
     {
-        const char *e = std::getenv("GBRL_HIP_DEVICE_LEVELS");
+        // the device-planned loop partitions INTO d_rows[depth parity]: it must never be handed the cached list (same latched flag as below)
         const char *e2 = std::getenv("GBRL_HIP_NO_IOTA_CACHE");   // measurement hook
-        if (!(oblivious && e && e[0] == '1') && !(e2 && e2[0] == '1')) {
+        if (!(oblivious && device_levels_requested()) && !(e2 && e2[0] == '1')) {
             int32_t *d_iota = static_cast<int32_t *>(d_rows_iota_.ensure(sizeof(int32_t) * N));
             if (d_iota != iota_ptr_ || iota_n_ < N) {
                 kern::iota_rows(d_iota, N, s);
@@ -1008,8 +1035,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // empty blocks of the worst-case grids cost what the host round trip (~30 us, partly hidden behind the partition) costs --
     // 2.301 vs 2.307 ms per step at 2^20 x 128, and 0.64 vs 0.59 ms at 4096 x 128 -- so the level-synchronous host loop stays the
     // default; the test suite checks that both grow the same bytes.
-    static const bool device_levels = [] { const char *e = std::getenv("GBRL_HIP_DEVICE_LEVELS"); return e && e[0] == '1'; }();
-    const bool host_levels = !device_levels;
+    const bool host_levels = !device_levels_requested();
     const bool device_plan = oblivious && !has_coll_ && !host_levels && MD > 0 && MD <= 11 /* k_plan_oblivious: <= 1024 nodes per level */ && n_cand > 0 && !l2_degenerate;
     if (device_plan) {
         const int mf = max_front;
@@ -1246,15 +1272,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 }
             } else {
                 // poll the sequence word; now and then ask the stream for errors (a faulted kernel would never publish)
-                int idle = 0;
-                for (unsigned spins = 1; *h_flag != seq; ++spins) {
-                    if ((spins & 0x3fff) == 0) {
-                        const hipError_t q = hipStreamQuery(s);
-                        if (q == hipSuccess) { if (++idle > 64) throw HipError("internal: level results were not published"); }
-                        else if (q != hipErrorNotReady) hip_check(q, "hipStreamQuery(level results)");
-                    }
-                }
-                std::atomic_thread_fence(std::memory_order_acquire);
+                spin_until_published(h_flag, seq, s, "level results");
             }
         }
         hip_check(hipGetLastError(), "growth kernels");
@@ -1319,15 +1337,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         *h_aflag = 0;
         kern::publish_block(d_leafacc, h_acc_dev, sizeof(int64_t) * n_acc_words, reinterpret_cast<uint32_t *>(static_cast<char *>(h_acc_dev) + acc_bytes), seq, s,
                             /*zero_src=*/true);
-        int idle = 0;
-        for (unsigned spins = 1; *h_aflag != seq; ++spins) {
-            if ((spins & 0x3fff) == 0) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q == hipSuccess) { if (++idle > 64) throw HipError("internal: leaf sums were not published"); }
-                else if (q != hipErrorNotReady) hip_check(q, "hipStreamQuery(leaf sums)");
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        spin_until_published(h_aflag, seq, s, "leaf sums");
         leafacc_clean_ptr_ = d_leafacc;   // only the copied words were ever written, and the kernel cleared them
     }
     acc.assign(h_acc, h_acc + n_acc_words);

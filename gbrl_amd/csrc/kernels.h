@@ -292,6 +292,7 @@ struct PredictModel {
 };
 int obl2_padded_outputs(int D);     // 4, 8, 16, 32, 64 (0: D > 64)
 int obl2_levels(int max_depth);     // 4, 6, 8 (0: max_depth > 8)
+bool obl2_feasible(int max_depth, int D, bool greedy);   // false: no launch plan can take the shape (the mirror is then not built)
 // Small / medium batches against large ensembles: leaf search spread over the chip, then one fused multiply-add chain per (row,
 // output) in tree order -- the bits of the one-chain-per-row kernels (predict_chain.hip).  false: not covered, nothing was launched.
 size_t predict_chain_slot_ints(int n, int trees);

@@ -704,17 +704,20 @@ __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_
     if (kReduceLanes > 1) {
         if (lane > 0) part[lane - 1][threadIdx.x] = s;
         __syncthreads();
-        if (lane != 0) return;
+        if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < kReduceLanes - 1; ++q) s += part[q][threadIdx.x];
+            for (int q = 0; q < kReduceLanes - 1; ++q) s += part[q][threadIdx.x];
+        }
     }
+    const bool writer = lane == 0;     // the other chunk lanes stay until the last barrier and store nothing
     // The partials have the feature as the fastest index (the LDS layout of k_hist_build), the histograms the (class, field) pair:
     // the block's 256 sums are 16 features x 16 consecutive (class, field) elements when FG == 16.  Through a small LDS tile every
     // 16 lanes write 128 consecutive bytes of one feature instead of 16 features x 8 bytes.
     if (FG == 16) {
         __shared__ int64_t tile[16][17];
-        tile[threadIdx.x & 15][threadIdx.x >> 4] = s;
+        if (writer) tile[threadIdx.x & 15][threadIdx.x >> 4] = s;
         __syncthreads();
+        if (!writer) return;
         const int fl = threadIdx.x >> 4, el = threadIdx.x & 15;
         const int e = blockIdx.x * 16 + el;                       // (class, field) element: cls * (D + 1) + d
         const int f = g * FG + fl;
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_
         hist[(static_cast<size_t>(slot) * Fp + f) * NB * (D + 1) + e] = v;
         return;
     }
-    if (i >= n_acc) return;
+    if (!writer || i >= n_acc) return;
     const int fl = i % FG, d = (i / FG) % (D + 1), cls = i / (FG * (D + 1));
     const int f = g * FG + fl;
     if (scatter_fs > 0) {   // send layout of the feature reduce-scatter: [owner rank][node k][feature inside the slice][class][D+1]

@@ -587,6 +587,15 @@ int obl2_padded_outputs(int D) {
     return D <= 64 ? 64 : 0;
 }
 int obl2_levels(int max_depth) { return max_depth <= 4 ? 4 : max_depth <= 6 ? 6 : max_depth <= 8 ? 8 : 0; }
+// Can ANY launch plan take this shape?  A group holds >= 4 trees and the group's records must lie below 64 KiB (16-bit offsets,
+// obl2_plan): shapes that fail this (8 levels with >= 32 padded outputs) never reach the kernel, so the engine does not build or
+// upload their (large, padded) mirror.
+bool obl2_feasible(int max_depth, int D, bool greedy) {
+    const int maxd = obl2_levels(max_depth), DMAX = obl2_padded_outputs(D);
+    if (maxd == 0 || DMAX == 0) return false;
+    const size_t vtb = (static_cast<size_t>(1) << maxd) * (DMAX * sizeof(float) + (greedy ? 16 : 0));
+    return 4 * vtb <= 65536;
+}
 
 bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
                   float *out, hipStream_t s) {

@@ -41,6 +41,24 @@ def test_mismatched_world_size_is_refused():
     assert out.returncode != 0
 
 
+def test_a_dead_rank_takes_the_launch_down_instead_of_hanging_it():
+    """one rank exits non-zero while the others are blocked (here: asleep) -- the launcher must terminate them and return
+    non-zero promptly, like torch.distributed.run, instead of waiting for ranks that will never finish."""
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                         env=_clean_env(BENCH_LAUNCH_ONLY="1", BENCH_LAUNCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert time.monotonic() - t0 < 60
+
+
+def test_the_launch_has_a_wall_clock_limit():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=_clean_env(BENCH_LAUNCH_ONLY="1", BENCH_LAUNCH_FAIL_RANK="7", BENCH_LAUNCH_TIMEOUT_S="2"), capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 124
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_report_n_gpus_2():
     """The real N=2 bench path on a single-GPU box: both ranks on cuda:0, reductions staged through gloo (numbers meaningless)."""

@@ -451,3 +451,36 @@ def test_feature_weights_changed_between_steps_are_picked_up(policy):
     e, o = models[0].get_ensemble_data(), models[1].get_ensemble_data()
     assert_structure_equal(e, o, what="weights changed between steps: ")
     assert_values_close(e, o, float(np.abs(G).mean()), TOL)
+
+
+@pytest.mark.parametrize("policy", ["greedy", "oblivious"])
+def test_empty_and_inverted_tree_ranges_return_the_bias_like_the_reference(policy):
+    """predict_cpu's tree loops run from start to stop (predictor.cpp:139-163), so start > stop, start == stop and
+    start > n_trees walk no tree and the result is the bias; stop > n_trees prints a warning and also returns the bias.  Round 2
+    raised for the first two.  Checked against the restatement (and the reference build when it travelled)."""
+    import oracle
+    case = _case("rng", D=3, policy=policy, trees=4, bias=[0.5, -1.0, 2.0])
+    X, Xc, G, y = K.make_inputs(case)
+    m, r = _check(case, X, Xc, G)
+    ref = oracle.load_ref()
+    rr = None
+    if ref is not None:
+        rr = ref.GBRL(**K.ctor_kwargs(case))
+        K.drive(rr, case, X, Xc, G, y)
+    bias = np.tile(np.array([0.5, -1.0, 2.0], np.float32), (len(X), 1))
+    for start, stop in [(3, 2), (2, 2), (0, 4), (1, 3), (3, 4)]:
+        p = np.asarray(m.predict(X, None, start, stop))
+        scale = float(np.abs(G).mean())
+        assert rel_err(p, np.asarray(r.predict(X, None, start, stop)), scale) <= TOL, (start, stop)
+        if rr is not None:
+            assert rel_err(p, np.asarray(rr.predict(X, None, start, stop)), scale) <= TOL, (start, stop)
+        if start >= stop:                                   # no tree walked: exactly the bias, in all three
+            assert np.array_equal(p, bias), (start, stop)
+            assert np.array_equal(np.asarray(r.predict(X, None, start, stop)), bias)
+            if rr is not None:
+                assert np.array_equal(np.asarray(rr.predict(X, None, start, stop)), bias)
+    # the binding's own bounds (binding.cpp:799-811): start >= n_trees and stop > n_trees raise before the engine is reached
+    for start, stop in [(7, 0), (4, 0), (1, 9), (-1, 2)]:
+        for model in (m,) + ((rr,) if rr is not None else ()):   # (the restatement mirrors predict_cpu, not the binding)
+            with pytest.raises(RuntimeError):
+                model.predict(X, None, start, stop)

@@ -434,7 +434,7 @@ def test_full_size_properties_config3_shape():
     assert np.array_equal(pred, want_pred)
 
 
-@pytest.mark.parametrize("N", [70001, 3001])
+@pytest.mark.parametrize("N", [70001, 70000, 3001])   # 70000: n % 4 == 0 -> the transpose counts the first radix digit (k_transpose_count)
 def test_fast_quantile_path_equals_bisection_path(N, monkeypatch):
     """The exact selections -- LDS sort of the whole column (small batches), MSD radix multi-select (radix_select.hip),
     sample-splitter selection (quantile.hip) and 32-pass bisection (kernels.hip) -- give identical trees, also on columns built
