@@ -577,7 +577,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
 // exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
 // On return d_thr / d_thrkeys hold them on the device (the caller copies them to the host when it needs them there).
 void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
-                                uint32_t *d_thrkeys) {
+                                uint32_t *d_thrkeys, int pass1_chunks) {
     hipStream_t s = stream_;
     const gbrl_hip_metadata &md = model.meta;
     uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
@@ -668,7 +668,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                     comm.gbuf = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * kern::radix_exchange_words(F)));
                     comm.partial_global = static_cast<uint32_t *>(d_radix_global_.ensure(kern::radix_global_partial_bytes(F)));
                 }
-                const int rc = kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s, has_coll_ ? &comm : nullptr);
+                const int rc = kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s, has_coll_ ? &comm : nullptr, pass1_chunks);
                 if (rc != 0) throw HipError(rc == 2 ? "allreduce failed" : "radix select failed");
                 last_quantile_fallback_ = false;
             } else {
@@ -1469,14 +1469,21 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     float *d_thr = static_cast<float *>(d_thr_.ensure(sizeof(float) * std::max<size_t>(1, n_thr)));
     uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, n_thr)));
     uint32_t *d_kt = nullptr;
+    int pass1_chunks = 0;
     if (F > 0) {
         // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
         d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
-        kern::transpose_keys(dobs, N, F, d_kt, s);
+        // quantile candidates by radix selection (the branch numeric_thresholds will take): the first digit is counted while the keys
+        // pass through LDS (k_transpose_count), which saves one of the selection's passes over the keys
+        const bool radix_path = fixed_thr_.empty() && md.generator_type != GBRL_HIP_GEN_UNIFORM && !force_bisection_ && !force_sample_select_ &&
+                                B <= kern::radix_max_targets() && n_global < (1ll << 32);
+        if (radix_path)
+            pass1_chunks = kern::transpose_keys_count(dobs, N, F, d_kt, static_cast<uint32_t *>(d_radix_partial_.ensure(kern::radix_partial_bytes(F))), s);
+        if (pass1_chunks == 0) kern::transpose_keys(dobs, N, F, d_kt, s);
     }
     phase_end("transpose");
     phase_begin();
-    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys);
+    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks);
     phase_end("candidates");
 
     // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the

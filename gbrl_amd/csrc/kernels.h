@@ -154,7 +154,11 @@ struct RadixComm {
 size_t radix_exchange_words(int F);
 size_t radix_global_partial_bytes(int F);
 int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
-                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm /*nullable: one GPU*/);
+                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm /*nullable: one GPU*/,
+                 int pass1_chunks = 0 /*> 0: `partial` already holds the first-digit counts written by transpose_keys_count*/);
+// obs [n][F] -> kt [F][n] keys AND the first radix digit counted on the way (partial: the radix_partial_bytes(F) buffer).
+// Returns the chunk count to pass to radix_select, or 0 when the shape does not qualify (nothing was done).
+int transpose_keys_count(const float *obs, int n, int F, uint32_t *kt, uint32_t *partial, hipStream_t s);
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s);
 void scatter_cat_codes_grouped(const uint16_t *cat_codes, int n, int Fc, int F, uint16_t *codes, hipStream_t s);
 constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [group][row][16]

@@ -218,6 +218,88 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
     }
 }
 
+// ---- transpose fused with the first counting pass ------------------------------------------------------------------------
+// The first digit (top 12 bits of the key) of every key is counted WHILE the observation matrix is transposed into the
+// feature-major keys: the keys pass through LDS anyway, and the separate first counting pass streamed the 4 N F bytes of keys once
+// more (0.12 ms of the 0.41 ms selection at 2^20 x 128).  One block = 16 features x one chunk of <= kTcChunk rows; counters
+// [16][4096] as uint16 pairs packed in uint32 words (128 KiB: a block sees < 65536 rows, so a half never carries into its
+// neighbour) -- stored as they are, i.e. as a uint16 partial [feature][chunk][4096] that the pass-1 target kernel sums over chunks.
+// The transposition is WAVE-private (no block barrier in the loop): a wave takes 16 rows x 16 features (one float4 per lane = 64-byte
+// row pieces), turns them through its own 16 x 20-word LDS patch and stores, per feature, 16 consecutive rows = 64 bytes; the 16
+// waves of a block work on adjacent row groups, so a block writes 1 KiB runs per feature.  Loads are clamped and UNCONDITIONAL: a
+// load inside a branch is followed by `s_waitcnt vmcnt(0)` and the wave's prefetch is gone (scripts/slab_stream_bench.hip).
+constexpr int kTcThreads = 1024;
+constexpr int kTcWaves = kTcThreads / 64;
+constexpr int kTcWaveRows = 16;              // rows per wave and step
+constexpr int kTcPatch = 20;                 // words per feature row of a wave's patch: 16-byte aligned
+constexpr int kTcChunk = 32768;              // rows per block (< 65536): 32 chunks x 8 slabs = 256 blocks at 2^20 x 128
+constexpr int kTcMaxChunks = 128;            // partial buffer: F x chunks x 8 KiB <= radix_partial_bytes(F)
+constexpr int kTcDepth = 2;                  // row groups a wave keeps in flight
+
+__device__ __forceinline__ uint32_t tc_float_to_key(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u << 1) == 0) u = 0;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(kTcThreads) void k_transpose_count(const float *__restrict__ obs, int n, int F, uint32_t *__restrict__ kt,
+                                                                uint16_t *__restrict__ partial16, int n_chunks) {
+    extern __shared__ uint32_t tc_lds[];
+    constexpr int CW = kBins1 / 2;                                            // counter words per feature
+    uint32_t *cnt = tc_lds;                                                   // [16][CW] packed uint16 pairs
+    const int chunk = blockIdx.x, f0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t *patch = tc_lds + 16 * CW + wave * (16 * kTcPatch);               // this wave's [16 features][kTcPatch]
+    {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = tid; i < 16 * CW / 4; i += kTcThreads) c4[i] = make_uint4(0, 0, 0, 0);
+    }
+    const int r_lo = chunk * kTcChunk, r_hi = min(n, r_lo + kTcChunk);
+    const int lr = lane >> 2, q = lane & 3;              // load: row of the group, quad of features
+    const int sf = lane >> 2, sq = lane & 3;             // store: feature, four consecutive rows
+    const bool fq_ok = f0 + 4 * q < F;                   // F % 4 == 0: a quad is inside or outside
+    const int fq = fq_ok ? f0 + 4 * q : 0;
+    constexpr int kStep = kTcWaveRows * kTcWaves;        // rows the block advances per step
+    auto load = [&](int r) -> float4 { return *reinterpret_cast<const float4 *>(obs + static_cast<size_t>(min(r, n - 1)) * F + fq); };
+    int g = r_lo + wave * kTcWaveRows;                   // first row of this wave's group
+    float4 buf[kTcDepth];
+#pragma unroll
+    for (int d = 0; d < kTcDepth; ++d) buf[d] = load(g + d * kStep + lr);
+    __syncthreads();                                     // counters zeroed
+    uint32_t *cbase = cnt + (4 * q) * CW;
+    for (; g < r_hi; g += kStep) {
+        const float4 cur = buf[0];
+#pragma unroll
+        for (int d = 0; d + 1 < kTcDepth; ++d) buf[d] = buf[d + 1];
+        buf[kTcDepth - 1] = load(g + kTcDepth * kStep + lr);
+        const uint32_t k0 = tc_float_to_key(cur.x), k1 = tc_float_to_key(cur.y), k2 = tc_float_to_key(cur.z), k3 = tc_float_to_key(cur.w);
+        uint32_t *t = patch + (4 * q) * kTcPatch + lr;
+        t[0] = k0; t[kTcPatch] = k1; t[2 * kTcPatch] = k2; t[3 * kTcPatch] = k3;
+        if (g + lr < r_hi && fq_ok) {
+            // digit = key >> 20; word = digit / 2, half = digit & 1
+            atomicAdd(cbase + (k0 >> 21), 1u << ((k0 >> 16) & 16));
+            atomicAdd(cbase + CW + (k1 >> 21), 1u << ((k1 >> 16) & 16));
+            atomicAdd(cbase + 2 * CW + (k2 >> 21), 1u << ((k2 >> 16) & 16));
+            atomicAdd(cbase + 3 * CW + (k3 >> 21), 1u << ((k3 >> 16) & 16));
+        }
+        __builtin_amdgcn_wave_barrier();                 // the patch is exchanged between the lanes of ONE wave: LDS order is program order
+        const uint4 o = *reinterpret_cast<const uint4 *>(patch + sf * kTcPatch + 4 * sq);
+        __builtin_amdgcn_wave_barrier();
+        if (f0 + sf < F && g + 4 * sq < r_hi)            // n % 4 == 0: four rows exist together
+            *reinterpret_cast<uint4 *>(kt + static_cast<size_t>(f0 + sf) * n + g + 4 * sq) = o;
+    }
+    __syncthreads();
+    // the block's counters leave as uint16 [feature][chunk][kBins1]
+    for (int i = tid; i < 16 * CW / 4; i += kTcThreads) {
+        const int fl = i / (CW / 4);
+        if (f0 + fl < F) {
+            uint4 *dst = reinterpret_cast<uint4 *>(partial16 + (static_cast<size_t>(f0 + fl) * n_chunks + chunk) * kBins1);
+            dst[i % (CW / 4)] = reinterpret_cast<const uint4 *>(cnt)[i];
+        }
+    }
+}
+
 // ---- target pass -------------------------------------------------------------------------------------------------------
 constexpr int kTgtThreads = 1024;
 
@@ -241,7 +323,7 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *scratc
 // One block per feature; thread k < B owns target k.  `pass` = the counting pass being consumed.
 __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const uint32_t *__restrict__ partial, int n_chunks,
                                                                const int64_t *__restrict__ cum, int B, RadixState st,
-                                                               uint32_t *__restrict__ thr_keys) {
+                                                               uint32_t *__restrict__ thr_keys, int p1_u16) {
     extern __shared__ uint32_t sums[];        // inclusive digit counts: pass 1 [4096]; later [n_slots][NB]
     __shared__ int tslot[kMaxTargets], tdig[kMaxTargets];
     __shared__ uint32_t scratch[16], total_slots;
@@ -253,6 +335,21 @@ __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const u
     if (pass == 1) {
         // 4 consecutive buckets per thread (one 16-byte load per chunk), block scan of the thread totals
         uint4 v = make_uint4(0, 0, 0, 0);
+        if (p1_u16) {   // partials of k_transpose_count: uint16 [feature][chunk][4096], eight chunks in flight
+            const uint16_t *q0 = reinterpret_cast<const uint16_t *>(partial) + static_cast<size_t>(f) * n_chunks * kBins1 + k * 4;
+            int c = 0;
+            for (; c + 8 <= n_chunks; c += 8) {
+                uint2 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const uint2 *>(q0 + static_cast<size_t>(c + u) * kBins1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v.x += t[u].x & 0xffffu; v.y += t[u].x >> 16; v.z += t[u].y & 0xffffu; v.w += t[u].y >> 16; }
+            }
+            for (; c < n_chunks; ++c) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(q0 + static_cast<size_t>(c) * kBins1);
+                v.x += t.x & 0xffffu; v.y += t.x >> 16; v.z += t.y & 0xffffu; v.w += t.y >> 16;
+            }
+        } else
         for (int c = 0; c < n_chunks; ++c) {
             const uint4 t = *reinterpret_cast<const uint4 *>(p0 + c * pstride + k * 4);
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
@@ -330,7 +427,7 @@ __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const u
 // Exchange format: two uint32 counters per int64 word (global row count < 2^32, so the low field never carries), layout
 // pass 1 [F][2048], later passes [slot][F][NB/2] so that the slots in use on any feature form a contiguous prefix.
 __global__ __launch_bounds__(256) void k_radix_globalize(int pass, const uint32_t *__restrict__ partial, int n_chunks, int F,
-                                                         RadixState st, int64_t *__restrict__ gbuf) {
+                                                         RadixState st, int64_t *__restrict__ gbuf, int p1_u16) {
     const int NB = radix_bins(pass), NBh = NB / 2;
     const int rows = pass == 1 ? 1 : kMaxTargets;
     const size_t pstride = pass == 1 ? kBins1 : kMaxTargets * kSlotStride;
@@ -341,7 +438,10 @@ __global__ __launch_bounds__(256) void k_radix_globalize(int pass, const uint32_
         const int slot = static_cast<int>(i / (static_cast<size_t>(NBh) * F));
         uint32_t a = 0, b = 0;
         const int live = pass == 1 ? 1 : static_cast<int>(st.n_slots[f * 4 + (pass - 2)]);
-        if (slot < live)
+        if (p1_u16 && pass == 1) {
+            const uint16_t *p = reinterpret_cast<const uint16_t *>(partial) + static_cast<size_t>(f) * n_chunks * kBins1 + 2 * pair;
+            for (int c = 0; c < n_chunks; ++c) { a += p[static_cast<size_t>(c) * kBins1]; b += p[static_cast<size_t>(c) * kBins1 + 1]; }
+        } else if (slot < live)
             for (int c = 0; c < n_chunks; ++c) {
                 const uint32_t *p = partial + (static_cast<size_t>(f) * n_chunks + c) * pstride + (pass == 1 ? 0 : slot * kSlotStride) + 2 * pair;
                 a += p[0]; b += p[1];
@@ -386,7 +486,7 @@ size_t radix_global_partial_bytes(int F) { return sizeof(uint32_t) * static_cast
 // Exact order statistics of every column: thr_keys[f][k] = key of 1-based rank cum[k] in column f of kt ([F][n] ordered keys).
 // cum must be non-decreasing, 1 <= cum[k] <= n, B <= 256.
 int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
-                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm) {
+                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm, int pass1_chunks) {
     char *p = static_cast<char *>(state);
     auto take = [&](size_t bytes) { char *q = p; p += align16(bytes); return q; };
     const size_t f = static_cast<size_t>(F);
@@ -421,9 +521,11 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
     auto finish_pass = [&](int pass, int n_chunks_pass) -> int {
         const uint32_t *src = partial;
         int chunks = n_chunks_pass;
+        int p1_u16 = (pass == 1 && pass1_chunks > 0) ? 1 : 0;
         if (comm) {
             int rows = 1;
-            hipLaunchKernelGGL(k_radix_globalize, dim3(1024), dim3(256), 0, s, pass, partial, n_chunks_pass, F, st, comm->gbuf);
+            hipLaunchKernelGGL(k_radix_globalize, dim3(1024), dim3(256), 0, s, pass, partial, n_chunks_pass, F, st, comm->gbuf, p1_u16);
+            p1_u16 = 0;   // the summed counts come back as uint32
             if (pass >= 2) {
                 h_slots.resize(static_cast<size_t>(F) * 4);
                 if (hipMemcpyAsync(h_slots.data(), st.n_slots, sizeof(uint32_t) * h_slots.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
@@ -440,19 +542,41 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
             chunks = 1;
         }
         const size_t lds = pass == 1 ? kBins1 * 4 : static_cast<size_t>(kMaxTargets) * radix_bins(pass) * 4;
-        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys);
+        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys, p1_u16);
         return 0;
     };
     int rc = 0;
     static const bool plain_loads = [] { const char *e = std::getenv("GBRL_HIP_RADIX_PLAIN_LOADS"); return e && e[0] == '1'; }();   // measurement hook
-    hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial, plain_loads);
-    if ((rc = finish_pass(1, c1)) != 0) return rc;
+    if (pass1_chunks > 0) {   // the first digit was counted by transpose_keys_count
+        if ((rc = finish_pass(1, pass1_chunks)) != 0) return rc;
+    } else {
+        hipLaunchKernelGGL(k_radix_count<1>, dim3(c1, F), dim3(kRadixThreads), lds1, s, kt, n, c1, B, st, partial, plain_loads);
+        if ((rc = finish_pass(1, c1)) != 0) return rc;
+    }
     hipLaunchKernelGGL(k_radix_count<2>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial, plain_loads);
     if ((rc = finish_pass(2, cn)) != 0) return rc;
     hipLaunchKernelGGL(k_radix_count<3>, dim3(cn, F), dim3(kRadixThreads), lds23, s, kt, n, cn, B, st, partial, plain_loads);
     if ((rc = finish_pass(3, cn)) != 0) return rc;
     hipLaunchKernelGGL(k_radix_count<4>, dim3(cn, F), dim3(kRadixThreads), lds4, s, kt, n, cn, B, st, partial, plain_loads);
     return finish_pass(4, cn);
+}
+
+// Transpose + first-digit counts in one pass over the observations.  Returns the number of row chunks of the uint16 partial
+// (to be handed to radix_select as pass1_chunks), or 0 when the shape does not fit (the caller then transposes with
+// transpose_keys and radix_select counts the first digit itself).
+int transpose_keys_count(const float *obs, int n, int F, uint32_t *kt, uint32_t *partial, hipStream_t s) {
+    const char *env_off = std::getenv("GBRL_HIP_TRANSPOSE_COUNT");   // measurement / test hook, read per call
+    const bool off = env_off && env_off[0] == '0';
+    const int chunks = (n + kTcChunk - 1) / kTcChunk;
+    if (off || n < (1 << 16) || (n & 3) || (F & 3) || chunks > kTcMaxChunks || (reinterpret_cast<uintptr_t>(obs) & 15) ||
+        (reinterpret_cast<uintptr_t>(kt) & 15))
+        return 0;
+    const size_t lds = sizeof(uint32_t) * (16 * (kBins1 / 2) + kTcWaves * 16 * kTcPatch);
+    static PerDeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transpose_count), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(k_transpose_count, dim3(chunks, (F + 15) / 16), dim3(kTcThreads), lds, s, obs, n, F, kt,
+                       reinterpret_cast<uint16_t *>(partial), chunks);
+    return chunks;
 }
 
 }  // namespace kern

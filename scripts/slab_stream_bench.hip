@@ -118,6 +118,41 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *__restrict__ obs, i
     if (acc == 0x1234567u) sink[0] = acc;
 }
 
+template <int WAVES, int DEPTH>
+__global__ __launch_bounds__(64 * WAVES) void k16(const float *__restrict__ obs, int n, int F, int chunk_rows, uint32_t *__restrict__ sink) {
+    const int chunk = blockIdx.x, f0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r_lo = chunk * chunk_rows, r_hi = min(n, r_lo + chunk_rows);
+    const int lr = lane >> 2, q = lane & 3;
+    constexpr int kStep = 16 * WAVES;
+    auto load = [&](int r) -> float4 { return *reinterpret_cast<const float4 *>(obs + static_cast<size_t>(min(r, n - 1)) * F + f0 + 4 * q); };
+    int g = r_lo + wave * 16;
+    float4 buf[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) buf[d] = load(g + d * kStep + lr);
+    uint32_t acc = 0;
+    for (; g < r_hi; g += kStep) {
+        const float4 c = buf[0];
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; ++d) buf[d] = buf[d + 1];
+        buf[DEPTH - 1] = load(g + DEPTH * kStep + lr);
+        acc ^= __float_as_uint(c.x) ^ __float_as_uint(c.y) ^ __float_as_uint(c.z) ^ __float_as_uint(c.w);
+    }
+    if (acc == 0x1234567u) sink[0] = acc;
+}
+template <int WAVES, int DEPTH>
+int run16(const float *dx, int N, int F, uint32_t *ds, int chunk_rows, const char *what) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((k16<WAVES, DEPTH>), dim3((N + chunk_rows - 1) / chunk_rows, F / 16), dim3(64 * WAVES), 0, 0, dx, N, F, chunk_rows, ds);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, a, b));
+    }
+    printf("%-44s waves %2d depth %d chunk %6d: %7.1f us  read %.2f TB/s\n", what, WAVES, DEPTH, chunk_rows, ms * 1e3, double(N) * F * 4 / ms / 1e9);
+    return 0;
+}
 template <int MODE, int WAVES, int DEPTH>
 int run(const float *dx, int N, int F, uint16_t *dc, uint32_t *ds, int chunk_rows, const char *what) {
     const size_t lds = (MODE == 1 || MODE == 3) ? 32 * 1024 * 4 : (MODE == 4 ? (32 * 513 * 2 + 64) * 4 : (MODE == 5 ? (32 * 513 + 32 + 32 * 66 + 32 * 131 + 32 * 257 + 64) * 4 : 0));
@@ -161,6 +196,9 @@ int main() {
         CK(hipMalloc(&g_tab, 512 * 4));
         CK(hipMemcpy(g_tab, tab.data(), 512 * 4, hipMemcpyHostToDevice));
     }
+    if (run16<16, 2>(dx, N, F, ds, 32768, "16-feature slabs (64-B pieces), read only")) return 1;
+    if (run16<16, 4>(dx, N, F, ds, 32768, "16-feature slabs (64-B pieces), read only")) return 1;
+    if (run16<16, 4>(dx, N, F, ds, 8192, "16-feature slabs (64-B pieces), read only")) return 1;
     if (run<0, 16, 2>(dx, N, F, dc, ds, 16384, "mode 0 read only")) return 1;
     if (run<0, 16, 4>(dx, N, F, dc, ds, 16384, "mode 0 read only")) return 1;
     if (run<0, 16, 8>(dx, N, F, dc, ds, 16384, "mode 0 read only")) return 1;

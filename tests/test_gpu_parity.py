@@ -434,7 +434,7 @@ def test_full_size_properties_config3_shape():
     assert np.array_equal(pred, want_pred)
 
 
-@pytest.mark.parametrize("N", [70001, 70000, 3001])   # 70000: n % 4 == 0 -> the transpose counts the first radix digit (k_transpose_count)
+@pytest.mark.parametrize("N", [70001, 70000, 3001])   # 70000: n % 4 == 0 and n >= 65536 -> the transpose counts the first radix digit (k_transpose_count)
 def test_fast_quantile_path_equals_bisection_path(N, monkeypatch):
     """The exact selections -- LDS sort of the whole column (small batches), MSD radix multi-select (radix_select.hip),
     sample-splitter selection (quantile.hip) and 32-pass bisection (kernels.hip) -- give identical trees, also on columns built
@@ -453,16 +453,18 @@ def test_fast_quantile_path_equals_bisection_path(N, monkeypatch):
     G = (np.tanh(X[:, :3]) + 0.3 * rng.standard_normal((N, 3))).astype(np.float32)
     case = dict(name="qq", seed=0, N=N, F=F, D=3, depth=6, n_bins=256, score="Cosine", gen="Quantile", policy="greedy", trees=2)
     outs = []
-    # (default: sort for N <= 16384, radix above), radix forced, sample splitters, bisection
-    for env in ({}, {"GBRL_HIP_QUANTILE_RADIX": "1"}, {"GBRL_HIP_QUANTILE_SAMPLE": "1"}, {"GBRL_HIP_FORCE_BISECTION": "1"}):
-        for k in ("GBRL_HIP_QUANTILE_RADIX", "GBRL_HIP_QUANTILE_SAMPLE", "GBRL_HIP_FORCE_BISECTION"):
-            monkeypatch.setenv(k, env.get(k, "0"))
+    # default (LDS sort for N <= 16384, radix above -- with the first digit counted inside the transpose when n % 4 == 0 and
+    # n >= 65536), radix forced, sample splitters, radix with the separate first counting pass, bisection (last: the reference point)
+    hooks = ("GBRL_HIP_QUANTILE_RADIX", "GBRL_HIP_QUANTILE_SAMPLE", "GBRL_HIP_FORCE_BISECTION", "GBRL_HIP_TRANSPOSE_COUNT")
+    for env in ({}, {"GBRL_HIP_QUANTILE_RADIX": "1"}, {"GBRL_HIP_QUANTILE_SAMPLE": "1"}, {"GBRL_HIP_TRANSPOSE_COUNT": "0"}, {"GBRL_HIP_FORCE_BISECTION": "1"}):
+        for k in hooks:
+            monkeypatch.setenv(k, env.get(k, "1" if k == "GBRL_HIP_TRANSPOSE_COUNT" else "0"))
         m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
         K.drive(m, case, X, None, G, None)
         outs.append({k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS})
     for k in K.ENSEMBLE_KEYS:
-        for i, what in enumerate(("default", "radix", "sample")):
-            assert np.array_equal(outs[i][k], outs[3][k]), (what + " vs bisection", k)
+        for i, what in enumerate(("default", "radix", "sample", "separate first pass")):
+            assert np.array_equal(outs[i][k], outs[4][k]), (what + " vs bisection", k)
 
 
 def test_more_rows_than_one_round_of_histogram_chunks():
