@@ -236,6 +236,10 @@ def leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, trees, N=1 << 20, F=192, Fc=
     # categorical columns carry signal too: output j is shifted for four tokens of column j and two tokens of column j + D
     catsig = ((tok[:, :D] % 8) == 3).to(torch.float32) * 2.0 + ((tok[:, D:2 * D] % 16) == 5).to(torch.float32) * 3.0
     G = (G + catsig).contiguous()
+    # Every fifth minibatch carries ONLY the categorical signal (plus noise): against the dense numeric signal a single token equality
+    # never wins a level (round 2: 78 categorical conditions in 60 000, so the categorical traversal was hardly exercised); with these
+    # batches about a fifth of the ensemble's conditions compare dictionary ids (reported as categorical_conditions / conditions).
+    Gc = (catsig + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)).contiguous()
     del catsig
     del tok
     m = make_model(gbrl_amd, np, "cfg5", F, Fc, D, depth, B, "bench_cfg5")
@@ -247,7 +251,7 @@ def leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, trees, N=1 << 20, F=192, Fc=
     for i in range(trees):
         o = (i % n_mb) * mini
         scale = 1.0 / (1.0 + 0.01 * i)                                    # later trees see smaller residual-like gradients
-        gi = (G[o:o + mini] * scale).contiguous()
+        gi = ((Gc if i % 5 == 4 else G)[o:o + mini] * scale).contiguous()
         m.step(tup(X[o:o + mini]), ctup(cells[o:o + mini]), tup(gi))
     torch.cuda.synchronize()
     grow_s = time.perf_counter() - t0
@@ -265,7 +269,8 @@ def leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, trees, N=1 << 20, F=192, Fc=
            "categorical_conditions": n_cat_conditions, "conditions": int(np.asarray(e["depths"]).sum()),
            "grown": "%d steps on %d-row minibatches in %.1f s (%.2f ms/step)" % (trees, mini, grow_s, grow_s * 1e3 / trees),
            "roofline": predict_roofline(N, F + Fc, D, T, depth, dtp)}
-    del X, cells, G
+    out["categorical_fraction"] = n_cat_conditions / max(1, out["conditions"])
+    del X, cells, G, Gc
     torch.cuda.empty_cache()
     return out
 
@@ -482,13 +487,21 @@ def main():
         # dominant kernel = k_hist_build: `depth` launches per tree; per-launch figures are the per-tree ones / depth
         achieved = alg / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
         traffic = None
+        traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "hist_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from the committed rocprofv3 PMC passes (scripts/pmc_summary.py)
             try:
-                traffic = json.load(open(tpath))["bytes_per_launch"]
+                tj = json.load(open(tpath))
+                traffic = tj["bytes_per_launch"]
+                traffic_src = "%s (PMC passes of commit %s, %s)" % (tj.get("source", "profiles/hist_traffic.json"), tj.get("commit", "?"), tj.get("taken", "?"))
             except Exception:
                 traffic = None
+        try:
+            build_info = json.load(open(os.path.join(ROOT, "gbrl_amd", "build_info.json")))
+        except Exception:
+            build_info = None
         out = {
+            "build": build_info,
             "metric": "trees-fit/sec + predict rows/sec at batch=2^20, feat=128, depth=6, out=8",
             "value": steps * world * (N / float(1 << 20)) / dt,
             "unit": "trees/s (2^20-row batches fitted per second; one tree per batch per step)",
@@ -507,7 +520,7 @@ def main():
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,
             "roofline": {"bound": "hbm", "kernel": "k_hist_build (split-score histogram build), %d launches per tree" % depth,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg / depth,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg / depth,
                          "avg_launch_us": build_ms * 1e3 / depth, "launches_per_tree": depth,
                          "algorithmic_bytes_per_tree": alg, "hist_build_ms_per_tree": build_ms,
                          "hist_build_plus_reduce_ms_per_tree": hist_ms,

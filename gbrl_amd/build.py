@@ -73,6 +73,29 @@ def build(force: bool = False) -> None:
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
               f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
               *[os.path.join(CSRC, s) for s in EXT_SRCS], f"-L{HERE}", "-lgbrl_hip", "-Wl,-rpath,$ORIGIN", "-o", EXT])
+    _write_build_info()
+
+
+def _write_build_info():
+    """gbrl_amd/build_info.json: which sources the shipped .so was built from (the GPU box has no .git; bench.py prints this next to
+    its numbers so that a figure can be tied to a commit)."""
+    import hashlib
+    import json
+    import time
+    h = hashlib.sha256()
+    for name in sorted(LIB_DEPS + EXT_SRCS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    root = os.path.dirname(HERE)
+    def git(*a):
+        try:
+            return subprocess.run(["git", "-C", root] + list(a), capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception:
+            return ""
+    info = {"commit": git("rev-parse", "--short", "HEAD") or "unknown", "dirty": bool(git("status", "--porcelain", "gbrl_amd", "include")),
+            "src_sha256": h.hexdigest()[:16], "built": time.strftime("%Y-%m-%d %H:%M:%S")}
+    with open(os.path.join(HERE, "build_info.json"), "w") as f:
+        json.dump(info, f)
 
 
 if __name__ == "__main__":

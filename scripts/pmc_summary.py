@@ -7,9 +7,16 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly
 read.  Calibrated here on kernels of this code base whose byte counts are known exactly (k_transpose_keys reads N*F*4 B and
 writes N*F*4 B; k_bin_cols reads N*F*4 B, writes N*F*2 B): FETCH_SIZE shows 0.500x of the read bytes for both (4 B/lane
 coalesced loads), WRITE_SIZE shows 1.000x of the written bytes.  Hence traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes)."""
-import glob, json, re, sqlite3, sys
+import glob, json, re, sqlite3, subprocess, sys, time
 
 fetch_dir, write_dir, out_txt, out_json = sys.argv[1:5]
+try:
+    COMMIT = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+    if subprocess.run(["git", "status", "--porcelain", "gbrl_amd"], capture_output=True, text=True).stdout.strip():
+        COMMIT += "+dirty"
+except Exception:
+    COMMIT = "unknown"
+STAMP = "commit %s, %s" % (COMMIT, time.strftime("%Y-%m-%d %H:%M"))
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*$", "", n); return n[:60]
 res = {}
@@ -18,7 +25,7 @@ for d, ctr in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
     cur = sqlite3.connect(db).cursor()
     for k, v, c in cur.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
         res.setdefault(short(k), {})[ctr] = (v, c)
-lines = ["# per-kernel HBM-side traffic, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline)",
+lines = ["# " + STAMP, "# per-kernel HBM-side traffic, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline)",
          "# corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests at 64 B; calibrated on k_transpose_keys / k_bin_cols, see scripts/pmc_summary.py)",
          "%-48s %6s %16s %16s %18s" % ("kernel", "calls", "FETCH_KiB/call", "WRITE_KiB/call", "corrected_MB/call")]
 summary = {}
@@ -33,6 +40,6 @@ open(out_txt, "w").write("\n".join(lines) + "\n")
 hb = [v for k, v in summary.items() if "k_hist_build" in k]
 if hb:
     json.dump({"kernel": "k_hist_build", "bytes_per_launch": hb[0]["corrected_bytes_per_call"], "launches_per_tree": 6,
-               "source": out_txt, "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; traffic = 2*FETCH + WRITE (gfx950 correction)"},
+               "source": out_txt, "commit": COMMIT, "taken": time.strftime("%Y-%m-%d %H:%M"), "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; traffic = 2*FETCH + WRITE (gfx950 correction)"},
               open(out_json, "w"), indent=1)
 print("\n".join(lines[:14]))
