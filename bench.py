@@ -297,6 +297,10 @@ def main():
                          "cfg3 = BASELINE configs[2] (greedy / Cosine / policy [0,D-1) lr 0.1 + value [D-1,D) lr 0.01)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the cfg3 and predict_cfg5 legs that follow the timed region (single GPU)")
     ap.add_argument("--cfg5-trees", type=int, default=10000, help="ensemble size of the predict_cfg5 leg (BASELINE configs[4]: 10 000)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="test hook (one process): the rows of K ranks (their seeds, concatenated in rank order) as ONE unsharded batch -- the "
+                         "single-process twin of `--gpus K` for tree-equality checks")
+    ap.add_argument("--dump-ensemble", default=None, help="test hook: rank 0 writes the grown ensemble's structure arrays to this .npz")
     ap.add_argument("--large-ensemble", type=int, default=1000,
                     help="also time predict() over an ensemble of this many trees (the row-trees/s rate is flat from ~100 trees on; "
                          "BASELINE configs[4] has 10000).  The extra trees are grown after the timed region with the same "
@@ -350,13 +354,25 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     N, F, D, depth, B = args.rows, args.features, args.out_dim, args.depth, args.bins
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    X = torch.randn((N, F), device=dev, dtype=torch.float32, generator=gen)
     wgen = torch.Generator(device=dev)
     wgen.manual_seed(99)
     W = torch.randn((8, D), device=dev, dtype=torch.float32, generator=wgen)
-    G = (torch.tanh(X[:, :8] @ W) + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)).contiguous()
+
+    def shard(r):   # the rows of rank r: its own generator, so that K ranks and one process emulating K ranks see the same global batch
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + r)
+        Xr = torch.randn((N, F), device=dev, dtype=torch.float32, generator=gen)
+        Gr = torch.tanh(Xr[:, :8] @ W) + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)
+        return Xr, Gr
+    if args.emulate_ranks > 1 and world == 1:
+        parts = [shard(r) for r in range(args.emulate_ranks)]
+        X = torch.cat([p[0] for p in parts]).contiguous()
+        G = torch.cat([p[1] for p in parts]).contiguous()
+        del parts
+        N = X.shape[0]
+    else:
+        X, G = shard(rank)
+        G = G.contiguous()
 
     m = make_model(gbrl_amd, np, args.workload, F, 0, D, depth, B, "bench")
     # level 1: one HIP event pair per k_hist_build launch, attached to the dispatch itself (hipExtLaunchKernelGGL start/stop
@@ -403,6 +419,11 @@ def main():
         t = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if args.dump_ensemble and rank == 0:   # test hook: the trees of the warm-up + timed steps (every rank grows the same ones)
+        e = m.get_ensemble_data()
+        np.savez(args.dump_ensemble, **{k: np.asarray(e[k]) for k in ("tree_indices", "depths", "feature_indices", "feature_values",
+                                                                    "inequality_directions", "edge_weights", "values")})
 
     # diagnostic pass (untimed): every phase bracketed with events
     m.set_profiling(2)

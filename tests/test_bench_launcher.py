@@ -68,3 +68,25 @@ def test_two_ranks_on_one_gpu_report_n_gpus_2():
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_grow_the_trees_of_one_process_on_the_same_rows(tmp_path):
+    """`bench.py --gpus 2` end to end (two ranks sharing cuda:0, reductions through gloo) must grow, tree for tree,
+    what ONE process grows on the concatenation of the two ranks' rows (--emulate-ranks 2): structure bit-identical, leaf values equal
+    (integer sums: the row partition does not enter any result)."""
+    import numpy as np
+    common = ["--steps", "2", "--warmup", "1", "--rows", "32768", "--features", "16", "--no-cpu-baseline", "--large-ensemble", "0", "--no-extra-legs"]
+    a, b = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump-ensemble", a] + common,
+                         env=_clean_env(BENCH_SHARE_DEVICE="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--emulate-ranks", "2", "--dump-ensemble", b] + common,
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    ea, eb = np.load(a), np.load(b)
+    assert len(ea["tree_indices"]) == 3
+    for k in ea.files:
+        assert np.array_equal(ea[k], eb[k]), k
