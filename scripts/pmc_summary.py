@@ -10,6 +10,7 @@ coalesced loads), WRITE_SIZE shows 1.000x of the written bytes.  Hence traffic =
 import glob, json, re, sqlite3, subprocess, sys, time
 
 fetch_dir, write_dir, out_txt, out_json = sys.argv[1:5]
+EXTRA = sys.argv[5] if len(sys.argv) > 5 else ""
 try:
     COMMIT = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
     if subprocess.run(["git", "status", "--porcelain", "gbrl_amd"], capture_output=True, text=True).stdout.strip():
@@ -17,6 +18,9 @@ try:
 except Exception:
     COMMIT = "unknown"
 STAMP = "commit %s, %s" % (COMMIT, time.strftime("%Y-%m-%d %H:%M"))
+if EXTRA:   # on the GPU box there is no .git: the caller passes the build stamp of the shipped library
+    STAMP = EXTRA + ", " + time.strftime("%Y-%m-%d %H:%M")
+    COMMIT = EXTRA
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*$", "", n); return n[:60]
 res = {}
