@@ -559,9 +559,11 @@ __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ k
         }
         __syncthreads();
         const int rows = min(256, n - r0);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(codes + (static_cast<size_t>(g) * n + r0) * kGroup);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(tile_buf);
-        for (int i = threadIdx.x; i < rows * kGroup / 2; i += 256) dst[i] = src[i];
+        {   // the tile's 8 KiB of codes leave in 16-byte pieces (tile_buf and the group's plane are 32-byte aligned per row)
+            uint4 *dst = reinterpret_cast<uint4 *>(codes + (static_cast<size_t>(g) * n + r0) * kGroup);
+            const uint4 *src = reinterpret_cast<const uint4 *>(tile_buf);
+            for (int i = threadIdx.x; i < rows * 2; i += 256) dst[i] = src[i];
+        }
         __syncthreads();
     }
 }
