@@ -83,12 +83,12 @@ __device__ __forceinline__ void apply_pairs(f32x2 &p, f32x2 nlr, const f32x2 (&v
 
 // LDS map (bytes from 0): leaf values vt[NB][TT][W][LS][DW] f32 (below 64 KiB: their byte offsets travel as 16-bit fields),
 // leaf offsets idx[2][W][R][NW] u32, row tile xt[R][xs] f32.
-template <int DMAX, int MAXD, bool CAT, bool GREEDY>
-__global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
+template <int DMAX, int MAXD, bool CAT, bool GREEDY, bool PERSIST>
+__global__ __launch_bounds__(PERSIST ? 256 : (DMAX >= 32 ? 512 : 1024)) void k_predict_obl2(const float *__restrict__ vsw, const int32_t *__restrict__ cond,
                                                        const float *__restrict__ bias, Obl2Coef<DMAX> coef, int D,
                                                        const float *__restrict__ obs, int F, const int32_t *__restrict__ cat_codes, int Fc,
                                                        int n, int start_tree, int stop_tree, float *__restrict__ out, int R, int TT, int NB,
-                                                       int xs, int tree_chunk) {
+                                                       int xs, int tree_chunk, int n_tiles, int resident) {
     extern __shared__ float lds[];
     constexpr int W = kObl2Workers, DW = DMAX / W, LS = 1 << MAXD, VT = LS * DMAX;
     // one tree's record in the mirror and in LDS: its leaf values [W][LS][DW] and -- greedy ensembles -- its nodes [LS] x int4
@@ -106,10 +106,11 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
     float *vt = lds;
     uint32_t *idx = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(vt) + static_cast<size_t>(NB) * TT * REC);
     float *xt = reinterpret_cast<float *>(idx + 2 * W * NW * R);
-    const int r0 = blockIdx.x * R;
-    const int rows = min(R, n - r0);
+    // (PERSIST: a block walks several row tiles; these three change from tile to tile -- everything below captures them by reference)
+    int r0 = blockIdx.x * R;
+    int rows = min(R, n - r0);
     const int row_l = rg * 64 + lane;
-    const bool live = row_l < rows;
+    bool live = row_l < rows;
     const int n_groups = (stop_tree - start_tree + TT - 1) / TT;
 
     // A group's values travel global -> registers (kObl2MaxVec = 4 float4 per thread) -> LDS.  The loads are unconditional and
@@ -148,9 +149,15 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
 #pragma unroll
         for (int w = 1; w < W; ++w) l = q == w ? coef.lr[w * DW + jj] : l;
         nlr[jj] = -l;
-        const int j = q * DW + jj;
-        p[jj] = (j < D && tree_chunk == 0) ? 0.0f + bias[j] : 0.0f;
     }
+    auto init_p = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < DW; ++jj) {
+            const int j = q * DW + jj;
+            p[jj] = (j < D && tree_chunk == 0) ? 0.0f + bias[j] : 0.0f;
+        }
+    };
+    init_p();
 
     // row tile: numeric features (coalesced 16-byte reads when F % 4 == 0), then the packed categorical ids
     auto stage_rows = [&]() __attribute__((always_inline)) {
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                 __syncthreads();
                 uint32_t word[W][NWK];
                 b_words(g, word);
-                if (NB == 2) {
+                if (NB == 2 && !resident) {
                     store_vals(g + 1);
                     load_vals(min(g + 2, n_groups - 1));
                 }
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
             uint32_t word[W][NWK];
             a_records(g + 1, fi, tv);
             b_words(g, word);
-            if (NB == 2) {
+            if (NB == 2 && !resident) {
                 store_vals(g + 1);
                 load_vals(min(g + 2, n_groups - 1));
             }
@@ -461,12 +468,7 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
         }
     };
 
-    if (n_groups > 0) load_vals(0);
-    stage_rows();
-    if (n_groups > 0) {
-        store_vals(0);
-        load_vals(min(1, n_groups - 1));
-        __syncthreads();
+    auto run_trees = [&]() __attribute__((always_inline)) {
         // wide outputs (DW >= 4 values per worker) keep at most 2 trees per worker in flight (registers); obl2_plan knows
         if constexpr (DW >= 4) {
             if (TPW == 1) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 2>{});
@@ -478,12 +480,89 @@ __global__ __launch_bounds__(DMAX >= 32 ? 512 : 1024) void k_predict_obl2(const 
                 default: run(std::integral_constant<int, 4>{}); break;
             }
         }
-    }
-    if (live) {
-        float *o = out + static_cast<size_t>(r0 + row_l) * D + q * DW;
+    };
+    auto write_out = [&]() __attribute__((always_inline)) {
+        if (live) {
+            float *o = out + static_cast<size_t>(r0 + row_l) * D + q * DW;
 #pragma unroll
-        for (int jj = 0; jj < DW; ++jj)
-            if (q * DW + jj < D) o[jj] = p[jj];
+            for (int jj = 0; jj < DW; ++jj)
+                if (q * DW + jj < D) o[jj] = p[jj];
+        }
+    };
+    if constexpr (!PERSIST) {
+        if (n_groups > 0) load_vals(0);
+        stage_rows();
+        if (n_groups > 0) {
+            store_vals(0);
+            load_vals(min(1, n_groups - 1));
+            __syncthreads();
+            run_trees();
+        }
+        write_out();
+    } else {
+        // Small ensembles are a streaming problem (0.59 GB per call, a few hundred cycles of tree walking per tile): a block walks
+        // tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the NEXT tile's rows are already on their way to registers (eight
+        // 16-byte loads per thread, clamped and unconditional) while this tile's trees are walked.  Host guarantees: numeric
+        // features only, F % 4 == 0, R * F / 4 <= 8 * blockDim.x, blockDim.x % (F / 4) == 0, tree_chunk == 0.
+        constexpr int UL = 8;
+        const int F4 = F >> 2;
+        auto load_tile = [&](int tile, float4 (&pf)[UL]) __attribute__((always_inline)) {
+            const int t0 = min(tile, n_tiles - 1) * R;            // (a tile beyond the batch: loaded from the last one, never stored)
+            const float4 *src4 = reinterpret_cast<const float4 *>(obs + static_cast<size_t>(t0) * F);
+            const int last4 = min(R, n - t0) * F4 - 1;
+#pragma unroll
+            for (int u = 0; u < UL; ++u) pf[u] = src4[min(tid + u * NT, last4)];
+        };
+        // thread -> (row, feature quad) of its eight pieces: with blockDim.x a multiple of F / 4 (the usual shapes) the quad is fixed and
+        // the row advances by blockDim.x / (F / 4) per piece -- no division per piece (eight runtime divisions per thread and tile were
+        // as many instructions as the walk of a 15-tree ensemble)
+        // (host guarantees blockDim.x % (F / 4) == 0)
+        const int tr = tid / F4, tf = (tid - tr * F4) << 2, rstep = NT / F4;
+        auto store_tile = [&](const float4 (&pf)[UL]) __attribute__((always_inline)) {
+            float *dst = xt + tr * xs + tf;
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                if (tr + u * rstep < rows) { dst[0] = pf[u].x; dst[1] = pf[u].y; dst[2] = pf[u].z; dst[3] = pf[u].w; }
+                dst += rstep * xs;
+            }
+            for (int i = rows * xs + tid; i < R * xs; i += NT) xt[i] = 0.0f;   // rows beyond the batch (last tile): defined words
+        };
+        // `resident` (host: n_groups <= NB == 2): the whole ensemble's leaf values fit the two value buffers, are staged ONCE and stay --
+        // otherwise every tile would copy them again (as many bytes as the row tile itself)
+        if (resident) {
+            for (int g = 0; g < n_groups; ++g) { load_vals(g); store_vals(g); }
+        }
+        auto walk_tile = [&](int tile, const float4 (&pf)[UL]) __attribute__((always_inline)) {
+            r0 = tile * R;
+            rows = min(R, n - r0);
+            live = row_l < rows;
+            if (n_groups > 0 && !resident) load_vals(0);
+            store_tile(pf);
+        };
+        auto finish_tile = [&]() __attribute__((always_inline)) {
+            init_p();
+            if (n_groups > 0) {
+                if (!resident) {
+                    store_vals(0);
+                    load_vals(min(1, n_groups - 1));
+                }
+                __syncthreads();
+                run_trees();
+            }
+            write_out();
+            __syncthreads();   // every wave is done with the tile and the value buffers before the next tile replaces them
+        };
+        // (a second register set with the tile after next in flight measured the same, 0.125 vs 0.121 ms: the loop is not waiting on HBM)
+        const int stride = static_cast<int>(gridDim.x);
+        float4 pa[UL];
+        int tile = blockIdx.x;
+        load_tile(tile, pa);
+        while (tile < n_tiles) {
+            walk_tile(tile, pa);
+            load_tile(tile + stride, pa);
+            finish_tile();
+            tile += stride;
+        }
     }
 }
 
@@ -543,16 +622,44 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
     (void)hipGetDevice(&dev);
     static uint64_t attr_done = 0;   // per device
     if (dev < 64 && !((attr_done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl2<DMAX, MAXD, CAT, GREEDY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl2<DMAX, MAXD, CAT, GREEDY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (!CAT)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_obl2<DMAX, MAXD, CAT, GREEDY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done |= 1ull << dev;
     }
     Obl2Coef<DMAX> coef;
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
     const int R = 64 * pl.RG;
     const int splits = pm.tree_chunk > 0 ? pm.tree_splits : 1;
-    hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT, GREEDY>), dim3((n + R - 1) / R, splits), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
+    const int n_tiles = (n + R - 1) / R;
+    if constexpr (!CAT) {
+        // small ensemble over a large batch: persistent blocks that prefetch their next row tile (the HBM-bound regime)
+        static const bool no_persist = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_PERSIST"); return e && e[0] == '1'; }();   // measurement hook
+        // (with <= 16 trees of <= 2 KiB of values each, two 8-tree value buffers hold the whole ensemble: staged once per block)
+        int resident_vals = 0;
+        {
+            const size_t vtb = (static_cast<size_t>(1) << MAXD) * (DMAX * sizeof(float) + (GREEDY ? 16 : 0));
+            static const bool no_res = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_RESIDENT"); return e && e[0] == '1'; }();   // measurement hook
+            if (!no_res && !GREEDY && pl.RG == 1 && trees <= 16 && DMAX <= 8 && 16 * vtb <= 65536) {
+                pl.TT = 8; pl.NB = 2;
+                const int nw = pl.TT / kObl2Workers > 2 ? 2 : 1;
+                pl.lds = static_cast<size_t>(pl.NB) * pl.TT * vtb + static_cast<size_t>(2) * kObl2Workers * nw * 64 * 4 + static_cast<size_t>(64) * pl.xs * 4;
+                resident_vals = 1;
+            }
+        }
+        const int per_cu2 = static_cast<int>(std::min<size_t>(8, (160 * 1024) / std::max<size_t>(1, pl.lds)));
+        const int resident_blocks = std::max(1, per_cu2) * 256;
+        if (!no_persist && pl.RG == 1 /* the persistent instantiation is compiled for 256-thread blocks */ && pm.tree_chunk == 0 && trees <= 48 && (F & 3) == 0 && F > 0 && R * (F >> 2) <= 8 * 256 * pl.RG && (256 * pl.RG) % (F >> 2) == 0 && n_tiles >= 2 * resident_blocks &&
+            (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {
+            hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT, GREEDY, true>), dim3(resident_blocks, 1), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
+                               pm.bias, coef, pm.D, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, R, pl.TT, pl.NB, pl.xs, 0, n_tiles, resident_vals);
+            return true;
+        }
+        if (resident_vals && !obl2_plan(F, Fc, CAT, MAXD, DMAX, GREEDY, trees, pl)) return false;   // not taken: back to the regular plan
+    }
+    hipLaunchKernelGGL((k_predict_obl2<DMAX, MAXD, CAT, GREEDY, false>), dim3(n_tiles, splits), dim3(256 * pl.RG), pl.lds, s, pm.values_sw, pm.cond_ra,
                        pm.bias, coef, pm.D, obs, F, cat_codes, Fc, n, start_tree, stop_tree, pm.tree_chunk > 0 ? pm.partial : out, R,
-                       pl.TT, pl.NB, pl.xs, pm.tree_chunk);
+                       pl.TT, pl.NB, pl.xs, pm.tree_chunk, n_tiles, 0);
     return true;
 }
 
