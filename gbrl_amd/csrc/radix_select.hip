@@ -195,7 +195,11 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_count(const uint32_t *_
         }
         i0 += iters * kRadixThreads * U;
     }
-    for (; i0 + (U - 1) * kRadixThreads < hi; i0 += kRadixThreads * U) {   // full strips: straight-line loads
+    // full strips: straight-line loads.  The condition is evaluated for the wave's LAST lane, so that a wave enters a strip with all its
+    // lanes or not at all: strip() compacts filter hits across the wave and keeps the queue length wave-uniform -- with a per-lane
+    // condition the lanes that sat out kept a stale length and the wave's last queued keys were never counted (round 3: found by
+    // scripts/selfcheck_sweep.py at N = 2^18 + 4, whose last chunk leaves 16 360 keys = a strip for lanes 0..999 only; passes 3 / 4)
+    for (; i0 - static_cast<int>(__lane_id()) + 63 + (U - 1) * kRadixThreads < hi; i0 += kRadixThreads * U) {
         uint32_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) key[u] = col[i0 + u * kRadixThreads];

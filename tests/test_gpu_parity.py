@@ -434,7 +434,7 @@ def test_full_size_properties_config3_shape():
     assert np.array_equal(pred, want_pred)
 
 
-@pytest.mark.parametrize("N", [70001, 70000, 3001])   # 70000: n % 4 == 0 and n >= 65536 -> the transpose counts the first radix digit (k_transpose_count)
+@pytest.mark.parametrize("N", [70001, 70000, 3001, 262148])   # 70000: n % 4 == 0 and n >= 65536 -> the transpose counts the first radix digit (k_transpose_count); 262148: a partial last strip inside one wave of the radix passes
 def test_fast_quantile_path_equals_bisection_path(N, monkeypatch):
     """The exact selections -- LDS sort of the whole column (small batches), MSD radix multi-select (radix_select.hip),
     sample-splitter selection (quantile.hip) and 32-pass bisection (kernels.hip) -- give identical trees, also on columns built
@@ -465,6 +465,18 @@ def test_fast_quantile_path_equals_bisection_path(N, monkeypatch):
     for k in K.ENSEMBLE_KEYS:
         for i, what in enumerate(("default", "radix", "sample", "separate first pass")):
             assert np.array_equal(outs[i][k], outs[4][k]), (what + " vs bisection", k)
+
+
+def test_large_batch_selection_paths_agree_on_random_shapes():
+    """scripts/selfcheck_sweep.py in the suite: at sizes the brute-force oracle cannot reach (65 536 ... 262 148 rows, discrete / constant /
+    heavy-tailed columns) the default path, the separate first counting pass and the 32-pass bisection must grow identical trees and every
+    threshold must be a rank-exact data value.  Round 3: this sweep found a round-2 bug of the radix passes (a partial last strip inside
+    one wave lost queued keys at N = 2^18 + 4); seeds 7000.. contain the two cases that exposed it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "selfcheck_sweep.py"), "300", "7000"], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "300 cases, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_more_rows_than_one_round_of_histogram_chunks():
