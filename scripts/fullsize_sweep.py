@@ -25,7 +25,8 @@ for i in range(n_cases):
     policy = str(rng.choice(["greedy", "oblivious"]))
     score = str(rng.choice(["L2", "Cosine"]))
     depth = int(rng.choice([3, 4, 6])) if policy == "oblivious" else int(rng.choice([3, 4, 5]))
-    case = dict(name="fs%d" % i, seed=seed0 + i, N=N, F=F, D=D, depth=depth, n_bins=B, score=score, gen="Quantile", policy=policy, trees=1)
+    gen = str(rng.choice(["Quantile", "Quantile", "Uniform"]))
+    case = dict(name="fs%d" % i, seed=seed0 + i, N=N, F=F, D=D, depth=depth, n_bins=B, score=score, gen=gen, policy=policy, trees=1)
     X = rng.standard_normal((N, F)).astype(np.float32)
     for f in range(F):
         kind = rng.integers(0, 8)
@@ -39,7 +40,7 @@ for i in range(n_cases):
     e = {kk: np.asarray(v) for kk, v in m.get_ensemble_data().items()}
     try:
         if policy == "oblivious":
-            recs = fullsize.check_oblivious_tree(X, G, e, B, score, rel_tol=1e-4)
+            recs = fullsize.check_oblivious_tree(X, G, e, B, score, rel_tol=1e-4, gen=gen)
         else:
             L = len(e["values"])
             leaves = [0, 0, L // 2, L - 1]
@@ -47,7 +48,7 @@ for i in range(n_cases):
             if int(e["depths"][0]) == 0:
                 recs = []
             else:
-                recs = fullsize.check_greedy_nodes(X, G, e, B, score, leaves, levels, rel_tol=1e-4)
+                recs = fullsize.check_greedy_nodes(X, G, e, B, score, leaves, levels, rel_tol=1e-4, gen=gen)
         g = max([r["gap_rel"] for r in recs], default=0.0)
         worst = max(worst, g)
         if all(r["exact"] for r in recs): exact += 1
@@ -56,6 +57,6 @@ for i in range(n_cases):
     except AssertionError as ex:
         bad += 1
         tag = "BAD " + str(ex)[:300]
-    print("case %d N=%d F=%d D=%d B=%d %s/%s depth %d signal %.1f: %s" % (i, N, F, D, B, policy, score, depth, sig, tag), flush=True)
+    print("case %d N=%d F=%d D=%d B=%d %s/%s/%s depth %d signal %.1f: %s" % (i, N, F, D, B, policy, score, gen, depth, sig, tag), flush=True)
 print("fullsize sweep: %d cases, exact %d, within 1e-4 of the float64 maximum %d (worst gap %.1e), bad %d, %.0f s" % (n_cases, exact, close, worst, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

@@ -32,6 +32,15 @@ def quantile_thresholds(X, n_bins):
     return out
 
 
+def uniform_thresholds(X, n_bins):
+    """[F, n_bins] float32: min + b * step with ONE rounding (the reference's contracted expression, split_candidate_generator.cpp:59-76, Q5);
+    step = (max - min) / float(n_bins) in float32."""
+    mn, mx = X.min(axis=0).astype(np.float32), X.max(axis=0).astype(np.float32)
+    step = ((mx - mn) / np.float32(n_bins)).astype(np.float32)
+    b = np.arange(n_bins, dtype=np.float64)
+    return (b[None, :] * step.astype(np.float64)[:, None] + mn.astype(np.float64)[:, None]).astype(np.float32)
+
+
 def class_codes(X, thr):
     """[F, N] int16: #{k : x > t_k} (thresholds ascending, duplicates kept)."""
     n, F = X.shape
@@ -72,12 +81,12 @@ def candidate_scores(codes, node_ids, n_nodes, bg, n_bins, cosine):
     return out
 
 
-def check_oblivious_tree(X, G, e, n_bins, score, report=None, rel_tol=1e-6):
+def check_oblivious_tree(X, G, e, n_bins, score, report=None, rel_tol=1e-6, gen="Quantile"):
     """Every level's stored (feature, threshold) of the FIRST tree must be the float64 arg-max (lowest index on ties) or within
     rel_tol of the maximum.  Returns the per-level records."""
     cosine = score.lower() == "cosine"
     bg = np.asarray(G, np.float64) if cosine else standardise(G)
-    thr = quantile_thresholds(X, n_bins)
+    thr = quantile_thresholds(X, n_bins) if gen.lower() == "quantile" else uniform_thresholds(X, n_bins)
     codes = class_codes(X, thr)
     depth = int(np.asarray(e["depths"])[0])
     fi = np.asarray(e["feature_indices"])[0]
@@ -111,12 +120,12 @@ def check_oblivious_tree(X, G, e, n_bins, score, report=None, rel_tol=1e-6):
     return out
 
 
-def check_greedy_nodes(X, G, e, n_bins, score, leaves, levels, rel_tol=1e-6):
+def check_greedy_nodes(X, G, e, n_bins, score, leaves, levels, rel_tol=1e-6, gen="Quantile"):
     """For the given leaves of a greedy tree: the condition stored at depth `lvl` of the leaf's path must be the float64
     arg-max of `score - parent` on the rows that satisfy the path prefix (feature weights 1)."""
     cosine = score.lower() == "cosine"
     bg = np.asarray(G, np.float64) if cosine else standardise(G)
-    thr = quantile_thresholds(X, n_bins)
+    thr = quantile_thresholds(X, n_bins) if gen.lower() == "quantile" else uniform_thresholds(X, n_bins)
     fi, fv = np.asarray(e["feature_indices"]), np.asarray(e["feature_values"])
     dirs, dep = np.asarray(e["inequality_directions"]), np.asarray(e["depths"])
     out = []
