@@ -76,7 +76,8 @@ def test_two_ranks_grow_the_trees_of_one_process_on_the_same_rows(tmp_path):
     what ONE process grows on the concatenation of the two ranks' rows (--emulate-ranks 2): structure bit-identical, leaf values equal
     (integer sums: the row partition does not enter any result)."""
     import numpy as np
-    common = ["--steps", "2", "--warmup", "1", "--rows", "32768", "--features", "16", "--no-cpu-baseline", "--large-ensemble", "0", "--no-extra-legs"]
+    common = ["--steps", "2", "--warmup", "1", "--rows", "66000", "--features", "16",   # >= 65 536 rows per rank: the fused transpose + its uint16 digit counts through the exchange
+              "--no-cpu-baseline", "--large-ensemble", "0", "--no-extra-legs"]
     a, b = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump-ensemble", a] + common,
                          env=_clean_env(BENCH_SHARE_DEVICE="1"), capture_output=True, text=True, timeout=600)
