@@ -29,6 +29,9 @@ def quantile_thresholds(X, n_bins):
     out = np.empty((F, n_bins), np.float32)
     for f in range(F):
         out[f] = np.sort(X[:, f])[ranks]
+    # a signed zero at a rank is stored as +0.0 by the product (the reference keeps whichever of -0.0 / +0.0 its sort leaves there;
+    # no comparison x > t can tell them apart: DESIGN.md section 9) -- canonicalise, the checks compare threshold BITS
+    out[out == 0] = np.float32(0.0)
     return out
 
 
