@@ -400,11 +400,17 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
 #ifdef GBRL_HIST_EXP_NOLOAD
         return static_cast<int>((static_cast<uint32_t>(row) * 2654435761u + coff * 40503u) >> 24);
 #endif
+#ifdef GBRL_HIST_EXP_NT_CODES
+        return __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(cgroup + (static_cast<uint32_t>(row) * (kCodeGroup * 2u) + coff)));
+#endif
         return *reinterpret_cast<const uint16_t *>(cgroup + (static_cast<uint32_t>(row) * (kCodeGroup * 2u) + coff));
     };
     auto ld_q = [&](int row) -> int {
 #ifdef GBRL_HIST_EXP_NOLOAD
         return row + static_cast<int>(qoff);
+#endif
+#ifdef GBRL_HIST_EXP_Q16
+        return *reinterpret_cast<const int16_t *>(qbase + (static_cast<uint32_t>(row) * static_cast<uint32_t>(DT * 2) + (qoff >> 1)));
 #endif
         return *reinterpret_cast<const int32_t *>(qbase + (static_cast<uint32_t>(row) * static_cast<uint32_t>(DT * 4) + qoff));
     };

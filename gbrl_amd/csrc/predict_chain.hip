@@ -251,6 +251,7 @@ bool predict_chain(const PredictModel &pm, const float *obs, int F, const int32_
     if (pm.oblivious ? !(pm.obl_ok && pm.cond_pack) : !(pm.grd_ok && pm.grd_nodes)) return false;
     if (static_cast<long long>(pm.n_leaves) * pm.D * 4 >= (1ll << 31)) return false;   // slots are 32-bit byte offsets into the values
     if (predict_chain_slot_ints(n, Tn) > pm.slot_ints) return false;
+    if (static_cast<long long>(n) * pm.D >= (1ll << 31)) return false;                 // the relay indexes (row, output) lanes with an int
     const int xs = F | 1;
     int rows = static_cast<int>(std::min<size_t>(64, (48 * 1024) / (static_cast<size_t>(xs) * sizeof(float))));
     if (rows < 1) return false;
@@ -269,7 +270,6 @@ bool predict_chain(const PredictModel &pm, const float *obs, int F, const int32_
     ChainCoef coef;
     for (int j = 0; j < 64; ++j) coef.c[j] = j < pm.D ? -pm.coef[j] : 0.0f;
     coef.cover = pm.coef_cover;
-    const long long n_el = static_cast<long long>(n) * pm.D;
     const int n_lanes = n * pm.D;
     hipLaunchKernelGGL((k_chain_relay<4, 64, 1>), dim3(static_cast<unsigned>((n_lanes + 63) / 64)), dim3(256), 0, s, pm.slots, Tn, Ts, pm.values,
                        pm.bias, coef, pm.D, n_lanes, out);
