@@ -24,7 +24,8 @@ __device__ __forceinline__ uint64_t load_cell_raw_hash(const char *cell, uint64_
 constexpr int kCatMaxProbes = 512;
 __global__ __launch_bounds__(256) void k_cat_distinct_insert(const char *__restrict__ cells, size_t n_cells, int Fc,
                                                              unsigned long long *__restrict__ keys, int32_t *__restrict__ first,
-                                                             int log2_cap, int32_t *__restrict__ flags) {
+                                                             int log2_cap, int32_t *__restrict__ flags, int32_t *__restrict__ list_slot,
+                                                             int32_t *__restrict__ counter, int list_cap) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n_cells) return;
     const int f = static_cast<int>(i % Fc), row = static_cast<int>(i / Fc);
@@ -35,10 +36,37 @@ __global__ __launch_bounds__(256) void k_cat_distinct_insert(const char *__restr
     const size_t base = static_cast<size_t>(f) << log2_cap;
     for (int p = 0; p < kCatMaxProbes; ++p) {
         const unsigned long long old = atomicCAS(&keys[base + slot], 0ull, static_cast<unsigned long long>(h));
-        if (old == 0ull || old == h) { atomicMin(&first[base + slot], row); return; }
+        if (old == 0ull || old == h) {
+            atomicMin(&first[base + slot], row);
+            if (old == 0ull && list_slot) {   // this thread created the entry: one list record per distinct (feature, cell)
+                const int idx = atomicAdd(counter, 1);
+                if (idx < list_cap) list_slot[idx] = static_cast<int32_t>(base + slot);
+                else flags[0] = 1;
+            }
+            return;
+        }
         slot = (slot + 1) & mask;
     }
     flags[0] = 1;   // table too full
+}
+// Everything the host needs about the distinct cells, written into MAPPED PINNED host memory by one launch (no copy-engine
+// transfers, one synchronisation): header {table overflow, hash collision, distinct count, records published}, then per record
+// the feature, the first row, the raw hash and the 128 bytes of the cell itself (gathered from its first row).
+__global__ __launch_bounds__(256) void k_cat_publish(const int32_t *__restrict__ meta, const int32_t *__restrict__ list_slot,
+                                                     const unsigned long long *__restrict__ keys, const int32_t *__restrict__ first,
+                                                     int log2_cap, const char *__restrict__ cells, int Fc, int cap,
+                                                     int32_t *__restrict__ h_hdr, int32_t *__restrict__ h_feat, int32_t *__restrict__ h_first,
+                                                     unsigned long long *__restrict__ h_hash, char *__restrict__ h_names) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece per thread
+    const int n = min(meta[2], cap);
+    if (i == 0) { h_hdr[0] = meta[0]; h_hdr[1] = meta[1]; h_hdr[2] = meta[2]; h_hdr[3] = n; }
+    if (i >= n * 8) return;
+    const int item = i >> 3, piece = i & 7;
+    const int32_t slot = list_slot[item];
+    const int feat = slot >> log2_cap, row = first[slot];
+    if (piece == 0) { h_feat[item] = feat; h_first[item] = row; h_hash[item] = keys[slot]; }
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(cells + (static_cast<size_t>(row) * Fc + feat) * 128);
+    reinterpret_cast<ulonglong2 *>(h_names + static_cast<size_t>(item) * 128)[piece] = src[piece];
 }
 __global__ __launch_bounds__(256) void k_cat_distinct_verify(const char *__restrict__ cells, size_t n_cells, int Fc,
                                                              const unsigned long long *__restrict__ keys, const int32_t *__restrict__ first,
@@ -66,28 +94,6 @@ __global__ __launch_bounds__(256) void k_cat_distinct_verify(const char *__restr
     }
     flags[0] = 1;
 }
-__global__ __launch_bounds__(256) void k_cat_distinct_compact(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ first,
-                                                              int Fc, int log2_cap, int32_t *__restrict__ out_feat,
-                                                              unsigned long long *__restrict__ out_hash, int32_t *__restrict__ out_first,
-                                                              int32_t *__restrict__ counter, int list_cap, int32_t *__restrict__ flags) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= (static_cast<size_t>(Fc) << log2_cap)) return;
-    const unsigned long long k = keys[i];
-    if (k == 0ull) return;
-    const int idx = atomicAdd(counter, 1);
-    if (idx >= list_cap) { flags[0] = 1; return; }
-    out_feat[idx] = static_cast<int32_t>(i >> log2_cap);
-    out_hash[idx] = k;
-    out_first[idx] = first[i];
-}
-__global__ void k_gather_cells(const char *__restrict__ cells, int Fc, const int32_t *__restrict__ rows, const int32_t *__restrict__ feats,
-                               int n_items, char *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece per thread
-    if (i >= n_items * 8) return;
-    const int item = i >> 3, piece = i & 7;
-    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(cells + (static_cast<size_t>(rows[item]) * Fc + feats[item]) * 128);
-    reinterpret_cast<ulonglong2 *>(out + static_cast<size_t>(item) * 128)[piece] = src[piece];
-}
 __global__ __launch_bounds__(256) void k_cat_step_codes(const char *__restrict__ cells, size_t n_cells, int n, int Fc, int F,
                                                         const int32_t *__restrict__ feat_off, const uint64_t *__restrict__ dict_hash,
                                                         const int32_t *__restrict__ dict_cls, const uint64_t *__restrict__ dict_words,
@@ -109,11 +115,18 @@ __global__ __launch_bounds__(256) void k_cat_step_codes(const char *__restrict__
     const int slot = F + f;
     codes[(static_cast<size_t>(slot / kCodeGroup) * n + r) * kCodeGroup + (slot % kCodeGroup)] = static_cast<uint16_t>(cls);
 }
-void cat_distinct_insert(const char *cells, int n, int Fc, uint64_t *keys, int32_t *first, int log2_cap, int32_t *flags, hipStream_t s) {
+void cat_distinct_insert(const char *cells, int n, int Fc, uint64_t *keys, int32_t *first, int log2_cap, int32_t *flags, int32_t *list_slot,
+                         int32_t *counter, int list_cap, hipStream_t s) {
     const size_t n_cells = static_cast<size_t>(n) * Fc;
     if (!n_cells) return;
     hipLaunchKernelGGL(k_cat_distinct_insert, dim3(static_cast<unsigned>((n_cells + 255) / 256)), dim3(256), 0, s, cells, n_cells, Fc,
-                       reinterpret_cast<unsigned long long *>(keys), first, log2_cap, flags);
+                       reinterpret_cast<unsigned long long *>(keys), first, log2_cap, flags, list_slot, counter, list_cap);
+}
+void cat_publish(const int32_t *meta, const int32_t *list_slot, const uint64_t *keys, const int32_t *first, int log2_cap, const char *cells,
+                 int Fc, int cap, int32_t *h_hdr, int32_t *h_feat, int32_t *h_first, uint64_t *h_hash, char *h_names, hipStream_t s) {
+    hipLaunchKernelGGL(k_cat_publish, dim3((std::max(1, cap) * 8 + 255) / 256), dim3(256), 0, s, meta, list_slot,
+                       reinterpret_cast<const unsigned long long *>(keys), first, log2_cap, cells, Fc, cap, h_hdr, h_feat, h_first,
+                       reinterpret_cast<unsigned long long *>(h_hash), h_names);
 }
 void cat_distinct_verify(const char *cells, int n, int Fc, const uint64_t *keys, const int32_t *first, int log2_cap, int32_t *flags,
                          hipStream_t s) {
@@ -121,17 +134,6 @@ void cat_distinct_verify(const char *cells, int n, int Fc, const uint64_t *keys,
     if (!n_cells) return;
     hipLaunchKernelGGL(k_cat_distinct_verify, dim3(static_cast<unsigned>((n_cells + 255) / 256)), dim3(256), 0, s, cells, n_cells, Fc,
                        reinterpret_cast<const unsigned long long *>(keys), first, log2_cap, flags);
-}
-void cat_distinct_compact(const uint64_t *keys, const int32_t *first, int Fc, int log2_cap, int32_t *out_feat, uint64_t *out_hash,
-                          int32_t *out_first, int32_t *counter, int list_cap, int32_t *flags, hipStream_t s) {
-    const size_t total = static_cast<size_t>(Fc) << log2_cap;
-    hipLaunchKernelGGL(k_cat_distinct_compact, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const unsigned long long *>(keys), first, Fc, log2_cap, out_feat,
-                       reinterpret_cast<unsigned long long *>(out_hash), out_first, counter, list_cap, flags);
-}
-void gather_cells(const char *cells, int Fc, const int32_t *rows, const int32_t *feats, int n_items, char *out, hipStream_t s) {
-    if (!n_items) return;
-    hipLaunchKernelGGL(k_gather_cells, dim3((n_items * 8 + 255) / 256), dim3(256), 0, s, cells, Fc, rows, feats, n_items, out);
 }
 void cat_step_codes(const char *cells, int n, int Fc, int F, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_cls,
                     const uint64_t *dict_words, uint16_t *codes, hipStream_t s) {

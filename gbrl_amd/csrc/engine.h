@@ -6,7 +6,10 @@
 
 #include <cstdint>
 #include <stdexcept>
+#include <array>
+#include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
@@ -57,7 +60,16 @@ class PinnedBuf {
 namespace detail {
 struct GrowCtx;
 struct HNode;
-struct CatCandidate { int feat; std::string name; int cls; };   // a categorical split candidate: class `cls` of feature `feat` is the category `name`
+// a categorical split candidate: class `cls` of feature `feat` is the category `name` (the raw 128-byte cell, types.h:55-58)
+struct CatCandidate {
+    int feat;
+    std::array<char, 128> name;
+    int cls;
+    CatCandidate(int f, const char *cell, int c) : feat(f), cls(c) { std::memcpy(name.data(), cell, 128); }
+};
+// A distinct (categorical feature, cell) pair the engine has met in some step: the hash of its key in the reference's candidate
+// container (std::hash of cell + "_" + feature, split_candidate_generator.cpp:121) is computed once.
+struct CatItem { int feat; int next; uint64_t lhash; size_t std_hash; char name[128]; };
 }  // namespace detail
 
 class Engine {
@@ -180,7 +192,7 @@ class Engine {
     DevBuf d_radix_state_, d_radix_partial_, d_radix_global_, d_scales_;
     DevBuf d_codes_, d_catcodes_, d_rows_[2], d_chunks_, d_chunk_begin_;
     DevBuf d_hist_prev_, d_slotmap_, d_am_v_, d_am_i_, d_stage_const_, d_stage_a_, d_stage_b_, d_results_;
-    PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_, pin_thr_, pin_acc_;
+    PinnedBuf pin_const_, pin_a_, pin_b_, pin_res_, pin_thr_, pin_acc_, pin_cat_, pin_cat_dict_;
     DevBuf d_hist_partials_, d_hist_, d_hist_local_, d_hist_recv_, d_gather_, d_slots_, d_scores_, d_parent_, d_cand_w_, d_cand_ref_;
     DevBuf d_path_len_, d_path_slot_, d_path_val_, d_path_bin_, d_isroot_;
     DevBuf d_best_idx_, d_best_score_, d_splits_, d_ntotal_, d_nright_, d_cursors_, d_leafacc_, d_plan_, d_res_all_;
@@ -203,8 +215,15 @@ class Engine {
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
-    DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lfeat_, d_cat_lhash_, d_cat_names_, d_sdict_off_, d_sdict_hash_, d_sdict_cls_,
-        d_sdict_words_, d_cat_xchg_;
+    DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lslot_, d_sdict_, d_cat_xchg_;
+    // the step's candidate dictionary inside d_sdict_ (one upload): per categorical feature the entries sorted by raw hash
+    const int32_t *sdict_off_ = nullptr, *sdict_cls_ = nullptr;
+    const uint64_t *sdict_hash_ = nullptr, *sdict_words_ = nullptr;
+    int cat_publish_guess_ = 256;                       // records the next step publishes with its header (the last count + 25 %)
+    std::vector<detail::CatItem> cat_items_;            // every distinct (feature, cell) met so far
+    std::unordered_map<uint64_t, int> cat_item_index_;  // (raw hash, feature) -> head of the chain through CatItem::next
+    std::vector<char> cat_host_;                        // the published distinct-cell block, copied out of the pinned mapping
+    std::vector<char> cat_pool_;                        // node storage of the per-step replay of the reference's container
     DevBuf d_fit_cells_, d_fit_cells2_;
     DevBuf d_fit_obs_, d_fit_targets_, d_fit_obs2_, d_fit_targets2_, d_fit_perm_, d_fit_preds_, d_fit_grads_, d_fit_zero_;
 };

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
+#include <memory_resource>
 #include <cstring>
 #include <limits>
 #include <unordered_map>
@@ -68,6 +69,8 @@ struct GrowCtx {
     const std::vector<int32_t> *cand_slot;
     bool const_cacheable;               // numeric-only step: the constants above live in Engine::step_const_
     const std::vector<CatCandidate> *cat_cands;
+    bool prefix_cacheable;     // mixed step: numeric table prefixes stay on the device, categorical tails are uploaded per step
+    int n_num_cand, cand_cap;  // numeric candidates (= prefix length), capacity of the fixed table layout
     const float *h_thr;                 // pinned; valid once the stream has passed the copy enqueued behind the binning
     const kern::StepScales *h_scales;   // pinned, same
     const float *d_thr;
@@ -120,6 +123,7 @@ class Stager {
         if (used_) hip_check(hipMemcpyAsync(dev_, host_, used_, hipMemcpyHostToDevice, s_), "H2D staged descriptors");
     }
     const void *device_base() const { return dev_; }
+    char *host_base() const { return host_; }
 
    private:
     hipStream_t s_;
@@ -164,7 +168,7 @@ void categorical_candidates(const char *hcat, const float *hgrads, int N, int Fc
         const Info &ci = uniq[vec[i].first];
         const int cls = ++cat_classes[ci.feat];
         if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
-        cat_cands.push_back({ci.feat, ci.name, cls});
+        cat_cands.emplace_back(ci.feat, ci.name.data(), cls);
         cls_of[vec[i].first] = cls;
     }
     h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
@@ -420,7 +424,7 @@ void Engine::sharded_categorical_ranking(const char *hcat, const float *hgrads, 
         const Info &ci = uniq[vec[i].first];
         const int cls = ++cat_classes[ci.feat];
         if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
-        cat_cands.push_back({ci.feat, ci.name, cls});
+        cat_cands.emplace_back(ci.feat, ci.name.data(), cls);
         cls_of_gid[ci.gid] = cls;
     }
     h_catcodes.assign(static_cast<size_t>(N) * Fc, 0);
@@ -429,30 +433,63 @@ void Engine::sharded_categorical_ranking(const char *hcat, const float *hgrads, 
 
 bool Engine::device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
                                            std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes) {
+    (void)hcells;   // the distinct cells are gathered from the device copy either way
     hipStream_t s = stream_;
     const long long keep = static_cast<long long>(Fc) * B;
     if (keep > (1 << 20)) return false;
     int log2_cap = 8;
     while ((1ll << log2_cap) < 4 * std::min<long long>(N, keep + 1) && log2_cap < 20) ++log2_cap;
     const size_t slots = static_cast<size_t>(Fc) << log2_cap;
+    if (slots >= (1ull << 31)) return false;   // list records are 32-bit table slots
     const int list_cap = static_cast<int>(keep) + 1;
     uint64_t *d_keys = static_cast<uint64_t *>(d_cat_keys_.ensure(sizeof(uint64_t) * slots));
     int32_t *d_first = static_cast<int32_t *>(d_cat_first_.ensure(sizeof(int32_t) * slots));
     int32_t *d_meta = static_cast<int32_t *>(d_cat_meta_.ensure(sizeof(int32_t) * 4));               // flags[2], counter
-    int32_t *d_lfeat = static_cast<int32_t *>(d_cat_lfeat_.ensure(sizeof(int32_t) * list_cap * 2));   // feat | first
-    int32_t *d_lfirst = d_lfeat + list_cap;
-    uint64_t *d_lhash = static_cast<uint64_t *>(d_cat_lhash_.ensure(sizeof(uint64_t) * list_cap));
+    int32_t *d_lslot = static_cast<int32_t *>(d_cat_lslot_.ensure(sizeof(int32_t) * list_cap));
     hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
     hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
     hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
-    kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+    kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, d_lslot, d_meta + 2, list_cap, s);
     kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
-    kern::cat_distinct_compact(d_keys, d_first, Fc, log2_cap, d_lfeat, d_lhash, d_lfirst, d_meta + 2, list_cap, d_meta, s);
-    int32_t meta[4];
-    hip_check(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s), "D2H cat meta");
-    hip_check(hipStreamSynchronize(s), "sync");
-    int n_distinct = meta[2];
-    bool declined = meta[0] != 0 || meta[1] != 0 || n_distinct > keep;
+    // ONE launch writes header + records + the distinct cells themselves into mapped pinned memory, ONE synchronisation reads them
+    // (round 2: three copies of lists sized by a count that needed its own round trip, then a gather + a fourth copy: four
+    // synchronisations per step).  The record count is guessed from the last step; a larger batch of distinct cells is published
+    // again with the exact count.
+    const int32_t *h_hdr = nullptr, *lfeat = nullptr, *lfirst = nullptr;
+    const uint64_t *lhash = nullptr;
+    const char *names = nullptr;
+    auto publish = [&](int cap) {
+        const size_t bytes = 64 + static_cast<size_t>(cap) * (8 + 4 + 4 + kCat);
+        char *h = static_cast<char *>(pin_cat_.ensure(bytes));
+        void *dv = nullptr;
+        hip_check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer");
+        char *d = static_cast<char *>(dv);
+        const size_t o_hash = 64, o_feat = o_hash + 8 * static_cast<size_t>(cap), o_first = o_feat + 4 * static_cast<size_t>(cap),
+                     o_names = o_first + 4 * static_cast<size_t>(cap);   // 64 + 16 cap: 16-byte aligned
+        kern::cat_publish(d_meta, d_lslot, d_keys, d_first, log2_cap, dcells, Fc, cap, reinterpret_cast<int32_t *>(d), reinterpret_cast<int32_t *>(d + o_feat),
+                          reinterpret_cast<int32_t *>(d + o_first), reinterpret_cast<uint64_t *>(d + o_hash), d + o_names, s);
+        hip_check(hipStreamSynchronize(s), "sync");
+        // the device wrote these lines over PCIe, so every first touch by the host misses its caches: ONE sequential pass (prefetcher
+        // friendly) into ordinary memory, sized by the published count, instead of the replay's scattered reads (3x slower measured)
+        const int n_pub = std::max(0, std::min(reinterpret_cast<const int32_t *>(h)[3], cap));
+        cat_host_.resize(64 + static_cast<size_t>(n_pub) * (8 + 4 + 4 + kCat));
+        char *c = cat_host_.data();
+        std::memcpy(c, h, 64);
+        const size_t c_hash = 64, c_feat = c_hash + 8 * static_cast<size_t>(n_pub), c_first = c_feat + 4 * static_cast<size_t>(n_pub),
+                     c_names = c_first + 4 * static_cast<size_t>(n_pub);
+        std::memcpy(c + c_hash, h + o_hash, 8 * static_cast<size_t>(n_pub));
+        std::memcpy(c + c_feat, h + o_feat, 4 * static_cast<size_t>(n_pub));
+        std::memcpy(c + c_first, h + o_first, 4 * static_cast<size_t>(n_pub));
+        std::memcpy(c + c_names, h + o_names, static_cast<size_t>(kCat) * n_pub);
+        h_hdr = reinterpret_cast<const int32_t *>(c);
+        lhash = reinterpret_cast<const uint64_t *>(c + c_hash);
+        lfeat = reinterpret_cast<const int32_t *>(c + c_feat);
+        lfirst = reinterpret_cast<const int32_t *>(c + c_first);
+        names = c + c_names;
+    };
+    publish(std::min(list_cap, std::max(256, cat_publish_guess_)));
+    int n_distinct = h_hdr[2];
+    bool declined = h_hdr[0] != 0 || h_hdr[1] != 0 || n_distinct > keep;
     if (has_coll_) {   // every rank must take the same path
         int64_t *d_flag = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t)));
         int64_t hv = declined ? 1 : 0;
@@ -463,29 +500,22 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         declined = hv != 0;
     }
     if (declined) return false;
-    std::vector<int32_t> lfeat(n_distinct), lfirst(n_distinct);
-    std::vector<uint64_t> lhash(n_distinct);
-    if (n_distinct > 0) {
-        hip_check(hipMemcpyAsync(lfeat.data(), d_lfeat, sizeof(int32_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipMemcpyAsync(lfirst.data(), d_lfirst, sizeof(int32_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipMemcpyAsync(lhash.data(), d_lhash, sizeof(uint64_t) * n_distinct, hipMemcpyDeviceToHost, s), "D2H");
-        hip_check(hipStreamSynchronize(s), "sync");
-    }
-    // the reference's insertion order: feature-major, then row of first occurrence
+    if (n_distinct > h_hdr[3]) publish(n_distinct);
+    cat_publish_guess_ = n_distinct + n_distinct / 4 + 64;
+    // the reference's insertion order: feature-major, then row of first occurrence (bucket by feature, sort the buckets by row)
     std::vector<int> order(n_distinct);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return lfeat[a] != lfeat[b] ? lfeat[a] < lfeat[b] : lfirst[a] < lfirst[b]; });
-    // the distinct cells themselves
-    std::vector<char> names(static_cast<size_t>(n_distinct) * kCat);
-    if (hcells) {
-        for (int q = 0; q < n_distinct; ++q)
-            std::memcpy(&names[static_cast<size_t>(q) * kCat], hcells + (static_cast<size_t>(lfirst[q]) * Fc + lfeat[q]) * kCat, kCat);
-    } else if (n_distinct > 0) {
-        char *d_names = static_cast<char *>(d_cat_names_.ensure(names.size()));
-        kern::gather_cells(dcells, Fc, d_lfirst, d_lfeat, n_distinct, d_names, s);
-        hip_check(hipMemcpyAsync(names.data(), d_names, names.size(), hipMemcpyDeviceToHost, s), "D2H names");
-        hip_check(hipStreamSynchronize(s), "sync");
+    {
+        std::vector<int> start(Fc + 1, 0);
+        for (int q = 0; q < n_distinct; ++q) ++start[lfeat[q] + 1];
+        for (int f = 0; f < Fc; ++f) start[f + 1] += start[f];
+        std::vector<int> cur(start.begin(), start.end() - 1);
+        for (int q = 0; q < n_distinct; ++q) order[cur[lfeat[q]]++] = q;
+        for (int f = 0; f < Fc; ++f)
+            std::sort(order.begin() + start[f], order.begin() + start[f + 1], [&](int a, int b2) { return lfirst[a] < lfirst[b2]; });
     }
+    std::vector<int32_t> g_feat;     // row-sharded: the global lists replace the local views
+    std::vector<uint64_t> g_hash;
+    std::vector<char> g_names;
     if (has_coll_) {
         // Row-sharded: every rank needs the distinct cells of ALL ranks, in the order a single process would meet them (rank
         // after rank = global row order).  All-gather through the sum exchange: counts first, then 18-word records
@@ -506,7 +536,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
             int64_t *r18 = &rec[(static_cast<size_t>(my_off) + q) * 18];
             r18[0] = lfeat[order[q]];
             r18[1] = lfirst[order[q]];
-            std::memcpy(r18 + 2, &names[static_cast<size_t>(order[q]) * kCat], kCat);
+            std::memcpy(r18 + 2, names + static_cast<size_t>(order[q]) * kCat, kCat);
         }
         if (total > 0) {
             int64_t *d_rec = static_cast<int64_t *>(d_cat_xchg_.ensure(sizeof(int64_t) * rec.size()));
@@ -517,58 +547,126 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         }
         // global list, already rank-major and (feature, first row)-sorted inside a rank: stable sort by feature keeps that order
         n_distinct = static_cast<int>(total);
-        lfeat.resize(n_distinct); lfirst.resize(n_distinct); lhash.resize(n_distinct);
-        names.resize(static_cast<size_t>(n_distinct) * kCat);
+        g_feat.resize(n_distinct); g_hash.resize(n_distinct);
+        g_names.resize(static_cast<size_t>(n_distinct) * kCat);
         for (int q = 0; q < n_distinct; ++q) {
             const int64_t *r18 = &rec[static_cast<size_t>(q) * 18];
-            lfeat[q] = static_cast<int32_t>(r18[0]);
-            lfirst[q] = q;                                             // position in global order
-            std::memcpy(&names[static_cast<size_t>(q) * kCat], r18 + 2, kCat);
+            g_feat[q] = static_cast<int32_t>(r18[0]);
+            std::memcpy(&g_names[static_cast<size_t>(q) * kCat], r18 + 2, kCat);
             uint64_t w[16];
             std::memcpy(w, r18 + 2, kCat);
-            lhash[q] = cat_cell_hash_raw(w);
+            g_hash[q] = cat_cell_hash_raw(w);
         }
+        lfeat = g_feat.data(); lhash = g_hash.data(); names = g_names.data(); lfirst = nullptr;
         order.resize(n_distinct);
         std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lfeat[a] < lfeat[b]; });
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return lfeat[a] < lfeat[b2]; });
     }
-    struct Info { int feat; int item; };
-    std::unordered_map<std::string, Info> uniq;
-    for (int q : order) {
-        std::string key(&names[static_cast<size_t>(q) * kCat], kCat);
-        key += "_" + std::to_string(lfeat[q]);
-        uniq.emplace(std::move(key), Info{lfeat[q], q});
-    }
-    if (static_cast<long long>(uniq.size()) > keep)
-        throw Unsupported("more distinct categories than Fc * n_bins in a row-sharded step (the reference's mean-gradient ranking is not available sharded)");
-    struct DictE { uint64_t h; int cls; int item; };
-    std::vector<std::vector<DictE>> per(Fc);
-    for (const auto &kv : uniq) {                                  // candidate order = the container's iteration order (Q8)
-        const Info &ci = kv.second;
-        const int cls = ++cat_classes[ci.feat];
-        if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
-        cat_cands.push_back({ci.feat, std::string(&names[static_cast<size_t>(ci.item) * kCat], kCat), cls});
-        per[ci.feat].push_back({lhash[ci.item], cls, ci.item});
-    }
-    std::vector<int32_t> off(Fc + 1, 0), clss;
-    std::vector<uint64_t> hs, ws;
-    for (int f = 0; f < Fc; ++f) {
-        std::sort(per[f].begin(), per[f].end(), [](const DictE &a, const DictE &b) { return a.h < b.h || (a.h == b.h && a.cls < b.cls); });
-        for (const DictE &e : per[f]) {
-            hs.push_back(e.h);
-            clss.push_back(e.cls);
-            uint64_t w[16];
-            std::memcpy(w, &names[static_cast<size_t>(e.item) * kCat], kCat);
-            ws.insert(ws.end(), w, w + 16);
+    // Replay of the reference's candidate container (std::unordered_map<std::string, ...> keyed by cell + "_" + feature, filled in
+    // the order above, split_candidate_generator.cpp:117-130): its ITERATION order is the candidate order (Q8).  The order of a
+    // libstdc++ hash table is a function of the keys' hash values and of the insertion sequence only, so the replay inserts small
+    // references that carry the key's std::hash -- computed once per distinct (feature, cell) the engine has ever met and kept in
+    // cat_items_ -- instead of building and hashing 130-byte strings every step; nodes come from a monotonic pool.
+    // GBRL_HIP_CAT_CHECK=1 (tests) replays the string-keyed container beside it and compares the two orders.
+    if (cat_items_.size() > (1u << 20)) { cat_items_.clear(); cat_item_index_.clear(); }
+    auto item_of = [&](int feat, uint64_t h, const char *cell) -> int {
+        const uint64_t key = h * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(feat);
+        auto it = cat_item_index_.find(key);
+        if (it != cat_item_index_.end())
+            for (int id = it->second; id >= 0; id = cat_items_[id].next) {
+                const detail::CatItem &ci = cat_items_[id];
+                if (ci.feat == feat && std::memcmp(ci.name, cell, kCat) == 0) return id;
+            }
+        detail::CatItem ci;
+        ci.feat = feat;
+        ci.lhash = h;
+        std::memcpy(ci.name, cell, kCat);
+        std::string ks(cell, kCat);
+        ks += "_" + std::to_string(feat);
+        ci.std_hash = std::hash<std::string>{}(ks);
+        ci.next = it != cat_item_index_.end() ? it->second : -1;
+        const int id = static_cast<int>(cat_items_.size());
+        cat_items_.push_back(ci);
+        cat_item_index_[key] = id;
+        return id;
+    };
+    struct Ref { int id; size_t h; };
+    struct RefHash { size_t operator()(const Ref &r) const noexcept { return r.h; } };
+    struct RefEq { bool operator()(const Ref &a, const Ref &b2) const noexcept { return a.id == b2.id; } };
+    const size_t pool_need = static_cast<size_t>(n_distinct) * 96 + 65536;
+    if (cat_pool_.size() < pool_need) cat_pool_.resize(pool_need);
+    std::pmr::monotonic_buffer_resource pool(cat_pool_.data(), cat_pool_.size());
+    std::vector<int> cand_item;   // distinct-list index of every candidate, in candidate order
+    cand_item.reserve(n_distinct);
+    {
+        std::pmr::unordered_map<Ref, int, RefHash, RefEq> uniq(&pool);
+        for (int q : order) {
+            const int id = item_of(lfeat[q], lhash[q], names + static_cast<size_t>(q) * kCat);
+            uniq.emplace(Ref{id, cat_items_[id].std_hash}, q);
         }
-        off[f + 1] = static_cast<int32_t>(hs.size());
+        for (const auto &kv : uniq) cand_item.push_back(kv.second);   // the container's iteration order (Q8)
     }
-    hs.push_back(0); clss.push_back(0); ws.resize(ws.size() + 16, 0);   // never empty
-    hip_check(hipMemcpyAsync(d_sdict_off_.ensure(off.size() * 4), off.data(), off.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
-    hip_check(hipMemcpyAsync(d_sdict_hash_.ensure(hs.size() * 8), hs.data(), hs.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
-    hip_check(hipMemcpyAsync(d_sdict_cls_.ensure(clss.size() * 4), clss.data(), clss.size() * 4, hipMemcpyHostToDevice, s), "H2D dict");
-    hip_check(hipMemcpyAsync(d_sdict_words_.ensure(ws.size() * 8), ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s), "H2D dict");
-    hip_check(hipStreamSynchronize(s), "sync");   // the host vectors go out of scope
+    static const bool check_replay = [] { const char *e = std::getenv("GBRL_HIP_CAT_CHECK"); return e && e[0] == '1'; }();
+    if (check_replay) {
+        std::unordered_map<std::string, int> ref_map;
+        for (int q : order) {
+            std::string key(names + static_cast<size_t>(q) * kCat, kCat);
+            key += "_" + std::to_string(lfeat[q]);
+            ref_map.emplace(std::move(key), q);
+        }
+        size_t k = 0;
+        bool same = ref_map.size() == cand_item.size();
+        for (const auto &kv : ref_map) { if (!same) break; same = cand_item[k++] == kv.second; }
+        if (!same) throw HipError("categorical candidates: the hash-replay order differs from the string-keyed container's");
+    }
+    if (static_cast<long long>(cand_item.size()) > keep)
+        throw Unsupported("more distinct categories than Fc * n_bins in a row-sharded step (the reference's mean-gradient ranking is not available sharded)");
+    // candidates + the step's dictionary (per feature: entries sorted by raw hash, then class), packed into ONE pinned block and
+    // uploaded with one copy that nothing waits for: the next write of the block happens behind the next step's synchronisation
+    const int n_ent = static_cast<int>(cand_item.size());
+    struct DictE { uint64_t h; int cls; int item; };
+    std::vector<DictE> ent(n_ent);
+    std::vector<int32_t> off(Fc + 1, 0);
+    for (int q : cand_item) ++off[lfeat[q] + 1];
+    for (int f = 0; f < Fc; ++f) off[f + 1] += off[f];
+    {
+        std::vector<int32_t> cur(off.begin(), off.end() - 1);
+        cat_cands.reserve(cat_cands.size() + n_ent);
+        for (int q : cand_item) {
+            const int f = lfeat[q];
+            const int cls = ++cat_classes[f];
+            if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+            cat_cands.emplace_back(f, names + static_cast<size_t>(q) * kCat, cls);
+            ent[cur[f]++] = {lhash[q], cls, q};
+        }
+    }
+    for (int f = 0; f < Fc; ++f)
+        std::sort(ent.begin() + off[f], ent.begin() + off[f + 1], [](const DictE &a, const DictE &b2) { return a.h < b2.h || (a.h == b2.h && a.cls < b2.cls); });
+    const size_t n1 = static_cast<size_t>(n_ent) + 1;   // one zero entry behind the last: the arrays are never empty
+    const size_t o_words = 0, o_hash = o_words + n1 * kCat, o_off = o_hash + n1 * 8, o_cls = o_off + (static_cast<size_t>(Fc) + 1) * 4,
+                 dict_bytes = o_cls + n1 * 4;
+    char *hd = static_cast<char *>(pin_cat_dict_.ensure((dict_bytes + 3) & ~static_cast<size_t>(3)));
+    for (int e = 0; e < n_ent; ++e) {
+        std::memcpy(hd + o_words + static_cast<size_t>(e) * kCat, names + static_cast<size_t>(ent[e].item) * kCat, kCat);
+        reinterpret_cast<uint64_t *>(hd + o_hash)[e] = ent[e].h;
+        reinterpret_cast<int32_t *>(hd + o_cls)[e] = ent[e].cls;
+    }
+    std::memset(hd + o_words + static_cast<size_t>(n_ent) * kCat, 0, kCat);
+    reinterpret_cast<uint64_t *>(hd + o_hash)[n_ent] = 0;
+    reinterpret_cast<int32_t *>(hd + o_cls)[n_ent] = 0;
+    std::memcpy(hd + o_off, off.data(), (static_cast<size_t>(Fc) + 1) * 4);
+    char *dd = static_cast<char *>(d_sdict_.ensure((dict_bytes + 3) & ~static_cast<size_t>(3)));
+    {
+        void *hd_dev = nullptr;
+        hip_check(hipHostGetDevicePointer(&hd_dev, hd, 0), "hipHostGetDevicePointer");
+        kern::FetchSegments fs{};
+        fs.n = 1; fs.dst[0] = dd; fs.src[0] = hd_dev; fs.words[0] = static_cast<uint32_t>((dict_bytes + 3) / 4);
+        kern::fetch_segments(fs, s);
+    }
+    sdict_words_ = reinterpret_cast<const uint64_t *>(dd + o_words);
+    sdict_hash_ = reinterpret_cast<const uint64_t *>(dd + o_hash);
+    sdict_off_ = reinterpret_cast<const int32_t *>(dd + o_off);
+    sdict_cls_ = reinterpret_cast<const int32_t *>(dd + o_cls);
     return true;
 }
 
@@ -832,7 +930,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     }
     // per-step constants: slots, candidate weights / reference order / slot lookup
     const std::vector<int32_t> &cand_slot = *c.cand_slot;
-    const size_t stage_bytes = 4096 + sizeof(FeatureSlot) * n_slots + static_cast<size_t>(n_cand) * 16 +
+    const size_t table_cap = c.prefix_cacheable ? static_cast<size_t>(std::max(c.cand_cap, n_cand)) : static_cast<size_t>(n_cand);
+    const size_t stage_bytes = 4096 + sizeof(FeatureSlot) * n_slots + table_cap * 16 + 5 * 256 +
                                sizeof(Chunk) * (static_cast<size_t>(max_chunks) + N / 4096 + 2 * max_nodes + 64) +
                                static_cast<size_t>(max_front) * (kern::kMaxPath * 12 + 256);
     Stager stc(pin_const_, d_stage_const_, stage_bytes, s), sta(pin_a_, d_stage_a_, stage_bytes, s), stb(pin_b_, d_stage_b_, stage_bytes, s);
@@ -840,7 +939,42 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     float *d_cand_w;
     int32_t *d_cand_ref, *d_ref_to_internal, *d_cand_slot;
     static_assert(sizeof(int) == sizeof(int32_t), "ref_to_internal is uploaded as int32");
-    if (c.const_cacheable && step_const_.dev_base == stc.device_base() && step_const_.stage_bytes == stage_bytes) {
+    if (c.prefix_cacheable) {
+        // fixed layout (capacity (F + Fc) * n_bins entries per table): the numeric prefixes are uploaded once per layout, every step
+        // uploads the slot table and the four categorical tails
+        const size_t np = static_cast<size_t>(c.n_num_cand), nt = static_cast<size_t>(n_cand) - np;
+        const bool have_prefix = step_const_.dev_base == stc.device_base() && step_const_.stage_bytes == stage_bytes;
+        d_slots = stc.reserve<FeatureSlot>(slots.size());
+        d_cand_w = stc.reserve<float>(table_cap);
+        d_cand_ref = stc.reserve<int32_t>(table_cap);
+        d_ref_to_internal = stc.reserve<int32_t>(table_cap);
+        d_cand_slot = stc.reserve<int32_t>(table_cap);
+        char *hb = stc.host_base();
+        const char *db = static_cast<const char *>(stc.device_base());
+        auto mirror = [&](const void *dptr) -> char * { return hb + (static_cast<const char *>(dptr) - db); };
+        void *hb_dev = nullptr;
+        hip_check(hipHostGetDevicePointer(&hb_dev, hb, 0), "hipHostGetDevicePointer");
+        kern::FetchSegments fs{};
+        static_assert(sizeof(FeatureSlot) % 4 == 0, "fetched as 32-bit words");
+        auto up = [&](void *dptr, const void *src, size_t first, size_t count, size_t elem) {   // one kernel fetches all five from the pinned mirror
+            if (!count) return;
+            char *hm = mirror(dptr) + first * elem;
+            std::memcpy(hm, static_cast<const char *>(src) + first * elem, count * elem);
+            fs.dst[fs.n] = static_cast<char *>(dptr) + first * elem;
+            fs.src[fs.n] = static_cast<const char *>(hb_dev) + (hm - hb);
+            fs.words[fs.n] = static_cast<uint32_t>(count * elem / 4);
+            ++fs.n;
+        };
+        const size_t lo = have_prefix ? np : 0, cnt = have_prefix ? nt : static_cast<size_t>(n_cand);
+        up(d_slots, slots.data(), 0, slots.size(), sizeof(FeatureSlot));
+        up(d_cand_w, cand_w.data(), lo, cnt, 4);
+        up(d_cand_ref, cand_ref.data(), lo, cnt, 4);
+        up(d_ref_to_internal, ref_to_internal.data(), lo, cnt, 4);
+        up(d_cand_slot, cand_slot.data(), lo, cnt, 4);
+        kern::fetch_segments(fs, s);
+        step_const_.dev_base = stc.device_base();
+        step_const_.stage_bytes = stage_bytes;
+    } else if (c.const_cacheable && step_const_.dev_base == stc.device_base() && step_const_.stage_bytes == stage_bytes) {
         d_slots = stc.reserve<FeatureSlot>(slots.size());          // uploaded by an earlier step, same layout
         d_cand_w = stc.reserve<float>(cand_w.size());
         d_cand_ref = stc.reserve<int32_t>(cand_ref.size());
@@ -1538,7 +1672,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         phases_resolve();
         return;
     }
-
     // ---- feature slots, candidate order, weights ---------------------------------------------------------------------
     const int n_slots = F + Fc;
     int NB = F > 0 ? B + 1 : 1;
@@ -1561,8 +1694,11 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     // numeric-only steps: these constants depend on (F, n_bins, policy, feature weights, feature mapping) only -- built once, kept in
     // Engine::step_const_ together with their uploaded copy (grow_tree)
     const bool const_cacheable = Fc == 0 && F > 0;
+    // mixed steps: the numeric candidates come first in every table and are the same from step to step -- only the categorical
+    // tails (this batch's candidates) are rebuilt and uploaded (51 200 numeric against ~2 000 categorical entries at configs[4])
+    const bool prefix_cacheable = Fc > 0 && F > 0;
     bool reuse = false;
-    if (const_cacheable) {
+    if (const_cacheable || prefix_cacheable) {
         StepConstCache &cc = step_const_;
         reuse = cc.valid && cc.F == F && cc.B == B && cc.oblivious == (oblivious ? 1 : 0) && cc.fw == model.feature_weights && cc.rev == model.reverse_num;
         if (!reuse) {
@@ -1573,30 +1709,44 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             cc.rev = model.reverse_num;
         }
     }
-    std::vector<FeatureSlot> &slots = const_cacheable ? step_const_.slots : slots_local;
-    std::vector<int32_t> &cand_ref = const_cacheable ? step_const_.cand_ref : cand_ref_local;
-    std::vector<int32_t> &cand_slot = const_cacheable ? step_const_.cand_slot : cand_slot_local;
-    std::vector<float> &cand_w = const_cacheable ? step_const_.cand_w : cand_w_local;
-    std::vector<int> &ref_to_internal = const_cacheable ? step_const_.ref_to_internal : ref_to_internal_local;
+    const bool shared_tables = const_cacheable || prefix_cacheable;
+    std::vector<FeatureSlot> &slots = shared_tables ? step_const_.slots : slots_local;
+    std::vector<int32_t> &cand_ref = shared_tables ? step_const_.cand_ref : cand_ref_local;
+    std::vector<int32_t> &cand_slot = shared_tables ? step_const_.cand_slot : cand_slot_local;
+    std::vector<float> &cand_w = shared_tables ? step_const_.cand_w : cand_w_local;
+    std::vector<int> &ref_to_internal = shared_tables ? step_const_.ref_to_internal : ref_to_internal_local;
     int n_cand = 0;
-    if (reuse) {
+    const int n_num_cand = F * B;
+    if (reuse && const_cacheable) {
         n_cand = static_cast<int>(cand_ref.size());
     } else {
-        slots.assign(n_slots, FeatureSlot{});
-        for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
+        const bool keep_prefix = reuse && prefix_cacheable;   // the numeric part of every table is in place
+        slots.resize(n_slots);
+        if (keep_prefix) {
+            n_cand = n_num_cand;
+        } else {
+            for (int f = 0; f < F; ++f) { slots[f] = {0, B, n_cand, 0}; n_cand += B; }
+        }
         for (int c = 0; c < Fc; ++c) { slots[F + c] = {1, cat_classes[c], n_cand, 0}; n_cand += cat_classes[c]; }
-        cand_ref.assign(n_cand, 0);
-        cand_w.assign(n_cand, 0.0f);
-        ref_to_internal.assign(n_cand, 0);
-        cand_slot.assign(n_cand, 0);
-        for (int f = 0; f < F; ++f)
-            for (int k = 0; k < B; ++k) {
-                const int j = slots[f].cand_base + k;
-                cand_ref[j] = f * B + k;
-                // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
-                const int wi = oblivious ? model.reverse_num[f] : f;
-                cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
-            }
+        if (keep_prefix) {
+            cand_ref.resize(n_cand); cand_w.resize(n_cand); ref_to_internal.resize(n_cand); cand_slot.resize(n_cand);
+        } else {
+            cand_ref.assign(n_cand, 0);
+            cand_w.assign(n_cand, 0.0f);
+            ref_to_internal.assign(n_cand, 0);
+            cand_slot.assign(n_cand, 0);
+            for (int f = 0; f < F; ++f)
+                for (int k = 0; k < B; ++k) {
+                    const int j = slots[f].cand_base + k;
+                    cand_ref[j] = f * B + k;
+                    // feature weight: greedy indexes by feature_idx, oblivious by the reverse mapping (fitter.cpp:331 vs 432-434, Q6)
+                    const int wi = oblivious ? model.reverse_num[f] : f;
+                    cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
+                }
+            for (int j = 0; j < n_num_cand; ++j) ref_to_internal[cand_ref[j]] = j;
+            for (int fs = 0; fs < F; ++fs)
+                for (int k = 0; k < slots[fs].n_cand; ++k) cand_slot[slots[fs].cand_base + k] = fs;
+        }
         for (size_t q = 0; q < cat_cands.size(); ++q) {
             const CatCandidate &cc = cat_cands[q];
             const int j = slots[F + cc.feat].cand_base + (cc.cls - 1);
@@ -1604,10 +1754,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             const int wi = oblivious ? model.reverse_cat[cc.feat] : cc.feat + F;
             cand_w[j] = (wi >= 0 && wi < md.input_dim) ? model.feature_weights[wi] : 0.0f;
         }
-        for (int j = 0; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
-        for (int fs = 0; fs < n_slots; ++fs)
+        for (int j = n_num_cand; j < n_cand; ++j) ref_to_internal[cand_ref[j]] = j;
+        for (int fs = F; fs < n_slots; ++fs)
             for (int k = 0; k < slots[fs].n_cand; ++k) cand_slot[slots[fs].cand_base + k] = fs;
-        if (const_cacheable) step_const_.valid = true;
+        if (shared_tables) step_const_.valid = true;
     }
 
     // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
@@ -1618,8 +1768,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
     if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
     if (Fc > 0 && cat_codes_on_device) {
-        kern::cat_step_codes(dcells, N, Fc, F, d_sdict_off_.as<int32_t>(), d_sdict_hash_.as<uint64_t>(), d_sdict_cls_.as<int32_t>(),
-                             d_sdict_words_.as<uint64_t>(), d_codes, s);
+        kern::cat_step_codes(dcells, N, Fc, F, sdict_off_, sdict_hash_, sdict_cls_, sdict_words_, d_codes, s);
     } else if (Fc > 0) {
         uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
         hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
@@ -1640,6 +1789,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     gc.n_slots = n_slots; gc.n_cand = n_cand; gc.chunk_rows = chunk_rows; gc.n_global = n_global; gc.cosine = cosine; gc.oblivious = oblivious;
     gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cand_slot = &cand_slot;
     gc.const_cacheable = const_cacheable; gc.cat_cands = &cat_cands;
+    gc.prefix_cacheable = prefix_cacheable; gc.n_num_cand = n_num_cand; gc.cand_cap = (F + Fc) * B;
     gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;

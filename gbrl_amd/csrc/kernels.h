@@ -104,6 +104,11 @@ void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);
 void publish_block(void *d_src, void *h_dst_mapped, size_t bytes, uint32_t *flag_mapped, uint32_t seq, hipStream_t s, bool zero_src = false /*clear the source words after copying them*/);
 // Two device arrays (sizes multiples of 4 bytes) into pinned, device-mapped host memory with one launch, no flag.
 void publish_pair(const void *d_a, void *h_a_mapped, size_t a_bytes, const void *d_b, void *h_b_mapped, size_t b_bytes, hipStream_t s);
+// Up to 8 small host -> device uploads with ONE launch: the sources live in pinned, device-mapped host memory (pass their DEVICE
+// aliases), every segment is a multiple of 4 bytes.  Replaces a handful of copy-engine transfers (each ~10 us of stream time for a
+// few KB) in steps that are bound by stream operations, not bytes.  The host must leave the sources alone until the kernel has run.
+struct FetchSegments { void *dst[8]; const void *src[8]; uint32_t words[8]; int n; };
+void fetch_segments(const FetchSegments &fs, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 
 // ---- exact quantile selection and binning on transposed keys (quantile.hip) ----
@@ -308,16 +313,18 @@ bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words
 // (16 uint64 per entry, normalised).  codes[i*Fc+f] = id of the matching entry, 0 when the cell is not in the dictionary.
 // Distinct categorical cells of a batch (A5 on the device).  cat_distinct_insert fills per-feature open-addressing tables
-// (keys = raw 128-byte hash, first = smallest row that holds the key); cat_distinct_verify confirms that every cell equals the
-// cell of its key's first row (flags[1] = 1 on a 64-bit hash collision); cat_distinct_compact lists the occupied slots.
-// flags[0] = 1 when a table or the list overflowed.  cat_step_codes writes the class of every cell (dictionary sorted by
+// (keys = raw 128-byte hash, first = smallest row that holds the key) and appends the table slot of every NEW key to list_slot
+// (counter = number of distinct (feature, cell) pairs); cat_distinct_verify confirms that every cell equals the cell of its
+// key's first row (flags[1] = 1 on a 64-bit hash collision); cat_publish writes header + (feature, first row, hash, cell) of the
+// first `cap` list records into mapped pinned host memory.  flags[0] = 1 when a table or the list overflowed.  cat_step_codes
+// writes the class of every cell (dictionary sorted by
 // hash per feature, id = class, words = raw cell) straight into the grouped u16 code array (slot F+f).
-void cat_distinct_insert(const char *cells, int n, int Fc, uint64_t *keys, int32_t *first, int log2_cap, int32_t *flags, hipStream_t s);
+void cat_distinct_insert(const char *cells, int n, int Fc, uint64_t *keys, int32_t *first, int log2_cap, int32_t *flags, int32_t *list_slot,
+                         int32_t *counter, int list_cap, hipStream_t s);
 void cat_distinct_verify(const char *cells, int n, int Fc, const uint64_t *keys, const int32_t *first, int log2_cap, int32_t *flags,
                          hipStream_t s);
-void cat_distinct_compact(const uint64_t *keys, const int32_t *first, int Fc, int log2_cap, int32_t *out_feat, uint64_t *out_hash,
-                          int32_t *out_first, int32_t *counter, int list_cap, int32_t *flags, hipStream_t s);
-void gather_cells(const char *cells, int Fc, const int32_t *rows, const int32_t *feats, int n_items, char *out, hipStream_t s);
+void cat_publish(const int32_t *meta, const int32_t *list_slot, const uint64_t *keys, const int32_t *first, int log2_cap, const char *cells,
+                 int Fc, int cap, int32_t *h_hdr, int32_t *h_feat, int32_t *h_first, uint64_t *h_hash, char *h_names, hipStream_t s);
 void cat_step_codes(const char *cells, int n, int Fc, int F, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_cls,
                     const uint64_t *dict_words, uint16_t *codes, hipStream_t s);
 void encode_categories(const char *cells, int n, int Fc, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_id,

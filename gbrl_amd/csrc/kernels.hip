@@ -772,6 +772,12 @@ __global__ __launch_bounds__(256) void k_publish_pair(const uint32_t *__restrict
     if (i < a_words) __builtin_nontemporal_store(a[i], &ha[i]);
     if (i < b_words) __builtin_nontemporal_store(b[i], &hb[i]);
 }
+__global__ __launch_bounds__(256) void k_fetch_segments(FetchSegments fs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < fs.n && i < fs.words[k]) static_cast<uint32_t *>(fs.dst[k])[i] = static_cast<const uint32_t *>(fs.src[k])[i];
+}
 __global__ void k_fill_f32(float *__restrict__ p, size_t n, float v) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1604,6 +1610,11 @@ void publish_pair(const void *d_a, void *h_a_mapped, size_t a_bytes, const void 
     const int aw = static_cast<int>(a_bytes / 4), bw = static_cast<int>(b_bytes / 4);
     hipLaunchKernelGGL(k_publish_pair, dim3((std::max(aw, bw) + 255) / 256), dim3(256), 0, s, static_cast<const uint32_t *>(d_a),
                        static_cast<uint32_t *>(h_a_mapped), aw, static_cast<const uint32_t *>(d_b), static_cast<uint32_t *>(h_b_mapped), bw);
+}
+void fetch_segments(const FetchSegments &fs, hipStream_t s) {
+    uint32_t mx = 0;
+    for (int k = 0; k < fs.n; ++k) mx = std::max(mx, fs.words[k]);
+    if (mx) hipLaunchKernelGGL(k_fetch_segments, dim3((mx + 255) / 256), dim3(256), 0, s, fs);
 }
 void fill_f32(float *p, size_t n, float v, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p, n, v);

@@ -5,6 +5,9 @@ import sys
 # summed per thread, math_ops.cpp:255-300, so their last bit depends on the thread count).  Pin it before
 # any OpenMP runtime starts.
 os.environ.setdefault("OMP_NUM_THREADS", "8")
+# Every categorical step of the test suite replays the reference's string-keyed candidate container beside the engine's
+# hash-replay of it and throws when the two iteration orders differ (engine_step.hip, device_categorical_candidates).
+os.environ.setdefault("GBRL_HIP_CAT_CHECK", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
