@@ -1354,10 +1354,13 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         phase_begin();
         // (row-sharded: this rank scores its own feature slots only; candidates of the other ranks stay at -inf)
         if (has_coll_ && oblivious) kern::fill_f32(d_scores, static_cast<size_t>(n_act) * n_cand, -INFINITY, s);
+        // last level on one GPU: the derived siblings are scored but not written back (nothing subtracts from them any more)
+        static const bool skip_hook = [] { const char *e = std::getenv("GBRL_HIP_KEEP_LAST_DERIVED"); return e && e[0] == '1'; }();   // measurement hook
+        const bool drop_derived = !has_coll_ && !skip_hook && depth > 0 && depth == MD - 1;
         if (own_slots > 0)
             kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                    d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
-                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0);
+                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0, !drop_derived);
         // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
         // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
         if (oblivious)
@@ -1371,7 +1374,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (seq == 0) seq = ++level_seq_;
         }
         kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
-                             d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, publish_in_resolve ? h_res_dev : nullptr, d_flag, seq, d_pub_done);
+                             d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, publish_in_resolve ? h_res_dev : nullptr, d_flag, seq, d_pub_done,
+                             drop_derived ? d_hist_prev : nullptr, drop_derived ? d_sub_par : nullptr, drop_derived ? d_sub_sib : nullptr);
         if (has_coll_) {
             // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
             const int n_win = oblivious ? 1 : n_act;

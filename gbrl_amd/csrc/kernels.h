@@ -204,7 +204,9 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       float *scores /*[n_nodes][n_cand]*/, float *parent /*[n_nodes]*/,
                       const float *cand_w, const int32_t *cand_ref, const int32_t *is_root,
                       float *part_v /*nullable.  greedy: [n_nodes][n_slots] best gain per feature -- arg-max stage 1 fused, scores not written*/,
-                      int32_t *part_i, hipStream_t s, int slot0 = 0 /* first feature slot scored (n_slots of them): feature-parallel scoring */);
+                      int32_t *part_i, hipStream_t s, int slot0 = 0 /* first feature slot scored (n_slots of them): feature-parallel scoring */,
+                      bool keep_derived = true /* false (last level only): derived slices are scored but not written back; resolve_splits
+                      must then be given hist_prev / sub_par / sub_sib */);
 // best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
 // result (sum over nodes); greedy: one per node.  part_v/part_i: scratch of n_nodes * argmax_parts(n_cand).
 int argmax_parts(int n_cand);
@@ -222,7 +224,9 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
                     int32_t *cursors, const uint32_t *thr_keys /*[F][B] ordered threshold keys*/, int B, hipStream_t s,
                     void *pub = nullptr /*pinned, device-mapped copy of the result block [best_idx | best_score | counts4]: mirrored, then ...*/,
                     uint32_t *pub_flag = nullptr /*... the last block stores pub_seq here (system scope)*/, uint32_t pub_seq = 0,
-                    unsigned *pub_done = nullptr /*device counter, zero between launches*/);
+                    unsigned *pub_done = nullptr /*device counter, zero between launches*/,
+                    const int64_t *hist_prev = nullptr, const int32_t *sub_par = nullptr /*non-null: derived nodes' counts = hist_prev[par] - hist_local[sib]*/,
+                    const int32_t *sub_sib = nullptr);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);

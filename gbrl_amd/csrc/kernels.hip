@@ -879,7 +879,8 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
                                                const float *__restrict__ path_val, const int32_t *__restrict__ path_bin,
                                                float *__restrict__ scores, float *__restrict__ parent,
                                                const float *__restrict__ cand_w, const int32_t *__restrict__ cand_ref,
-                                               const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i, int slot0) {
+                                               const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i, int slot0,
+                                               int keep_derived) {
     extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
     const double inv_scale = scp->inv_scale;
     const int node = blockIdx.y, fs = slot0 + blockIdx.x;
@@ -889,7 +890,9 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     const int par = sub_par ? sub_par[node] : -1;
     if (par >= 0) {
         // sibling subtraction fused here: this node was not accumulated from the data; its histogram is parent - sibling (exact
-        // integers).  The slice is written back because the next level subtracts from it and k_resolve_splits reads it.
+        // integers).  The slice is written back because the next level subtracts from it and k_resolve_splits reads it -- except at
+        // the LAST level (keep_derived == 0): nothing subtracts from it any more, and k_resolve_splits derives the winner's class
+        // counts from the same two slices (one third of this kernel's traffic at the deepest, most expensive level).
         const int sib = sub_sib[node];
         const int64_t *pp = hist_prev + (static_cast<size_t>(par) * Fp + fs) * NB * W;
         const int64_t *ss = sib >= 0 ? hist + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * step;
-                if (i < tot) { const int64_t v = a[u] - b[u]; sh64[i] = v; src[i] = v; }
+                if (i < tot) { const int64_t v = a[u] - b[u]; sh64[i] = v; if (keep_derived) src[i] = v; }
             }
         }
     } else {
@@ -1125,7 +1128,8 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                                                        NodeSplit *__restrict__ out, int64_t *__restrict__ counts4, int max_front,
                                                        const int32_t *__restrict__ seg_start /*nullable*/, int32_t *__restrict__ cursors,
                                                        const uint32_t *__restrict__ thr_keys, int B, char *pub, uint32_t *pub_flag,
-                                                       uint32_t pub_seq, unsigned *pub_done) {
+                                                       uint32_t pub_seq, unsigned *pub_done, const int64_t *__restrict__ hist_prev,
+                                                       const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib) {
     const int node = blockIdx.x;
     // pub != nullptr: the result block [best_idx | best_score | counts4] is mirrored into pinned, device-mapped host memory of the same
     // layout and the LAST block to finish stores pub_seq to pub_flag (system scope) -- the host polls it (no publishing launch)
@@ -1156,11 +1160,24 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     int n_left = 0;
     for (int pass = 0; pass < (hist_global ? 2 : 1); ++pass) {
         const int64_t *src = (pass ? hist_global : hist_local) + (static_cast<size_t>(node) * Fp + fs) * NB * W;
+        // sub_par != nullptr (last level, one GPU): k_score did not write the derived slices back; a derived node's counts are
+        // parent - sibling here as well (sub_sib < 0: the sibling has no rows)
+        const int par = (sub_par && pass == 0) ? sub_par[node] : -1;
+        const int64_t *sub = nullptr;
+        if (par >= 0) {
+            const int sib = sub_sib[node];
+            src = hist_prev + (static_cast<size_t>(par) * Fp + fs) * NB * W;
+            sub = sib >= 0 ? hist_local + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
+        }
         long long tot = 0, right = 0;
         for (int c0 = threadIdx.x; c0 < NB; c0 += 8 * kWave) {     // the class counts of the winner's slice: eight loads in flight per lane
             long long n[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] = c < NB ? src[c * W + D] : 0; }
+            if (sub) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] -= c < NB ? sub[c * W + D] : 0; }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u * kWave;
@@ -1635,14 +1652,15 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
-                      int32_t *part_i, hipStream_t s, int slot0) {
+                      int32_t *part_i, hipStream_t s, int slot0, bool keep_derived) {
     const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
-                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i, slot0);
+                       cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i, slot0,
+                       keep_derived ? 1 : 0);
 }
 
 int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }
@@ -1658,10 +1676,11 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const 
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
                     NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, const uint32_t *thr_keys,
-                    int B, hipStream_t s, void *pub, uint32_t *pub_flag, uint32_t pub_seq, unsigned *pub_done) {
+                    int B, hipStream_t s, void *pub, uint32_t *pub_flag, uint32_t pub_seq, unsigned *pub_done, const int64_t *hist_prev,
+                    const int32_t *sub_par, const int32_t *sub_sib) {
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, part_v, part_i, n_parts, best_idx, best_score, oblivious ? 1 : 0,
                        ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors, thr_keys, B,
-                       static_cast<char *>(pub), pub_flag, pub_seq, pub_done);
+                       static_cast<char *>(pub), pub_flag, pub_seq, pub_done, hist_prev, sub_par, sub_sib);
 }
 
 // Row-sharded runs: k_resolve_splits wrote GLOBAL left sizes; the partition needs this rank's.
