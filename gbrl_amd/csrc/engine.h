@@ -223,7 +223,8 @@ class Engine {
     std::vector<detail::CatItem> cat_items_;            // every distinct (feature, cell) met so far
     std::unordered_map<uint64_t, int> cat_item_index_;  // (raw hash, feature) -> head of the chain through CatItem::next
     std::vector<char> cat_host_;                        // the published distinct-cell block, copied out of the pinned mapping
-    std::vector<char> cat_pool_;                        // node storage of the per-step replay of the reference's container
+    std::vector<uint32_t> cat_seen_;                    // per item: tag of the last replay that inserted it
+    uint32_t cat_seen_tag_ = 0;
     DevBuf d_fit_cells_, d_fit_cells2_;
     DevBuf d_fit_obs_, d_fit_targets_, d_fit_obs2_, d_fit_targets2_, d_fit_perm_, d_fit_preds_, d_fit_grads_, d_fit_zero_;
 };

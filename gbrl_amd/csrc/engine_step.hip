@@ -14,13 +14,13 @@
 #include <numeric>
 #include <random>
 #include "cat_hash.h"
+#include "hash_order_replay.h"
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
-#include <memory_resource>
 #include <cstring>
 #include <limits>
 #include <unordered_map>
@@ -509,9 +509,10 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         for (int q = 0; q < n_distinct; ++q) ++start[lfeat[q] + 1];
         for (int f = 0; f < Fc; ++f) start[f + 1] += start[f];
         std::vector<int> cur(start.begin(), start.end() - 1);
-        for (int q = 0; q < n_distinct; ++q) order[cur[lfeat[q]]++] = q;
-        for (int f = 0; f < Fc; ++f)
-            std::sort(order.begin() + start[f], order.begin() + start[f + 1], [&](int a, int b2) { return lfirst[a] < lfirst[b2]; });
+        std::vector<std::pair<int32_t, int32_t>> fr(n_distinct);   // (first row, list index), bucketed by feature
+        for (int q = 0; q < n_distinct; ++q) fr[cur[lfeat[q]]++] = {lfirst[q], q};
+        for (int f = 0; f < Fc; ++f) std::sort(fr.begin() + start[f], fr.begin() + start[f + 1]);   // first rows of one feature are distinct
+        for (int q = 0; q < n_distinct; ++q) order[q] = fr[q].second;
     }
     std::vector<int32_t> g_feat;     // row-sharded: the global lists replace the local views
     std::vector<uint64_t> g_hash;
@@ -565,10 +566,10 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     // Replay of the reference's candidate container (std::unordered_map<std::string, ...> keyed by cell + "_" + feature, filled in
     // the order above, split_candidate_generator.cpp:117-130): its ITERATION order is the candidate order (Q8).  The order of a
     // libstdc++ hash table is a function of the keys' hash values and of the insertion sequence only, so the replay inserts small
-    // references that carry the key's std::hash -- computed once per distinct (feature, cell) the engine has ever met and kept in
-    // cat_items_ -- instead of building and hashing 130-byte strings every step; nodes come from a monotonic pool.
+    // the keys' std::hash values -- computed once per distinct (feature, cell) the engine has ever met and kept in cat_items_ --
+    // instead of building and hashing 130-byte strings every step.
     // GBRL_HIP_CAT_CHECK=1 (tests) replays the string-keyed container beside it and compares the two orders.
-    if (cat_items_.size() > (1u << 20)) { cat_items_.clear(); cat_item_index_.clear(); }
+    if (cat_items_.size() > (1u << 18)) { cat_items_.clear(); cat_item_index_.clear(); std::fill(cat_seen_.begin(), cat_seen_.end(), 0u); }
     auto item_of = [&](int feat, uint64_t h, const char *cell) -> int {
         const uint64_t key = h * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(feat);
         auto it = cat_item_index_.find(key);
@@ -590,21 +591,24 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         cat_item_index_[key] = id;
         return id;
     };
-    struct Ref { int id; size_t h; };
-    struct RefHash { size_t operator()(const Ref &r) const noexcept { return r.h; } };
-    struct RefEq { bool operator()(const Ref &a, const Ref &b2) const noexcept { return a.id == b2.id; } };
-    const size_t pool_need = static_cast<size_t>(n_distinct) * 96 + 65536;
-    if (cat_pool_.size() < pool_need) cat_pool_.resize(pool_need);
-    std::pmr::monotonic_buffer_resource pool(cat_pool_.data(), cat_pool_.size());
+    // The replay itself: hash_order_replay.h (libstdc++'s unique-key insertion restated on index arrays).
     std::vector<int> cand_item;   // distinct-list index of every candidate, in candidate order
     cand_item.reserve(n_distinct);
     {
-        std::pmr::unordered_map<Ref, int, RefHash, RefEq> uniq(&pool);
+        std::vector<size_t> hcode;
+        std::vector<int> node_q;
+        hcode.reserve(n_distinct); node_q.reserve(n_distinct);
+        const uint32_t tag = ++cat_seen_tag_;
+        if (tag == 0) { std::fill(cat_seen_.begin(), cat_seen_.end(), 0u); cat_seen_tag_ = 1; }
         for (int q : order) {
             const int id = item_of(lfeat[q], lhash[q], names + static_cast<size_t>(q) * kCat);
-            uniq.emplace(Ref{id, cat_items_[id].std_hash}, q);
+            if (static_cast<size_t>(id) >= cat_seen_.size()) cat_seen_.resize(std::max<size_t>(2 * cat_seen_.size(), static_cast<size_t>(id) + 1), 0);
+            if (cat_seen_[id] == cat_seen_tag_) continue;      // key already in the container (row-sharded lists): emplace() finds it, inserts nothing
+            cat_seen_[id] = cat_seen_tag_;
+            hcode.push_back(cat_items_[id].std_hash);
+            node_q.push_back(q);
         }
-        for (const auto &kv : uniq) cand_item.push_back(kv.second);   // the container's iteration order (Q8)
+        for (int k : libstdcxx_unique_insert_order(hcode)) cand_item.push_back(node_q[k]);   // the container's iteration order (Q8)
     }
     static const bool check_replay = [] { const char *e = std::getenv("GBRL_HIP_CAT_CHECK"); return e && e[0] == '1'; }();
     if (check_replay) {

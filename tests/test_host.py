@@ -269,3 +269,14 @@ def test_corrupt_model_files_are_refused_not_loaded(tmp_path):
     bad = bytearray(ref); struct.pack_into("<i", bad, pos + 4, -5)                # second tree starts at a negative leaf
     with pytest.raises(RuntimeError):
         gbrl_amd.GBRL.load(write(tmp_path / "b4.gbrl_model", bad))
+
+
+def test_candidate_order_replay_equals_the_libstdcxx_container(tmp_path):
+    """hash_order_replay.h (the order the engine gives a step's categorical candidates, Q8) against the real std::unordered_map on
+    500 random insertion sequences: uniform, heavily colliding and string-key hashes (tests/cxx/replay_check.cpp)."""
+    import subprocess
+    exe = tmp_path / "replay_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "gbrl_amd", "csrc"), os.path.join(ROOT, "tests", "cxx", "replay_check.cpp"),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr
