@@ -219,6 +219,7 @@ class Engine {
     // the step's candidate dictionary inside d_sdict_ (one upload): per categorical feature the entries sorted by raw hash
     const int32_t *sdict_off_ = nullptr, *sdict_cls_ = nullptr;
     const uint64_t *sdict_hash_ = nullptr, *sdict_words_ = nullptr;
+    int cat_log2_hint_ = 20;                            // log2 of the per-feature table size the next step starts with (20: the full size)
     int cat_publish_guess_ = 256;                       // records the next step publishes with its header (the last count + 25 %)
     std::vector<detail::CatItem> cat_items_;            // every distinct (feature, cell) met so far
     std::unordered_map<uint64_t, int> cat_item_index_;  // (raw hash, feature) -> head of the chain through CatItem::next

@@ -437,20 +437,18 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     hipStream_t s = stream_;
     const long long keep = static_cast<long long>(Fc) * B;
     if (keep > (1 << 20)) return false;
-    int log2_cap = 8;
-    while ((1ll << log2_cap) < 4 * std::min<long long>(N, keep + 1) && log2_cap < 20) ++log2_cap;
-    const size_t slots = static_cast<size_t>(Fc) << log2_cap;
-    if (slots >= (1ull << 31)) return false;   // list records are 32-bit table slots
+    int full_log2 = 8;
+    while ((1ll << full_log2) < 4 * std::min<long long>(N, keep + 1) && full_log2 < 20) ++full_log2;
+    if ((static_cast<size_t>(Fc) << full_log2) >= (1ull << 31)) return false;   // list records are 32-bit table slots
+    // The per-feature tables are sized for the worst case (every row a new category: 4 N slots); real columns hold a few dozen
+    // categories, so the step starts with four times the largest distinct count the previous step saw and repeats with the full size
+    // only if a table overflowed (12 MB of memsets and atomics on a 12 MB table -> 0.2 MB at configs[4]).
+    int log2_cap = std::min(full_log2, std::max(8, cat_log2_hint_));
     const int list_cap = static_cast<int>(keep) + 1;
-    uint64_t *d_keys = static_cast<uint64_t *>(d_cat_keys_.ensure(sizeof(uint64_t) * slots));
-    int32_t *d_first = static_cast<int32_t *>(d_cat_first_.ensure(sizeof(int32_t) * slots));
     int32_t *d_meta = static_cast<int32_t *>(d_cat_meta_.ensure(sizeof(int32_t) * 4));               // flags[2], counter
     int32_t *d_lslot = static_cast<int32_t *>(d_cat_lslot_.ensure(sizeof(int32_t) * list_cap));
-    hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
-    hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
-    hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
-    kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, d_lslot, d_meta + 2, list_cap, s);
-    kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+    uint64_t *d_keys = nullptr;
+    int32_t *d_first = nullptr;
     // ONE launch writes header + records + the distinct cells themselves into mapped pinned memory, ONE synchronisation reads them
     // (round 2: three copies of lists sized by a count that needed its own round trip, then a gather + a fourth copy: four
     // synchronisations per step).  The record count is guessed from the last step; a larger batch of distinct cells is published
@@ -487,7 +485,19 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         lfirst = reinterpret_cast<const int32_t *>(c + c_first);
         names = c + c_names;
     };
-    publish(std::min(list_cap, std::max(256, cat_publish_guess_)));
+    for (;;) {
+        const size_t slots = static_cast<size_t>(Fc) << log2_cap;
+        d_keys = static_cast<uint64_t *>(d_cat_keys_.ensure(sizeof(uint64_t) * slots));
+        d_first = static_cast<int32_t *>(d_cat_first_.ensure(sizeof(int32_t) * slots));
+        hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
+        hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
+        hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
+        kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, d_lslot, d_meta + 2, list_cap, s);
+        kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+        publish(std::min(list_cap, std::max(256, cat_publish_guess_)));
+        if (h_hdr[0] != 0 && log2_cap < full_log2) { log2_cap = full_log2; continue; }   // a table (or the list) overflowed: once more at full size
+        break;
+    }
     int n_distinct = h_hdr[2];
     bool declined = h_hdr[0] != 0 || h_hdr[1] != 0 || n_distinct > keep;
     if (has_coll_) {   // every rank must take the same path
@@ -507,6 +517,13 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     {
         std::vector<int> start(Fc + 1, 0);
         for (int q = 0; q < n_distinct; ++q) ++start[lfeat[q] + 1];
+        {
+            int mx = 1;
+            for (int f = 0; f < Fc; ++f) mx = std::max(mx, start[f + 1]);
+            int l2 = 8;
+            while ((1 << l2) < 4 * mx && l2 < 20) ++l2;
+            cat_log2_hint_ = l2;                       // table size the next step starts with
+        }
         for (int f = 0; f < Fc; ++f) start[f + 1] += start[f];
         std::vector<int> cur(start.begin(), start.end() - 1);
         std::vector<std::pair<int32_t, int32_t>> fr(n_distinct);   // (first row, list index), bucketed by feature

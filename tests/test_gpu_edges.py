@@ -484,3 +484,46 @@ def test_empty_and_inverted_tree_ranges_return_the_bias_like_the_reference(polic
         for model in (m,) + ((rr,) if rr is not None else ()):   # (the restatement mirrors predict_cpu, not the binding)
             with pytest.raises(RuntimeError):
                 model.predict(X, None, start, stop)
+
+
+@pytest.mark.parametrize("policy", ["greedy", "oblivious"])
+def test_categorical_steps_with_changing_cardinality_and_weights(policy):
+    """Mixed numeric + categorical steps keep state between calls: the numeric prefix of the per-step tables, the size of the distinct-cell
+    hash tables (four times the last step's largest per-feature count, repeated at full size on overflow) and the count of published
+    records.  A column whose cardinality jumps from 3 to 300 between steps, a batch-size change and a feature-weight change in
+    between must still give the oracle's trees (candidate ORDER included: conftest sets GBRL_HIP_CAT_CHECK=1).  Every column has more
+    categories than depth + 1: once a tree has split a column on all but two of its categories, the last two candidates partition the
+    node into the same two sets -- an exact tie that the reference resolves by the rounding of its contracted float32 expression, the
+    product by the lowest index (the "explained near-tie" class of scripts/parity_sweep.py; scripts/catjump_diag.py shows one)."""
+    import gbrl_amd
+    import oracle
+    F, Fc, D = 3, 4, 2
+    case = _case("catjump", policy=policy, score="L2", N=2000, F=F, Fc=Fc, D=D, depth=4, n_bins=256, trees=0)
+    X, Xc, G, y = K.make_inputs(case)
+    rng = np.random.default_rng(11)
+    N = X.shape[0]
+
+    def cells(card):
+        out = np.empty((N, Fc), dtype="S128")
+        for c in range(Fc):
+            ids = rng.integers(0, card[c], size=N)
+            out[:, c] = np.array([("k%d_%d" % (c, i)).encode() for i in range(card[c])], dtype="S128")[ids]
+        return out
+
+    few, many, mid = cells([6, 7, 6, 8]), cells([300, 7, 6, 8]), cells([40, 7, 120, 8])
+    g2 = (G + (many[:, 0] == b"k0_7").astype(np.float32)[:, None] * 2.0).astype(np.float32)
+    w = np.array([1.0, 0.5, 2.0, 1.0, 3.0, 0.25, 1.0], np.float32)
+    steps = [("step", X, few, G), ("step", X, few, G), ("step", X, many, g2), ("step", X[:700], many[:700], g2[:700]), ("w", w),
+             ("step", X, mid, g2), ("step", X, few, G), ("step", X, many, g2)]
+    models = [gbrl_amd.GBRL(**K.ctor_kwargs(case)), oracle.OracleGBRL(**K.ctor_kwargs(case))]
+    for m in models:
+        K.drive(m, case, X, Xc, G, y)        # optimizers, mapping, unit weights; no trees
+        for op in steps:
+            if op[0] == "w":
+                m.set_feature_weights(op[1])
+            else:
+                m.step(np.ascontiguousarray(op[1]), np.ascontiguousarray(op[2]), np.ascontiguousarray(op[3]))
+    e, o = models[0].get_ensemble_data(), models[1].get_ensemble_data()
+    assert_structure_equal(e, o, what="categorical cardinality jump: ")
+    assert_values_close(e, o, float(np.abs(G).mean()), TOL)
+    assert int((np.asarray(e["is_numerics"]) == 0).sum()) > 0, "no categorical condition was chosen: the test would not see a wrong candidate order"
