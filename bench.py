@@ -388,7 +388,7 @@ def main():
                 install_rccl(m, dev)
                 exchange = "rccl (native, stream-ordered)"
             except Exception as e:
-                print("bench: native RCCL exchange unavailable (%r); falling back to torch.distributed hooks" % (e,), flush=True)
+                print("bench: native RCCL exchange unavailable (%r); falling back to torch.distributed hooks" % (e,), file=sys.stderr, flush=True)
         if exchange is None:
             coll = install_torch_collective(m, dev)
             exchange = "torch.distributed hooks (host-synchronous)"
