@@ -594,7 +594,9 @@ static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, bool greedy, 
                                                                 // group either way, so one value buffer (and larger groups) is the better trade
     if (rg_env >= 1 && rg_env <= rg_max) {
         best_rg = rg_env; best_nb = nb_env == 1 ? 1 : nb_env == 2 ? 2 : best_nb; best_tt = tt_for(rg_env, best_nb);
-    } else if (trees <= 48) {
+    } else if (trees <= 80) {
+        // (up to 80 trees: scripts/predict_mid_sweep.py -- 0.238 against 0.253 ms at 49 trees, 0.258 against 0.278 ms at 64; from 96 trees on the
+        // larger blocks below win.  The persistent mode of this plan stops at 48 trees, launch_obl2.)
         // HBM-bound regime: 64-row blocks with ONE value buffer (53 KB of LDS at 128 features: three blocks per CU, whose tile loads
         // overlap each other's walks): 0.145 ms against 0.17 ms with two buffers at 2^20 x 128, 15 trees
         best_nb = 1;
