@@ -19,8 +19,8 @@ LIB = os.path.join(HERE, "libgbrl_hip.so")
 EXT = os.path.join(HERE, "gbrl_cpp" + sysconfig.get_config_var("EXT_SUFFIX"))
 ARCH = os.environ.get("PYTORCH_ROCM_ARCH", "gfx950").split(";")[0]
 
-LIB_SRCS = ["kernels.hip", "predict.hip", "predict_obl2.hip", "predict_chain.hip", "categorical.hip", "quantile.hip", "radix_select.hip", "engine.hip", "engine_step.hip", "engine_predict.hip", "engine_explain.hip", "shap.hip", "c_api.cpp", "model.cpp", "rccl_dyn.cpp", "explain.cpp"]
-LIB_DEPS = LIB_SRCS + ["kernels.h", "kernels_common.h", "engine.h", "model.h", "explain.h", "cat_hash.h", "rccl_dyn.h", os.path.join("..", "..", "include", "gbrl_hip.h")]
+LIB_SRCS = ["kernels.hip", "predict.hip", "predict_obl2.hip", "predict_reg.hip", "predict_chain.hip", "categorical.hip", "quantile.hip", "radix_select.hip", "engine.hip", "engine_step.hip", "engine_predict.hip", "engine_explain.hip", "shap.hip", "c_api.cpp", "model.cpp", "rccl_dyn.cpp", "explain.cpp"]
+LIB_DEPS = LIB_SRCS + ["kernels.h", "kernels_common.h", "predict_reg_asm.h", "engine.h", "model.h", "explain.h", "cat_hash.h", "rccl_dyn.h", os.path.join("..", "..", "include", "gbrl_hip.h")]
 EXT_SRCS = ["binding.cpp"]
 
 
@@ -54,7 +54,7 @@ def _compile_objects(hipcc, force):
         objs.append(obj)
         path = os.path.join(CSRC, src)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
-            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-c", path, "-o", obj])
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-inline-asm", "-c", path, "-o", obj])
     workers = max(1, min(len(jobs), int(os.environ.get("GBRL_BUILD_JOBS", "6"))))
     if jobs:
         with ThreadPoolExecutor(workers) as pool:

@@ -313,6 +313,9 @@ bool predict_chain(const PredictModel &pm, const float *obs, int F, const int32_
                    float *out, hipStream_t s);
 bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
                   float *out, hipStream_t s);   // false: shape not covered, nothing was launched
+// Third-generation oblivious path for large batches (predict_reg.hip): the row tile lives in a bank of VGPRs, every level is a
+// VGPR-relative compare, the only LDS traffic is the leaf-value gather.  Same mirrors as predict_obl2; false: not covered.
+bool predict_reg(const PredictModel &pm, const float *obs, int F, int Fc, int n, int start_tree, int stop_tree, float *out, hipStream_t s);
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words
 // (16 uint64 per entry, normalised).  codes[i*Fc+f] = id of the matching entry, 0 when the cell is not in the dictionary.

@@ -642,7 +642,9 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
         {
             const size_t vtb = (static_cast<size_t>(1) << MAXD) * (DMAX * sizeof(float) + (GREEDY ? 16 : 0));
             static const bool no_res = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_RESIDENT"); return e && e[0] == '1'; }();   // measurement hook
-            if (!no_res && !GREEDY && pl.RG == 1 && trees <= 16 && DMAX <= 8 && 16 * vtb <= 65536) {
+            // (a 256-thread block stages kObl2MaxVec float4 per thread = 16 KiB per group: an 8-tree group must fit that, i.e. <= 2 KiB
+            // of values per tree -- depth 7-8 trees with 4 outputs, 4 KiB each, keep the regular plan)
+            if (!no_res && !GREEDY && pl.RG == 1 && trees <= 16 && DMAX <= 8 && 8 * vtb <= static_cast<size_t>(kObl2MaxVec) * 256 * 16) {
                 pl.TT = 8; pl.NB = 2;
                 const int nw = pl.TT / kObl2Workers > 2 ? 2 : 1;
                 pl.lds = static_cast<size_t>(pl.NB) * pl.TT * vtb + static_cast<size_t>(2) * kObl2Workers * nw * 64 * 4 + static_cast<size_t>(64) * pl.xs * 4;
