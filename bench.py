@@ -439,7 +439,7 @@ def main():
     # predict over the ensemble (rows stay sharded; no exchange)
     n_trees = m.get_num_trees()
     torch.cuda.synchronize()
-    reps = 5
+    reps = 20   # (5 calls read 6-9 % high: the first calls after the step loop run slower, scripts/predict_overhead_probe.py)
     m.predict(xo, None, 0, 0)
     torch.cuda.synchronize()
     t1 = time.perf_counter()

@@ -208,6 +208,13 @@ class Engine {
     // dictionary of the categorical strings that occur in the model's conditions: (cat feature, string) -> id >= 1
     std::vector<int32_t> cat_ids_host_, cond_pack_host_, grd_nodes_host_, grd_off_host_, cond_ra_host_;
     std::vector<float> values_sw_host_;   // second-generation oblivious predict: see kern::PredictModel::values_sw
+    // packed-code predict (kern::predict_pc): the ensemble's code book -- per numeric feature the sorted distinct thresholds, per
+    // mentioned category a bit slot, per tree level a (word, shift, T) record -- rebuilt when the model has changed
+    bool ensure_pc_book(int n_num, int n_cat);
+    DevBuf m_pc_cond_, m_pc_thr_, m_pc_thr_off_, m_pc_cat_slot_, m_pc_word_cols_, d_pc_rows_;
+    size_t pc_version_ = static_cast<size_t>(-1);
+    int pc_f_ = -1, pc_fc_ = -1, pc_wn_ = 0, pc_nw_ = 0, pc_row_words_ = 0, pc_iters_ = 1;
+    bool pc_ok_ = false;
     bool grd_ok_ = true;
     int grd_max_nodes_ = 0, grd_max_leaves_ = 1;
     size_t grd_up_nodes_ = 0;

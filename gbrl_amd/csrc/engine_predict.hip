@@ -65,7 +65,7 @@ void Engine::sync_model_to_device() {
     if (model.oblivious() && kern::obl2_feasible(static_cast<int>(MD), static_cast<int>(D), false)) {
         const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
         const size_t LS = size_t(1) << MX, VT = LS * DMAX;   // leaves padded to 2^levels: the kernel's tree stride is a compile-time constant
-        constexpr size_t kPadTrees = 16;                     // the kernel fetches whole groups of records (<= 16 trees) past the last tree
+        constexpr size_t kPadTrees = 32;                     // the kernels fetch whole groups of records (<= 32 trees) past the last tree
         if (up_trees_ == 0) { cond_ra_host_.clear(); values_sw_host_.clear(); }
         cond_ra_host_.resize((T + kPadTrees) * 2 * MX);
         // the kernel loads whole groups (<= 16 trees) and up to 4 x 1024 x 16 bytes per block unconditionally: zero padding behind the last tree
@@ -155,7 +155,7 @@ void Engine::sync_model_to_device() {
         if (grd_ok_ && kern::obl2_feasible(static_cast<int>(MD), static_cast<int>(D), true)) {
             const size_t MX = kern::obl2_levels(static_cast<int>(MD)), DMAX = kern::obl2_padded_outputs(static_cast<int>(D)), DW = DMAX / 4;
             const size_t LS = size_t(1) << MX, VT = LS * DMAX, RECF = VT + LS * 4;   // floats (= dwords) per record
-            constexpr size_t kPadTrees = 16;
+            constexpr size_t kPadTrees = 32;
             const size_t vpad = kPadTrees * RECF + (size_t(64) << 10) / sizeof(float);
             if (up_trees_ == 0) values_sw_host_.clear();
             values_sw_host_.resize(T * RECF + vpad);
@@ -182,6 +182,113 @@ void Engine::sync_model_to_device() {
     append(m_opt_lr_, olr.data(), 4, 0, olr.size());
     hip_check(hipStreamSynchronize(s), "sync model upload");
     mirror_version_ = model.version;
+}
+
+
+// The code book of the packed-code predict path (kern::predict_pc, predict_reg.hip).  Every numeric condition `x > t` of the
+// ensemble becomes `field < (0xffff - rank(t)) << 16`, where the field of a row is 0xffff - #{distinct thresholds of the feature
+// below x}; every categorical condition `cell == category` becomes "bit `slot` of the row's inverted one-hot words is clear".
+// Conditions that can never pass (threshold +inf or NaN, the padding in front of a shallow tree) get T = 0.  Rebuilt from the
+// host model whenever it has changed (a new threshold shifts the ranks of its feature).
+bool Engine::ensure_pc_book(int n_num, int n_cat) {
+    if (pc_version_ == model.version && pc_f_ == n_num && pc_fc_ == n_cat) return pc_ok_;
+    pc_version_ = model.version; pc_f_ = n_num; pc_fc_ = n_cat; pc_ok_ = false;
+    hipStream_t s = stream_;
+    const gbrl_hip_metadata &md = model.meta;
+    const size_t T = md.n_trees, MD = md.max_depth;
+    const size_t MX = kern::obl2_levels(static_cast<int>(MD));
+    if (MX == 0 || T == 0) return false;
+    auto never = [](float v) { return v != v || v == std::numeric_limits<float>::infinity(); };
+    std::vector<std::vector<float>> thr(n_num);
+    std::vector<std::vector<int32_t>> ids(n_cat);
+    for (size_t t = 0; t < T; ++t) {
+        const size_t depth = static_cast<size_t>(model.depths[t]);
+        for (size_t d = 0; d < depth; ++d) {
+            const size_t c = t * MD + d;
+            const int f = model.feature_indices[c];
+            if (model.is_numerics[c]) {
+                if (f < 0 || f >= n_num) return false;
+                const float v = model.feature_values[c];
+                if (!never(v)) thr[f].push_back(v == 0.0f ? 0.0f : v);   // -0 and +0 are one threshold
+            } else {
+                if (f < 0 || f >= n_cat || cat_ids_host_[c] <= 0) return false;
+                ids[f].push_back(cat_ids_host_[c]);
+            }
+        }
+    }
+    std::vector<int32_t> thr_off(n_num + 1, 0);
+    std::vector<float> thr_all;
+    size_t max_m = 1;
+    for (int f = 0; f < n_num; ++f) {
+        std::sort(thr[f].begin(), thr[f].end());
+        thr[f].erase(std::unique(thr[f].begin(), thr[f].end()), thr[f].end());
+        if (thr[f].size() > 65534) return false;
+        max_m = std::max(max_m, thr[f].size());
+        thr_all.insert(thr_all.end(), thr[f].begin(), thr[f].end());
+        thr_off[f + 1] = static_cast<int32_t>(thr_all.size());
+    }
+    thr_all.push_back(0.0f);   // never empty
+    int iters = 1;
+    while ((size_t(1) << iters) <= max_m) ++iters;   // 2^iters > max_m: the descent can reach every count 0..max_m
+    std::vector<int32_t> cat_slot(cat_dict_.size() + 1, -1);
+    std::vector<int32_t> col_first_slot(n_cat + 1, 0);
+    int n_slots = 0;
+    for (int c = 0; c < n_cat; ++c) {
+        std::sort(ids[c].begin(), ids[c].end());
+        ids[c].erase(std::unique(ids[c].begin(), ids[c].end()), ids[c].end());
+        col_first_slot[c] = n_slots;
+        for (int32_t id : ids[c]) {
+            if (id >= static_cast<int32_t>(cat_slot.size())) return false;
+            cat_slot[id] = n_slots++;
+        }
+    }
+    col_first_slot[n_cat] = n_slots;
+    const int wn = (n_num + 1) / 2, cw = (n_slots + 31) / 32, nw = wn + cw, row_words = (nw + 3) & ~3;
+    if (row_words > kern::predict_pc_bank_words() || row_words == 0) return false;
+    std::vector<int32_t> word_cols(2 * std::max(cw, 1), 0);
+    for (int q = 0; q < cw; ++q) {
+        int first = n_cat, last = 0;
+        for (int c = 0; c < n_cat; ++c)
+            if (col_first_slot[c + 1] > 32 * q && col_first_slot[c] < 32 * (q + 1) && col_first_slot[c + 1] > col_first_slot[c]) { first = std::min(first, c); last = std::max(last, c + 1); }
+        word_cols[2 * q] = first; word_cols[2 * q + 1] = std::max(first, last);
+    }
+    constexpr size_t kPadTrees = 32;
+    std::vector<int32_t> rec((T + kPadTrees) * MX * 3, 0);
+    for (size_t t = 0; t < T; ++t) {
+        const size_t depth = static_cast<size_t>(model.depths[t]);
+        if (depth > MX) return false;
+        int32_t *r = &rec[(t * MX + (MX - depth)) * 3];
+        for (size_t d = 0; d < depth; ++d, r += 3) {
+            const size_t c = t * MD + d;
+            const int f = model.feature_indices[c];
+            if (model.is_numerics[c]) {
+                const float v0 = model.feature_values[c];
+                if (never(v0)) continue;   // (0, 0, 0): never true
+                const float v = v0 == 0.0f ? 0.0f : v0;
+                const size_t k = static_cast<size_t>(std::lower_bound(thr[f].begin(), thr[f].end(), v) - thr[f].begin());
+                r[0] = f >> 1;
+                r[1] = (f & 1) ? 0 : 16;
+                r[2] = static_cast<int32_t>(static_cast<uint32_t>(0xffffu - k) << 16);
+            } else {
+                const int slot = cat_slot[cat_ids_host_[c]];
+                r[0] = wn + (slot >> 5);
+                r[1] = 31 - (slot & 31);
+                r[2] = static_cast<int32_t>(0x80000000u);
+            }
+        }
+    }
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) {
+        hip_check(hipMemcpyAsync(b.ensure(bytes), src, bytes, hipMemcpyHostToDevice, s), "H2D code book");
+    };
+    up(m_pc_cond_, rec.data(), rec.size() * 4);
+    up(m_pc_thr_, thr_all.data(), thr_all.size() * 4);
+    up(m_pc_thr_off_, thr_off.data(), thr_off.size() * 4);
+    up(m_pc_cat_slot_, cat_slot.data(), cat_slot.size() * 4);
+    up(m_pc_word_cols_, word_cols.data(), word_cols.size() * 4);
+    hip_check(hipStreamSynchronize(s), "sync code book");   // the host vectors go out of scope
+    pc_wn_ = wn; pc_nw_ = nw; pc_row_words_ = row_words; pc_iters_ = iters;
+    pc_ok_ = true;
+    return true;
 }
 
 // Dictionary ids of a batch of categorical cells (0 = a category no condition of the model mentions).  Needs sync_model_to_device().
@@ -298,6 +405,24 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     } else if (!model.oblivious() && grd_ok_ && kern::obl2_feasible(md.max_depth, D, true) && md.n_trees > 0) {
         pm.obl2_maxd = kern::obl2_levels(md.max_depth);   // greedy mode of the same kernel: records = values + nodes
         pm.values_sw = m_values_sw_.as<float>();
+    }
+    // Packed-code path: large batches of rows the fp32 register-tile kernel does not take (categorical columns, more than 128 or an
+    // odd number of features, unaligned rows).  The code book follows the model; the rows are packed inside kern::predict.
+    pm.pc_cond = nullptr; pm.pc_rows = nullptr;
+    {
+        const char *no_pc = std::getenv("GBRL_HIP_PREDICT_NO_PC"), *no_reg = std::getenv("GBRL_HIP_PREDICT_NO_REG"), *mr = std::getenv("GBRL_HIP_PREDICT_REG_MIN_ROWS");
+        const int min_rows = mr ? std::atoi(mr) : 32768;
+        const bool fp32_takes_it = n_cat == 0 && n_num <= 128 && (n_num & 3) == 0 && (reinterpret_cast<uintptr_t>(dobs) & 15) == 0 && !(no_reg && no_reg[0] == '1');
+        if (!(no_pc && no_pc[0] == '1') && !in_fit_ && pm.values_sw != nullptr && model.oblivious() && n >= min_rows && !fp32_takes_it &&
+            kern::predict_pc_shape_ok(pm.obl2_maxd, D) && ensure_pc_book(n_num, n_cat)) {
+            pm.pc_cond = m_pc_cond_.as<int32_t>();
+            pm.pc_thr = m_pc_thr_.as<float>();
+            pm.pc_thr_off = m_pc_thr_off_.as<int32_t>();
+            pm.pc_cat_slot = m_pc_cat_slot_.as<int32_t>();
+            pm.pc_word_cols = m_pc_word_cols_.as<int32_t>();
+            pm.pc_wn = pc_wn_; pm.pc_nw = pc_nw_; pm.pc_row_words = pc_row_words_; pm.pc_iters = pc_iters_;
+            pm.pc_rows = static_cast<uint32_t *>(d_pc_rows_.ensure(static_cast<size_t>(n) * pc_row_words_ * sizeof(uint32_t)));
+        }
     }
     if (const char *e = std::getenv("GBRL_HIP_PREDICT_OBL1")) {      // test / measurement hook: the first-generation oblivious kernel
         if (e[0] == '1') pm.obl2_maxd = 0;

@@ -302,6 +302,16 @@ struct PredictModel {
     const int32_t *cond_ra;
     int obl2_maxd;
     int cat_dict_size;       // dictionary ids of categorical conditions are 1..cat_dict_size (the kernel packs them in 16 bits)
+    // packed-code path (predict_reg.hip, k_pack_codes + k_predict_pc): the ensemble's code book, built by the engine when the shape
+    // qualifies (nullptr otherwise).  A row becomes pc_row_words dwords: pc_wn numeric words (two 16-bit fields: 0xffff - number of
+    // the feature's sorted distinct thresholds below x), then categorical words (one inverted one-hot bit per mentioned category).
+    const int32_t *pc_cond;       // per tree obl2_maxd x (word, shift, T), right-aligned like cond_ra (padding: 0, 0, 0 = never true)
+    const float *pc_thr;          // sorted distinct thresholds, feature by feature
+    const int32_t *pc_thr_off;    // [F + 1]
+    const int32_t *pc_cat_slot;   // [cat_dict_size + 1]: dictionary id -> bit slot (-1: none; id 0 = unknown cell)
+    const int32_t *pc_word_cols;  // [2 x categorical words]: first and last + 1 column with a slot in the word
+    uint32_t *pc_rows;            // scratch [n][pc_row_words]
+    int pc_wn, pc_nw, pc_row_words, pc_iters;
 };
 int obl2_padded_outputs(int D);     // 4, 8, 16, 32, 64 (0: D > 64)
 int obl2_levels(int max_depth);     // 4, 6, 8 (0: max_depth > 8)
@@ -316,6 +326,11 @@ bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t
 // Third-generation oblivious path for large batches (predict_reg.hip): the row tile lives in a bank of VGPRs, every level is a
 // VGPR-relative compare, the only LDS traffic is the leaf-value gather.  Same mirrors as predict_obl2; false: not covered.
 bool predict_reg(const PredictModel &pm, const float *obs, int F, int Fc, int n, int start_tree, int stop_tree, float *out, hipStream_t s);
+// The same walk over PACKED rows (categorical columns, rows wider than the fp32 bank, feature counts that are not multiples of 4).
+bool predict_pc(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree, float *out,
+                hipStream_t s);
+int predict_pc_bank_words();                      // dwords of a packed row the kernel can hold
+bool predict_pc_shape_ok(int obl2_maxd, int D);   // levels / outputs the packed-code kernels are compiled for
 // Dictionary encoding of categorical cells on the device (predict): cells [n][Fc][128 B]; the dictionary holds, per
 // categorical feature f, its entries sorted by hash: feat_off[f] .. feat_off[f+1] index dict_hash / dict_id / dict_words
 // (16 uint64 per entry, normalised).  codes[i*Fc+f] = id of the matching entry, 0 when the cell is not in the dictionary.

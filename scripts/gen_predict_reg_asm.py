@@ -151,6 +151,136 @@ class Variant:
         return L
 
 
+
+# ======================================================================================================================
+# Packed-code variant ("pc"): rows wider than the fp32 bank, or with categorical columns, are first rewritten as packed codes
+# (engine_predict.hip / k_pack_codes): a numeric feature becomes a 16-bit field holding 0xffff - #{ensemble thresholds below x},
+# a categorical column one INVERTED one-hot bit per category the ensemble mentions.  Every condition is then
+#     D = word << shift          (field / bit to the top, zeros below)
+#     mask = D < T               (numeric: T = (0xffff - rank) << 16;  categorical: T = 0x80000000, i.e. "the bit is clear")
+# -- the same two instructions for both kinds, so mixed trees need no branch.  Register map:
+#   v0 .. v61 compiler (amdgpu_num_vgpr(31));  v62 .. v221 the bank (160 words);  v222, v223 leaves / shifted words;
+#   v224 .. v255 two sets of leaf values (the multiply-adds run two steps behind the search: the record buffer is single, so
+#   every s_waitcnt drains BOTH counters -- value reads are issued right behind a wait and consumed two waits later).
+#   s[26:27] record pointer;  s28 .. records of one step (3 dwords per level: word index, shift, T);  then the masks.
+PC_TB = 62
+PC_NF = 160
+PC_LA, PC_LB = 222, 223
+PC_V0 = 224
+
+
+class VariantPC:
+    def __init__(self, maxd, dmax):
+        self.maxd, self.dmax = maxd, dmax
+        self.dw = dmax // 4
+        self.ls = 1 << maxd
+        self.rec = self.ls * dmax * 4
+        self.slice = self.ls * self.dw * 4
+        self.tree_dw = 3 * maxd
+        self.step_dw = 2 * self.tree_dw
+        self.step_bytes = 4 * self.step_dw
+        self.r0 = 28
+        self.m0 = self.r0 + self.step_dw
+        self.s_end = self.m0 + 4 * maxd
+        assert self.s_end <= 100
+        self.v_end = PC_V0 + 4 * dmax
+        assert self.v_end <= 256
+        self.sfx = f"D{maxd}O{dmax}"
+
+    def loads(self, off, dw=None):
+        out, dw, r, o = [], (self.step_dw if dw is None else dw), self.r0, off
+        for width in (16, 8, 4, 2, 1):
+            while dw >= width:
+                out.append(f"s_load_dword{'x%d' % width if width > 1 else ''} {sreg(r, width)}, s[26:27], {hex(o)}")
+                dw -= width; r += width; o += 4 * width
+        assert dw == 0
+        return out
+
+    def cmps(self, trees=2):
+        out, first = [], True
+        for t in range(trees):
+            for d in range(self.maxd):
+                a = self.r0 + 3 * (t * self.maxd + d)
+                m = self.m0 + 2 * (t * self.maxd + d)
+                tmp = PC_LA if (d & 1) == 0 else PC_LB
+                out.append(f"s_set_gpr_idx_on {sreg(a)}, gpr_idx(SRC1)" if first else f"s_set_gpr_idx_idx {sreg(a)}")
+                first = False
+                out.append(f"v_lshlrev_b32_e32 {vreg(tmp)}, {sreg(a + 1)}, {vreg(PC_TB)}")
+                out.append(f"v_cmp_lt_u32_e64 {sreg(m, 2)}, {vreg(tmp)}, {sreg(a + 2)}")
+        out.append("s_set_gpr_idx_off")
+        return out
+
+    def addcs(self, trees=2):
+        out = []
+        regs = [PC_LA, PC_LB][:trees]
+        for d in range(self.maxd):
+            for t, l in enumerate(regs):
+                m = self.m0 + 2 * (t * self.maxd + d)
+                src = "0, 0" if d == 0 else f"{vreg(l)}, {vreg(l)}"
+                out.append(f"v_addc_co_u32_e64 {vreg(l)}, vcc, {src}, {sreg(m, 2)}")
+        return out
+
+    def dsreads(self, vset, trees=2):
+        out = []
+        sh = {1: 2, 2: 3}[self.dw]
+        regs = [PC_LA, PC_LB][:trees]
+        for l in regs:
+            out.append(f"v_lshl_add_u32 {vreg(l)}, {vreg(l)}, {sh}, %[vb]")
+        for t, l in enumerate(regs):
+            base = PC_V0 + vset * 2 * self.dmax + t * self.dmax
+            for sl in range(4):
+                off = t * self.rec + sl * self.slice
+                width = {1: "b32", 2: "b64"}[self.dw]
+                out.append(f"ds_read_{width} {vreg(base + self.dw * sl, self.dw)}, {vreg(l)} offset:{off}")
+        out.append(f"s_add_u32 %[vb], %[vb], {trees * self.rec}")
+        return out
+
+    def fmas(self, vset, trees=2):
+        out = []
+        for t in range(trees):
+            base = PC_V0 + vset * 2 * self.dmax + t * self.dmax
+            for pr in range(self.dmax // 2):
+                out.append(f"v_pk_fma_f32 %[p{pr}], %[n{pr}], {vreg(base + 2 * pr, 2)}, %[p{pr}]")
+        return out
+
+    def walk_steps(self):
+        """n >= 1 steps.  Iteration s: wait; value reads of step s - 1 -> set (s - 1) % 2; compares of s; records of s + 1; leaves of s;
+        multiply-adds of step s - 2 from set s % 2."""
+        sb = self.step_bytes
+        adv = [f"s_add_u32 s26, s26, {sb}", "s_addc_u32 s27, s27, 0"]
+        def it(s_par, with_ds, with_fma):
+            L = ["s_waitcnt lgkmcnt(0)"]
+            if with_ds:
+                L += self.dsreads((s_par + 1) % 2)
+            L += self.cmps() + adv + self.loads(0) + self.addcs()
+            if with_fma:
+                L += self.fmas(s_par)
+            return L
+        dec = ["s_sub_u32 %[n], %[n], 1", "s_cmp_eq_u32 %[n], 0"]
+        L = ["s_mov_b32 s26, %[cpl]", "s_mov_b32 s27, %[cph]"] + self.loads(0)
+        L += it(0, False, False) + dec + ["s_cbranch_scc1 4f"]
+        L += it(1, True, False) + dec + ["s_cbranch_scc1 5f"]
+        L += ["1:"] + it(0, True, True) + dec + ["s_cbranch_scc1 6f"]
+        L += it(1, True, True) + ["s_sub_u32 %[n], %[n], 1", "s_cmp_lg_u32 %[n], 0", "s_cbranch_scc1 1b"]
+        # the last step had parity 1: its values go to set 1; pending multiply-adds: the step before it (set 0), then it
+        L += ["5:"] + self.dsreads(1) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(0) + self.fmas(1) + ["s_branch 9f"]
+        L += ["6:"] + self.dsreads(0) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(1) + self.fmas(0) + ["s_branch 9f"]
+        L += ["4:"] + self.dsreads(0) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(0) + ["9:"]
+        return L
+
+    def walk_one(self):
+        L = ["s_mov_b32 s26, %[cpl]", "s_mov_b32 s27, %[cph]"] + self.loads(0, self.tree_dw) + ["s_waitcnt lgkmcnt(0)"]
+        L += self.cmps(1) + self.addcs(1) + self.dsreads(0, 1) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(0, 1)
+        return L
+
+
+def load_tile_pc():
+    L = ["s_getpc_b64 s[26:27]", "s_add_u32 s26, s26, %[skip]", "s_addc_u32 s27, s27, 0", "s_setpc_b64 s[26:27]"]
+    for piece in range(PC_NF // 4 - 1, -1, -1):
+        L.append(f"global_load_dwordx4 {vreg(PC_TB + 4 * piece, 4)}, %[row], off offset:{16 * piece}")
+    return L
+
+
 def load_tile():
     """The lane's row -> bank, 16 bytes per load, LAST piece first: a computed jump skips the pieces a narrower row does not have
     (every global_load is 8 bytes of code)."""
@@ -190,6 +320,19 @@ def generate():
         out.append(f"#define PR_CLOB_SGPR_{v.sfx} \\\n    " + clob("s", 26, v.s_end))
         out.append(f"#define PR_ASM_WALK_STEPS_{v.sfx} \\\n" + cstr(v.walk_steps()))
         out.append(f"#define PR_ASM_WALK_ONE_{v.sfx} \\\n" + cstr(v.walk_one()))
+    out.append("// ==== packed-code variant (rows wider than the fp32 bank, categorical columns): see VariantPC in the generator")
+    out.append(f"#define PC_TILE_BASE {PC_TB}")
+    out.append(f"#define PC_TILE_REGS {PC_NF}")
+    out.append(f"#define PC_COMPILER_VGPR_HALF {PC_TB // 2}")
+    out.append("#define PC_CLOB_TILE \\\n    " + clob("v", PC_TB, PC_TB + PC_NF))
+    out.append("#define PC_ASM_LOAD_TILE \\\n" + cstr(load_tile_pc()))
+    for maxd, dmax in ((6, 8), (4, 8), (6, 4), (4, 4)):
+        v = VariantPC(maxd, dmax)
+        out.append(f"// ---- packed codes, {maxd} levels, {dmax} padded outputs: {v.step_bytes} bytes of records per step")
+        out.append(f"#define PC_CLOB_TEMPS_{v.sfx} \\\n    " + clob("v", PC_LA, v.v_end))
+        out.append(f"#define PC_CLOB_SGPR_{v.sfx} \\\n    " + clob("s", 26, v.s_end))
+        out.append(f"#define PC_ASM_WALK_STEPS_{v.sfx} \\\n" + cstr(v.walk_steps()))
+        out.append(f"#define PC_ASM_WALK_ONE_{v.sfx} \\\n" + cstr(v.walk_one()))
     return "\n".join(out) + "\n"
 
 

@@ -1,10 +1,9 @@
 set -e
-B="hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWALK2 scripts/rowreg_bench.hip"
-$B -o /tmp/rb2 2>/dev/null
-for f in NOIDX NOCMP CMPONLY IDXONLY NOADDC NOSMEM NOFMA NODS; do $B -DEXP_$f -o /tmp/rb2_$f 2>/dev/null; done
-echo "== pure walk: 24 resident trees walked 40 times per tile (960 trees), 2^18 rows"
-for bpc in 1 2 3; do timeout 60 /tmp/rb2 1 24 262144 $bpc 16 40; done
-for f in NOIDX NOCMP CMPONLY IDXONLY NOADDC NOSMEM NOFMA NODS; do echo $f; timeout 60 /tmp/rb2_$f 1 24 262144 2 16 40; done
-echo "== grouped"
-for TT in 8 16; do timeout 120 /tmp/rb2 2 1000 1048576 2 $TT; done
-for T in 16 28 36; do timeout 60 /tmp/rb2 1 $T 1048576 2; done
+B="hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm scripts/rowreg_bench.hip"
+$B -DWALK=2 -o /tmp/rb_w2 2>/dev/null
+$B -DWALK=2 -DPREFETCH -o /tmp/rb_w2p 2>/dev/null
+for b in rb_w2 rb_w2p; do
+echo "== $b"
+for T in 2 16 28 36; do for bpc in 1 2; do timeout 60 /tmp/$b 1 $T 1048576 $bpc | head -1; done; done
+done
+python scripts/predict_overhead_probe.py 28

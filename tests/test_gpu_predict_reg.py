@@ -14,7 +14,7 @@ import cases as K
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ("GBRL_HIP_PREDICT_GENERIC", "GBRL_HIP_PREDICT_NO_REG", "GBRL_HIP_PREDICT_REG_ONLY", "GBRL_HIP_PREDICT_REG_MIN_ROWS",
+HOOKS = ("GBRL_HIP_PREDICT_GENERIC", "GBRL_HIP_PREDICT_NO_REG", "GBRL_HIP_PREDICT_NO_PC", "GBRL_HIP_PREDICT_REG_ONLY", "GBRL_HIP_PREDICT_REG_MIN_ROWS",
          "GBRL_HIP_PREDICT_REG_GROUPED", "GBRL_HIP_PREDICT_OBL1")
 
 
@@ -46,7 +46,8 @@ MODES = (("reg", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_RO
          ("reg_grouped", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_REG_GROUPED": "1"}),
          ("reg_groups_of_4", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_REG_GROUPED": "4"}),
          ("reg_groups_of_3", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_REG_GROUPED": "3"}),
-         ("gen2", {"GBRL_HIP_PREDICT_NO_REG": "1"}),
+         ("packed", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_NO_REG": "1"}),   # the same rows as packed codes
+         ("gen2", {"GBRL_HIP_PREDICT_NO_REG": "1", "GBRL_HIP_PREDICT_NO_PC": "1"}),
          ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"}))
 
 
@@ -88,18 +89,20 @@ def test_register_tile_kernel_on_a_large_batch_and_a_large_ensemble(monkeypatch)
     Xp = _batch(case, (1 << 17) + 77, seed=5)
     ranges = ((0, 30), (1, 30), (0, 60), (7, 66), (0, 0), (3, 130), (0, 129))
     outs = {}
-    for mode, env in (("reg", {"GBRL_HIP_PREDICT_REG_ONLY": "1"}), ("gen2", {"GBRL_HIP_PREDICT_NO_REG": "1"}), ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"})):
+    for mode, env in (("reg", {"GBRL_HIP_PREDICT_REG_ONLY": "1"}), ("packed", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_NO_REG": "1"}),
+                      ("gen2", {"GBRL_HIP_PREDICT_NO_REG": "1", "GBRL_HIP_PREDICT_NO_PC": "1"}), ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"})):
         _set(monkeypatch, env)
         outs[mode] = [np.asarray(m.predict(Xp, None, a, b)) for a, b in ranges]
-    for mode in ("reg", "gen2"):
+    for mode in ("reg", "packed", "gen2"):
         for r, a, b in zip(ranges, outs[mode], outs["generic"]):
             assert np.array_equal(a, b), (mode, r)
 
 
 def test_register_tile_kernel_takes_device_inputs_and_declines_what_it_does_not_cover(monkeypatch):
-    """Device-resident inputs (the bench's path) through DLPack; a feature count that is not a multiple of four and a categorical
-    model are declined (REG_ONLY raises) and predicted by the older kernels as before."""
+    """Device-resident inputs (the bench's path) through DLPack; a feature count that is not a multiple of four goes to the
+    packed-code kernel; trees deeper than six levels are declined by both (REG_ONLY raises) and predicted by the older kernels."""
     import torch
+    import gbrl_amd
     case = dict(name="prd", seed=77, N=2000, F=24, Fc=0, D=4, depth=4, n_bins=32, score="L2", gen="Uniform", policy="oblivious", trees=9)
     m, _ = _grow(case)
     Xp = _batch(case, 40000, seed=1)
@@ -107,20 +110,99 @@ def test_register_tile_kernel_takes_device_inputs_and_declines_what_it_does_not_
     want = np.asarray(m.predict(Xp, None, 0, 0))
     _set(monkeypatch, {})
     t = torch.from_numpy(Xp).to("cuda:0")
-    md = __import__("gbrl_amd").GBRL(**K.ctor_kwargs(case, device="cuda"))
+    md = gbrl_amd.GBRL(**K.ctor_kwargs(case, device="cuda"))
     X, Xc, G, y = K.make_inputs(case)
     K.drive(md, case, X, Xc, G, y)
     _set(monkeypatch, {"GBRL_HIP_PREDICT_REG_ONLY": "1"})
     got = torch.from_dlpack(md.predict((t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda"), None, 0, 0)).cpu().numpy()
     assert np.array_equal(got, want)
-    odd = dict(case, F=23, name="prd_odd")
+    for variant, taken in ((dict(case, F=23, name="prd_odd"), True), (dict(case, depth=7, name="prd_deep"), False)):
+        _set(monkeypatch, {})
+        mo, _ = _grow(variant)
+        Xo = _batch(variant, 40000, seed=2)
+        _set(monkeypatch, {"GBRL_HIP_PREDICT_GENERIC": "1"})
+        ref = np.asarray(mo.predict(Xo, None, 0, 0))
+        _set(monkeypatch, {"GBRL_HIP_PREDICT_REG_ONLY": "1"})
+        if taken:
+            assert np.array_equal(np.asarray(mo.predict(Xo, None, 0, 0)), ref)
+        else:
+            with pytest.raises(RuntimeError, match="REG_ONLY"):
+                mo.predict(Xo, None, 0, 0)
+            _set(monkeypatch, {})
+            assert np.array_equal(np.asarray(mo.predict(Xo, None, 0, 0)), ref)
+
+
+def _cat_batch(case, n, seed):
+    """rows of the case's numeric and categorical widths; one cell in eleven holds a category no tree has seen"""
+    rng = np.random.default_rng(seed)
+    X, Xc, _, _ = K.make_inputs(case)
+    idx = rng.integers(0, (X if X is not None else Xc).shape[0], size=n)
+    Xn = None if X is None else np.ascontiguousarray(X[idx] + rng.standard_normal((n, X.shape[1])).astype(np.float32) * np.float32(0.05))
+    Cn = None
+    if Xc is not None:
+        Cn = np.ascontiguousarray(Xc[idx])
+        unseen = rng.integers(0, 11, size=Cn.shape) == 0
+        Cn[unseen] = b"never-seen"
+    return Xn, Cn
+
+
+PC_MODES = (("packed", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1"}),
+            ("packed_grouped", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_REG_GROUPED": "1"}),
+            ("packed_groups_of_3", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_REG_GROUPED": "3"}),
+            ("gen2", {"GBRL_HIP_PREDICT_NO_REG": "1", "GBRL_HIP_PREDICT_NO_PC": "1"}),
+            ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"}))
+
+
+@pytest.mark.parametrize("depth,D", [(3, 3), (4, 8), (6, 8), (5, 4), (6, 1)])
+@pytest.mark.parametrize("F,Fc", [(9, 2), (5, 3), (0, 3), (130, 1), (200, 0), (31, 7)])
+def test_packed_code_kernel_equals_the_general_kernel(F, Fc, depth, D, monkeypatch):
+    """Rows as packed codes (k_pack_codes + k_predict_pc): numeric features as 16-bit rank fields (two per register, both halves
+    exercised), categorical columns as inverted one-hot bits (equality conditions, cells no tree has seen, several columns per word),
+    models with only categorical columns, rows wider than the fp32 bank, mixed trees -- bitwise the general kernel, over sub-ranges,
+    ragged batches and both launch shapes."""
+    n_trees = 21
+    case = dict(name="pc", seed=1300 + 3 * depth + F + Fc, N=1500, F=F, Fc=Fc, D=D, depth=depth, n_bins=32, score="L2", gen="Uniform", policy="oblivious",
+                trees=n_trees, loop="rmse" if F > 0 and D == 1 else None, y_cat_weight=0.5, n_tokens=6)
+    if case["loop"] is None:
+        del case["loop"]
+    m, _ = _grow(case)
+    e = m.get_ensemble_data()
+    if Fc > 0:
+        assert (np.asarray(e["is_numerics"]) == 0).any() or F > 0   # (a purely categorical model has only categorical conditions)
+    ranges = ((0, 0), (0, 1), (2, 17), (5, 6), (20, 21))
+    for n in (1, 65, 1000, 4133):
+        Xn, Cn = _cat_batch(case, n, seed=n + F)
+        outs = {}
+        for mode, env in PC_MODES:
+            _set(monkeypatch, env)
+            outs[mode] = [np.asarray(m.predict(Xn, Cn, a, b)) for a, b in ranges]
+        for mode, _ in PC_MODES:
+            for r, a, b in zip(ranges, outs[mode], outs["generic"]):
+                assert a.shape == b.shape and np.array_equal(a, b), (mode, n, r)
+        assert np.abs(outs["packed"][0]).max() > 0
+
+
+def test_packed_code_kernel_on_the_cfg5_miniature_and_what_it_declines(monkeypatch):
+    """BASELINE configs[4] in miniature (24 numeric + 8 categorical columns, 320 trees grown by the rmse loop: the fixture's case), a
+    large batch through the default dispatch; 330 numeric features need 165 words > the bank: declined, older kernels as before."""
+    case = next(c for c in K.CASES if c["name"] == "obl_l2_u_cfg5mini")
+    m, _ = _grow(case)
+    Xn, Cn = _cat_batch(case, 40000, seed=9)
+    outs = {}
+    for mode, env in (("packed", {"GBRL_HIP_PREDICT_REG_ONLY": "1"}), ("gen2", {"GBRL_HIP_PREDICT_NO_PC": "1"}), ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"})):
+        _set(monkeypatch, env)
+        outs[mode] = [np.asarray(m.predict(Xn, Cn, a, b)) for a, b in ((0, 0), (17, 300), (0, 33))]
+    for mode in ("packed", "gen2"):
+        for a, b in zip(outs[mode], outs["generic"]):
+            assert np.array_equal(a, b), mode
+    wide = dict(name="pcw", seed=5, N=1200, F=330, Fc=0, D=2, depth=4, n_bins=16, score="L2", gen="Uniform", policy="oblivious", trees=5)
     _set(monkeypatch, {})
-    mo, _ = _grow(odd)
-    Xo = _batch(odd, 40000, seed=2)
+    mw, _ = _grow(wide)
+    Xw = _batch(wide, 33000, seed=3)
+    _set(monkeypatch, {"GBRL_HIP_PREDICT_GENERIC": "1"})
+    ref = np.asarray(mw.predict(Xw, None, 0, 0))
     _set(monkeypatch, {"GBRL_HIP_PREDICT_REG_ONLY": "1"})
     with pytest.raises(RuntimeError, match="REG_ONLY"):
-        mo.predict(Xo, None, 0, 0)
+        mw.predict(Xw, None, 0, 0)
     _set(monkeypatch, {})
-    a = np.asarray(mo.predict(Xo, None, 0, 0))
-    _set(monkeypatch, {"GBRL_HIP_PREDICT_GENERIC": "1"})
-    assert np.array_equal(a, np.asarray(mo.predict(Xo, None, 0, 0)))
+    assert np.array_equal(np.asarray(mw.predict(Xw, None, 0, 0)), ref)
