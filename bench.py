@@ -133,11 +133,16 @@ def launch_ranks(n):
 
 # ---- predict roofline -------------------------------------------------------------------------------------------------
 # Small ensembles are HBM-bound: N*(F + D)*4 bytes + model per call.  Large ensembles are bound by instruction
-# issue: per (64 rows, depth-6 tree, 8 outputs) the traversal needs at least 6 feature reads + 6 compares + 6 index updates and, for
-# the 4 output pairs, 4 offset extractions + 4 value reads + 4 packed FMAs: 30 VALU instructions (4 cycles each on a SIMD-32 for
-# the compare / carry / packed forms, 4 SIMDs per CU) and 10 LDS reads (2 cycles each per CU).  VALU issue: 30 * 4 / 4 = 30 cycles per
-# CU per (64 rows, tree) -> 256 CUs * 2.4e9 / 30 * 64 = 1.31e12 row-trees/s; LDS: 20 cycles -> 1.97e12.  The VALU figure is the bound.
+# issue.  Two bounds are reported:
+#   "issue" (rounds 2-3, kept so that records stay comparable): a traversal that reads features from an LDS tile needs, per (64 rows,
+#       depth-6 tree, 8 outputs), 6 feature reads + 6 compares + 6 index updates and, for the 4 output pairs, 4 offset extractions +
+#       4 value reads + 4 packed FMAs: 30 VALU instructions (4 cycles each on a SIMD-32 for the compare / carry / packed forms, 4 SIMDs
+#       per CU) and 10 LDS reads -> 30 cycles per CU -> 256 CUs * 2.4e9 / 30 * 64 = 1.31e12 row-trees/s.
+#   "issue_reg" (round 4): the register-tile kernel (predict_reg.hip) keeps the row in VGPRs -- 6 VGPR-relative compares + 6 add-with-
+#       carry + 1 address + 4 packed FMAs = 17 VALU, 4 LDS value reads, 6 scalar M0 writes: 17 cycles per CU by the same accounting ->
+#       2.31e12 row-trees/s.  This is the bound of the formulation that ships.
 PREDICT_ISSUE_BOUND = 256 * 2.4e9 / 30.0 * 64.0
+PREDICT_ISSUE_BOUND_REG = 256 * 2.4e9 / 17.0 * 64.0
 
 
 def predict_roofline(n_rows, n_feat, out_dim, trees, depth, seconds):
@@ -147,7 +152,124 @@ def predict_roofline(n_rows, n_feat, out_dim, trees, depth, seconds):
     return {"hbm": {"bound": "hbm", "achieved": alg / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / seconds / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_call": alg},
             "issue": {"bound": "valu-issue", "achieved": rt, "peak": PREDICT_ISSUE_BOUND, "unit": "row-trees/s", "frac": rt / PREDICT_ISSUE_BOUND,
-                      "note": "30 VALU (4 clk) + 10 LDS (2 clk) instructions per (64 rows, depth-6 tree, 8 outputs); see bench.py / DESIGN.md section 5"}}
+                      "note": "LDS-tile formulation (rounds 2-3): 30 VALU (4 clk) + 10 LDS (2 clk) instructions per (64 rows, depth-6 tree, 8 outputs); see bench.py / DESIGN.md section 5"},
+            "issue_reg": {"bound": "valu-issue", "achieved": rt, "peak": PREDICT_ISSUE_BOUND_REG, "unit": "row-trees/s", "frac": rt / PREDICT_ISSUE_BOUND_REG,
+                          "note": "register-tile formulation (round 4): 17 VALU + 4 LDS reads + 6 scalar M0 writes per (64 rows, depth-6 tree, 8 outputs)"}}
+
+
+class _QuietStdout:
+    """The reference's load() prints a banner with printf: keep it out of this script's one-line stdout."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)
+        os.close(null)
+    def __exit__(self, *a):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def cpu_predict_baseline(np, model_path, n_feat, rows, budget_s=8.0):
+    """The reference's own predict_cpu (predictor.cpp:122-265) on this host: the ensemble the bench grew, written by the product as a
+    .gbrl_model file and loaded by oracle/_ref (the file format is the reference's), `rows` synthetic rows; repeated while the leg
+    stays within `budget_s`."""
+    import oracle
+    mod = oracle.load_ref()
+    if mod is None:
+        return {"error": "oracle/_ref not built"}
+    with _QuietStdout():
+        ref = mod.GBRL.load(model_path)
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((rows, n_feat)).astype(np.float32)
+    ref.predict(X, None, 0, 0)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        ref.predict(X, None, 0, 0)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 20:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    trees = int(ref.get_num_trees())
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"rows_per_s": rows / dt, "row_trees_per_s": rows * trees / dt, "trees": trees, "rows": rows, "seconds_per_call": dt, "calls": reps, "cores": cores,
+            "kind": "reference", "what": "Predictor::predict_cpu of oracle/_ref on the model file the product saved"}
+
+
+def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
+    """BASELINE configs[0], the reference's own CPU-runnable case (tests/test_gbt_single.py:46-61): single-output MultiRMSE loop --
+    predict, gradient = prediction - target, step -- 4096 rows x 16 features, greedy / L2 / quantile, depth 4, 30 trees.  The product
+    on the GPU (device tensors in, DLPack out) and the REFERENCE's CPU path (oracle/_ref) on this box's host cores at full size, same
+    inputs; the final predictions are compared (1e-5 of the target's scale: the two grow the same trees unless a float32 near-tie
+    intervenes, tests/neartie.py)."""
+    import oracle
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    x0 = np.clip(X[:, 0], -2, 2)
+    y = (x0 - x0 ** 3 / 6.0 + 0.1 * rng.standard_normal(N)).astype(np.float32).reshape(N, 1)
+    kw = dict(input_dim=F, output_dim=1, policy_dim=1, max_depth=depth, min_data_in_leaf=0, n_bins=B, par_th=10, cv_beta=0.9, split_score_func="L2",
+              generator_type="Quantile", use_control_variates=False, batch_size=5000, grow_policy="greedy", verbose=0, learner_name="bench_cfg1")
+
+    def setup(m):
+        m.set_feature_weights(np.ones(F, np.float32))
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=1)
+        m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+        m.set_bias(np.array([float(y.mean())], np.float32))
+    out = {"workload": "BASELINE configs[0]: single-output MultiRMSE loop, %d rows x %d features, greedy / L2 / quantile, depth %d, %d trees" % (N, F, depth, trees)}
+    # product
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    best = None
+    for rep in range(3):   # (the first pass pays allocations and code loading)
+        m = gbrl_amd.GBRL(device="cuda", **kw)
+        setup(m)
+        torch.cuda.synchronize()
+        t_pred = t_step = 0.0
+        t0 = time.perf_counter()
+        for _ in range(trees):
+            ta = time.perf_counter()
+            pred = torch.from_dlpack(m.predict(tup(Xd), None, 0, 0)).reshape(N, 1)
+            g = (pred - yd).contiguous()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            m.step(tup(Xd), None, tup(g))
+            tc = time.perf_counter()
+            t_pred += tb - ta
+            t_step += tc - tb
+        loop = time.perf_counter() - t0
+        if best is None or loop < best[0]:
+            best = (loop, t_pred, t_step)
+        final = torch.from_dlpack(m.predict(tup(Xd), None, 0, 0)).cpu().numpy().reshape(N, 1)
+    out["product"] = {"ms_per_iteration": best[0] / trees * 1e3, "ms_per_step": best[2] / trees * 1e3, "ms_per_predict_and_gradient": best[1] / trees * 1e3,
+                      "trees_per_s": trees / best[0], "rmse": float(np.sqrt(np.mean((final - y) ** 2)))}
+    # the reference's CPU path at full size on this host
+    mod = oracle.load_ref()
+    if mod is None:
+        out["cpu_reference"] = {"error": "oracle/_ref not built"}
+        return out
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cbest = None
+    for rep in range(2):
+        r = mod.GBRL(device="cpu", **kw)
+        setup(r)
+        t_step = 0.0
+        t0 = time.perf_counter()
+        for _ in range(trees):
+            pred = np.asarray(r.predict(X, None, 0, 0)).reshape(N, 1)
+            g = np.ascontiguousarray((pred - y).astype(np.float32))
+            tb = time.perf_counter()
+            r.step(X, None, g)
+            t_step += time.perf_counter() - tb
+        loop = time.perf_counter() - t0
+        if cbest is None or loop < cbest[0]:
+            cbest = (loop, t_step)
+        rfinal = np.asarray(r.predict(X, None, 0, 0)).reshape(N, 1)
+    out["cpu_reference"] = {"ms_per_iteration": cbest[0] / trees * 1e3, "ms_per_step": cbest[1] / trees * 1e3, "trees_per_s": trees / cbest[0], "cores": cores,
+                            "kind": "reference", "rmse": float(np.sqrt(np.mean((rfinal - y) ** 2))), "note": "Fitter::step_cpu + Predictor::predict_cpu of oracle/_ref, full size, no extrapolation"}
+    out["speedup_per_iteration"] = cbest[0] / best[0]
+    out["max_abs_prediction_difference"] = float(np.max(np.abs(final - rfinal)))
+    return out
 
 
 def make_model(gbrl_amd, np, kind, F, Fc, D, depth, B, name):
@@ -449,6 +571,12 @@ def main():
     torch.cuda.synchronize()
     dtp = (time.perf_counter() - t1) / reps
     pk = m.last_phase_times().get("predict", 0.0)
+    model_files = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import tempfile
+        tmpdir = tempfile.mkdtemp(prefix="gbrl_bench_")
+        model_files["small"] = os.path.join(tmpdir, "small.gbrl_model")
+        m.save(model_files["small"])
 
     # predict over a large ensemble: extra trees grown with the same full-size step(), outside every timed region above
     large = None
@@ -482,6 +610,9 @@ def main():
             dts = time_predict(torch, m, xr, None, 20)
             small[str(rows)] = {"ms_per_call": dts * 1e3, "kernel_ms": m.last_phase_times().get("predict", 0.0), "row_trees_per_s": rows * T2 / dts}
         large["small_batches"] = small
+        if model_files:
+            model_files["large"] = os.path.join(os.path.dirname(model_files["small"]), "large.gbrl_model")
+            m.save(model_files["large"])
 
     extra = {}
     if world == 1 and not args.no_extra_legs and not args.force_collective:
@@ -498,6 +629,10 @@ def main():
             extra["predict_cfg5"] = leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, args.cfg5_trees)
         except Exception as e:
             extra["predict_cfg5"] = {"error": repr(e)}
+        try:
+            extra["cfg1"] = leg_cfg1(torch, np, gbrl_amd, dev)
+        except Exception as e:
+            extra["cfg1"] = {"error": repr(e)}
 
     if rank == 0:
         steps = args.steps
@@ -535,7 +670,7 @@ def main():
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
                         "row_trees_per_s": world * N * n_trees / dtp, "roofline": predict_roofline(N, F, D, n_trees, depth, dtp)},
             "predict_large_ensemble": large,
-            "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"),
+            "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"), "cfg1": extra.get("cfg1"),
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
             "collective": ({"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)} if coll is not None else None),
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,
@@ -553,6 +688,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(F, D, depth, B, 1 << 20, args.cpu_sample_rows)
             except Exception as e:  # the baseline is reporting only; never let it hide the measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            try:   # the reference's predict_cpu on the ensembles the bench grew (rows/s on this host's cores)
+                import numpy as _np
+                if "small" in model_files:
+                    out["cpu_baseline"]["predict"] = cpu_predict_baseline(_np, model_files["small"], F, 1 << 18)
+                if "large" in model_files:
+                    out["cpu_baseline"]["predict_large_ensemble"] = cpu_predict_baseline(_np, model_files["large"], F, 1 << 16)
+            except Exception as e:
+                out["cpu_baseline"]["predict"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

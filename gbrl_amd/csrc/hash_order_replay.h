@@ -12,6 +12,9 @@
 
 #include <cstddef>
 #include <unordered_map>
+#if !defined(__GLIBCXX__)
+#error "hash_order_replay.h restates libstdc++'s unordered_map insertion (bits/hashtable.h); build the product with libstdc++, the reference's standard library"
+#endif
 #include <utility>
 #include <vector>
 

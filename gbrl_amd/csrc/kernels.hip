@@ -354,7 +354,18 @@ struct RowAtomics<DT, DT> {
 // gradients (32 contiguous bytes per row for D = 8) and the D values are handed to all 16 lanes with row_newbcast moves,
 // instead of every lane loading all D values (which made the vector-memory path, not the LDS atomics, the bottleneck).
 // Every row-slot keeps U rows in flight: all loads of the U rows are issued before the first atomic.
-template <int DT, int U, bool PIPE>
+// `Ld`: how a lane fetches its row's class code and gradient word (the product's loads below; the stand-alone harness
+// scripts/hist_bench.hip instantiates the kernel with experiment loaders of its own).
+struct HistLoads {
+    static __device__ __forceinline__ int code(const char *cgroup, uint32_t row, uint32_t coff) {
+        return *reinterpret_cast<const uint16_t *>(cgroup + (row * (kCodeGroup * 2u) + coff));
+    }
+    template <int DT>
+    static __device__ __forceinline__ int grad(const char *qbase, uint32_t row, uint32_t qoff) {
+        return *reinterpret_cast<const int32_t *>(qbase + (row * static_cast<uint32_t>(DT * 4) + qoff));
+    }
+};
+template <int DT, int U, bool PIPE, class Ld = HistLoads>
 __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
                                                               const int32_t *__restrict__ qg, int D_rt,
                                                               const int32_t *__restrict__ rows,
@@ -396,24 +407,8 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const char *cgroup = reinterpret_cast<const char *>(codes + static_cast<size_t>(g) * n_rows * kCodeGroup);   // FG == 16: group g
     const char *qbase = reinterpret_cast<const char *>(qg);
     const uint32_t coff = static_cast<uint32_t>(fl) * 2u, qoff = static_cast<uint32_t>(qlane) * 4u;
-    auto ld_code = [&](int row) -> int {
-#ifdef GBRL_HIST_EXP_NOLOAD
-        return static_cast<int>((static_cast<uint32_t>(row) * 2654435761u + coff * 40503u) >> 24);
-#endif
-#ifdef GBRL_HIST_EXP_NT_CODES
-        return __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(cgroup + (static_cast<uint32_t>(row) * (kCodeGroup * 2u) + coff)));
-#endif
-        return *reinterpret_cast<const uint16_t *>(cgroup + (static_cast<uint32_t>(row) * (kCodeGroup * 2u) + coff));
-    };
-    auto ld_q = [&](int row) -> int {
-#ifdef GBRL_HIST_EXP_NOLOAD
-        return row + static_cast<int>(qoff);
-#endif
-#ifdef GBRL_HIST_EXP_Q16
-        return *reinterpret_cast<const int16_t *>(qbase + (static_cast<uint32_t>(row) * static_cast<uint32_t>(DT * 2) + (qoff >> 1)));
-#endif
-        return *reinterpret_cast<const int32_t *>(qbase + (static_cast<uint32_t>(row) * static_cast<uint32_t>(DT * 4) + qoff));
-    };
+    auto ld_code = [&](int row) -> int { return Ld::code(cgroup, static_cast<uint32_t>(row), coff); };
+    auto ld_q = [&](int row) -> int { return Ld::template grad<DT>(qbase, static_cast<uint32_t>(row), qoff); };
     int p0 = slot;
     if (DT && PIPE) {
         // Software-pipelined main loop (three stages, U rows per slot and stage): while the 9U atomics of iteration i occupy the

@@ -576,10 +576,21 @@ int transpose_keys_count(const float *obs, int n, int F, uint32_t *kt, uint32_t 
         (reinterpret_cast<uintptr_t>(kt) & 15))
         return 0;
     const size_t lds = sizeof(uint32_t) * (16 * (kBins1 / 2) + kTcWaves * 16 * kTcPatch);
+    // The kernel needs 148 KiB of dynamic LDS.  A device that refuses the opt-in (or the launch) is remembered: 0 = "nothing was
+    // done", the caller falls back to transpose_keys + a separate first counting pass.
     static PerDeviceOnce attr;
-    if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_transpose_count), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    static uint64_t unsupported = 0;   // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0;
+    if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_transpose_count), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+        (void)hipGetLastError();
+        unsupported |= bit;
+    }
+    if (unsupported & bit) return 0;
     hipLaunchKernelGGL(k_transpose_count, dim3(chunks, (F + 15) / 16), dim3(kTcThreads), lds, s, obs, n, F, kt,
                        reinterpret_cast<uint16_t *>(partial), chunks);
+    if (hipGetLastError() != hipSuccess) { unsupported |= bit; return 0; }
     return chunks;
 }
 

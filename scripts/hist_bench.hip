@@ -1,6 +1,36 @@
-// Stand-alone timing harness for k_hist_build (includes the kernel source directly so variants can be tried with -D flags).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gbrl_amd/csrc scripts/hist_bench.hip -o scripts/bin/hist_bench
+// Stand-alone timing harness for k_hist_build (includes the kernel source directly).  The experiment variants of rounds 2-3 live
+// HERE, as loader policies handed to the kernel's `Ld` template parameter (-DVARIANT=n), not in the product source:
+//   0 (default) the product's launch;  1 no loads at all (class code and gradient from register arithmetic: the bare atomic loop);
+//   2 non-temporal class-code loads;  3 16-bit gradient records (the harness then reads the int32 array as int16 pairs: timing only)
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gbrl_amd/csrc [-DVARIANT=n] scripts/hist_bench.hip -o scripts/bin/hist_bench
 #include "../gbrl_amd/csrc/kernels.hip"
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+namespace gbrl { namespace kern {
+struct ExpNoLoad {
+    static __device__ __forceinline__ int code(const char *, uint32_t row, uint32_t coff) { return static_cast<int>((row * 2654435761u + coff * 40503u) >> 24); }
+    template <int DT> static __device__ __forceinline__ int grad(const char *, uint32_t row, uint32_t qoff) { return static_cast<int>(row + qoff); }
+};
+struct ExpNtCodes : HistLoads {
+    static __device__ __forceinline__ int code(const char *cgroup, uint32_t row, uint32_t coff) {
+        return __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(cgroup + (row * (kCodeGroup * 2u) + coff)));
+    }
+};
+struct ExpQ16 : HistLoads {
+    template <int DT> static __device__ __forceinline__ int grad(const char *qbase, uint32_t row, uint32_t qoff) {
+        return *reinterpret_cast<const int16_t *>(qbase + (row * static_cast<uint32_t>(DT * 2) + (qoff >> 1)));
+    }
+};
+template <class Ld>
+static void launch_variant(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, int n_groups,
+                           int NB, int32_t *partials) {
+    auto k = k_hist_build<8, 8, true, Ld>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = static_cast<size_t>(NB) * (D + 1) * 16 * sizeof(int32_t);
+    hipLaunchKernelGGL(k, dim3(8 * n_groups * ((n_chunks + 7) / 8)), dim3(kHistThreads), lds, 0, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, 16, 4, NB, partials);
+}
+}}
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -32,7 +62,15 @@ int main(int argc, char **argv) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(a));
+#if VARIANT == 0
         hist_build(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, FG, NB, dp, 0);
+#elif VARIANT == 1
+        launch_variant<ExpNoLoad>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
+#elif VARIANT == 2
+        launch_variant<ExpNtCodes>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
+#else
+        launch_variant<ExpQ16>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
+#endif
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         const double atomics = double(M) * F * (D + 1);

@@ -280,3 +280,47 @@ def test_candidate_order_replay_equals_the_libstdcxx_container(tmp_path):
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr
+
+
+def test_register_tile_asm_header_is_current_and_the_compiler_keeps_out_of_the_bank(tmp_path):
+    """predict_reg.hip keeps a row tile in a bank of VGPRs that the compiler must never allocate (amdgpu_num_vgpr caps it below the
+    bank; the bank is only named in clobber lists).  (1) The generated assembly text is the generator's current output.  (2) Audit of
+    the gfx950 ISA (hipcc cross-compiles here): outside the inline-assembly statements no instruction of the register-tile kernels
+    touches a register at or above the bank's base, nothing spills (no scratch), and every kernel fits two waves per SIMD."""
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "scripts", "gen_predict_reg_asm.py")
+    out = subprocess.run([sys.executable, gen, "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    hdr = open(os.path.join(ROOT, "gbrl_amd", "csrc", "predict_reg_asm.h")).read()
+    base = {"k_predict_reg": int(re.search(r"#define PR_TILE_BASE (\d+)", hdr).group(1)), "k_predict_pc": int(re.search(r"#define PC_TILE_BASE (\d+)", hdr).group(1))}
+    asm = tmp_path / "predict_reg.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "gbrl_amd", "csrc", "predict_reg.hip"), "-o", str(asm)], check=True, capture_output=True)
+    cur, in_asm, top, seen = None, False, {}, {}
+    for line in asm.read_text().split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+            top[cur] = -1
+        if "ASMSTART" in line:
+            in_asm = True
+            continue
+        if "ASMEND" in line:
+            in_asm = False
+            continue
+        m = re.match(r"^; (NumVgprs|ScratchSize|Occupancy): (\d+)", line)
+        if m and cur is not None:
+            seen.setdefault(cur, {})[m.group(1)] = int(m.group(2))
+        s = line.strip()
+        if in_asm or cur is None or not s or s[0] in ";.":
+            continue
+        for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", s):
+            top[cur] = max(top[cur], int(m.group(1)) if m.group(1) else int(m.group(3)))
+    kernels = [k for k in top if "k_predict_reg" in k or "k_predict_pc" in k]
+    assert len(kernels) == 16, kernels
+    for k in kernels:
+        limit = base["k_predict_pc"] if "k_predict_pc" in k else base["k_predict_reg"]
+        assert 0 <= top[k] < limit, (k, top[k], limit)
+        assert seen[k]["ScratchSize"] == 0 and seen[k]["NumVgprs"] <= 256 and seen[k]["Occupancy"] >= 2, (k, seen[k])
