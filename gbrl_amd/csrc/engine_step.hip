@@ -759,8 +759,9 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 // exchange as floats (max / min are exact)
                 float *tmp = static_cast<float *>(d_trial_.ensure(sizeof(float) * 2 * F));
                 kern::keys_to_floats(d_mm, tmp, 2 * static_cast<size_t>(F), s);
-                exchange(Red::MinF32, tmp, F);
-                exchange(Red::MaxF32, tmp + F, F);
+                kern::negate_f32(tmp, F, s);                 // min = -max(-x): minima and maxima in ONE max all-reduce
+                exchange(Red::MaxF32, tmp, 2 * static_cast<size_t>(F));
+                kern::negate_f32(tmp, F, s);
                 kern::floats_to_keys(tmp, d_mm, 2 * static_cast<size_t>(F), s);
             }
             kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s);
@@ -1604,13 +1605,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // sums (fp64) and take the maxima (fp32, exact) over ranks between the kernels; the arithmetic stays on the device,
         // so one GPU and N GPUs execute the same instructions on the same global sums.
         double *d_stat2 = d_stat + 2 * D;
-        float *d_maxf = static_cast<float *>(d_maxbits_.ensure(sizeof(float) * D));
+        // one message per statistics round: the sums and every rank's maxima (gathered through the sum, kern::stats_pack)
+        double *d_smsg = has_coll_ ? static_cast<double *>(d_maxbits_.ensure(sizeof(double) * static_cast<size_t>(D) * (world + 1))) : nullptr;
         auto exchange_stats = [&](double *st) {
             if (!has_coll_) return;
-            kern::f64_to_f32(st + D, d_maxf, D, s);
-            exchange(Red::SumF64, st, D);
-            exchange(Red::MaxF32, d_maxf, D);
-            kern::f32_to_f64(d_maxf, st + D, D, s);
+            kern::stats_pack(st, D, world, coll_.rank, d_smsg, s);
+            exchange(Red::SumF64, d_smsg, static_cast<size_t>(D) * (world + 1));
+            kern::stats_unpack(d_smsg, D, world, st, s);
         };
         kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
         exchange_stats(d_stat);

@@ -95,6 +95,10 @@ void qsel_update(uint32_t *prefix, uint32_t *trial, const int64_t *counts, const
 void sub_arrays(const float *a, const float *b, float *out, size_t n, hipStream_t s);
 void gather_rows(const float *src, const int32_t *perm, float *dst, int n, int width, hipStream_t s);
 void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
+// row-sharded statistics: [D sums | P x D maxima, one row per rank] summed over ranks = sums + gathered maxima (kernels.hip)
+void stats_pack(const double *st, int D, int P, int rank, double *msg, hipStream_t s);
+void stats_unpack(const double *msg, int D, int P, double *st, hipStream_t s);
+void negate_f32(float *p, int n, hipStream_t s);
 void f32_to_f64(const float *in, double *out, int n, hipStream_t s);
 void keys_to_floats(uint32_t *keys /*NaN-range keys are raised to -inf's key in place*/, float *out, size_t n, hipStream_t s);
 void floats_to_keys(const float *in, uint32_t *keys, size_t n, hipStream_t s);

@@ -1404,6 +1404,34 @@ __global__ void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = static_cast<double>(in[i]);
 }
+// Row-sharded statistics in ONE sum all-reduce: msg = [D column sums | P rows of D maxima, one per rank].  A rank writes its maxima
+// into its own row and zeros into the others, so the SUM over ranks is a gather (x + 0 = x exactly; maxima are >= 0), and the maximum
+// over the P rows is taken locally afterwards.  Replaces a sum all-reduce + a max all-reduce (and two conversion launches).
+__global__ void k_stats_pack(const double *__restrict__ st /*[2D] sums | maxima*/, int D, int P, int rank, double *__restrict__ msg /*[D + P D]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) msg[i] = st[i];
+    if (i < P * D) msg[D + i] = (i / D == rank) ? st[D + i % D] : 0.0;
+}
+__global__ void k_stats_unpack(const double *__restrict__ msg, int D, int P, double *__restrict__ st) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    st[d] = msg[d];
+    double m = 0.0;
+    for (int r = 0; r < P; ++r) m = fmax(m, msg[D + r * D + d]);
+    st[D + d] = m;
+}
+void stats_pack(const double *st, int D, int P, int rank, double *msg, hipStream_t s) {
+    hipLaunchKernelGGL(k_stats_pack, dim3((std::max(1, P) * D + D + 255) / 256), dim3(256), 0, s, st, D, P, rank, msg);
+}
+void stats_unpack(const double *msg, int D, int P, double *st, hipStream_t s) {
+    hipLaunchKernelGGL(k_stats_unpack, dim3((D + 255) / 256), dim3(256), 0, s, msg, D, P, st);
+}
+// -x for the first n floats (min over ranks = -max(-x): the column minima and maxima of uniform candidates travel in ONE max all-reduce)
+__global__ void k_negate_f32(float *__restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = -p[i];
+}
+void negate_f32(float *p, int n, hipStream_t s) { hipLaunchKernelGGL(k_negate_f32, dim3((n + 255) / 256), dim3(256), 0, s, p, n); }
 void f64_to_f32(const double *in, float *out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_f64_to_f32, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
 }
