@@ -119,7 +119,7 @@ class Engine {
     void sharded_categorical_ranking(const char *hcat, const float *hgrads, int N, int Fc, int D, int B, std::vector<detail::CatCandidate> &cat_cands,
                                      std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes);
     void numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
-                            uint32_t *d_thrkeys, int pass1_chunks = 0);
+                            uint32_t *d_thrkeys, int pass1_chunks = 0, uint16_t *d_codes_out = nullptr, bool *codes_written = nullptr);
     void phase_begin(bool key = false);
     void phase_end(const char *name, bool key = false);
     void phases_resolve();

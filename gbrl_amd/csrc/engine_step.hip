@@ -708,7 +708,8 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
 // exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
 // On return d_thr / d_thrkeys hold them on the device (the caller copies them to the host when it needs them there).
 void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
-                                uint32_t *d_thrkeys, int pass1_chunks) {
+                                uint32_t *d_thrkeys, int pass1_chunks, uint16_t *d_codes_out, bool *codes_written) {
+    if (codes_written) *codes_written = false;
     hipStream_t s = stream_;
     const gbrl_hip_metadata &md = model.meta;
     uint32_t *d_qflags = static_cast<uint32_t *>(d_qflags_.ensure(sizeof(uint32_t) * 4));  // [0,1] allocator, [2] overflow
@@ -783,7 +784,11 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && N <= kern::sort_quantiles_max_rows()) {
                 // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
                 int64_t *d_cum = upload_cum(cum);
-                kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, d_thr, s);
+                // (the sort kernel also writes the class codes of its feature: no separate binning launch)
+                static const bool no_fuse = [] { const char *e = std::getenv("GBRL_HIP_SORT_NO_CODES"); return e && e[0] == '1'; }();   // test / measurement hook
+                uint16_t *cdst = no_fuse ? nullptr : d_codes_out;
+                kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, d_thr, s, cdst);
+                if (cdst && codes_written) *codes_written = true;
                 floats_done = true;
                 last_quantile_fallback_ = false;
             } else if (!force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32)) {
@@ -1599,6 +1604,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     // the same for any sharding of the same rows.
     const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
     kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
+    bool stats_fused = false;
     {
         // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
         // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
@@ -1613,6 +1619,13 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             exchange(Red::SumF64, d_smsg, static_cast<size_t>(D) * (world + 1));
             kern::stats_unpack(d_smsg, D, world, st, s);
         };
+        // RL-sized batch on one GPU: statistics and quantisation in ONE launch with the same reduction tree (kern::small_stats)
+        static const bool no_small = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_STATS"); return e && e[0] == '1'; }();   // test / measurement hook
+        int32_t *d_qg_small = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
+        if (!has_coll_ && !no_small && n_global == N && kern::small_stats(dgrads, N, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg_small, s)) {
+            stats_fused = true;
+            if (!cosine) { d_mean = d_meanden; d_den = d_meanden + D; }
+        } else {
         kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
         exchange_stats(d_stat);
         if (!cosine) {
@@ -1625,9 +1638,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         } else {
             kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
         }
+        }
     }
     int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
-    kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
+    if (!stats_fused) kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
     phase_end("grad_stats");
 
     // ---- 2. split candidates ----------------------------------------------------------------------------------------
@@ -1655,7 +1669,15 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     }
     phase_end("transpose");
     phase_begin();
-    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks);
+    // class codes (group-major: [slot/16][row][slot%16], u16): allocated here because the RL-sized selection (one sort kernel per
+    // step) writes the numeric codes itself
+    const int n_slots_codes = F + Fc;
+    const int n_code_groups = (n_slots_codes + kern::kCodeGroup - 1) / kern::kCodeGroup;
+    const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
+    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
+    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
+    bool codes_from_sort = false;
+    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);
     phase_end("candidates");
 
     // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the
@@ -1800,11 +1822,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
 
     // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
     phase_begin();
-    const int n_code_groups = (n_slots + kern::kCodeGroup - 1) / kern::kCodeGroup;
-    const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
-    uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
-    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
-    if (F > 0) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
+    if (F > 0 && !codes_from_sort) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
     if (Fc > 0 && cat_codes_on_device) {
         kern::cat_step_codes(dcells, N, Fc, F, sdict_off_, sdict_hash_, sdict_cls_, sdict_words_, d_codes, s);
     } else if (Fc > 0) {

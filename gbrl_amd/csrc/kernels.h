@@ -77,6 +77,9 @@ int column_sums_blocks(int n, int D);
 void stats_mean(const double *stat /*[2D] sums | max*/, long long n, int D, float *meanden /*[2D] mean | denom*/, hipStream_t s);
 void stats_finish(const double *stat_raw /*[2D] sums | max|g|*/, const double *stat_centred /*nullable [2D] sum sq | max|g-mean|*/,
                   long long n, int D, int chunk_rows, float *meanden, StepScales *sc, hipStream_t s);
+// RL-sized batches on one GPU: the whole chain above + the quantisation in one launch, same bits (k_small_stats); false: not covered
+bool small_stats(const float *g, int n, int D, bool centred, int chunk_rows, double *stat /*[4D]*/, float *meanden /*[2D]*/, StepScales *sc, int32_t *qg,
+                 hipStream_t s);
 // qg = rint(((g - mean) / denom) * scale) as int32  (mean/denom nullable)
 void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const float *denom, const StepScales *sc,
                     int32_t *qg, hipStream_t s);
@@ -146,7 +149,7 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 // codes[(slot/16)*n*16 + row*16 + slot%16] (u16) = #{k : thr_key[f][k] < key(row, f)}
 // small batches: one LDS sort per column (n <= sort_quantiles_max_rows()); thr_keys[f][k] = key of 1-based rank cum[k]
 int sort_quantiles_max_rows();
-void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats /*the same thresholds as floats*/, hipStream_t s);
+void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats /*the same thresholds as floats*/, hipStream_t s, uint16_t *codes = nullptr /* also write the class codes (k_bin_cols' output) */);
 // radix_select.hip: exact order statistics by MSD radix counting (one GPU)
 size_t radix_state_bytes(int F, int B);
 size_t radix_partial_bytes(int F);

@@ -141,51 +141,89 @@ __device__ __forceinline__ float key_to_float_q(uint32_t k) {
     const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __uint_as_float(u);
 }
+// `codes` (nullable; round 4): the block also writes its feature's class codes -- codes[g][row][fl] = #{k : thr_key[f][k] < key(row, f)},
+// what k_bin_cols computes -- from the thresholds it has just selected (a binary search per row in LDS), so an RL-sized step needs no
+// separate binning launch.  The grid then covers the padding features of the last group of 16 too: their blocks write zeros.
 __global__ __launch_bounds__(1024) void k_sort_quantiles(const uint32_t *__restrict__ kt, int n, int S, const int64_t *__restrict__ cum, int B,
-                                                         uint32_t *__restrict__ thr_keys, float *__restrict__ thr_floats) {
-    extern __shared__ uint32_t s[];
+                                                         uint32_t *__restrict__ thr_keys, float *__restrict__ thr_floats, int F,
+                                                         uint16_t *__restrict__ codes) {
+    extern __shared__ uint32_t s[];   // [S] keys, then [B] selected thresholds
     const int f = blockIdx.x;
-    const uint32_t *col = kt + static_cast<size_t>(f) * n;
-    for (int i = threadIdx.x; i < S; i += blockDim.x) s[i] = i < n ? col[i] : 0xffffffffu;
-    __syncthreads();
-    // Bitonic sort with block-wide barriers only where a compare-exchange crosses waves: every wave owns an aligned chunk of
-    // C = S / waves elements, and the stages with distance j < C touch one chunk only -- they run wave-locally (LDS operations of
-    // a wave execute in order; a wave barrier keeps the compiler from reordering across stages).  S = 2048: 21 block barriers
-    // instead of 66 (the kernel was barrier-latency bound): 27 -> 18 us for 24 columns of 2048 keys.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = static_cast<int>(blockDim.x) >> 6;
-    const int C = S / n_waves;                       // power of two, >= 64
-    uint32_t *chunk = s + wave * C;
-    for (int k = 2; k <= S; k <<= 1) {
-        int j = k >> 1;
-        for (; j >= C; j >>= 1) {                    // pairs in different chunks: the whole block, one barrier per stage
-            for (int i = threadIdx.x; i < S; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = s[i], b = s[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-        for (; j > 0; j >>= 1) {                     // pairs inside the wave's chunk
-            for (int p = lane; p < C / 2; p += 64) {
-                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));     // element of the pair with bit j clear
-                const int hi = lo | j;
-                const uint32_t a = chunk[lo], b = chunk[hi];
-                const bool up = ((wave * C + lo) & k) == 0;
-                if ((a > b) == up) { chunk[lo] = b; chunk[hi] = a; }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();                             // the next k starts with pairs across chunks (or the ranks are read)
+    if (f >= F) {                     // padding feature of the last code group (codes != nullptr only)
+        uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[static_cast<size_t>(i) * kCodeGroup] = 0;
+        return;
     }
+    const uint32_t *col = kt + static_cast<size_t>(f) * n;
+    // Bitonic sort, four keys per thread (blockDim.x = S / 4, S >= 256): element i = 256 * wave + 4 * lane + r.  Compare-exchange
+    // distances 1 and 2 stay inside a thread's registers, 4 .. 128 are lane exchanges inside the wave (no LDS memory, no barrier), and
+    // only the distances >= 256 cross waves through LDS (10 of the 78 stages at S = 4096).  Round 3 kept every key in LDS and paid two
+    // dependent LDS round trips per stage: 31 us for 4096 keys, the largest kernel of an RL-sized step.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = wave * 256 + lane * 4;
+    uint32_t a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = base + r < n ? col[base + r] : 0xffffffffu;
+    for (int k = 2; k <= S; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 256) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[base + r] = a[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = base + r;
+                    const uint32_t other = s[i ^ j];
+                    const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+                    a[r] = take_min ? min(a[r], other) : max(a[r], other);
+                }
+                __syncthreads();
+            } else if (j >= 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = base + r;
+                    const uint32_t other = __shfl_xor(a[r], j >> 2, 64);
+                    const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+                    a[r] = take_min ? min(a[r], other) : max(a[r], other);
+                }
+            } else {
+                // (static register pairs: a dynamically indexed a[r | j] would be demoted to scratch)
+                auto cx = [&](uint32_t &x, uint32_t &y, int i) {
+                    const bool up = (i & k) == 0;
+                    const uint32_t lo = min(x, y), hi = max(x, y);
+                    x = up ? lo : hi;
+                    y = up ? hi : lo;
+                };
+                if (j == 2) { cx(a[0], a[2], base); cx(a[1], a[3], base + 1); }
+                else { cx(a[0], a[1], base); cx(a[2], a[3], base + 2); }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[base + r] = a[r];
+    __syncthreads();
     // keys and floats at once (what k_keys_to_floats does for the other selections: a key in the NaN range is raised to -inf's key)
+    uint32_t *thr_s = s + S;
     for (int k = threadIdx.x; k < B; k += blockDim.x) {
         uint32_t key = s[cum[k] - 1];
         if (key < 0x007fffffu) key = 0x007fffffu;
         thr_keys[static_cast<size_t>(f) * B + k] = key;
         thr_floats[static_cast<size_t>(f) * B + k] = key_to_float_q(key);
+        if (codes) thr_s[k] = key;
+    }
+    if (codes == nullptr) return;
+    __syncthreads();
+    int top = 1;
+    while (top <= B) top <<= 1;                      // 2^m > B: the descent can reach every count 0 .. B
+    uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t key = col[i];
+        int pos = 0;
+        for (int step = top >> 1; step > 0; step >>= 1) {
+            const int np = pos + step;
+            if (np <= B && thr_s[np - 1] < key) pos = np;   // thresholds are sorted: the predicate is monotone
+        }
+        dst[static_cast<size_t>(i) * kCodeGroup] = static_cast<uint16_t>(pos);
     }
 }
 
@@ -656,12 +694,13 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 }
 
 int sort_quantiles_max_rows() { return 4096; }   // beyond this the bitonic sort (O(n log^2 n) in one block per feature) loses to the radix passes
-void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats, hipStream_t s) {
-    int S = 64;
+void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats, hipStream_t s, uint16_t *codes) {
+    int S = 256;   // four keys per thread, whole waves: 256 keys per wave
     while (S < n) S <<= 1;
     static PerDeviceOnce attr;
     if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_quantiles), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }
-    hipLaunchKernelGGL(k_sort_quantiles, dim3(F), dim3(std::min(1024, S / 2 > 64 ? S / 2 : 64)), static_cast<size_t>(S) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys, thr_floats);
+    const int blocks = codes ? ((F + kCodeGroup - 1) / kCodeGroup) * kCodeGroup : F;   // with codes: the padding features of the last group too
+    hipLaunchKernelGGL(k_sort_quantiles, dim3(blocks), dim3(S / 4), (static_cast<size_t>(S) + B) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys, thr_floats, F, codes);
 }
 
 void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B, uint16_t *codes, hipStream_t s) {

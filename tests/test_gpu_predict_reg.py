@@ -39,7 +39,19 @@ def _batch(case, n, seed):
     rng = np.random.default_rng(seed)
     X, _, _, _ = K.make_inputs(case)
     idx = rng.integers(0, X.shape[0], size=n)
-    return np.ascontiguousarray(X[idx] + rng.standard_normal((n, X.shape[1])).astype(np.float32) * np.float32(0.05))
+    return _specials(rng, np.ascontiguousarray(X[idx] + rng.standard_normal((n, X.shape[1])).astype(np.float32) * np.float32(0.05)))
+
+
+def _specials(rng, X):
+    """one cell in forty is a value a threshold comparison must treat like the reference's `x > t`: NaN (never greater), +-inf, +-0,
+    and exact copies of other cells (ties with thresholds that are data values)"""
+    pick = rng.integers(0, 40, size=X.shape)
+    X[pick == 0] = np.float32(np.nan)
+    X[pick == 1] = np.float32(np.inf)
+    X[pick == 2] = np.float32(-np.inf)
+    X[pick == 3] = np.float32(0.0)
+    X[pick == 4] = np.float32(-0.0)
+    return X
 
 
 MODES = (("reg", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_ROWS": "1"}),
@@ -137,7 +149,7 @@ def _cat_batch(case, n, seed):
     rng = np.random.default_rng(seed)
     X, Xc, _, _ = K.make_inputs(case)
     idx = rng.integers(0, (X if X is not None else Xc).shape[0], size=n)
-    Xn = None if X is None else np.ascontiguousarray(X[idx] + rng.standard_normal((n, X.shape[1])).astype(np.float32) * np.float32(0.05))
+    Xn = None if X is None else _specials(rng, np.ascontiguousarray(X[idx] + rng.standard_normal((n, X.shape[1])).astype(np.float32) * np.float32(0.05)))
     Cn = None
     if Xc is not None:
         Cn = np.ascontiguousarray(Xc[idx])
