@@ -146,9 +146,9 @@ constexpr int kSmallStatsThreads = 1024;
 __global__ __launch_bounds__(kSmallStatsThreads) void k_small_stats(const float *__restrict__ g, int n, int D, int n_blocks, int bs, int centred /*L2: standardise*/,
                                                                     int chunk_rows, double *__restrict__ stat /*[4D]*/, float *__restrict__ meanden /*[2D]*/,
                                                                     StepScales *__restrict__ sc, int32_t *__restrict__ qg) {
-    extern __shared__ double sd[];                       // [V] sums, [V] maxima, then [n_blocks][2D] partials, then [4][256] tree rows
+    extern __shared__ double sd[];                       // [V] sums, [V] maxima, then [n_blocks][2D] partials
     const int V = n_blocks * bs;
-    double *vacc = sd, *vmax = sd + V, *part = sd + 2 * V, *tree = part + static_cast<size_t>(n_blocks) * 2 * D;
+    double *vacc = sd, *vmax = sd + V, *part = sd + 2 * V;
     __shared__ float s_center[16], s_den[16];
     __shared__ double s_stat[64];                        // the block's own copy of stat[4D] (D <= 16): no global round trip between phases
     const size_t n_el = static_cast<size_t>(n) * D;
@@ -191,27 +191,29 @@ __global__ __launch_bounds__(kSmallStatsThreads) void k_small_stats(const float 
             part[static_cast<size_t>(b) * 2 * D + D + d] = m;
         }
         __syncthreads();
-        // k_column_sums_final: output o (D sums, then D maxima): 256 threads fold the partials b = x, x + 256, ..., then the 128..1 tree
-        for (int o0 = 0; o0 < 2 * D; o0 += 4) {
-            const int o = o0 + (threadIdx.x >> 8), x = threadIdx.x & 255;
+        // k_column_sums_final, output o (D sums, then D maxima): its 256 threads fold the partials b = x, x + 256, ... (here n_blocks <= 32:
+        // one term, 0.0 + partial) and run the 128 .. 1 tree.  Entries x >= n_blocks are +0.0 and no folded sum is ever -0.0, so the
+        // stages 128, 64 and 32 add exact zeros: the tree is replayed from stage 16 on 32 entries, by one thread per output, in registers
+        // (a block-wide replay cost ten barriers per four outputs: 33 us for 8 outputs, more than the launches it saved).
+        if (threadIdx.x < 2 * D) {
+            const int o = threadIdx.x;
             const bool is_max = o >= D;
-            double *row = tree + (threadIdx.x >> 8) * 256;
-            if (o < 2 * D) {
-                double s2 = 0.0;
-                for (int b = x; b < n_blocks; b += 256) {
-                    const double v2 = part[static_cast<size_t>(b) * 2 * D + o];
-                    s2 = is_max ? fmax(s2, v2) : s2 + v2;
-                }
-                row[x] = s2;
+            double t[32];
+#pragma unroll
+            for (int x = 0; x < 32; ++x) {
+                const double v2 = x < n_blocks ? part[static_cast<size_t>(x) * 2 * D + o] : 0.0;
+                t[x] = is_max ? fmax(0.0, v2) : 0.0 + v2;
             }
-            __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if (o < 2 * D && x < w) row[x] = is_max ? fmax(row[x], row[x + w]) : row[x] + row[x + w];
-                __syncthreads();
+#pragma unroll
+            for (int w = 16; w > 0; w >>= 1) {
+#pragma unroll
+                for (int x = 0; x < 16; ++x)
+                    if (x < w) t[x] = is_max ? fmax(t[x], t[x + w]) : t[x] + t[x + w];
             }
-            if (o < 2 * D && x == 0) { out[o] = row[0]; s_stat[(out - stat) + o] = row[0]; }
-            __syncthreads();
+            out[o] = t[0];
+            s_stat[(out - stat) + o] = t[0];
         }
+        __syncthreads();
     };
     sums(false, stat);
     __syncthreads();
@@ -1513,8 +1515,8 @@ void column_sums(const float *g, int n, int D, const float *center, double *bloc
 bool small_stats(const float *g, int n, int D, bool centred, int chunk_rows, double *stat, float *meanden, StepScales *sc, int32_t *qg, hipStream_t s) {
     const int n_blocks = column_sums_blocks(n, D);
     const int bs = D <= 256 ? (256 / D) * D : D;
-    if (D > 16 || n_blocks * bs > kSmallStatsVirtual || n < 2) return false;
-    const size_t lds = sizeof(double) * (2 * static_cast<size_t>(n_blocks) * bs + static_cast<size_t>(n_blocks) * 2 * D + 4 * 256);
+    if (D > 16 || n_blocks * bs > kSmallStatsVirtual || n_blocks > 32 || n < 2) return false;
+    const size_t lds = sizeof(double) * (2 * static_cast<size_t>(n_blocks) * bs + static_cast<size_t>(n_blocks) * 2 * D);
     static PerDeviceOnce attr;
     if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         (void)hipGetLastError();

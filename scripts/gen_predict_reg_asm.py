@@ -313,7 +313,7 @@ def generate():
     out.append("#define PR_CLOB_TILE \\\n    " + clob("v", TB, TB + NF))
     out.append("#define PR_ASM_LOAD_TILE \\\n" + cstr(load_tile()))
     out.append('#define PR_CLOB_LOAD_TILE "s26", "s27", "scc"')
-    for maxd, dmax in ((6, 8), (4, 8), (6, 4), (4, 4)):
+    for maxd, dmax in ((6, 8), (4, 8), (6, 4), (4, 4), (6, 16), (4, 16)):
         v = Variant(maxd, dmax)
         out.append(f"// ---- {maxd} levels, {dmax} padded outputs: {v.rec} bytes of values per tree, {v.step_bytes} bytes of records per step")
         out.append(f"#define PR_CLOB_TEMPS_{v.sfx} \\\n    " + clob("v", LA, v.v_end))
