@@ -32,9 +32,9 @@ def _grow(case, monkeypatch, env):
 @pytest.mark.parametrize("N", [2, 37, 256, 1000, 4096])
 @pytest.mark.parametrize("policy,score,gen,D,F,Fc", [("greedy", "L2", "Quantile", 1, 16, 0), ("oblivious", "L2", "Quantile", 8, 24, 0),
                                                     ("greedy", "Cosine", "Quantile", 3, 5, 2), ("oblivious", "Cosine", "Uniform", 16, 33, 0),
-                                                    ("oblivious", "L2", "Quantile", 5, 40, 3)])
+                                                    ("oblivious", "L2", "Quantile", 5, 40, 3), ("greedy", "L2", "Uniform", 8, 130, 1)])
 def test_fused_small_step_kernels_keep_every_bit(policy, score, gen, D, F, Fc, N, monkeypatch):
-    case = dict(name="ss", seed=40 + N + D, N=N, F=F, Fc=Fc, D=D, depth=4, n_bins=64, score=score, gen=gen, policy=policy, trees=4,
+    case = dict(name="ss", seed=40 + N + D, N=N, F=F, Fc=Fc, D=D, depth=5 if F > 100 else 4, n_bins=64, score=score, gen=gen, policy=policy, trees=4, min_data_in_leaf=2 if D == 3 else 0,
                 loop="rmse" if D == 1 else None)
     if case["loop"] is None:
         del case["loop"]
