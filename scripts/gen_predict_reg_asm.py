@@ -17,6 +17,7 @@ import argparse
 import os
 import sys
 
+PREFETCH_STEPS = int(os.environ.get("GBRL_GEN_PREFETCH_STEPS", "0"))   # experiment: touch the records this many steps ahead (0 = off)
 TB = 88            # first bank register
 NF = 128           # bank size
 LA, LB = 216, 217  # leaf registers
@@ -136,10 +137,12 @@ class Variant:
         L += ["s_sub_u32 %[n], %[n], 1", "s_waitcnt lgkmcnt(0)"]
         L += self.cmps(self.r0) + self.loads(self.r0, 2 * sb) + self.addcs() + self.dsreads()
         L += ["s_cmp_eq_u32 %[n], 0", "s_cbranch_scc1 3f", "1:"]
-        L += self.cmps(self.r1) + self.addcs() + ["s_waitcnt lgkmcnt(0)"] + self.loads(self.r1, 3 * sb) + self.fmas() + self.dsreads()
+        pf1 = [f"s_load_dword s100, s[26:27], {hex((3 + PREFETCH_STEPS) * sb)}"] if PREFETCH_STEPS else []
+        pf0 = [f"s_load_dword s100, s[26:27], {hex((2 + PREFETCH_STEPS) * sb)}"] if PREFETCH_STEPS else []
+        L += self.cmps(self.r1) + self.addcs() + ["s_waitcnt lgkmcnt(0)"] + self.loads(self.r1, 3 * sb) + pf1 + self.fmas() + self.dsreads()
         L += ["s_sub_u32 %[n], %[n], 1", "s_cmp_eq_u32 %[n], 0", "s_cbranch_scc1 3f"]
         L += self.cmps(self.r0) + self.addcs() + ["s_waitcnt lgkmcnt(0)", f"s_add_u32 s26, s26, {2 * sb}", "s_addc_u32 s27, s27, 0"]
-        L += self.loads(self.r0, 2 * sb) + self.fmas() + self.dsreads()
+        L += self.loads(self.r0, 2 * sb) + pf0 + self.fmas() + self.dsreads()
         L += ["s_sub_u32 %[n], %[n], 1", "s_cmp_lg_u32 %[n], 0", "s_cbranch_scc1 1b", "3:", "s_waitcnt lgkmcnt(0)"]
         L += self.fmas()
         return L
@@ -317,7 +320,7 @@ def generate():
         v = Variant(maxd, dmax)
         out.append(f"// ---- {maxd} levels, {dmax} padded outputs: {v.rec} bytes of values per tree, {v.step_bytes} bytes of records per step")
         out.append(f"#define PR_CLOB_TEMPS_{v.sfx} \\\n    " + clob("v", LA, v.v_end))
-        out.append(f"#define PR_CLOB_SGPR_{v.sfx} \\\n    " + clob("s", 26, v.s_end))
+        out.append(f"#define PR_CLOB_SGPR_{v.sfx} \\\n    " + clob("s", 26, max(v.s_end, 101 if PREFETCH_STEPS else 0)))
         out.append(f"#define PR_ASM_WALK_STEPS_{v.sfx} \\\n" + cstr(v.walk_steps()))
         out.append(f"#define PR_ASM_WALK_ONE_{v.sfx} \\\n" + cstr(v.walk_one()))
     out.append("// ==== packed-code variant (rows wider than the fp32 bank, categorical columns): see VariantPC in the generator")
@@ -339,8 +342,9 @@ def generate():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--out", default=None, help="write the header somewhere else (experiments: GBRL_GEN_PREFETCH_STEPS=n)")
     args = ap.parse_args()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gbrl_amd", "csrc", "predict_reg_asm.h")
+    path = args.out or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gbrl_amd", "csrc", "predict_reg_asm.h")
     text = generate()
     if args.check:
         cur = open(path).read() if os.path.exists(path) else ""
