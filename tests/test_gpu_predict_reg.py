@@ -219,3 +219,15 @@ def test_packed_code_kernel_on_the_cfg5_miniature_and_what_it_declines(monkeypat
         mw.predict(Xw, None, 0, 0)
     _set(monkeypatch, {})
     assert np.array_equal(np.asarray(mw.predict(Xw, None, 0, 0)), ref)
+
+
+def test_random_sweep_of_the_register_tile_kernels_has_no_mismatch():
+    """120 random ensembles / batches / tree ranges (scripts/predict_reg_sweep.py: 1-70 trees, depth 1-6, 1-16 outputs, up to 300 numeric
+    and 9 categorical columns, special float values, unseen categories): register-tile kernels == general kernel, byte for byte."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "predict_reg_sweep.py"), "120", "424242"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "0 mismatches" in out.stdout
