@@ -1,5 +1,6 @@
-"""Where do the microseconds of a predict() call go (28 trees, 2^20 x 128, D 8, depth 6, device inputs)?
-wall time per call with profiling off / on, and the kernel's own time."""
+"""Where do the microseconds of a predict() call go (T trees, 2^20 x 128 and 1024 x 128 rows, D 8, depth 6, device inputs)?
+wall time per call with profiling off / on, and the kernel's own time.
+    python scripts/predict_overhead_probe.py [trees]         (GBRL_HIP_PREDICT_SYNC=1: hipStreamSynchronize instead of the published flag)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,17 +18,16 @@ trees = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 for _ in range(trees):
     m.step(tup(X), None, tup(G))
 torch.cuda.synchronize()
-for waves in ("1", "2", "1", "2"):
-  os.environ["GBRL_HIP_PREDICT_REG_WAVES"] = waves
-  print("waves per SIMD", waves)
-  for prof in (0, 1):
-    m.set_profiling(prof)
-    for reps in (5, 50):
-        m.predict(tup(X), None, 0, 0); torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(reps):
-            p = m.predict(tup(X), None, 0, 0); del p
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / reps
-        print("  ", end="")
-        print("profiling %d reps %2d: %.2f us per call, kernel %.2f us" % (prof, reps, dt * 1e6, m.last_phase_times().get("predict", 0.0) * 1e3))
+print("GBRL_HIP_PREDICT_SYNC =", os.environ.get("GBRL_HIP_PREDICT_SYNC", "0"))
+for rows in (N, 1024):
+    xr = tup(X[:rows])
+    for prof in (0, 1):
+        m.set_profiling(prof)
+        for reps in (5, 50):
+            m.predict(xr, None, 0, 0); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                p = m.predict(xr, None, 0, 0); del p
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / reps
+            print("  rows %7d profiling %d reps %2d: %.2f us per call, kernel %.2f us" % (rows, prof, reps, dt * 1e6, m.last_phase_times().get("predict", 0.0) * 1e3))
