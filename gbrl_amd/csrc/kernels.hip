@@ -1022,6 +1022,23 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     const FeatureSlot sl = slots[fs];
     const int W = D + 1;
     int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
+    // the node's path conditions on THIS feature slot, staged once per block (a candidate that repeats one of them is rejected,
+    // node.cpp:154-166); reading the path arrays from global memory inside the candidate loop costs a memory round trip per
+    // path entry and thread at the deep levels.  The first wave reads one path entry per lane (kMaxPath <= 64) and the four loads
+    // are issued HERE, unconditionally (the arrays hold kMaxPath entries per node), so that they are in flight with the histogram
+    // loads below instead of three dependent round trips after the scan; they are consumed just before the loads' barrier.
+    __shared__ float s_pval[kMaxPath];
+    __shared__ int s_pbin[kMaxPath];
+    __shared__ int s_np;
+    static_assert(kMaxPath <= kWave, "one lane per path entry");
+    int q_len = 0, q_slot = -1, q_bin = 0;
+    float q_val = 0.0f;
+    if (threadIdx.x < kMaxPath) {
+        q_len = path_len[node];
+        q_slot = path_slot[node * kMaxPath + threadIdx.x];
+        q_val = path_val[node * kMaxPath + threadIdx.x];
+        q_bin = path_bin[node * kMaxPath + threadIdx.x];
+    }
     const int par = sub_par ? sub_par[node] : -1;
     if (par >= 0) {
         // sibling subtraction fused here: this node was not accumulated from the data; its histogram is parent - sibling (exact
@@ -1056,6 +1073,17 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int i = i0 + u * step; if (i < tot) sh64[i] = a[u]; }
         }
+    }
+    if (threadIdx.x < kWave) {
+        const int p = threadIdx.x;
+        const bool hit = p < kMaxPath && p < q_len && q_slot == fs;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int pos = __popcll(m & ((1ull << p) - 1));
+            s_pval[pos] = q_val;
+            s_pbin[pos] = q_bin;
+        }
+        if (p == 0) s_np = __popcll(m);
     }
     __syncthreads();
     // totals = sum over all classes; also turn numeric features into suffix sums in place.  Block-wide scan: thread t of a
@@ -1131,26 +1159,6 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     // root parent = 0, lowest reference index among maxima)
     const float par_sub = (part_v && is_root[node]) ? 0.0f : par_score;
     Best mine{-INFINITY, 0x7fffffff};
-    // the node's path conditions on THIS feature slot, staged once per block (a candidate that repeats one of them is rejected,
-    // node.cpp:154-166); reading the path arrays from global memory inside the candidate loop costs a memory round trip per
-    // path entry and thread at the deep levels
-    __shared__ float s_pval[kMaxPath];
-    __shared__ int s_pbin[kMaxPath];
-    __shared__ int s_np;
-    if (threadIdx.x < kWave) {   // the first wave, one path entry per lane (kMaxPath <= 64): all loads in flight together, not one round trip per entry
-        static_assert(kMaxPath <= kWave, "one lane per path entry");
-        const int plen = path_len[node];
-        const int p = threadIdx.x;
-        const bool hit = p < plen && path_slot[node * kMaxPath + p] == fs;
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const int pos = __popcll(m & ((1ull << p) - 1));
-            s_pval[pos] = path_val[node * kMaxPath + p];
-            s_pbin[pos] = path_bin[node * kMaxPath + p];
-        }
-        if (p == 0) s_np = __popcll(m);
-    }
-    __syncthreads();
     const int np = s_np;
     for (int k = threadIdx.x; k < sl.n_cand; k += blockDim.x) {
         const int64_t *R = sh64 + (k + 1) * W;
