@@ -115,7 +115,7 @@ class Engine {
     void grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
                    double &leaf_scale);
     bool device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
-                                       std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes);
+                                       std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes, bool launch_only = false);
     void sharded_categorical_ranking(const char *hcat, const float *hgrads, int N, int Fc, int D, int B, std::vector<detail::CatCandidate> &cat_cands,
                                      std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes);
     void numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
@@ -152,6 +152,7 @@ class Engine {
     bool in_fit_ = false;   // predict() called from fit(): keep one accumulation chain per row in tree order (no tree-range split)
     std::vector<std::pair<std::string, float>> phases_;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_;
+    bool cat_launched_ = false;       // device_categorical_candidates(launch_only) has enqueued the first round of the scan
     hipEvent_t ev_level_ = nullptr;   // marks the per-level result read-back (GBRL_HIP_EVENT_RESULTS=1: the copy-engine path)
     // Per-step constants of numeric-only steps (feature slots, candidate weights / reference order / slot lookup): they depend on
     // (F, n_bins, growth policy, feature weights, feature mapping) only, so they are built and uploaded once and reused while those
@@ -222,14 +223,19 @@ class Engine {
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
-    DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lslot_, d_sdict_, d_cat_xchg_;
+    DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lslot_, d_sdict_, d_cat_xchg_, d_cat_slotq_, d_cat_clsq_;
+    PinnedBuf pin_cat_cls_;
+    uint32_t cat_pub_seq_ = 0;                          // sequence word of k_cat_publish's completion flag
+    // ordinary steps on one GPU: the class codes come from the scan's own tables (k_cat_step_codes_table) instead of a dictionary
+    struct { bool valid = false; const uint64_t *keys = nullptr; const int32_t *slot_q = nullptr, *cls_of_q = nullptr; int log2_cap = 0; } cat_table_;
     // the step's candidate dictionary inside d_sdict_ (one upload): per categorical feature the entries sorted by raw hash
     const int32_t *sdict_off_ = nullptr, *sdict_cls_ = nullptr;
     const uint64_t *sdict_hash_ = nullptr, *sdict_words_ = nullptr;
     int cat_log2_hint_ = 20;                            // log2 of the per-feature table size the next step starts with (20: the full size)
     int cat_publish_guess_ = 256;                       // records the next step publishes with its header (the last count + 25 %)
     std::vector<detail::CatItem> cat_items_;            // every distinct (feature, cell) met so far
-    std::unordered_map<uint64_t, int> cat_item_index_;  // (raw hash, feature) -> head of the chain through CatItem::next
+    std::vector<uint64_t> cat_tab_key_;                 // (raw hash, feature) -> head of the chain through CatItem::next: open-addressed
+    std::vector<int32_t> cat_tab_id_;                   //   table (keys | item ids, -1 = empty), at most half full
     std::vector<char> cat_host_;                        // the published distinct-cell block, copied out of the pinned mapping
     std::vector<uint32_t> cat_seen_;                    // per item: tag of the last replay that inserted it
     uint32_t cat_seen_tag_ = 0;

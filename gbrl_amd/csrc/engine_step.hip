@@ -437,8 +437,12 @@ void Engine::sharded_categorical_ranking(const char *hcat, const float *hgrads, 
     for (size_t c = 0; c < cell_lid.size(); ++c) h_catcodes[c] = static_cast<uint16_t>(cls_of_gid[lid_to_gid[cell_lid[c]]]);
 }
 
+// Two stages (round 4): `launch_only` enqueues the scan (tables, insert, verify, publish) -- step() calls it BEFORE the gradient
+// statistics, the numeric candidates and the numeric binning, none of which depend on it -- and the second call polls the publish
+// kernel's own completion word, so the host's replay of the reference's container (~0.1 ms at configs[4]) runs while the device works through
+// the numeric preparation instead of in front of an idle device (0.17 ms per 4096-row step, profiles/r04_cfg5_timeline_*.txt).
 bool Engine::device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
-                                           std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes) {
+                                           std::vector<detail::CatCandidate> &cat_cands, std::vector<int> &cat_classes, bool launch_only) {
     (void)hcells;   // the distinct cells are gathered from the device copy either way
     hipStream_t s = stream_;
     const long long keep = static_cast<long long>(Fc) * B;
@@ -446,6 +450,8 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     int full_log2 = 8;
     while ((1ll << full_log2) < 4 * std::min<long long>(N, keep + 1) && full_log2 < 20) ++full_log2;
     if ((static_cast<size_t>(Fc) << full_log2) >= (1ull << 31)) return false;   // list records are 32-bit table slots
+    const bool resume = cat_launched_;   // the first round of the loop below is already on the stream
+    cat_launched_ = false;
     // The per-feature tables are sized for the worst case (every row a new category: 4 N slots); real columns hold a few dozen
     // categories, so the step starts with four times the largest distinct count the previous step saw and repeats with the full size
     // only if a table overflowed (12 MB of memsets and atomics on a 12 MB table -> 0.2 MB at configs[4]).
@@ -454,7 +460,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     int32_t *d_meta = static_cast<int32_t *>(d_cat_meta_.ensure(sizeof(int32_t) * 4));               // flags[2], counter
     int32_t *d_lslot = static_cast<int32_t *>(d_cat_lslot_.ensure(sizeof(int32_t) * list_cap));
     uint64_t *d_keys = nullptr;
-    int32_t *d_first = nullptr;
+    int32_t *d_first = nullptr, *d_slotq = nullptr;
     // ONE launch writes header + records + the distinct cells themselves into mapped pinned memory, ONE synchronisation reads them
     // (round 2: three copies of lists sized by a count that needed its own round trip, then a gather + a fourth copy: four
     // synchronisations per step).  The record count is guessed from the last step; a larger batch of distinct cells is published
@@ -462,7 +468,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     const int32_t *h_hdr = nullptr, *lfeat = nullptr, *lfirst = nullptr;
     const uint64_t *lhash = nullptr;
     const char *names = nullptr;
-    auto publish = [&](int cap) {
+    auto publish = [&](int cap, bool launch, bool collect) {
         const size_t bytes = 64 + static_cast<size_t>(cap) * (8 + 4 + 4 + kCat);
         char *h = static_cast<char *>(pin_cat_.ensure(bytes));
         void *dv = nullptr;
@@ -470,9 +476,15 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         char *d = static_cast<char *>(dv);
         const size_t o_hash = 64, o_feat = o_hash + 8 * static_cast<size_t>(cap), o_first = o_feat + 4 * static_cast<size_t>(cap),
                      o_names = o_first + 4 * static_cast<size_t>(cap);   // 64 + 16 cap: 16-byte aligned
-        kern::cat_publish(d_meta, d_lslot, d_keys, d_first, log2_cap, dcells, Fc, cap, reinterpret_cast<int32_t *>(d), reinterpret_cast<int32_t *>(d + o_feat),
-                          reinterpret_cast<int32_t *>(d + o_first), reinterpret_cast<uint64_t *>(d + o_hash), d + o_names, s);
-        hip_check(hipStreamSynchronize(s), "sync");
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(h) + 4;   // header word 4: written last, by the last block
+        if (launch) {
+            *flag = 0;
+            d_slotq = static_cast<int32_t *>(d_cat_slotq_.ensure(sizeof(int32_t) * (static_cast<size_t>(Fc) << log2_cap)));
+            kern::cat_publish(d_meta, d_lslot, d_keys, d_first, log2_cap, dcells, Fc, cap, reinterpret_cast<int32_t *>(d), reinterpret_cast<int32_t *>(d + o_feat),
+                              reinterpret_cast<int32_t *>(d + o_first), reinterpret_cast<uint64_t *>(d + o_hash), d + o_names, d_slotq, ++cat_pub_seq_, s);
+        }
+        if (!collect) return;
+        spin_until_published(flag, cat_pub_seq_, s, "the batch's distinct categorical cells");   // the publish only: kernels enqueued behind it keep running
         // the device wrote these lines over PCIe, so every first touch by the host misses its caches: ONE sequential pass (prefetcher
         // friendly) into ordinary memory, sized by the published count, instead of the replay's scattered reads (3x slower measured)
         const int n_pub = std::max(0, std::min(reinterpret_cast<const int32_t *>(h)[3], cap));
@@ -491,16 +503,21 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         lfirst = reinterpret_cast<const int32_t *>(c + c_first);
         names = c + c_names;
     };
-    for (;;) {
+    for (bool first = true;; first = false) {
         const size_t slots = static_cast<size_t>(Fc) << log2_cap;
         d_keys = static_cast<uint64_t *>(d_cat_keys_.ensure(sizeof(uint64_t) * slots));
         d_first = static_cast<int32_t *>(d_cat_first_.ensure(sizeof(int32_t) * slots));
-        hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
-        hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
-        hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
-        kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, d_lslot, d_meta + 2, list_cap, s);
-        kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
-        publish(std::min(list_cap, std::max(256, cat_publish_guess_)));
+        const bool enqueued = first && resume;   // (the hints that size this round are only updated by the collecting call)
+        if (enqueued) d_slotq = static_cast<int32_t *>(d_cat_slotq_.ensure(sizeof(int32_t) * slots));
+        if (!enqueued) {
+            hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
+            hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
+            hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
+            kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, d_lslot, d_meta + 2, list_cap, s);
+            kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
+        }
+        publish(std::min(list_cap, std::max(256, cat_publish_guess_)), !enqueued, !launch_only);
+        if (launch_only) { cat_launched_ = true; return true; }
         if (h_hdr[0] != 0 && log2_cap < full_log2) { log2_cap = full_log2; continue; }   // a table (or the list) overflowed: once more at full size
         break;
     }
@@ -516,26 +533,32 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         declined = hv != 0;
     }
     if (declined) return false;
-    if (n_distinct > h_hdr[3]) publish(n_distinct);
+    if (n_distinct > h_hdr[3]) publish(n_distinct, true, true);
     cat_publish_guess_ = n_distinct + n_distinct / 4 + 64;
-    // the reference's insertion order: feature-major, then row of first occurrence (bucket by feature, sort the buckets by row)
+    // the reference's insertion order: feature-major, then row of first occurrence -- one LSD radix sort (11-bit digits) of
+    // feature * N + first row with the list index in the low 21 bits (std::sort of the per-feature buckets: 30 us at configs[4])
     std::vector<int> order(n_distinct);
     {
-        std::vector<int> start(Fc + 1, 0);
-        for (int q = 0; q < n_distinct; ++q) ++start[lfeat[q] + 1];
-        {
-            int mx = 1;
-            for (int f = 0; f < Fc; ++f) mx = std::max(mx, start[f + 1]);
-            int l2 = 8;
-            while ((1 << l2) < 4 * mx && l2 < 20) ++l2;
-            cat_log2_hint_ = l2;                       // table size the next step starts with
+        std::vector<int> per_feat(Fc, 0);
+        for (int q = 0; q < n_distinct; ++q) ++per_feat[lfeat[q]];
+        int mx = 1;
+        for (int f = 0; f < Fc; ++f) mx = std::max(mx, per_feat[f]);
+        int l2 = 8;
+        while ((1 << l2) < 4 * mx && l2 < 20) ++l2;
+        cat_log2_hint_ = l2;                       // table size the next step starts with
+        std::vector<uint64_t> ka(n_distinct), kb(n_distinct);
+        for (int q = 0; q < n_distinct; ++q)
+            ka[q] = ((static_cast<uint64_t>(lfeat[q]) * static_cast<uint64_t>(N) + static_cast<uint64_t>(lfirst[q])) << 21) | static_cast<uint64_t>(q);
+        int key_bits = 1;
+        while (key_bits < 43 && (static_cast<uint64_t>(Fc) * static_cast<uint64_t>(N)) >> key_bits) ++key_bits;
+        for (int sh = 21; sh < 21 + key_bits; sh += 11) {
+            uint32_t cnt[2049] = {0};
+            for (int q = 0; q < n_distinct; ++q) ++cnt[((ka[q] >> sh) & 2047u) + 1];
+            for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+            for (int q = 0; q < n_distinct; ++q) kb[cnt[(ka[q] >> sh) & 2047u]++] = ka[q];
+            ka.swap(kb);
         }
-        for (int f = 0; f < Fc; ++f) start[f + 1] += start[f];
-        std::vector<int> cur(start.begin(), start.end() - 1);
-        std::vector<std::pair<int32_t, int32_t>> fr(n_distinct);   // (first row, list index), bucketed by feature
-        for (int q = 0; q < n_distinct; ++q) fr[cur[lfeat[q]]++] = {lfirst[q], q};
-        for (int f = 0; f < Fc; ++f) std::sort(fr.begin() + start[f], fr.begin() + start[f + 1]);   // first rows of one feature are distinct
-        for (int q = 0; q < n_distinct; ++q) order[q] = fr[q].second;
+        for (int q = 0; q < n_distinct; ++q) order[q] = static_cast<int>(ka[q] & ((1u << 21) - 1));
     }
     std::vector<int32_t> g_feat;     // row-sharded: the global lists replace the local views
     std::vector<uint64_t> g_hash;
@@ -592,15 +615,34 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     // the keys' std::hash values -- computed once per distinct (feature, cell) the engine has ever met and kept in cat_items_ --
     // instead of building and hashing 130-byte strings every step.
     // GBRL_HIP_CAT_CHECK=1 (tests) replays the string-keyed container beside it and compares the two orders.
-    if (cat_items_.size() > (1u << 18)) { cat_items_.clear(); cat_item_index_.clear(); std::fill(cat_seen_.begin(), cat_seen_.end(), 0u); }
+    if (cat_items_.size() > (1u << 18)) { cat_items_.clear(); cat_tab_key_.clear(); cat_tab_id_.clear(); std::fill(cat_seen_.begin(), cat_seen_.end(), 0u); }
+    // (raw hash, feature) -> head of the chain through CatItem::next: open addressing, linear probing, at most half full
+    // (round 4: std::unordered_map cost 2 000 node lookups = 40 us per 4096-row step of configs[4])
+    auto tab_slot = [&](uint64_t key) -> size_t {
+        const size_t mask = cat_tab_key_.size() - 1;
+        size_t i = static_cast<size_t>(key ^ (key >> 29)) & mask;
+        while (cat_tab_id_[i] >= 0 && cat_tab_key_[i] != key) i = (i + 1) & mask;
+        return i;
+    };
+    auto tab_reserve = [&](size_t n_items) {
+        if (!cat_tab_key_.empty() && 2 * n_items <= cat_tab_key_.size()) return;
+        size_t cap = 4096;
+        while (cap < 4 * n_items) cap <<= 1;
+        std::vector<uint64_t> ok; std::vector<int32_t> oi;
+        ok.swap(cat_tab_key_); oi.swap(cat_tab_id_);
+        cat_tab_key_.assign(cap, 0); cat_tab_id_.assign(cap, -1);
+        for (size_t i = 0; i < ok.size(); ++i)
+            if (oi[i] >= 0) { const size_t j = tab_slot(ok[i]); cat_tab_key_[j] = ok[i]; cat_tab_id_[j] = oi[i]; }
+    };
+    tab_reserve(cat_items_.size() + static_cast<size_t>(n_distinct));
     auto item_of = [&](int feat, uint64_t h, const char *cell) -> int {
         const uint64_t key = h * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(feat);
-        auto it = cat_item_index_.find(key);
-        if (it != cat_item_index_.end())
-            for (int id = it->second; id >= 0; id = cat_items_[id].next) {
-                const detail::CatItem &ci = cat_items_[id];
-                if (ci.feat == feat && std::memcmp(ci.name, cell, kCat) == 0) return id;
-            }
+        const size_t slot = tab_slot(key);
+        const int head = cat_tab_id_[slot];
+        for (int id = head; id >= 0; id = cat_items_[id].next) {
+            const detail::CatItem &ci = cat_items_[id];
+            if (ci.feat == feat && std::memcmp(ci.name, cell, kCat) == 0) return id;
+        }
         detail::CatItem ci;
         ci.feat = feat;
         ci.lhash = h;
@@ -608,10 +650,11 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         std::string ks(cell, kCat);
         ks += "_" + std::to_string(feat);
         ci.std_hash = std::hash<std::string>{}(ks);
-        ci.next = it != cat_item_index_.end() ? it->second : -1;
+        ci.next = head;
         const int id = static_cast<int>(cat_items_.size());
         cat_items_.push_back(ci);
-        cat_item_index_[key] = id;
+        cat_tab_key_[slot] = key;
+        cat_tab_id_[slot] = id;
         return id;
     };
     // The replay itself: hash_order_replay.h (libstdc++'s unique-key insertion restated on index arrays).
@@ -657,6 +700,27 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     // candidates + the step's dictionary (per feature: entries sorted by raw hash, then class), packed into ONE pinned block and
     // uploaded with one copy that nothing waits for: the next write of the block happens behind the next step's synchronisation
     const int n_ent = static_cast<int>(cand_item.size());
+    cat_table_.valid = false;
+    if (!has_coll_ && !candidates_only_) {
+        // ordinary step on one GPU: the scan's tables ARE the dictionary; the host hands back the class of every list record only
+        int32_t *hc = static_cast<int32_t *>(pin_cat_cls_.ensure(sizeof(int32_t) * static_cast<size_t>(std::max(1, n_distinct))));
+        cat_cands.reserve(cat_cands.size() + n_ent);
+        for (int q : cand_item) {
+            const int f = lfeat[q];
+            const int cls = ++cat_classes[f];
+            if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
+            cat_cands.emplace_back(f, names + static_cast<size_t>(q) * kCat, cls);
+            hc[q] = cls;
+        }
+        int32_t *dc = static_cast<int32_t *>(d_cat_clsq_.ensure(sizeof(int32_t) * static_cast<size_t>(std::max(1, n_distinct))));
+        void *hc_dev = nullptr;
+        hip_check(hipHostGetDevicePointer(&hc_dev, hc, 0), "hipHostGetDevicePointer");
+        kern::FetchSegments fs{};
+        fs.n = 1; fs.dst[0] = dc; fs.src[0] = hc_dev; fs.words[0] = static_cast<uint32_t>(std::max(1, n_distinct));
+        kern::fetch_segments(fs, s);
+        cat_table_.valid = true; cat_table_.keys = d_keys; cat_table_.slot_q = d_slotq; cat_table_.cls_of_q = dc; cat_table_.log2_cap = log2_cap;
+        return true;
+    }
     struct DictE { uint64_t h; int cls; int item; };
     std::vector<DictE> ent(n_ent);
     std::vector<int32_t> off(Fc + 1, 0);
@@ -1112,6 +1176,22 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // Host bookkeeping of one level from its result block [best_idx | best_score | counts]: decisions, children, paths.  Shared by the
     // level-synchronous host loop below and by the replay after a device-planned tree (one synchronisation per tree).
     struct LevelOutcome { bool stop = false; std::vector<int> splitting, new_leaves, next; };
+    // (categorical feature, class) -> index into cat_cands, built at the first categorical split of the step (a linear search per
+    // splitting node walked 2 000 x 136-byte records: 50 us per level at level 5 of configs[4])
+    std::vector<int> cat_index, cat_index_off;
+    auto cat_cand_of = [&](int feat, int cls) -> int {
+        const int Fc = c.Fc;
+        if (cat_index_off.empty()) {
+            cat_index_off.assign(static_cast<size_t>(Fc) + 1, 0);
+            for (const CatCandidate &cc : cat_cands) cat_index_off[cc.feat + 1] = std::max(cat_index_off[cc.feat + 1], cc.cls);
+            for (int f = 0; f < Fc; ++f) cat_index_off[f + 1] += cat_index_off[f];
+            cat_index.assign(static_cast<size_t>(cat_index_off[Fc]), -1);
+            for (size_t z = 0; z < cat_cands.size(); ++z)
+                if (cat_cands[z].cls >= 1) cat_index[cat_index_off[cat_cands[z].feat] + cat_cands[z].cls - 1] = static_cast<int>(z);
+        }
+        if (feat < 0 || feat >= Fc || cls < 1 || cls > cat_index_off[feat + 1] - cat_index_off[feat]) return -1;
+        return cat_index[cat_index_off[feat] + cls - 1];
+    };
     auto digest_level = [&](const std::vector<int> &active, const char *hres) -> LevelOutcome {
         LevelOutcome out;
         const int n_act = static_cast<int>(active.size());
@@ -1159,9 +1239,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (c.is_cat) {
                 c.feat_idx = q.fslot - F;
                 c.value = INFINITY;
-                c.cat_cand = -1;
-                for (size_t z = 0; z < cat_cands.size(); ++z)
-                    if (cat_cands[z].feat == c.feat_idx && cat_cands[z].cls == q.bin) c.cat_cand = static_cast<int>(z);
+                c.cat_cand = cat_cand_of(c.feat_idx, q.bin);
             } else {
                 c.feat_idx = q.fslot;
                 c.value = h_thr[static_cast<size_t>(q.fslot) * B + q.bin];
@@ -1585,6 +1663,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         dcells = t;
     }
     phase_end("inputs");
+    // the scan for the batch's distinct categorical cells goes first: its result is read by the HOST (device_categorical_candidates)
+    const bool cat_early = Fc > 0 && !fixed_cat_valid_ && (has_coll_ || !force_host_categorical_);
+    cat_launched_ = false;   // (a step that threw between the two stages must not be resumed)
+    if (cat_early) {
+        std::vector<CatCandidate> none;
+        std::vector<int> none_classes(Fc, 0);
+        (void)device_categorical_candidates(dcells, cat_dev ? nullptr : cat, N, Fc, B, none, none_classes, /*launch_only=*/true);
+    }
 
     // ---- 1. gradient statistics and quantisation (A2) -----------------------------------------------------------------
     phase_begin();
@@ -1679,6 +1765,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     bool codes_from_sort = false;
     if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);
     phase_end("candidates");
+    // numeric class codes (3. below) before the host waits for the categorical scan
+    phase_begin();
+    if (F > 0 && !codes_from_sort) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
+    phase_end("binning");
 
     // categorical candidates (A5): distinct cells found on the device, inserted into the reference's container in the
     // reference's insertion order on the host => same candidate order (Q8).  Falls back to the host scan of every cell when
@@ -1822,15 +1912,17 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
 
     // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
     phase_begin();
-    if (F > 0 && !codes_from_sort) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);
     if (Fc > 0 && cat_codes_on_device) {
-        kern::cat_step_codes(dcells, N, Fc, F, sdict_off_, sdict_hash_, sdict_cls_, sdict_words_, d_codes, s);
+        if (cat_table_.valid && !fixed_cat_valid_)
+            kern::cat_step_codes_table(dcells, N, Fc, F, cat_table_.keys, cat_table_.slot_q, cat_table_.cls_of_q, cat_table_.log2_cap, d_codes, s);
+        else
+            kern::cat_step_codes(dcells, N, Fc, F, sdict_off_, sdict_hash_, sdict_cls_, sdict_words_, d_codes, s);
     } else if (Fc > 0) {
         uint16_t *d_cc2 = static_cast<uint16_t *>(d_catcodes_.ensure(sizeof(uint16_t) * h_catcodes.size()));
         hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
         kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
     }
-    phase_end("binning");
+    phase_end("cat_codes");
     {   // thresholds and scales into the pinned block with ONE launch (device-written host memory) instead of two copy-engine transfers
         static_assert(sizeof(kern::StepScales) % 4 == 0, "copied as 32-bit words");
         void *pin_dev = nullptr;

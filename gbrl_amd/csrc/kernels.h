@@ -352,8 +352,12 @@ void cat_distinct_insert(const char *cells, int n, int Fc, uint64_t *keys, int32
                          int32_t *counter, int list_cap, hipStream_t s);
 void cat_distinct_verify(const char *cells, int n, int Fc, const uint64_t *keys, const int32_t *first, int log2_cap, int32_t *flags,
                          hipStream_t s);
-void cat_publish(const int32_t *meta, const int32_t *list_slot, const uint64_t *keys, const int32_t *first, int log2_cap, const char *cells,
-                 int Fc, int cap, int32_t *h_hdr, int32_t *h_feat, int32_t *h_first, uint64_t *h_hash, char *h_names, hipStream_t s);
+void cat_publish(int32_t *meta, const int32_t *list_slot, const uint64_t *keys, const int32_t *first, int log2_cap, const char *cells,
+                 int Fc, int cap, int32_t *h_hdr, int32_t *h_feat, int32_t *h_first, uint64_t *h_hash, char *h_names, int32_t *slot_q,
+                 uint32_t seq, hipStream_t s);
+// class codes of a step batch from the scan's own tables: cls_of_q[slot_q[slot of the cell]] (see k_cat_step_codes_table)
+void cat_step_codes_table(const char *cells, int n, int Fc, int F, const uint64_t *keys, const int32_t *slot_q, const int32_t *cls_of_q,
+                          int log2_cap, uint16_t *codes, hipStream_t s);
 void cat_step_codes(const char *cells, int n, int Fc, int F, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_cls,
                     const uint64_t *dict_words, uint16_t *codes, hipStream_t s);
 void encode_categories(const char *cells, int n, int Fc, const int32_t *feat_off, const uint64_t *dict_hash, const int32_t *dict_id,
