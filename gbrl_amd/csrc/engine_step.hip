@@ -849,7 +849,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
                 int64_t *d_cum = upload_cum(cum);
                 // (the sort kernel also writes the class codes of its feature: no separate binning launch)
-                static const bool no_fuse = [] { const char *e = std::getenv("GBRL_HIP_SORT_NO_CODES"); return e && e[0] == '1'; }();   // test / measurement hook
+                const bool no_fuse = [] { const char *e = std::getenv("GBRL_HIP_SORT_NO_CODES"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
                 uint16_t *cdst = no_fuse ? nullptr : d_codes_out;
                 kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, d_thr, s, cdst);
                 if (cdst && codes_written) *codes_written = true;
@@ -1403,7 +1403,24 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // chunk table of ALL active nodes (row-sharded runs count the local child sizes from the rows themselves)
         std::vector<Chunk> count_chunks;
         if (has_coll_) { make_chunks(active, kern::kPartitionRows, false); count_chunks = h_chunks; }
-        make_chunks(compute_ids, balanced_chunk_rows(compute_ids, hist_chunk_budget), false);
+        // RL-sized levels on one GPU: every accumulated node is ONE chunk (empty nodes included) and k_hist_build stores the node's
+        // int64 histogram itself -- no partials, no hist_reduce launch (kern::HistDirect).  A block then walks up to `direct_cap` rows
+        // alone: the cap keeps that below ~10 us of LDS atomics ((D + 1) per row and feature).
+        const bool no_direct = [] { const char *e = std::getenv("GBRL_HIP_NO_DIRECT_HIST"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
+        const int direct_cap = std::min(8192, std::max(1024, 9216 / (D + 1)));
+        bool hist_direct = !has_coll_ && !no_direct && kern::hist_direct_supported(FG) && !compute_ids.empty() && compute_ids.size() <= static_cast<size_t>(hist_max_chunks);
+        for (int id : compute_ids) hist_direct = hist_direct && nodes[id].n_local <= direct_cap;
+        if (hist_direct) {
+            h_chunks.clear();
+            h_chunk_begin.assign(1, 0);
+            for (size_t k = 0; k < compute_ids.size(); ++k) {
+                const HNode &nd = nodes[compute_ids[k]];
+                h_chunks.push_back({static_cast<int32_t>(k), nd.seg_start, nd.n_local, 0});
+                h_chunk_begin.push_back(static_cast<int32_t>(h_chunks.size()));
+            }
+        } else {
+            make_chunks(compute_ids, balanced_chunk_rows(compute_ids, hist_chunk_budget), false);
+        }
         if (h_chunks.size() > static_cast<size_t>(hist_max_chunks)) throw HipError("internal: chunk table overflow");
         // paths (duplicate-on-path rejection, node.cpp:154-166)
         std::vector<int32_t> pl(n_act), ps(static_cast<size_t>(n_act) * kern::kMaxPath, -1), pb(static_cast<size_t>(n_act) * kern::kMaxPath, 0), root(n_act);
@@ -1447,14 +1464,17 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         int32_t *d_seg_starts = sta.put(seg_starts.data(), seg_starts.size());
         int32_t *d_n_locals = sta.put(n_locals.data(), n_locals.size());
         sta.flush();
+        bool hist_written = false;
         if (!h_chunks.empty()) {
             const auto ev = kernel_events("hist_build", /*key=*/true);   // the dispatch's own timestamps: no bubble in the stream
-            kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s,
-                             ev.first, ev.second);
+            kern::HistDirect hd;
+            if (hist_direct) { hd.hist = d_hist; hd.slot_map = d_slotmap; hd.Fp = Fp; }
+            hist_written = kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s,
+                                            ev.first, ev.second, hist_direct ? &hd : nullptr);
         }
-        phase_begin();
+        if (!hist_written) phase_begin();   // (no phase record for a level whose histograms k_hist_build stored itself)
         if (!has_coll_) {
-            if (!compute_ids.empty())
+            if (!compute_ids.empty() && !hist_written)
                 kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s,
                                   static_cast<int>(h_chunks.size() / compute_ids.size()));
         } else if (!compute_ids.empty()) {
@@ -1466,7 +1486,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             reduce_scatter_i64(d_hist_coll, d_hist_recv, static_cast<size_t>(nc) * coll_Fs * feat_elems);
             kern::hist_place_slice(d_hist_recv, d_hist, d_slotmap, nc, coll_Fs, coll_lo, Fp, feat_elems, s);
         }
-        phase_end("hist_reduce");
+        if (!hist_written) phase_end("hist_reduce");
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
         // (row-sharded: this rank scores its own feature slots only; candidates of the other ranks stay at -inf)
@@ -1706,7 +1726,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             kern::stats_unpack(d_smsg, D, world, st, s);
         };
         // RL-sized batch on one GPU: statistics and quantisation in ONE launch with the same reduction tree (kern::small_stats)
-        static const bool no_small = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_STATS"); return e && e[0] == '1'; }();   // test / measurement hook
+        const bool no_small = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_STATS"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
         int32_t *d_qg_small = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
         if (!has_coll_ && !no_small && n_global == N && kern::small_stats(dgrads, N, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg_small, s)) {
             stats_fused = true;

@@ -177,9 +177,20 @@ constexpr int kCodeGroup = 16;  // code layout: groups of 16 feature slots, [gro
 
 // ---- split-score histograms (A6) ----
 size_t hist_lds_bytes(int NB, int D, int FG);
-void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
+// HistDirect (optional): every node of the level is ONE chunk (RL-sized batches), so a block's LDS tile already holds the node's
+// complete sums for its feature group and leaves as hist[slot_map ? slot_map[chunk.slot] : chunk.slot][feature][class][D+1] (int64)
+// -- no partials, no hist_reduce launch.  hist_build returns true when it wrote the histograms this way (the wide / quad variants
+// for more than 16 outputs do not: the caller then reduces the partials as usual).
+struct HistDirect {
+    int64_t *hist = nullptr;
+    const int32_t *slot_map = nullptr;
+    int Fp = 0;
+};
+bool hist_direct_supported(int FG);   // the kernel hist_build will take for this layout can store the histograms itself
+bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
                 const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s,
-                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /*the dispatch's own begin / end timestamps*/);
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /*the dispatch's own begin / end timestamps*/,
+                const HistDirect *direct = nullptr);
 // hist[slot_map ? slot_map[k] : k] = sum of the partials of chunk-slot k
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
                  int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s,

@@ -510,7 +510,8 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
                                                               const int32_t *__restrict__ qg, int D_rt,
                                                               const int32_t *__restrict__ rows,
                                                               const Chunk *__restrict__ chunks, int n_chunks, int n_groups,
-                                                              int FG, int fg_shift, int NB, int32_t *__restrict__ partials) {
+                                                              int FG, int fg_shift, int NB, int32_t *__restrict__ partials,
+                                                              HistDirect direct = HistDirect{}) {
     extern __shared__ int32_t h[];
     const int D = DT ? DT : D_rt;
     if (DT) { FG = 16; fg_shift = 4; }
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     const int chunk_id = (jj / n_groups) * 8 + xcd;
     if (chunk_id >= n_chunks) return;
     const Chunk ck = chunks[chunk_id];
-    if (ck.len <= 0) return;   // block-uniform: an unused entry of a device-planned chunk table
+    if (ck.len <= 0 && !direct.hist) return;   // block-uniform: an unused entry of a device-planned chunk table (direct: an empty node's zeros)
     const int n_acc = NB * (D + 1) * FG;
     if ((n_acc & 3) == 0) {   // 16-byte LDS writes (FG = 16: always)
         int4 *h4 = reinterpret_cast<int4 *>(h);
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
     auto ld_code = [&](int row) -> int { return Ld::code(cgroup, static_cast<uint32_t>(row), coff); };
     auto ld_q = [&](int row) -> int { return Ld::template grad<DT>(qbase, static_cast<uint32_t>(row), qoff); };
     int p0 = slot;
-    if (DT && PIPE) {
+    if (DT && PIPE && ck.len > 0) {
         // Software-pipelined main loop (three stages, U rows per slot and stage): while the 9U atomics of iteration i occupy the
         // LDS atomic unit, the codes / gradients of iteration i+1 (their row ids were loaded one iteration earlier) and the row
         // ids of iteration i+2 are already in flight.  Without it every wave of the block (one block per CU) waits for the two
@@ -633,6 +634,24 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
         }
     }
     __syncthreads();
+    if (direct.hist) {
+        // the node's only chunk: the tile is the node's histogram of this feature group (LDS index = element * FG + feature).
+        // FG == 16: 256 threads take 16 elements x 16 features with the ELEMENT as the lane-fastest index, so every 16 lanes store
+        // 128 consecutive bytes of one feature (a 4-way LDS bank conflict on the read side, which is the cheaper side).
+        const int hslot = direct.slot_map ? direct.slot_map[ck.slot] : ck.slot;
+        int64_t *dst = direct.hist + (static_cast<size_t>(hslot) * direct.Fp + static_cast<size_t>(g) * FG) * NB * (D + 1);
+        const size_t fstride = static_cast<size_t>(NB) * (D + 1);
+        if (FG == 16) {
+            const int n_el = NB * (D + 1);
+            for (int i = threadIdx.x; i < ((n_el + 15) & ~15) * 16; i += kHistThreads) {
+                const int e = (i >> 8) * 16 + (i & 15), f = (i >> 4) & 15;
+                if (e < n_el) dst[f * fstride + e] = h[e * 16 + f];
+            }
+        } else {
+            for (int i = threadIdx.x; i < n_acc; i += kHistThreads) dst[(i & (FG - 1)) * fstride + (i >> fg_shift)] = h[i];
+        }
+        return;
+    }
     int32_t *out = partials + (static_cast<size_t>(chunk_id) * n_groups + g) * n_acc;
     if ((n_acc & 3) == 0) {   // the block's 148 KB of partial sums leave in 16-byte pieces
         const int4 *h4 = reinterpret_cast<const int4 *>(h);
@@ -1671,7 +1690,7 @@ size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * 
 template <int DT, int U, bool PIPE>
 static void launch_hist_p(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                           int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
-                          hipEvent_t ev_start, hipEvent_t ev_stop) {
+                          hipEvent_t ev_start, hipEvent_t ev_stop, const HistDirect &direct) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1681,17 +1700,17 @@ static void launch_hist_p(const uint16_t *codes, int n_rows, const int32_t *qg, 
     // ev_start / ev_stop (nullable): the dispatch's own begin / end timestamps -- no extra packets in the stream, unlike
     // hipEventRecord around the launch
     hipExtLaunchKernelGGL((k_hist_build<DT, U, PIPE>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D, rows,
-                          chunks, n_chunks, n_groups, FG, shift, NB, partials);
+                          chunks, n_chunks, n_groups, FG, shift, NB, partials, direct);
 }
 template <int DT, int U>
 static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                         int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
-                        hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        hipEvent_t ev_start, hipEvent_t ev_stop, const HistDirect &direct = HistDirect{}) {
     static const bool pipe = []() { const char *e = std::getenv("GBRL_HIP_HIST_PIPE"); return !(e && e[0] == '0'); }();   // measurement hook
     if constexpr (DT != 0) {
-        if (pipe) { launch_hist_p<DT, U, true>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop); return; }
+        if (pipe) { launch_hist_p<DT, U, true>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct); return; }
     }
-    launch_hist_p<DT, U, false>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
+    launch_hist_p<DT, U, false>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct);
 }
 
 template <int P, int H>
@@ -1757,21 +1776,25 @@ static bool launch_hist_wide(int P, int H, const uint16_t *codes, int n_rows, co
     return false;
 }
 
-void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
-                int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+// (FG 8 / 4 may go to the wide / quad kernels, which only write partials -- and skip empty chunks)
+bool hist_direct_supported(int FG) { return FG != 8 && FG != 4; }
+bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
+                int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
+                const HistDirect *direct) {
+    const HistDirect dir = direct ? *direct : HistDirect{};
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
     static const bool generic_only = [] { const char *e = std::getenv("GBRL_HIP_HIST_GENERIC"); return e && e[0] == '1'; }();   // test hook
     // the compile-time-D kernels address codes and gradients with 32-bit byte offsets from block-uniform bases (64 bytes per row at D = 16)
     if (generic_only || n_rows > (1 << 26)) {
-        launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
-        return;
+        launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, dir);
+        return dir.hist != nullptr;
     }
 #ifndef GBRL_HIST_U
 #define GBRL_HIST_U 8
 #endif
-#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop); return;
+#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, dir); return dir.hist != nullptr;
     if (FG == 16) {
         switch (D) {
             GBRL_HIST_CASE(1) GBRL_HIST_CASE(2) GBRL_HIST_CASE(3) GBRL_HIST_CASE(4) GBRL_HIST_CASE(5) GBRL_HIST_CASE(6)
@@ -1784,12 +1807,13 @@ void hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
     // 8 features per block: the fields of a row are split over the two halves of the 16-lane DPP row (k_hist_build_wide);
     // 4 features per block: one DPP quad per data row (k_hist_build_quad)
     if (FG == 8 && D + 1 <= 32) {
-        if (launch_hist_wide(2, (D + 2) / 2, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop)) return;
+        if (launch_hist_wide(2, (D + 2) / 2, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop)) return false;
     }
     if (FG == 4 && D + 1 <= 64) {
-        if (QuadDispatch<16>::run((D + 4) / 4, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop)) return;
+        if (QuadDispatch<16>::run((D + 4) / 4, codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, NB, partials, lds, s, ev_start, ev_stop)) return false;
     }
-    launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop);
+    launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, dir);
+    return dir.hist != nullptr;
 }
 
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,
