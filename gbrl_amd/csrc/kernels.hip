@@ -1040,6 +1040,10 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     const int node = blockIdx.y, fs = slot0 + blockIdx.x;
     const FeatureSlot sl = slots[fs];
     const int W = D + 1;
+    // classes this slot really has (numeric: n_bins thresholds + 1; categorical: its candidates + "none of them"): the slices are NB
+    // classes apart, but the classes beyond NBe hold nothing -- not loaded, not scanned, not written back (a 33-class categorical
+    // slot beside 257-class numeric ones moved 8x the bytes it needed; k_resolve_splits applies the same bound)
+    const int NBe = min(NB, sl.n_cand + 1);
     int64_t *src = hist + (static_cast<size_t>(node) * Fp + fs) * NB * W;
     // the node's path conditions on THIS feature slot, staged once per block (a candidate that repeats one of them is rejected,
     // node.cpp:154-166); reading the path arrays from global memory inside the candidate loop costs a memory round trip per
@@ -1068,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         const int64_t *pp = hist_prev + (static_cast<size_t>(par) * Fp + fs) * NB * W;
         const int64_t *ss = sib >= 0 ? hist + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
         // four elements per thread in flight (the slice is ~2300 words: nine dependent round trips per thread otherwise)
-        const int tot = NB * W, step = static_cast<int>(blockDim.x);
+        const int tot = NBe * W, step = static_cast<int>(blockDim.x);
         for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * step) {
             int64_t a[4], b[4];
 #pragma unroll
@@ -1084,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
             }
         }
     } else {
-        const int tot = NB * W, step = static_cast<int>(blockDim.x);
+        const int tot = NBe * W, step = static_cast<int>(blockDim.x);
         for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * step) {
             int64_t a[4];
 #pragma unroll
@@ -1118,9 +1122,9 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         for (int j = 0; j < WCH; ++j) run_base[j] = 0;
         // (a last tile of at most 4 classes -- 257 classes = 256 + 1 is the usual shape -- is added serially below instead of
         // paying a block-wide scan and two barriers for it)
-        const int n_tiles = (NB + 255) / 256 - ((NB % 256) != 0 && (NB % 256) <= 4 && NB > 256 ? 1 : 0);
+        const int n_tiles = (NBe + 255) / 256 - ((NBe % 256) != 0 && (NBe % 256) <= 4 && NBe > 256 ? 1 : 0);
         for (int tile = 0; tile < n_tiles; ++tile) {
-            const int c = NB - 1 - (tile * 256 + static_cast<int>(threadIdx.x));
+            const int c = NBe - 1 - (tile * 256 + static_cast<int>(threadIdx.x));
             long long v[WCH];
 #pragma unroll
             for (int j = 0; j < WCH; ++j) v[j] = (c >= 0 && w0 + j < W) ? sh64[c * W + w0 + j] : 0;
@@ -1150,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
             }
             __syncthreads();
         }
-        const int rem = NB - n_tiles * 256;       // classes 0 .. rem-1 not covered by a tile (0 or 1..4): suffix sums by one thread per field
+        const int rem = NBe - n_tiles * 256;       // classes 0 .. rem-1 not covered by a tile (0 or 1..4): suffix sums by one thread per field
         if (static_cast<int>(threadIdx.x) < WCH && w0 + static_cast<int>(threadIdx.x) < W) {
             const int j = threadIdx.x;
             long long run = 0;
@@ -1319,6 +1323,7 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     const FeatureSlot sl = slots[fs];
     const int bin = sl.is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
     const int W = D + 1;
+    const int NBe = min(NB, sl.n_cand + 1);   // classes of the winner's slot (k_score wrote / derived only those)
     int n_left = 0;
     for (int pass = 0; pass < (hist_global ? 2 : 1); ++pass) {
         const int64_t *src = (pass ? hist_global : hist_local) + (static_cast<size_t>(node) * Fp + fs) * NB * W;
@@ -1332,19 +1337,19 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
             sub = sib >= 0 ? hist_local + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
         }
         long long tot = 0, right = 0;
-        for (int c0 = threadIdx.x; c0 < NB; c0 += 8 * kWave) {     // the class counts of the winner's slice: eight loads in flight per lane
+        for (int c0 = threadIdx.x; c0 < NBe; c0 += 8 * kWave) {     // the class counts of the winner's slice: eight loads in flight per lane
             long long n[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] = c < NB ? src[c * W + D] : 0; }
+            for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] = c < NBe ? src[c * W + D] : 0; }
             if (sub) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] -= c < NB ? sub[c * W + D] : 0; }
+                for (int u = 0; u < 8; ++u) { const int c = c0 + u * kWave; n[u] -= c < NBe ? sub[c * W + D] : 0; }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u * kWave;
                 tot += n[u];
-                if (c < NB && (sl.is_cat ? (c == bin) : (c > bin))) right += n[u];
+                if (c < NBe && (sl.is_cat ? (c == bin) : (c > bin))) right += n[u];
             }
         }
         for (int o = kWave / 2; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, kWave); right += __shfl_xor(right, o, kWave); }
