@@ -1931,7 +1931,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     }
 
     // ---- 3. class codes (group-major: [slot/16][row][slot%16], u16) ---------------------------------------------------
-    phase_begin();
+    if (Fc > 0) phase_begin();
     if (Fc > 0 && cat_codes_on_device) {
         if (cat_table_.valid && !fixed_cat_valid_)
             kern::cat_step_codes_table(dcells, N, Fc, F, cat_table_.keys, cat_table_.slot_q, cat_table_.cls_of_q, cat_table_.log2_cap, d_codes, s);
@@ -1942,7 +1942,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         hip_check(hipMemcpyAsync(d_cc2, h_catcodes.data(), sizeof(uint16_t) * h_catcodes.size(), hipMemcpyHostToDevice, s), "H2D cat codes");
         kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
     }
-    phase_end("cat_codes");
+    if (Fc > 0) phase_end("cat_codes");
     {   // thresholds and scales into the pinned block with ONE launch (device-written host memory) instead of two copy-engine transfers
         static_assert(sizeof(kern::StepScales) % 4 == 0, "copied as 32-bit words");
         void *pin_dev = nullptr;
