@@ -1852,7 +1852,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     while (D > 16 && FG > 4 && (16 / FG) * 16 < D + 1) FG >>= 1;
     if (kern::hist_lds_bytes(NB, D, FG) > 160 * 1024 - 512)
         throw Unsupported("(classes per feature) x (output_dim + 1) does not fit the 160 KiB LDS");
-    if (static_cast<size_t>(NB + 1) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");
+    if (static_cast<size_t>(NB + 2) * (D + 1) * 8 > 150 * 1024) throw Unsupported("score kernel LDS limit");
     const int Fp = ((n_slots + FG - 1) / FG) * FG;
     const int n_groups = Fp / FG;
     // internal candidate order = slot-grouped; cand_ref maps to the reference's candidate index (numeric f-major, then the

@@ -1018,14 +1018,58 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 }
 // Wave-wide inclusive scan step on a 64-bit value with DPP (VALU only; __shfl_up would go through the LDS crossbar, which
 // is what k_score is short of).  ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+// Steps inside a row (all rows enabled) take bound_ctrl: a lane whose source falls outside its row reads 0 without the destination
+// being zeroed first (two v_mov per step saved: k_score is bound by its VALU instruction count, section 5 of DESIGN.md).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ long long dpp_scan_step(long long x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    int lo, hi;
+    if constexpr (ROW_MASK == 0xf) {
+        lo = __builtin_amdgcn_mov_dpp(static_cast<int>(x), CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(static_cast<int>(x >> 32), CTRL, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    }
     return x + ((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
 }
 
-__global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const int64_t *__restrict__ hist_prev,
+// Inclusive scan over the 64 lanes of NINE 64-bit values at once (k_score's fields), every step as two DPP-fused adds per value:
+//   v_add_co_u32_dpp lo, vcc, lo, lo <ctrl>   ;  v_addc_co_u32_dpp hi, vcc, hi, hi, vcc <ctrl>
+// A lane whose source is outside its row (row_shr) or whose row is masked (row_bcast) is simply not written, i.e. keeps x -- no
+// zero-initialised temporary, no separate 64-bit add: 2 VALU instructions per value and step instead of 5 (the kernel is bound by its
+// VALU instruction count).  gfx9 hazard "VALU writes a VGPR, DPP reads it: 2 wait states": inside a step the nine values are
+// independent, and a value is touched again 16 instructions later; the s_nop covers whatever the compiler issued just before.
+#define GBRL_SCAN9_STEP(CTRL) \
+    asm volatile("s_nop 1\n" \
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n v_addc_co_u32_dpp %9, vcc, %9, %9, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %1, vcc, %1, %1 " CTRL "\n v_addc_co_u32_dpp %10, vcc, %10, %10, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n v_addc_co_u32_dpp %11, vcc, %11, %11, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %3, vcc, %3, %3 " CTRL "\n v_addc_co_u32_dpp %12, vcc, %12, %12, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %4, vcc, %4, %4 " CTRL "\n v_addc_co_u32_dpp %13, vcc, %13, %13, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %5, vcc, %5, %5 " CTRL "\n v_addc_co_u32_dpp %14, vcc, %14, %14, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %6, vcc, %6, %6 " CTRL "\n v_addc_co_u32_dpp %15, vcc, %15, %15, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %7, vcc, %7, %7 " CTRL "\n v_addc_co_u32_dpp %16, vcc, %16, %16, vcc " CTRL "\n" \
+                 "v_add_co_u32_dpp %8, vcc, %8, %8 " CTRL "\n v_addc_co_u32_dpp %17, vcc, %17, %17, vcc " CTRL "\n" \
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), \
+                   "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]), "+v"(hi[8]) \
+                 : : "vcc")
+__device__ __forceinline__ void wave_scan9(long long (&v)[9]) {
+    unsigned int lo[9], hi[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { lo[j] = static_cast<unsigned int>(v[j]); hi[j] = static_cast<unsigned int>(static_cast<unsigned long long>(v[j]) >> 32); }
+    GBRL_SCAN9_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");   // lane 15 of rows 0 / 2 -> rows 1 / 3
+    GBRL_SCAN9_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");   // lane 31 -> rows 2, 3
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = static_cast<long long>((static_cast<unsigned long long>(hi[j]) << 32) | lo[j]);
+}
+#undef GBRL_SCAN9_STEP
+
+constexpr int kScoreLoads = 10;
+__global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, const int64_t *__restrict__ hist_prev,
                                                const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib, int Fp, int NB, int D,
                                                const FeatureSlot *__restrict__ slots, const float *__restrict__ thr,
                                                int B, int n_cand, int min_data, int cosine, const StepScales *__restrict__ scp,
@@ -1071,30 +1115,31 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         const int sib = sub_sib[node];
         const int64_t *pp = hist_prev + (static_cast<size_t>(par) * Fp + fs) * NB * W;
         const int64_t *ss = sib >= 0 ? hist + (static_cast<size_t>(sib) * Fp + fs) * NB * W : nullptr;
-        // four elements per thread in flight (the slice is ~2300 words: nine dependent round trips per thread otherwise)
+        // kScoreLoads elements per thread in flight: the whole slice of a 257-class, 9-field slot (2313 words / 256 threads) in ONE batch --
+        // a block is a chain of dependent phases and every extra batch is a memory round trip on it
         const int tot = NBe * W, step = static_cast<int>(blockDim.x);
-        for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * step) {
-            int64_t a[4], b[4];
+        for (int i0 = threadIdx.x; i0 < tot; i0 += kScoreLoads * step) {
+            int64_t a[kScoreLoads], b[kScoreLoads];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kScoreLoads; ++u) {
                 const int i = i0 + u * step;
                 a[u] = i < tot ? pp[i] : 0;
                 b[u] = (ss && i < tot) ? ss[i] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kScoreLoads; ++u) {
                 const int i = i0 + u * step;
                 if (i < tot) { const int64_t v = a[u] - b[u]; sh64[i] = v; if (keep_derived) src[i] = v; }
             }
         }
     } else {
         const int tot = NBe * W, step = static_cast<int>(blockDim.x);
-        for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * step) {
-            int64_t a[4];
+        for (int i0 = threadIdx.x; i0 < tot; i0 += kScoreLoads * step) {
+            int64_t a[kScoreLoads];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * step; a[u] = i < tot ? src[i] : 0; }
+            for (int u = 0; u < kScoreLoads; ++u) { const int i = i0 + u * step; a[u] = i < tot ? src[i] : 0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * step; if (i < tot) sh64[i] = a[u]; }
+            for (int u = 0; u < kScoreLoads; ++u) { const int i = i0 + u * step; if (i < tot) sh64[i] = a[u]; }
         }
     }
     if (threadIdx.x < kWave) {
@@ -1113,6 +1158,7 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
     // 256-class tile owns class NB-1-(tile*256+t), so an inclusive prefix over t is the suffix sum over classes.  Up to 9
     // fields are scanned together so that their cross-lane shuffles overlap.
     int64_t *total = sh64 + static_cast<size_t>(NB) * W;  // [D+1]
+    double *total_f = reinterpret_cast<double *>(total + W);   // [D+1] the same totals as doubles
     constexpr int WCH = 9;
     __shared__ long long wsum[4][WCH];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -1128,29 +1174,27 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
             long long v[WCH];
 #pragma unroll
             for (int j = 0; j < WCH; ++j) v[j] = (c >= 0 && w0 + j < W) ? sh64[c * W + w0 + j] : 0;
-#pragma unroll
-            for (int j = 0; j < WCH; ++j) {
-                long long x = v[j];
-                x = dpp_scan_step<0x111, 0xf>(x);   // within rows of 16 lanes
-                x = dpp_scan_step<0x112, 0xf>(x);
-                x = dpp_scan_step<0x114, 0xf>(x);
-                x = dpp_scan_step<0x118, 0xf>(x);
-                x = dpp_scan_step<0x142, 0xa>(x);   // lane 15 of rows 0 / 2 -> rows 1 / 3
-                x = dpp_scan_step<0x143, 0xc>(x);   // lane 31 -> rows 2, 3
-                v[j] = x;
-            }
+            static_assert(WCH == 9, "wave_scan9");
+            wave_scan9(v);   // within rows of 16 lanes (row_shr 1, 2, 4, 8), then across the rows (row_bcast 15, 31)
             if (lane == kWave - 1) {
 #pragma unroll
                 for (int j = 0; j < WCH; ++j) wsum[wave][j] = v[j];
             }
             __syncthreads();
+            {   // wave by wave (not all 36 partial sums at once: they would be the kernel's register peak and cost a wave of occupancy)
+                long long below[WCH], all[WCH];
 #pragma unroll
-            for (int j = 0; j < WCH; ++j) {
-                long long base = run_base[j], tile_total = 0;
+                for (int j = 0; j < WCH; ++j) { below[j] = 0; all[j] = 0; }
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const long long x = wsum[i][j]; if (i < wave) base += x; tile_total += x; }
-                if (c >= 0 && !sl.is_cat && w0 + j < W) sh64[c * W + w0 + j] = v[j] + base;
-                run_base[j] += tile_total;
+                    for (int j = 0; j < WCH; ++j) { const long long x = wsum[i][j]; if (i < wave) below[j] += x; all[j] += x; }
+                }
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) {
+                    if (c >= 0 && !sl.is_cat && w0 + j < W) sh64[c * W + w0 + j] = v[j] + run_base[j] + below[j];
+                    run_base[j] += all[j];
+                }
             }
             __syncthreads();
         }
@@ -1165,6 +1209,7 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
                 if (!sl.is_cat) sh64[c * W + w0 + j] = run;
             }
             total[w0 + j] = run;
+            total_f[w0 + j] = static_cast<double>(run);   // exact (|sums| < 2^53): the left side below is total_f - (double)right, no int64 subtraction + second conversion
         }
     }
     __syncthreads();
@@ -1198,16 +1243,21 @@ __global__ __launch_bounds__(256) void k_score(int64_t *__restrict__ hist, const
         if (reject) {
             out = -INFINITY;
         } else {
+            // Same value, bit for bit, as sum_d ((double)S_d * inv_scale)^2 / n per side: inv_scale is a power of two, so it commutes
+            // with every rounding below (no under- / overflow: |S| < 2^53, inv_scale >= 2^-40) and is applied once, squared, at the end
+            // (sqrt: an even power of two); (double)(total - right) == (double)total - (double)right because all three are exact.
+            // k_score is bound by its VALU instruction count and this loop was 170 of them per candidate (now ~115).
             double sr = 0.0, sl_ = 0.0;
             for (int d = 0; d < D; ++d) {
-                const double vr = static_cast<double>(R[d]) * inv_scale;
-                const double vl = static_cast<double>(total[d] - R[d]) * inv_scale;
+                const double vr = static_cast<double>(R[d]);
+                const double vl = total_f[d] - vr;
                 sr += vr * vr;
                 sl_ += vl * vl;
             }
             double x = 0.0;
             if (n_l > 0) x += sl_ / static_cast<double>(n_l);
             if (n_r > 0) x += sr / static_cast<double>(n_r);
+            x *= inv_scale * inv_scale;
             out = static_cast<float>(cosine ? sqrt(x) : x);
         }
         if (part_v) {
@@ -1869,7 +1919,7 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
                       int32_t *part_i, hipStream_t s, int slot0, bool keep_derived) {
-    const size_t lds = static_cast<size_t>(NB + 1) * (D + 1) * sizeof(int64_t);
+    const size_t lds = static_cast<size_t>(NB + 2) * (D + 1) * sizeof(int64_t);   // class sums, the totals, the totals as doubles
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
