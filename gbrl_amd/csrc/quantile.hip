@@ -606,6 +606,172 @@ __global__ __launch_bounds__(256) void k_bin_cols(const uint32_t *__restrict__ k
     }
 }
 
+#define GBRL_BIN_STEP_L8_F0(U, T, K) \
+    asm volatile("v_lshl_add_u32 %8, %0, 2, %24\n ds_read_b32 %8, %8 offset:0\n" \
+                 "v_lshl_add_u32 %9, %1, 2, %24\n ds_read_b32 %9, %9 offset:1024\n" \
+                 "v_lshl_add_u32 %10, %2, 2, %24\n ds_read_b32 %10, %10 offset:2048\n" \
+                 "v_lshl_add_u32 %11, %3, 2, %24\n ds_read_b32 %11, %11 offset:3072\n" \
+                 "v_lshl_add_u32 %12, %4, 2, %24\n ds_read_b32 %12, %12 offset:4096\n" \
+                 "v_lshl_add_u32 %13, %5, 2, %24\n ds_read_b32 %13, %13 offset:5120\n" \
+                 "v_lshl_add_u32 %14, %6, 2, %24\n ds_read_b32 %14, %14 offset:6144\n" \
+                 "v_lshl_add_u32 %15, %7, 2, %24\n ds_read_b32 %15, %15 offset:7168\n" \
+                 "s_waitcnt lgkmcnt(0)\n" \
+                 "v_cmp_lt_u32 vcc, %8, %16\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %9, %17\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %10, %18\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %11, %19\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %12, %20\n v_addc_co_u32 %4, vcc, %4, %4, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %13, %21\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %14, %22\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %15, %23\n v_addc_co_u32 %7, vcc, %7, %7, vcc\n" \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]), \
+                   "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]) \
+                 : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "s"(lds_base) \
+                 : "vcc", "memory")
+#define GBRL_BIN_STEP_L8_F8(U, T, K) \
+    asm volatile("v_lshl_add_u32 %8, %0, 2, %24\n ds_read_b32 %8, %8 offset:8192\n" \
+                 "v_lshl_add_u32 %9, %1, 2, %24\n ds_read_b32 %9, %9 offset:9216\n" \
+                 "v_lshl_add_u32 %10, %2, 2, %24\n ds_read_b32 %10, %10 offset:10240\n" \
+                 "v_lshl_add_u32 %11, %3, 2, %24\n ds_read_b32 %11, %11 offset:11264\n" \
+                 "v_lshl_add_u32 %12, %4, 2, %24\n ds_read_b32 %12, %12 offset:12288\n" \
+                 "v_lshl_add_u32 %13, %5, 2, %24\n ds_read_b32 %13, %13 offset:13312\n" \
+                 "v_lshl_add_u32 %14, %6, 2, %24\n ds_read_b32 %14, %14 offset:14336\n" \
+                 "v_lshl_add_u32 %15, %7, 2, %24\n ds_read_b32 %15, %15 offset:15360\n" \
+                 "s_waitcnt lgkmcnt(0)\n" \
+                 "v_cmp_lt_u32 vcc, %8, %16\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %9, %17\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %10, %18\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %11, %19\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %12, %20\n v_addc_co_u32 %4, vcc, %4, %4, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %13, %21\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %14, %22\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %15, %23\n v_addc_co_u32 %7, vcc, %7, %7, vcc\n" \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]), \
+                   "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]) \
+                 : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "s"(lds_base) \
+                 : "vcc", "memory")
+#define GBRL_BIN_STEP_L9_F0(U, T, K) \
+    asm volatile("v_lshl_add_u32 %8, %0, 2, %24\n ds_read_b32 %8, %8 offset:0\n" \
+                 "v_lshl_add_u32 %9, %1, 2, %24\n ds_read_b32 %9, %9 offset:2048\n" \
+                 "v_lshl_add_u32 %10, %2, 2, %24\n ds_read_b32 %10, %10 offset:4096\n" \
+                 "v_lshl_add_u32 %11, %3, 2, %24\n ds_read_b32 %11, %11 offset:6144\n" \
+                 "v_lshl_add_u32 %12, %4, 2, %24\n ds_read_b32 %12, %12 offset:8192\n" \
+                 "v_lshl_add_u32 %13, %5, 2, %24\n ds_read_b32 %13, %13 offset:10240\n" \
+                 "v_lshl_add_u32 %14, %6, 2, %24\n ds_read_b32 %14, %14 offset:12288\n" \
+                 "v_lshl_add_u32 %15, %7, 2, %24\n ds_read_b32 %15, %15 offset:14336\n" \
+                 "s_waitcnt lgkmcnt(0)\n" \
+                 "v_cmp_lt_u32 vcc, %8, %16\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %9, %17\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %10, %18\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %11, %19\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %12, %20\n v_addc_co_u32 %4, vcc, %4, %4, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %13, %21\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %14, %22\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %15, %23\n v_addc_co_u32 %7, vcc, %7, %7, vcc\n" \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]), \
+                   "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]) \
+                 : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "s"(lds_base) \
+                 : "vcc", "memory")
+#define GBRL_BIN_STEP_L9_F8(U, T, K) \
+    asm volatile("v_lshl_add_u32 %8, %0, 2, %24\n ds_read_b32 %8, %8 offset:16384\n" \
+                 "v_lshl_add_u32 %9, %1, 2, %24\n ds_read_b32 %9, %9 offset:18432\n" \
+                 "v_lshl_add_u32 %10, %2, 2, %24\n ds_read_b32 %10, %10 offset:20480\n" \
+                 "v_lshl_add_u32 %11, %3, 2, %24\n ds_read_b32 %11, %11 offset:22528\n" \
+                 "v_lshl_add_u32 %12, %4, 2, %24\n ds_read_b32 %12, %12 offset:24576\n" \
+                 "v_lshl_add_u32 %13, %5, 2, %24\n ds_read_b32 %13, %13 offset:26624\n" \
+                 "v_lshl_add_u32 %14, %6, 2, %24\n ds_read_b32 %14, %14 offset:28672\n" \
+                 "v_lshl_add_u32 %15, %7, 2, %24\n ds_read_b32 %15, %15 offset:30720\n" \
+                 "s_waitcnt lgkmcnt(0)\n" \
+                 "v_cmp_lt_u32 vcc, %8, %16\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %9, %17\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %10, %18\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %11, %19\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %12, %20\n v_addc_co_u32 %4, vcc, %4, %4, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %13, %21\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %14, %22\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n" \
+                 "v_cmp_lt_u32 vcc, %15, %23\n v_addc_co_u32 %7, vcc, %7, %7, vcc\n" \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]), \
+                   "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]) \
+                 : "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "s"(lds_base) \
+                 : "vcc", "memory")
+
+// k_bin_cols_fast<LEVELS> (round 4): the same class codes with 3 VALU instructions per probe instead of 5.  PMC (scripts/step_pmc.sh): k_bin_cols
+// kept the VALU busy 79 % of its 224 us -- 13 300 VALU instructions per wave, 52 per key -- so it is bound by its instruction count, not by
+// HBM (its 0.8 GB would take 0.16 ms) or LDS (16 %).  Here the threshold tree of a feature sits in LDS in 1-based heap order with a stride
+// of 2^LEVELS words (element 0 unused), so that the descent is u <- 2u + (t[u] < key): ONE v_addc_co_u32 with the compare's carry, the
+// address is one shift, and the feature's offset is the ds_read's immediate.  Eight descents run side by side inside one asm block (their
+// eight LDS reads in flight together); the class is u - 2^LEVELS; two codes leave in one 32-bit word.  LEVELS = 8 / 9 cover 129..511
+// thresholds per feature (n_bins 130..512); other sizes take k_bin_cols.  Same codes bit for bit (the selection tests and every golden
+// fixture run through it; `GBRL_HIP_BIN_PLAIN=1` = k_bin_cols).
+template <int LEVELS>
+__global__ __launch_bounds__(256) void k_bin_cols_fast(const uint32_t *__restrict__ kt, int n, int F, const uint32_t *__restrict__ thr,
+                                                       int B, int tiles_per_block, uint16_t *__restrict__ codes) {
+    constexpr int S = 1 << LEVELS;
+    extern __shared__ uint32_t lds[];
+    uint32_t *t = lds;                                                     // [16][S]: heap node u of feature fl at fl * S + u, u = 1 .. S - 1
+    uint32_t *tile_buf = lds + kGroup * S;                                 // [256][8] words = [256][16] codes
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(t));   // LDS byte address of t (low half of the flat address)
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < kGroup * S; i += 256) {
+        const int fl = i >> LEVELS, u = i & (S - 1), f = g * kGroup + fl;
+        uint32_t v = 0xffffffffu;
+        if (u > 0) {
+            const int L = 31 - __clz(u), pp = u - (1 << L);
+            const int q = ((2 * pp + 1) << (LEVELS - 1 - L)) - 1;          // sorted index held by heap node u
+            if (f < F && q < B) v = thr[static_cast<size_t>(f) * B + q];
+        }
+        t[i] = v;
+    }
+    __syncthreads();
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int r0 = (blockIdx.x * tiles_per_block + tile) * 256;
+        if (r0 >= n) break;
+        const int r = r0 + threadIdx.x;
+        const int rr = r < n ? r : n - 1;
+        uint32_t key[kGroup];
+#pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+            const int f = g * kGroup + q;
+            key[q] = kt[static_cast<size_t>(f < F ? f : F - 1) * n + rr];
+        }
+        uint32_t word[kGroup / 2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t u[8], tv[8], kk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { u[q] = 1; kk[q] = key[half * 8 + q]; }
+#pragma unroll
+            for (int l = 0; l < LEVELS; ++l) {
+                if constexpr (LEVELS == 8) { if (half == 0) { GBRL_BIN_STEP_L8_F0(u, tv, kk); } else { GBRL_BIN_STEP_L8_F8(u, tv, kk); } }
+                else                       { if (half == 0) { GBRL_BIN_STEP_L9_F0(u, tv, kk); } else { GBRL_BIN_STEP_L9_F8(u, tv, kk); } }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                const int f0 = g * kGroup + half * 8 + q;
+                uint32_t c0 = min(u[q] - S, static_cast<uint32_t>(B)), c1 = min(u[q + 1] - S, static_cast<uint32_t>(B));
+                if (!(f0 < F && r < n)) c0 = 0;
+                if (!(f0 + 1 < F && r < n)) c1 = 0;
+                word[half * 4 + q / 2] = c0 | (c1 << 16);
+            }
+        }
+        uint4 *row = reinterpret_cast<uint4 *>(tile_buf + threadIdx.x * 8);
+        row[0] = make_uint4(word[0], word[1], word[2], word[3]);
+        row[1] = make_uint4(word[4], word[5], word[6], word[7]);
+        __syncthreads();
+        const int rows = min(256, n - r0);
+        {
+            uint4 *dst = reinterpret_cast<uint4 *>(codes + (static_cast<size_t>(g) * n + r0) * kGroup);
+            const uint4 *src = reinterpret_cast<const uint4 *>(tile_buf);
+            for (int i = threadIdx.x; i < rows * 2; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+}
+#undef GBRL_BIN_STEP_L8_F0
+#undef GBRL_BIN_STEP_L8_F8
+#undef GBRL_BIN_STEP_L9_F0
+#undef GBRL_BIN_STEP_L9_F8
+
 __global__ void k_scatter_cat_codes_grouped(const uint16_t *__restrict__ cat_codes, int n, int Fc, int F,
                                             uint16_t *__restrict__ codes) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -714,6 +880,18 @@ void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B,
     const long long tiles = (static_cast<long long>(n) + 255) / 256;
     int tpb = static_cast<int>(std::min<long long>(kBinTiles, std::max<long long>(1, tiles * groups / 1024)));
     dim3 grid(static_cast<unsigned>((tiles + tpb - 1) / tpb), groups);
+    const bool plain = [] { const char *e = std::getenv("GBRL_HIP_BIN_PLAIN"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    if (!plain && (levels == 8 || levels == 9)) {
+        const size_t lds_fast = static_cast<size_t>(kGroup) * (1u << levels) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
+        static PerDeviceOnce attr_fast;
+        if (attr_fast.first()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols_fast<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_cols_fast<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        }
+        if (levels == 8) hipLaunchKernelGGL(k_bin_cols_fast<8>, grid, dim3(256), lds_fast, s, kt, n, F, thr_keys, B, tpb, codes);
+        else hipLaunchKernelGGL(k_bin_cols_fast<9>, grid, dim3(256), lds_fast, s, kt, n, F, thr_keys, B, tpb, codes);
+        return;
+    }
     hipLaunchKernelGGL(k_bin_cols, grid, dim3(256), lds, s, kt, n, F, thr_keys, B, levels, tpb, codes);
 }
 

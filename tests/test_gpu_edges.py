@@ -250,6 +250,29 @@ def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
     assert len(lines) >= 12 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("n_bins,F,gen", [(256, 40, "Quantile"), (200, 17, "Uniform"), (511, 33, "Quantile"), (130, 16, "Quantile"), (512, 5, "Uniform")])
+def test_fast_binning_kernel_equals_the_plain_one(n_bins, F, gen, monkeypatch):
+    """k_bin_cols_fast (heap descent with the compare's carry, thresholds per feature 129..511) against k_bin_cols (`GBRL_HIP_BIN_PLAIN=1`,
+    read per call): byte-identical ensembles and predictions on batches that take the separate binning kernel (more than 8192 rows),
+    feature counts with a partial last group of 16, special values among the observations."""
+    import gbrl_amd
+    case = _case("binfast", seed=n_bins + F, N=20000 + F, F=F, D=3, depth=5, n_bins=n_bins, policy="oblivious", gen=gen, trees=3)
+    X, Xc, G, y = K.make_inputs(case)
+    X = X.copy()
+    X[::97, 0] = np.inf; X[5::89, F - 1] = -np.inf; X[7::83, 1 % F] = 0.0; X[11::79, 2 % F] = -0.0; X[::1013, 3 % F] = np.nan
+    got = []
+    for plain in ("1", "0"):
+        monkeypatch.setenv("GBRL_HIP_BIN_PLAIN", plain)
+        m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+        pred = np.asarray(K.drive(m, case, X, Xc, G, y))
+        got.append((m.get_ensemble_data(), pred))
+    for k in got[0][0]:
+        a, b = np.asarray(got[0][0][k]), np.asarray(got[1][0][k])
+        assert a.shape == b.shape and a.tobytes() == b.tobytes(), k
+    assert got[0][1].tobytes() == got[1][1].tobytes()
+    assert int(np.asarray(got[0][0]["depths"]).sum()) > 0
+
+
 @pytest.mark.parametrize("gen", ["Quantile", "Uniform"])
 @pytest.mark.parametrize("policy", ["greedy", "oblivious"])
 def test_nan_observations_are_routed_the_same_way_by_step_and_predict(gen, policy):
