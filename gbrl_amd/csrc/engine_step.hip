@@ -510,9 +510,18 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         const bool enqueued = first && resume;   // (the hints that size this round are only updated by the collecting call)
         if (enqueued) d_slotq = static_cast<int32_t *>(d_cat_slotq_.ensure(sizeof(int32_t) * slots));
         if (!enqueued) {
-            hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
-            hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
-            hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
+            if (slots <= (size_t(1) << 22)) {   // the usual few-KiB tables: one launch clears all three
+                kern::FillSegments fz{};
+                fz.n = 3;
+                fz.dst[0] = d_keys; fz.words[0] = static_cast<uint32_t>(2 * slots); fz.value[0] = 0u;
+                fz.dst[1] = d_first; fz.words[1] = static_cast<uint32_t>(slots); fz.value[1] = 0x7f7f7f7fu;
+                fz.dst[2] = d_meta; fz.words[2] = 4; fz.value[2] = 0u;
+                kern::fill_segments(fz, s);
+            } else {
+                hip_check(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * slots, s), "memset");
+                hip_check(hipMemsetAsync(d_first, 0x7f, sizeof(int32_t) * slots, s), "memset");
+                hip_check(hipMemsetAsync(d_meta, 0, sizeof(int32_t) * 4, s), "memset");
+            }
             kern::cat_distinct_insert(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, d_lslot, d_meta + 2, list_cap, s);
             kern::cat_distinct_verify(dcells, N, Fc, d_keys, d_first, log2_cap, d_meta, s);
         }
@@ -817,8 +826,13 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
     } else if (F > 0) {
         if (md.generator_type == GBRL_HIP_GEN_UNIFORM) {
             uint32_t *d_mm = static_cast<uint32_t *>(d_minmax_.ensure(sizeof(uint32_t) * 2 * F));
-            hip_check(hipMemsetAsync(d_mm, 0xff, sizeof(uint32_t) * F, s), "memset");
-            hip_check(hipMemsetAsync(d_mm + F, 0x00, sizeof(uint32_t) * F, s), "memset");
+            {
+                kern::FillSegments fz{};
+                fz.n = 2;
+                fz.dst[0] = d_mm; fz.words[0] = static_cast<uint32_t>(F); fz.value[0] = 0xffffffffu;
+                fz.dst[1] = d_mm + F; fz.words[1] = static_cast<uint32_t>(F); fz.value[1] = 0u;
+                kern::fill_segments(fz, s);
+            }
             kern::column_minmax(d_kt, N, F, d_mm, d_mm + F, s);
             if (has_coll_) {
                 // exchange as floats (max / min are exact)

@@ -116,6 +116,9 @@ void publish_pair(const void *d_a, void *h_a_mapped, size_t a_bytes, const void 
 // few KB) in steps that are bound by stream operations, not bytes.  The host must leave the sources alone until the kernel has run.
 struct FetchSegments { void *dst[8]; const void *src[8]; uint32_t words[8]; int n; };
 void fetch_segments(const FetchSegments &fs, hipStream_t s);
+// up to four regions filled with a 32-bit pattern each by ONE launch (an RL-sized step pays 4-5 us per hipMemsetAsync)
+struct FillSegments { void *dst[4]; uint32_t words[4]; uint32_t value[4]; int n; };
+void fill_segments(const FillSegments &fs, hipStream_t s);
 void iota_rows(int32_t *rows, int n, hipStream_t s);
 
 // ---- exact quantile selection and binning on transposed keys (quantile.hip) ----

@@ -932,6 +932,12 @@ __global__ __launch_bounds__(256) void k_fetch_segments(FetchSegments fs) {
     for (int k = 0; k < 8; ++k)
         if (k < fs.n && i < fs.words[k]) static_cast<uint32_t *>(fs.dst[k])[i] = static_cast<const uint32_t *>(fs.src[k])[i];
 }
+__global__ __launch_bounds__(256) void k_fill_segments(FillSegments fs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < fs.n && i < fs.words[k]) static_cast<uint32_t *>(fs.dst[k])[i] = fs.value[k];
+}
 __global__ void k_fill_f32(float *__restrict__ p, size_t n, float v) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1898,6 +1904,11 @@ void fetch_segments(const FetchSegments &fs, hipStream_t s) {
     uint32_t mx = 0;
     for (int k = 0; k < fs.n; ++k) mx = std::max(mx, fs.words[k]);
     if (mx) hipLaunchKernelGGL(k_fetch_segments, dim3((mx + 255) / 256), dim3(256), 0, s, fs);
+}
+void fill_segments(const FillSegments &fs, hipStream_t s) {
+    uint32_t mx = 0;
+    for (int k = 0; k < fs.n; ++k) mx = std::max(mx, fs.words[k]);
+    if (mx) hipLaunchKernelGGL(k_fill_segments, dim3((mx + 255) / 256), dim3(256), 0, s, fs);
 }
 void fill_f32(float *p, size_t n, float v, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p, n, v);
