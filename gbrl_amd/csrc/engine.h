@@ -223,6 +223,8 @@ class Engine {
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
+    DevBuf d_root_le_;
+    const uint32_t *root_le_ = nullptr;   // this step's #{keys <= threshold} table (radix selection, one GPU), null otherwise
     DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lslot_, d_sdict_, d_cat_xchg_, d_cat_slotq_, d_cat_clsq_;
     PinnedBuf pin_cat_cls_;
     uint32_t cat_pub_seq_ = 0;                          // sequence word of k_cat_publish's completion flag

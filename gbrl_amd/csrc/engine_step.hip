@@ -75,6 +75,7 @@ struct GrowCtx {
     const kern::StepScales *h_scales;   // pinned, same
     const float *d_thr;
     const uint32_t *d_thrkeys;   // [F][B] ordered keys of the thresholds
+    const uint32_t *root_le;     // [F][B] #{keys <= threshold} from the radix selection (one GPU, numeric-only steps), else null
     const uint32_t *d_kt;        // [F][N] feature-major ordered keys of the observations (null when F == 0)
     const uint16_t *d_codes;
     const int32_t *d_qg;
@@ -883,7 +884,10 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                     comm.gbuf = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * kern::radix_exchange_words(F)));
                     comm.partial_global = static_cast<uint32_t *>(d_radix_global_.ensure(kern::radix_global_partial_bytes(F)));
                 }
-                const int rc = kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s, has_coll_ ? &comm : nullptr, pass1_chunks);
+                // (one GPU: the selection also reports #{keys <= threshold}, from which the ROOT's class counts follow -- grow_tree, root_le)
+                uint32_t *d_le = has_coll_ ? nullptr : static_cast<uint32_t *>(d_root_le_.ensure(sizeof(uint32_t) * (static_cast<size_t>(F) * B + F)));
+                const int rc = kern::radix_select(d_kt, N, F, d_cum, B, d_rs, d_rp, d_rl, d_thrkeys, s, has_coll_ ? &comm : nullptr, pass1_chunks, d_le);
+                root_le_ = d_le;
                 if (rc != 0) throw HipError(rc == 2 ? "allreduce failed" : "radix select failed");
                 last_quantile_fallback_ = false;
             } else {
@@ -1478,19 +1482,25 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         int32_t *d_seg_starts = sta.put(seg_starts.data(), seg_starts.size());
         int32_t *d_n_locals = sta.put(n_locals.data(), n_locals.size());
         sta.flush();
+        // root of a numeric-only tree on one GPU whose candidates came from the radix selection: the class counts are known from the
+        // selection's ranks, so the histogram build skips the count atomic (8 instead of 9 per (row, feature) at D = 8) and hist_reduce
+        // writes the counts (GBRL_HIP_ROOT_COUNTS=0: accumulate them like every other level; =2: do both and compare, the tests)
+        const int root_mode = [] { const char *e = std::getenv("GBRL_HIP_ROOT_COUNTS"); return e ? std::atoi(e) : 1; }();   /* read per call: the tests flip it; 2 = verify */
+        const bool root_countless = depth == 0 && c.root_le != nullptr && root_mode != 0 && !hist_direct && !has_coll_ && n_global == N && NB == B + 1 &&
+                                    kern::hist_countless_supported(D, FG, N);
         bool hist_written = false;
         if (!h_chunks.empty()) {
             const auto ev = kernel_events("hist_build", /*key=*/true);   // the dispatch's own timestamps: no bubble in the stream
             kern::HistDirect hd;
             if (hist_direct) { hd.hist = d_hist; hd.slot_map = d_slotmap; hd.Fp = Fp; }
             hist_written = kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s,
-                                            ev.first, ev.second, hist_direct ? &hd : nullptr);
+                                            ev.first, ev.second, hist_direct ? &hd : nullptr, !root_countless);
         }
         if (!hist_written) phase_begin();   // (no phase record for a level whose histograms k_hist_build stored itself)
         if (!has_coll_) {
             if (!compute_ids.empty() && !hist_written)
                 kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s,
-                                  static_cast<int>(h_chunks.size() / compute_ids.size()));
+                                  static_cast<int>(h_chunks.size() / compute_ids.size()), 0, root_countless ? c.root_le : nullptr, F, B, N);
         } else if (!compute_ids.empty()) {
             // local sums of the computed nodes in the feature-scattered send layout -> ONE reduce-scatter -> this rank's feature
             // slice of the global sums goes to the nodes' level slots (the other features of d_hist are never read on this rank)
@@ -1499,6 +1509,25 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, d_hist_coll, s, static_cast<int>(h_chunks.size() / nc), coll_Fs);
             reduce_scatter_i64(d_hist_coll, d_hist_recv, static_cast<size_t>(nc) * coll_Fs * feat_elems);
             kern::hist_place_slice(d_hist_recv, d_hist, d_slotmap, nc, coll_Fs, coll_lo, Fp, feat_elems, s);
+        }
+        if (root_countless && root_mode == 2) {
+            // GBRL_HIP_ROOT_COUNTS=2 (tests): the root's count fields once more by accumulation, compared entry by entry
+            int64_t *d_alt = d_hist_lvl[(depth & 1) ^ 1];
+            kern::hist_build(d_codes, N, d_qg, D, d_rows[cur], d_chunks, static_cast<int>(h_chunks.size()), n_groups, FG, NB, d_partials, s, nullptr, nullptr, nullptr, true);
+            kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_alt, s, static_cast<int>(h_chunks.size() / compute_ids.size()));
+            const size_t ne = static_cast<size_t>(Fp) * NB * (D + 1);
+            std::vector<int64_t> ha(ne), hb(ne);
+            hip_check(hipMemcpyAsync(ha.data(), d_hist, ne * 8, hipMemcpyDeviceToHost, s), "D2H root histogram");
+            hip_check(hipMemcpyAsync(hb.data(), d_alt, ne * 8, hipMemcpyDeviceToHost, s), "D2H root histogram");
+            hip_check(hipStreamSynchronize(s), "sync");
+            for (int f = 0; f < F; ++f)
+                for (int cl = 0; cl < NB; ++cl)
+                    for (int d = 0; d <= D; ++d) {
+                        const size_t i = (static_cast<size_t>(f) * NB + cl) * (D + 1) + d;
+                        if (ha[i] != hb[i])
+                            throw HipError("root histogram check: feature " + std::to_string(f) + " class " + std::to_string(cl) + " field " + std::to_string(d) + ": " +
+                                           std::to_string(ha[i]) + " from the selection's ranks, " + std::to_string(hb[i]) + " accumulated");
+                    }
         }
         if (!hist_written) phase_end("hist_reduce");
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
@@ -1797,6 +1826,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
     if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
     bool codes_from_sort = false;
+    root_le_ = nullptr;
     if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);
     phase_end("candidates");
     // numeric class codes (3. below) before the host waits for the categorical scan
@@ -1972,7 +2002,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cand_slot = &cand_slot;
     gc.const_cacheable = const_cacheable; gc.cat_cands = &cat_cands;
     gc.prefix_cacheable = prefix_cacheable; gc.n_num_cand = n_num_cand; gc.cand_cap = (F + Fc) * B;
-    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.root_le = (Fc == 0 && !has_coll_) ? root_le_ : nullptr; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;
     std::vector<int64_t> acc;

@@ -170,7 +170,9 @@ size_t radix_exchange_words(int F);
 size_t radix_global_partial_bytes(int F);
 int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
                  uint32_t *thr_keys, hipStream_t s, const RadixComm *comm /*nullable: one GPU*/,
-                 int pass1_chunks = 0 /*> 0: `partial` already holds the first-digit counts written by transpose_keys_count*/);
+                 int pass1_chunks = 0 /*> 0: `partial` already holds the first-digit counts written by transpose_keys_count*/,
+                 uint32_t *le_out = nullptr /*[F][B] + [F]: number of keys <= each threshold (global, after the NaN-range fix-up of
+                 keys_to_floats), for the root's class counts; the F trailing words are scratch*/);
 // obs [n][F] -> kt [F][n] keys AND the first radix digit counted on the way (partial: the radix_partial_bytes(F) buffer).
 // Returns the chunk count to pass to radix_select, or 0 when the shape does not qualify (nothing was done).
 int transpose_keys_count(const float *obs, int n, int F, uint32_t *kt, uint32_t *partial, hipStream_t s);
@@ -193,13 +195,19 @@ bool hist_direct_supported(int FG);   // the kernel hist_build will take for thi
 bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows,
                 const Chunk *chunks, int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s,
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /*the dispatch's own begin / end timestamps*/,
-                const HistDirect *direct = nullptr);
+                const HistDirect *direct = nullptr,
+                bool count_rows = true /* false: the rows' count field is NOT accumulated (FG == 16, D <= 16 kernels only; returns as if
+                true otherwise -- check hist_countless_supported): the root's class counts come from the selection, hist_reduce root_le */);
+bool hist_countless_supported(int D, int FG, int n_rows);
 // hist[slot_map ? slot_map[k] : k] = sum of the partials of chunk-slot k
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin /*[n_slots+1]*/, const int32_t *slot_map, int n_slots,
                  int n_groups, int FG, int NB, int D, int Fp, int64_t *hist, hipStream_t s,
                  int chunks_per_slot = 1 /* average chunks per node: picks the kernel variant */,
                  int scatter_fs = 0 /* > 0: write the feature-scattered send layout [f / fs][n_slots][f % fs][class][D+1] of a
-                                       reduce-scatter over feature slices of fs features instead of hist[slot][Fp][class][D+1] */);
+                                       reduce-scatter over feature slices of fs features instead of hist[slot][Fp][class][D+1] */,
+                 const uint32_t *root_le = nullptr /* [F][B] keys <= threshold: the count field of numeric feature f, class c becomes
+                                       le[c] - le[c-1] (c = B: n_total - le[B-1]) instead of the partials' sum (root level, FG == 16) */,
+                 int root_F = 0, int root_B = 0, long long root_n = 0);
 // Row-sharded runs, feature-parallel scoring: the reduce-scattered slice [n][fs][class][D+1] of this rank's features goes to its
 // place hist[slot_map[k]][lo + f][class][D+1] (f < min(fs, Fp - lo))
 void hist_place_slice(const int64_t *recv, int64_t *hist, const int32_t *slot_map, int n, int fs, int lo, int Fp, size_t feat_elems, hipStream_t s);

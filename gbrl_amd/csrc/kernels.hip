@@ -505,7 +505,9 @@ struct HistLoads {
         return *reinterpret_cast<const int32_t *>(qbase + (row * static_cast<uint32_t>(DT * 4) + qoff));
     }
 };
-template <int DT, int U, bool PIPE, class Ld = HistLoads>
+// COUNT = false (root level, one GPU, radix-selected quantile candidates): the row count of a class is not accumulated -- eight LDS atomics
+// per (row, feature) instead of nine at D = 8; kern::hist_reduce fills the count field from the selection's ranks (root_le).
+template <int DT, int U, bool PIPE, class Ld = HistLoads, bool COUNT = true>
 __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__restrict__ codes, int n_rows,
                                                               const int32_t *__restrict__ qg, int D_rt,
                                                               const int32_t *__restrict__ rows,
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
             for (int u = 0; u < U; ++u) {
                 int32_t *dst = h + codeA[u] * row_stride + fl;
                 RowAtomics<DT, 0>::run(dst, 16, qA[u]);
-                atomicAdd(dst + DT * 16, 1);
+                if (COUNT) atomicAdd(dst + DT * 16, 1);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) { codeA[u] = codeB[u]; qA[u] = qB[u]; rowB[u] = rowC[u]; }
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
             for (int u = 0; u < U; ++u) {
                 int32_t *dst = h + code[u] * row_stride + fl;
                 RowAtomics<DT, 0>::run(dst, 16, myq[u]);
-                atomicAdd(dst + DT * 16, 1);
+                if (COUNT) atomicAdd(dst + DT * 16, 1);
             }
         } else {
 #pragma unroll
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_build(const uint16_t *__r
             int32_t *dst = h + ld_code(row) * row_stride + fl;
             const int myq = ld_q(row);
             RowAtomics<DT, 0>::run(dst, 16, myq);
-            atomicAdd(dst + DT * 16, 1);
+            if (COUNT) atomicAdd(dst + DT * 16, 1);
         } else {
             const int code = cbase[static_cast<size_t>(row) * kCodeGroup];
             int32_t *dst = h + code * row_stride + fl;
@@ -835,7 +837,8 @@ template <int kReduceLanes>
 __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_t *__restrict__ partials,
                                                                      const int32_t *__restrict__ slot_chunk_begin,
                                                                      const int32_t *__restrict__ slot_map, int n_groups, int FG, int NB,
-                                                                     int D, int Fp, int64_t *__restrict__ hist, int scatter_fs) {
+                                                                     int D, int Fp, int64_t *__restrict__ hist, int scatter_fs,
+                                                                     const uint32_t *__restrict__ root_le, int root_F, int root_B, long long root_n) {
     __shared__ int64_t part[kReduceLanes > 1 ? kReduceLanes - 1 : 1][256];
     const int n_acc = NB * (D + 1) * FG;
     const int k = blockIdx.z, g = blockIdx.y;
@@ -882,7 +885,16 @@ __global__ __launch_bounds__(256 * kReduceLanes) void k_hist_reduce(const int32_
         const int e = blockIdx.x * 16 + el;                       // (class, field) element: cls * (D + 1) + d
         const int f = g * FG + fl;
         if (e >= NB * (D + 1)) return;
-        const int64_t v = tile[fl][el];
+        int64_t v = tile[fl][el];
+        if (root_le && f < root_F) {   // the root's class counts from the selection: #{keys <= thr[c]} - #{keys <= thr[c-1]} (k_hist_build<COUNT = false>)
+            const int cls = e / (D + 1);
+            if (e - cls * (D + 1) == D) {
+                const uint32_t *le = root_le + static_cast<size_t>(f) * root_B;
+                const long long hi = cls < root_B ? static_cast<long long>(le[cls]) : root_n;
+                const long long lo = cls == 0 ? 0ll : (cls - 1 < root_B ? static_cast<long long>(le[cls - 1]) : root_n);
+                v = cls <= root_B ? hi - lo : 0;
+            }
+        }
         if (scatter_fs > 0) {   // send layout of the feature reduce-scatter: [owner rank][node k][feature inside the slice][class][D+1]
             if (f < Fp) hist[((static_cast<size_t>(f / scatter_fs) * gridDim.z + k) * scatter_fs + f % scatter_fs) * NB * (D + 1) + e] = v;
             return;
@@ -1748,27 +1760,28 @@ void iota_rows(int32_t *rows, int n, hipStream_t s) {
 
 size_t hist_lds_bytes(int NB, int D, int FG) { return static_cast<size_t>(NB) * (D + 1) * FG * sizeof(int32_t); }
 
-template <int DT, int U, bool PIPE>
+template <int DT, int U, bool PIPE, bool COUNT = true>
 static void launch_hist_p(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                           int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
                           hipEvent_t ev_start, hipEvent_t ev_stop, const HistDirect &direct) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_build<DT, U, PIPE, HistLoads, COUNT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
     }
     const int grid = 8 * n_groups * ((n_chunks + 7) / 8);
     // ev_start / ev_stop (nullable): the dispatch's own begin / end timestamps -- no extra packets in the stream, unlike
     // hipEventRecord around the launch
-    hipExtLaunchKernelGGL((k_hist_build<DT, U, PIPE>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D, rows,
+    hipExtLaunchKernelGGL((k_hist_build<DT, U, PIPE, HistLoads, COUNT>), dim3(grid), dim3(kHistThreads), lds, s, ev_start, ev_stop, 0, codes, n_rows, qg, D, rows,
                           chunks, n_chunks, n_groups, FG, shift, NB, partials, direct);
 }
 template <int DT, int U>
 static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                         int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
-                        hipEvent_t ev_start, hipEvent_t ev_stop, const HistDirect &direct = HistDirect{}) {
+                        hipEvent_t ev_start, hipEvent_t ev_stop, const HistDirect &direct = HistDirect{}, bool count_rows = true) {
     static const bool pipe = []() { const char *e = std::getenv("GBRL_HIP_HIST_PIPE"); return !(e && e[0] == '0'); }();   // measurement hook
     if constexpr (DT != 0) {
+        if (pipe && !count_rows) { launch_hist_p<DT, U, true, false>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct); return; }
         if (pipe) { launch_hist_p<DT, U, true>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct); return; }
     }
     launch_hist_p<DT, U, false>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct);
@@ -1839,9 +1852,15 @@ static bool launch_hist_wide(int P, int H, const uint16_t *codes, int n_rows, co
 
 // (FG 8 / 4 may go to the wide / quad kernels, which only write partials -- and skip empty chunks)
 bool hist_direct_supported(int FG) { return FG != 8 && FG != 4; }
+// the count-less variant exists for the compile-time-D kernels with the software pipeline (what hist_build takes for FG == 16, D <= 16)
+bool hist_countless_supported(int D, int FG, int n_rows) {
+    static const bool generic_only = [] { const char *e = std::getenv("GBRL_HIP_HIST_GENERIC"); return e && e[0] == '1'; }();
+    static const bool pipe = []() { const char *e = std::getenv("GBRL_HIP_HIST_PIPE"); return !(e && e[0] == '0'); }();
+    return !generic_only && pipe && FG == 16 && D >= 1 && D <= 16 && n_rows <= (1 << 26);
+}
 bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                 int n_chunks, int n_groups, int FG, int NB, int32_t *partials, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
-                const HistDirect *direct) {
+                const HistDirect *direct, bool count_rows) {
     const HistDirect dir = direct ? *direct : HistDirect{};
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
@@ -1855,7 +1874,7 @@ bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
 #ifndef GBRL_HIST_U
 #define GBRL_HIST_U 8
 #endif
-#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, dir); return dir.hist != nullptr;
+#define GBRL_HIST_CASE(DD) case DD: launch_hist<DD, GBRL_HIST_U>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, dir, count_rows); return dir.hist != nullptr;
     if (FG == 16) {
         switch (D) {
             GBRL_HIST_CASE(1) GBRL_HIST_CASE(2) GBRL_HIST_CASE(3) GBRL_HIST_CASE(4) GBRL_HIST_CASE(5) GBRL_HIST_CASE(6)
@@ -1878,13 +1897,15 @@ bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
 }
 
 void hist_reduce(const int32_t *partials, const int32_t *slot_chunk_begin, const int32_t *slot_map, int n_slots, int n_groups, int FG,
-                 int NB, int D, int Fp, int64_t *hist, hipStream_t s, int chunks_per_slot, int scatter_fs) {
+                 int NB, int D, int Fp, int64_t *hist, hipStream_t s, int chunks_per_slot, int scatter_fs, const uint32_t *root_le, int root_F,
+                 int root_B, long long root_n) {
     const int n_acc = NB * (D + 1) * FG;
     dim3 grid((n_acc + 255) / 256, n_groups, n_slots);
+    if (FG != 16) root_le = nullptr;   // (the override lives in the FG == 16 store path; callers check hist_countless_supported)
     if (chunks_per_slot >= 48)
-        hipLaunchKernelGGL(k_hist_reduce<4>, grid, dim3(256, 4), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist, scatter_fs);
+        hipLaunchKernelGGL(k_hist_reduce<4>, grid, dim3(256, 4), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist, scatter_fs, root_le, root_F, root_B, root_n);
     else
-        hipLaunchKernelGGL(k_hist_reduce<1>, grid, dim3(256, 1), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist, scatter_fs);
+        hipLaunchKernelGGL(k_hist_reduce<1>, grid, dim3(256, 1), 0, s, partials, slot_chunk_begin, slot_map, n_groups, FG, NB, D, Fp, hist, scatter_fs, root_le, root_F, root_B, root_n);
 }
 void hist_place_slice(const int64_t *recv, int64_t *hist, const int32_t *slot_map, int n, int fs, int lo, int Fp, size_t feat_elems, hipStream_t s) {
     if (n <= 0 || fs <= 0) return;

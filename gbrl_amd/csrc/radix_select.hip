@@ -327,7 +327,7 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *scratc
 // One block per feature; thread k < B owns target k.  `pass` = the counting pass being consumed.
 __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const uint32_t *__restrict__ partial, int n_chunks,
                                                                const int64_t *__restrict__ cum, int B, RadixState st,
-                                                               uint32_t *__restrict__ thr_keys, int p1_u16) {
+                                                               uint32_t *__restrict__ thr_keys, int p1_u16, uint32_t *__restrict__ le_out) {
     extern __shared__ uint32_t sums[];        // inclusive digit counts: pass 1 [4096]; later [n_slots][NB]
     __shared__ int tslot[kMaxTargets], tdig[kMaxTargets];
     __shared__ uint32_t scratch[16], total_slots;
@@ -389,8 +389,16 @@ __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const u
         int lo = 0, hi = NB - 1;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (hs[mid] < rank) lo = mid + 1; else hi = mid; }
         digit = lo;
+        // last pass: #{keys <= this threshold} = (keys in front of the target's slot = its global rank - its rank inside the slot) + the
+        // slot's inclusive count at the found digit.  The class counts of the tree's ROOT follow from these (kern::hist_reduce, root_le).
+        if (pass == 1 && k == 0 && le_out) le_out[static_cast<size_t>(gridDim.x) * B + f] = sums[7];   // #{keys <= key(-inf)}, see below
+        const uint32_t le_here = static_cast<uint32_t>(static_cast<uint64_t>(cum[k]) - rank + hs[lo]);
         rank -= lo ? hs[lo - 1] : 0u;
         prefix |= static_cast<uint32_t>(digit) << radix_shift(pass);
+        // A selected key in the NaN range is raised to -inf's key afterwards (k_keys_to_floats): the count that belongs to the threshold the
+        // step will really use is #{keys <= key(-inf)} = all keys whose first digit is <= 0x007 (NaNs are key 0, -inf is 0x007fffff, nothing
+        // else lives below 0x00800000), which pass 1 left behind the table.
+        if (pass == 4 && le_out) le_out[static_cast<size_t>(f) * B + k] = prefix < 0x007fffffu ? le_out[static_cast<size_t>(gridDim.x) * B + f] : le_here;
     }
     if (pass == 4) {
         if (k < B) thr_keys[static_cast<size_t>(f) * B + k] = prefix;
@@ -490,7 +498,7 @@ size_t radix_global_partial_bytes(int F) { return sizeof(uint32_t) * static_cast
 // Exact order statistics of every column: thr_keys[f][k] = key of 1-based rank cum[k] in column f of kt ([F][n] ordered keys).
 // cum must be non-decreasing, 1 <= cum[k] <= n, B <= 256.
 int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, void *state, uint32_t *partial, uint32_t *lists,
-                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm, int pass1_chunks) {
+                 uint32_t *thr_keys, hipStream_t s, const RadixComm *comm, int pass1_chunks, uint32_t *le_out) {
     char *p = static_cast<char *>(state);
     auto take = [&](size_t bytes) { char *q = p; p += align16(bytes); return q; };
     const size_t f = static_cast<size_t>(F);
@@ -546,7 +554,7 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
             chunks = 1;
         }
         const size_t lds = pass == 1 ? kBins1 * 4 : static_cast<size_t>(kMaxTargets) * radix_bins(pass) * 4;
-        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys, p1_u16);
+        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys, p1_u16, le_out);
         return 0;
     };
     int rc = 0;

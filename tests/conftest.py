@@ -8,6 +8,9 @@ os.environ.setdefault("OMP_NUM_THREADS", "8")
 # Every categorical step of the test suite replays the reference's string-keyed candidate container beside the engine's
 # hash-replay of it and throws when the two iteration orders differ (engine_step.hip, device_categorical_candidates).
 os.environ.setdefault("GBRL_HIP_CAT_CHECK", "1")
+# Every root level that takes its class counts from the radix selection's ranks (k_hist_build without the count atomic) also accumulates
+# them and compares entry by entry; a difference raises (engine_step.hip, grow_tree, root_mode).
+os.environ.setdefault("GBRL_HIP_ROOT_COUNTS", "2")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):

@@ -250,6 +250,34 @@ def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
     assert len(lines) >= 12 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("N,F,D,n_bins,policy", [(70000, 20, 8, 256, "oblivious"), (131072 + 4, 33, 3, 100, "greedy"), (20000, 16, 1, 256, "greedy"), (90000, 7, 16, 64, "oblivious")])
+def test_root_class_counts_from_the_selection_ranks(N, F, D, n_bins, policy, monkeypatch):
+    """Root level of a numeric-only quantile tree on one GPU: k_hist_build skips the count atomic and k_hist_reduce writes the class counts from
+    the radix selection's ranks (#{keys <= threshold}).  `GBRL_HIP_ROOT_COUNTS=0` accumulates them as on every other level: same bytes.  Columns
+    with heavy duplicates (a constant, a two-valued, an integer-valued one, +-inf, NaN) make thresholds repeat and classes empty."""
+    import gbrl_amd
+    case = _case("rootle", seed=N % 97 + F, N=N, F=F, D=D, depth=4, n_bins=n_bins, policy=policy, gen="Quantile", trees=2)
+    X, Xc, G, y = K.make_inputs(case)
+    X = X.copy()
+    X[:, 0] = 1.5
+    X[:, 1] = (X[:, 1] > 0).astype(np.float32)
+    X[:, 2] = np.round(X[:, 2] * 3)
+    X[::101, 3] = np.inf; X[3::103, 3] = -np.inf; X[::997, 4] = np.nan
+    X[::5, 5] = np.nan; X[1::7, 5] = -np.inf          # more NaNs than one quantile step: NaN-range thresholds are raised to -inf
+    X[::3, 6] = np.nan
+    got = []
+    for flag in ("0", "2"):     # 2 = from the ranks AND accumulated, compared entry by entry inside the engine (raises on a difference)
+        monkeypatch.setenv("GBRL_HIP_ROOT_COUNTS", flag)
+        m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+        pred = np.asarray(K.drive(m, case, X, Xc, G, y))
+        got.append((m.get_ensemble_data(), pred))
+    for k in got[0][0]:
+        a, b = np.asarray(got[0][0][k]), np.asarray(got[1][0][k])
+        assert a.shape == b.shape and a.tobytes() == b.tobytes(), k
+    assert got[0][1].tobytes() == got[1][1].tobytes()
+    assert int(np.asarray(got[0][0]["depths"]).sum()) > 0
+
+
 @pytest.mark.parametrize("n_bins,F,gen", [(256, 40, "Quantile"), (200, 17, "Uniform"), (511, 33, "Quantile"), (130, 16, "Quantile"), (512, 5, "Uniform")])
 def test_fast_binning_kernel_equals_the_plain_one(n_bins, F, gen, monkeypatch):
     """k_bin_cols_fast (heap descent with the compare's carry, thresholds per feature 129..511) against k_bin_cols (`GBRL_HIP_BIN_PLAIN=1`,
