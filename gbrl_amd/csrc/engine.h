@@ -103,7 +103,7 @@ class Engine {
     void set_rccl(const void *id128, int world_size, int rank);
     int device_ordinal();                 // latches the device like the first step()/predict() would
     void set_stream(hipStream_t s);       // nullptr: back to the engine's own blocking stream
-    void set_profiling(int level) { profiling_ = level; }   // 0 off, 1 histogram build only, 2 every phase
+    void set_profiling(int level) { profiling_ = level; }   // 0 off, 1 histogram build only (one launch in seven, every level in turn), 2 every phase
     void set_force_bisection(bool on) { force_bisection_ = on; }   // test hook: exercise the slow exact quantile path
     bool last_quantile_fallback() const { return last_quantile_fallback_; }
     const std::vector<std::pair<std::string, float>> &phase_times() const { return phases_; }
@@ -142,6 +142,7 @@ class Engine {
 
     // measurement
     int profiling_ = 0;
+    unsigned key_calls_ = 0;   // key-kernel launches seen at profiling level 1 (every seventh carries an event pair)
     bool force_bisection_ = false, force_sample_select_ = false, force_host_categorical_ = false, force_radix_ = false, last_quantile_fallback_ = false;
     // fit(): numeric thresholds computed once from the whole data set and reused by every batch's step()
     std::vector<float> fixed_thr_;

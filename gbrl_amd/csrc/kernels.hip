@@ -1034,23 +1034,6 @@ __device__ __forceinline__ Best better(Best a, Best b) {
     if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
     return a;
 }
-// Wave-wide inclusive scan step on a 64-bit value with DPP (VALU only; __shfl_up would go through the LDS crossbar, which
-// is what k_score is short of).  ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
-// Steps inside a row (all rows enabled) take bound_ctrl: a lane whose source falls outside its row reads 0 without the destination
-// being zeroed first (two v_mov per step saved: k_score is bound by its VALU instruction count, section 5 of DESIGN.md).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ long long dpp_scan_step(long long x) {
-    int lo, hi;
-    if constexpr (ROW_MASK == 0xf) {
-        lo = __builtin_amdgcn_mov_dpp(static_cast<int>(x), CTRL, 0xf, 0xf, true);
-        hi = __builtin_amdgcn_mov_dpp(static_cast<int>(x >> 32), CTRL, 0xf, 0xf, true);
-    } else {
-        lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x >> 32), CTRL, ROW_MASK, 0xf, false);
-    }
-    return x + ((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
-}
-
 // Inclusive scan over the 64 lanes of NINE 64-bit values at once (k_score's fields), every step as two DPP-fused adds per value:
 //   v_add_co_u32_dpp lo, vcc, lo, lo <ctrl>   ;  v_addc_co_u32_dpp hi, vcc, hi, hi, vcc <ctrl>
 // A lane whose source is outside its row (row_shr) or whose row is masked (row_bcast) is simply not written, i.e. keeps x -- no
