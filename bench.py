@@ -497,11 +497,11 @@ def main():
         G = G.contiguous()
 
     m = make_model(gbrl_amd, np, args.workload, F, 0, D, depth, B, "bench")
-    # level 1: one HIP event pair per k_hist_build launch, attached to the dispatch itself (hipExtLaunchKernelGGL start/stop
+    # level 1: a HIP event pair on one k_hist_build launch in seven (every tree level in turn), attached to the dispatch itself (hipExtLaunchKernelGGL start/stop
     # events on the engine's own stream: the kernel's begin/end timestamps, no extra packet in the stream), resolved after each
     # call -- no sync inside the step.  The full phase table needs ~60 hipEventRecord calls per step, each a few-microsecond
     # stream bubble, so it is taken in a separate diagnostic pass after the timed region.
-    m.set_profiling(int(os.environ.get("BENCH_TIMED_PROFILING", "1")))
+    m.set_profiling(int(os.environ.get("BENCH_TIMED_PROFILING", "1")))   # (measurement hook: 0 = no events at all, 2 = every phase inside the timed region)
     coll, exchange = None, None
     if world > 1 or args.force_collective:
         from gbrl_amd.dist import install_rccl, install_torch_collective
