@@ -220,8 +220,10 @@ def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
     # product
     Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
     tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
-    best = None
-    for rep in range(3):   # (the first pass pays allocations and code loading)
+    best = None        # the loop as a user runs it: no synchronisation inside (step() returns with the tree in the model)
+    best_split = None  # the same loop with a device synchronisation between its two halves, to time them separately
+    for rep in range(4):   # (the first pass pays allocations and code loading)
+        split = rep % 2 == 1
         m = gbrl_amd.GBRL(device="cuda", **kw)
         setup(m)
         torch.cuda.synchronize()
@@ -231,18 +233,24 @@ def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
             ta = time.perf_counter()
             pred = torch.from_dlpack(m.predict(tup(Xd), None, 0, 0)).reshape(N, 1)
             g = (pred - yd).contiguous()
-            torch.cuda.synchronize()
+            if split:
+                torch.cuda.synchronize()
             tb = time.perf_counter()
             m.step(tup(Xd), None, tup(g))
             tc = time.perf_counter()
             t_pred += tb - ta
             t_step += tc - tb
+        torch.cuda.synchronize()
         loop = time.perf_counter() - t0
-        if best is None or loop < best[0]:
-            best = (loop, t_pred, t_step)
+        if split and (best_split is None or loop < best_split[0]):
+            best_split = (loop, t_pred, t_step)
+        if not split and rep > 0 and (best is None or loop < best):
+            best = loop
         final = torch.from_dlpack(m.predict(tup(Xd), None, 0, 0)).cpu().numpy().reshape(N, 1)
-    out["product"] = {"ms_per_iteration": best[0] / trees * 1e3, "ms_per_step": best[2] / trees * 1e3, "ms_per_predict_and_gradient": best[1] / trees * 1e3,
-                      "trees_per_s": trees / best[0], "rmse": float(np.sqrt(np.mean((final - y) ** 2)))}
+    out["product"] = {"ms_per_iteration": best / trees * 1e3, "trees_per_s": trees / best,
+                      "ms_per_step": best_split[2] / trees * 1e3, "ms_per_predict_and_gradient": best_split[1] / trees * 1e3,
+                      "ms_per_iteration_with_a_synchronisation_between_the_halves": best_split[0] / trees * 1e3,
+                      "rmse": float(np.sqrt(np.mean((final - y) ** 2)))}
     # the reference's CPU path at full size on this host
     mod = oracle.load_ref()
     if mod is None:
@@ -267,7 +275,7 @@ def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
         rfinal = np.asarray(r.predict(X, None, 0, 0)).reshape(N, 1)
     out["cpu_reference"] = {"ms_per_iteration": cbest[0] / trees * 1e3, "ms_per_step": cbest[1] / trees * 1e3, "trees_per_s": trees / cbest[0], "cores": cores,
                             "kind": "reference", "rmse": float(np.sqrt(np.mean((rfinal - y) ** 2))), "note": "Fitter::step_cpu + Predictor::predict_cpu of oracle/_ref, full size, no extrapolation"}
-    out["speedup_per_iteration"] = cbest[0] / best[0]
+    out["speedup_per_iteration"] = cbest[0] / best
     out["max_abs_prediction_difference"] = float(np.max(np.abs(final - rfinal)))
     return out
 

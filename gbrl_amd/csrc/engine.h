@@ -35,6 +35,7 @@ class DevBuf {
     void *ensure_keep(size_t bytes, size_t keep_bytes, hipStream_t s);  // preserves the first keep_bytes
     template <typename T>
     T *as() const { return static_cast<T *>(ptr_); }
+    const void *raw() const { return ptr_; }
     size_t capacity() const { return cap_; }
     void release();
 
@@ -224,6 +225,8 @@ class Engine {
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;
+    PinnedBuf pin_model_stage_;           // the slices sync_model_to_device appends, staged for one kern::stage_copy launch
+    hipEvent_t ev_model_stage_ = nullptr; // behind that launch: the block is not refilled before it has been read
     DevBuf d_root_le_;
     const uint32_t *root_le_ = nullptr;   // this step's #{keys <= threshold} table (radix selection, one GPU), null otherwise
     DevBuf d_cat_keys_, d_cat_first_, d_cat_meta_, d_cat_lslot_, d_sdict_, d_cat_xchg_, d_cat_slotq_, d_cat_clsq_;

@@ -78,6 +78,7 @@ Engine::~Engine() {
         for (auto &e : ev_pool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (rccl_comm_ && rccl_api().ok) (void)rccl_api().CommDestroy(rccl_comm_);
         if (ev_level_) (void)hipEventDestroy(ev_level_);
+        if (ev_model_stage_) (void)hipEventDestroy(ev_model_stage_);
         if (own_stream_) (void)hipStreamDestroy(own_stream_);
     }
 }
@@ -98,6 +99,7 @@ void Engine::ensure_device() {
     if (device_ordinal_ >= count) throw InvalidArgument("device ordinal out of range");
     hip_check(hipSetDevice(device_ordinal_), "hipSetDevice");
     hip_check(hipEventCreateWithFlags(&ev_level_, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&ev_model_stage_, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipStreamCreate(&own_stream_), "hipStreamCreate");  // blocking stream: ordered with the null stream torch uses by default
     if (stream_ == nullptr) stream_ = own_stream_;
     device_ready_ = true;

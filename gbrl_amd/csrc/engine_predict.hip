@@ -36,10 +36,53 @@ void Engine::sync_model_to_device() {
         if (id == 0) { cat_dict_.emplace_back(f, name); id = static_cast<int>(cat_dict_.size()); }
         cat_ids_host_[c] = id;
     }
+    // The appended slices (one new tree after a step: a dozen pieces of a few hundred bytes) are collected here and leave together at the end
+    // (flush_segments): staged in ONE pinned block and copied by one kernel launch, instead of a hipMemcpyAsync from pageable memory per
+    // piece plus a stream synchronisation -- 0.1 ms per predict-after-step in an RL loop (round 4).
+    struct Seg { char *dst; const char *src; size_t bytes; };
+    std::vector<Seg> segs;
     auto append = [&](DevBuf &buf, const void *host, size_t elem, size_t old_n, size_t new_n) {
         char *p = static_cast<char *>(buf.ensure_keep(std::max<size_t>(new_n, 1) * elem, old_n * elem, s));
-        if (new_n > old_n)
-            hip_check(hipMemcpyAsync(p + old_n * elem, static_cast<const char *>(host) + old_n * elem, (new_n - old_n) * elem, hipMemcpyHostToDevice, s), "H2D model");
+        if (new_n > old_n) segs.push_back({p + old_n * elem, static_cast<const char *>(host) + old_n * elem, (new_n - old_n) * elem});
+    };
+    // records followed by `pad` zero elements that the kernels read past the last tree: when the buffer did not move, the old padding is still
+    // in place and only the new records and the padding's extension travel (the padding is 128 KiB for the value records)
+    auto append_padded = [&](DevBuf &buf, const float *host, size_t old_recs, size_t new_recs, size_t rec, size_t pad) {
+        const void *before = buf.raw();
+        char *p = static_cast<char *>(buf.ensure_keep((new_recs * rec + pad) * 4, old_recs * rec * 4, s));
+        if (p != before || old_recs == 0 || old_recs > new_recs) {
+            segs.push_back({p + old_recs * rec * 4, reinterpret_cast<const char *>(host + old_recs * rec), ((new_recs - old_recs) * rec + pad) * 4});
+        } else if (new_recs > old_recs) {
+            segs.push_back({p + old_recs * rec * 4, reinterpret_cast<const char *>(host + old_recs * rec), (new_recs - old_recs) * rec * 4});
+            segs.push_back({p + (old_recs * rec + pad) * 4, reinterpret_cast<const char *>(host + old_recs * rec + pad), (new_recs - old_recs) * rec * 4});
+        }
+    };
+    auto flush_segments = [&]() {
+        size_t total = 0;
+        for (const Seg &g : segs) total += (g.bytes + 15) & ~static_cast<size_t>(15);
+        if (segs.empty()) return;
+        if (segs.size() <= 32 && total <= (size_t(1) << 20)) {
+            hip_check(hipEventSynchronize(ev_model_stage_), "sync");   // the previous use of the staging block has been read (normally long ago)
+            char *st = static_cast<char *>(pin_model_stage_.ensure(total));
+            void *st_dev = nullptr;
+            hip_check(hipHostGetDevicePointer(&st_dev, st, 0), "hipHostGetDevicePointer");
+            size_t off = 0;
+            for (size_t i = 0; i < segs.size(); i += 16) {
+                kern::StageSegments ss{};
+                for (size_t k = i; k < segs.size() && k < i + 16; ++k) {
+                    std::memcpy(st + off, segs[k].src, segs[k].bytes);
+                    ss.dst[ss.n] = segs[k].dst; ss.src_off[ss.n] = static_cast<uint32_t>(off); ss.bytes[ss.n] = static_cast<uint32_t>(segs[k].bytes);
+                    ++ss.n;
+                    off += (segs[k].bytes + 15) & ~static_cast<size_t>(15);
+                }
+                kern::stage_copy(ss, st_dev, s);
+            }
+            hip_check(hipEventRecord(ev_model_stage_, s), "hipEventRecord");
+        } else {   // a whole loaded ensemble: ordinary copies, and the host arrays must outlive them
+            for (const Seg &g : segs) hip_check(hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, s), "H2D model");
+            hip_check(hipStreamSynchronize(s), "sync model upload");
+        }
+        segs.clear();
     };
     append(m_tree_indices_, model.tree_indices.data(), 4, up_trees_, T);
     append(m_depths_, model.depths.data(), 4, up_splits_, S);
@@ -93,7 +136,7 @@ void Engine::sync_model_to_device() {
         for (size_t t = T; t < T + kPadTrees; ++t)
             for (size_t d = 0; d < MX; ++d) { cond_ra_host_[(t * MX + d) * 2] = inf_pad[0]; cond_ra_host_[(t * MX + d) * 2 + 1] = inf_pad[1]; }
         append(m_cond_ra_, cond_ra_host_.data(), 4, up_trees_ * 2 * MX, (T + kPadTrees) * 2 * MX);
-        append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * VT, T * VT + vpad);
+        append_padded(m_values_sw_, values_sw_host_.data(), up_trees_, T, VT, vpad);
     }
     // Greedy ensembles: rebuild every new tree as a binary tree from its leaves' paths (leaves are stored depth-first, left
     // first; fitter.cpp:364-365), for the descent of k_predict_grd.  A tree whose leaves do not form a proper binary tree (a
@@ -168,7 +211,7 @@ void Engine::sync_model_to_device() {
                 const size_t n0 = static_cast<size_t>(grd_off_host_[t]), n1 = static_cast<size_t>(grd_off_host_[t + 1]);
                 if (n1 - n0 <= LS) std::memcpy(rec + VT, &grd_nodes_host_[n0 * 4], (n1 - n0) * 16);
             }
-            append(m_values_sw_, values_sw_host_.data(), 4, up_trees_ * RECF, T * RECF + vpad);
+            append_padded(m_values_sw_, values_sw_host_.data(), up_trees_, T, RECF, vpad);
         }
     }
     up_trees_ = T; up_leaves_ = L; up_splits_ = S;
@@ -180,7 +223,7 @@ void Engine::sync_model_to_device() {
     append(m_opt_start_, os.data(), 4, 0, os.size());
     append(m_opt_stop_, oe.data(), 4, 0, oe.size());
     append(m_opt_lr_, olr.data(), 4, 0, olr.size());
-    hip_check(hipStreamSynchronize(s), "sync model upload");
+    flush_segments();
     mirror_version_ = model.version;
 }
 

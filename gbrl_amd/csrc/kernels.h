@@ -116,6 +116,10 @@ void publish_pair(const void *d_a, void *h_a_mapped, size_t a_bytes, const void 
 // few KB) in steps that are bound by stream operations, not bytes.  The host must leave the sources alone until the kernel has run.
 struct FetchSegments { void *dst[8]; const void *src[8]; uint32_t words[8]; int n; };
 void fetch_segments(const FetchSegments &fs, hipStream_t s);
+// up to 16 byte ranges out of one mapped pinned staging block by ONE launch (the model's device mirror after a step: a dozen appended slices
+// of a few hundred bytes each; a hipMemcpyAsync per slice from pageable memory cost ~10 us apiece).  Ranges need no alignment.
+struct StageSegments { void *dst[16]; uint32_t src_off[16]; uint32_t bytes[16]; int n; };
+void stage_copy(const StageSegments &ss, const void *stage_mapped, hipStream_t s);
 // up to four regions filled with a 32-bit pattern each by ONE launch (an RL-sized step pays 4-5 us per hipMemsetAsync)
 struct FillSegments { void *dst[4]; uint32_t words[4]; uint32_t value[4]; int n; };
 void fill_segments(const FillSegments &fs, hipStream_t s);

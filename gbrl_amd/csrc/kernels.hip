@@ -944,6 +944,20 @@ __global__ __launch_bounds__(256) void k_fetch_segments(FetchSegments fs) {
     for (int k = 0; k < 8; ++k)
         if (k < fs.n && i < fs.words[k]) static_cast<uint32_t *>(fs.dst[k])[i] = static_cast<const uint32_t *>(fs.src[k])[i];
 }
+__global__ __launch_bounds__(256) void k_stage_copy(StageSegments ss, const char *__restrict__ stage) {
+    const int k = blockIdx.y;
+    if (k >= ss.n) return;
+    char *dst = static_cast<char *>(ss.dst[k]);
+    const char *src = stage + ss.src_off[k];
+    const uint32_t n = ss.bytes[k];
+    const uint32_t i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3u) == 0) {
+        for (uint32_t i = i0; i < n / 4; i += stride) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+        for (uint32_t i = (n & ~3u) + i0; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (uint32_t i = i0; i < n; i += stride) dst[i] = src[i];
+    }
+}
 __global__ __launch_bounds__(256) void k_fill_segments(FillSegments fs) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
@@ -1908,6 +1922,13 @@ void fetch_segments(const FetchSegments &fs, hipStream_t s) {
     uint32_t mx = 0;
     for (int k = 0; k < fs.n; ++k) mx = std::max(mx, fs.words[k]);
     if (mx) hipLaunchKernelGGL(k_fetch_segments, dim3((mx + 255) / 256), dim3(256), 0, s, fs);
+}
+void stage_copy(const StageSegments &ss, const void *stage_mapped, hipStream_t s) {
+    uint32_t mx = 0;
+    for (int k = 0; k < ss.n; ++k) mx = std::max(mx, ss.bytes[k]);
+    if (!mx || ss.n <= 0) return;
+    const unsigned bx = std::min<unsigned>(64, (mx / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_stage_copy, dim3(bx, ss.n), dim3(256), 0, s, ss, static_cast<const char *>(stage_mapped));
 }
 void fill_segments(const FillSegments &fs, hipStream_t s) {
     uint32_t mx = 0;
