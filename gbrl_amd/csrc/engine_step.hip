@@ -844,8 +844,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 kern::negate_f32(tmp, F, s);
                 kern::floats_to_keys(tmp, d_mm, 2 * static_cast<size_t>(F), s);
             }
-            kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s);
-            kern::floats_to_keys(d_thr, d_thrkeys, static_cast<size_t>(F) * B, s);
+            kern::uniform_thresholds(d_mm, d_mm + F, F, B, d_thr, s, d_thrkeys);
         } else {
             // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1.  With
             // fewer rows than buckets the remainder loop still gives the first n_samples buckets one row each, so cum_i =
@@ -1824,7 +1823,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const int n_code_groups = (n_slots_codes + kern::kCodeGroup - 1) / kern::kCodeGroup;
     const size_t code_elems = static_cast<size_t>(std::max(1, n_code_groups)) * N * kern::kCodeGroup;
     uint16_t *d_codes = static_cast<uint16_t *>(d_codes_.ensure(sizeof(uint16_t) * code_elems));
-    if (Fc > 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
+    // Only the padding slots behind the last categorical column are written by nobody (the numeric writers fill whole groups of 16, padding
+    // included, the categorical ones every (row, column)): no clearing when the slots fill their groups exactly (configs[4]: 192 + 64).
+    if (Fc > 0 && (F + Fc) % kern::kCodeGroup != 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
     bool codes_from_sort = false;
     root_le_ = nullptr;
     if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);

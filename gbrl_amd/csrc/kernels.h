@@ -86,7 +86,8 @@ void quantize_grads(const float *g, size_t n_el, int D, const float *mean, const
 
 // ---- split candidates (A3, A4) ----
 void column_minmax(const uint32_t *kt /*feature-major keys [F][n]*/, int n, int F, uint32_t *mn, uint32_t *mx, hipStream_t s);  // ordered keys
-void uniform_thresholds(const uint32_t *min_keys, const uint32_t *max_keys, int F, int B, float *thr, hipStream_t s);
+void uniform_thresholds(const uint32_t *min_keys, const uint32_t *max_keys, int F, int B, float *thr, hipStream_t s,
+                        uint32_t *thr_keys = nullptr /*the thresholds' ordered keys, written by the same launch*/);
 // counts[f][j] += #{rows : j == #{k : trial[f][k] (strict ? < : <=) key(x)}}; optionally writes codes[row*code_stride + code_off + f]
 void bin_rows(const float *obs, int n, int F, const uint32_t *trial_keys, int B, bool strict, int64_t *counts,
               uint16_t *codes, int code_stride, int code_off, hipStream_t s);

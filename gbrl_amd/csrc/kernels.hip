@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_column_minmax(const uint32_t *__restric
     }
 }
 __global__ void k_uniform_thresholds(const uint32_t *__restrict__ mn, const uint32_t *__restrict__ mx, int F, int B,
-                                     float *__restrict__ thr) {
+                                     float *__restrict__ thr, uint32_t *__restrict__ thr_keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F * B) return;
     const int f = i / B, b = i % B;
@@ -339,6 +339,7 @@ __global__ void k_uniform_thresholds(const uint32_t *__restrict__ mn, const uint
     // -inf is stored instead so that the key comparison of step() (NaN has no key above it) and predict()'s float comparison agree
     if (t != t) t = -INFINITY;
     thr[i] = t;
+    if (thr_keys) thr_keys[i] = float_to_key(t);   // (what a k_floats_to_keys launch behind this one did)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1705,8 +1706,8 @@ void column_minmax(const uint32_t *kt, int n, int F, uint32_t *mn, uint32_t *mx,
     hipLaunchKernelGGL(k_column_minmax, grid, dim3(256), 0, s, kt, n, rows_per_block, mn, mx);
 }
 
-void uniform_thresholds(const uint32_t *mn, const uint32_t *mx, int F, int B, float *thr, hipStream_t s) {
-    hipLaunchKernelGGL(k_uniform_thresholds, dim3((F * B + 255) / 256), dim3(256), 0, s, mn, mx, F, B, thr);
+void uniform_thresholds(const uint32_t *mn, const uint32_t *mx, int F, int B, float *thr, hipStream_t s, uint32_t *thr_keys) {
+    hipLaunchKernelGGL(k_uniform_thresholds, dim3((F * B + 255) / 256), dim3(256), 0, s, mn, mx, F, B, thr, thr_keys);
 }
 
 template <bool STRICT, int FT>

@@ -250,6 +250,37 @@ def test_wide_histogram_kernel_equals_the_runtime_d_kernel():
     assert len(lines) >= 12 and all("wide==generic: True" in ln for ln in lines), out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("host_cat", [False, True])
+@pytest.mark.parametrize("N,F,Fc", [(600, 9, 7), (600, 16, 16), (500, 0, 16), (20000, 30, 2), (20000, 16, 16), (9000, 3, 29), (700, 5, 4)])
+def test_class_codes_are_complete_without_the_clearing_pass(N, F, Fc, host_cat, monkeypatch):
+    """When the numeric + categorical slots fill their groups of 16 exactly, step() does not clear the code planes first: every writer must
+    cover its slots (numeric writers whole groups including the mixed one, categorical writers every (row, column)).  Two DIFFERENT batches
+    go through the same engine one after the other -- a slot nobody wrote would keep the first batch's code -- and the trees must be the
+    oracle's; (700, 5, 4) is a shape that still clears.  Both categorical paths (device scan / host scan)."""
+    import gbrl_amd
+    import oracle
+    if host_cat:
+        monkeypatch.setenv("GBRL_HIP_HOST_CATEGORICAL", "1")
+    case = _case("codes", seed=N + F, N=N, F=F, Fc=Fc, D=2, depth=4, n_bins=32, policy="oblivious", gen="Quantile" if N < 10000 else "Uniform", trees=1)
+    batches = []
+    for sd in (1, 2):
+        c2 = dict(case); c2["seed"] = case["seed"] * 10 + sd
+        batches.append(K.make_inputs(c2))
+    models = []
+    for mod in (gbrl_amd.GBRL, oracle.OracleGBRL):
+        m = mod(**K.ctor_kwargs(case))
+        m.set_feature_weights(np.ones(F + Fc, np.float32))
+        for o in K.optimizers(case):
+            m.set_optimizer(**o)
+        m.set_feature_mapping(np.arange(F + Fc, dtype=np.int32), np.array([True] * F + [False] * Fc, dtype=bool))
+        for X, Xc, G, y in batches + batches[:1]:
+            m.step(X, Xc, np.ascontiguousarray(G))
+        models.append(m)
+    e, o = models[0].get_ensemble_data(), models[1].get_ensemble_data()
+    assert_structure_equal(e, o, what="codes: ")
+    assert_values_close(e, o, max(float(np.abs(batches[0][2]).mean()), 1e-30), TOL)
+
+
 @pytest.mark.parametrize("N,F,D,n_bins,policy", [(70000, 20, 8, 256, "oblivious"), (131072 + 4, 33, 3, 100, "greedy"), (20000, 16, 1, 256, "greedy"), (90000, 7, 16, 64, "oblivious")])
 def test_root_class_counts_from_the_selection_ranks(N, F, D, n_bins, policy, monkeypatch):
     """Root level of a numeric-only quantile tree on one GPU: k_hist_build skips the count atomic and k_hist_reduce writes the class counts from
