@@ -178,6 +178,8 @@ class Engine {
     const void *pub_done_ptr_ = nullptr;
     const void *leafacc_clean_ptr_ = nullptr;   // leaf accumulators known to be zero (handed back clean by the last publication)
     size_t leafacc_clean_bytes_ = 0;
+    DevBuf d_sg_bests_, d_sg_sync_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
+    const void *sg_sync_ptr_ = nullptr;
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;

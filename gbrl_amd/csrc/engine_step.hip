@@ -1010,44 +1010,13 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const int max_nodes = 2 * (1 << MD);
     const int max_chunks = std::max((N + 1023) / 1024, (N + kern::kPartitionRows - 1) / kern::kPartitionRows) + 2 * (1 << MD) + 2;
     const size_t n_acc = static_cast<size_t>(NB) * (D + 1) * FG;
-    int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
-                          static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
-    // A level is one balanced round of (chunks x feature groups) histogram blocks, one block per CU: 256 / n_groups chunks, at least
-    // 32 (few features => more, smaller chunks; the chunk length only has an upper bound, `chunk_rows`, from the fixed-point scale).
-    const int hist_chunk_budget = std::max(32, 256 / std::max(1, n_groups));
-    const int hist_max_chunks = std::max(hist_chunk_budget, (N + chunk_rows - 1) / chunk_rows) + 2 * (1 << MD) + 2;
-    int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(sizeof(int32_t) * static_cast<size_t>(hist_max_chunks) * n_groups * n_acc));
-    const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
-    // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
-    int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(sizeof(int64_t) * max_front * hist_node_elems)),
-                              static_cast<int64_t *>(d_hist_prev_.ensure(sizeof(int64_t) * max_front * hist_node_elems))};
-    // Row-sharded runs exchange the level histograms by FEATURE (SURVEY.md 8e): the local sums of the accumulated nodes are laid out
-    // [owner rank][node][feature of the rank's slice] and reduce-scattered, so every rank receives the GLOBAL sums of its own
-    // Fs = ceil(Fp / P) features only (half the bytes of an all-reduce on the xGMI ring), scores its own candidates, and the
-    // level's winner is agreed with ONE small all-reduce (kern::winner_pack / winner_adopt).
-    const int coll_P = has_coll_ ? std::max(1, coll_.world_size) : 1;
-    const int coll_Fs = (Fp + coll_P - 1) / coll_P;                          // features per rank slice
-    const int coll_lo = has_coll_ ? coll_.rank * coll_Fs : 0;                // first feature (= feature slot) of this rank
-    const int own_slots = has_coll_ ? std::max(0, std::min(n_slots, coll_lo + coll_Fs) - coll_lo) : n_slots;
-    const size_t feat_elems = static_cast<size_t>(NB) * (D + 1);
-    int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_P) * coll_Fs * feat_elems)) : nullptr;
-    int64_t *d_hist_recv = has_coll_ ? static_cast<int64_t *>(d_hist_recv_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_Fs) * feat_elems)) : nullptr;
-    int64_t *d_gather = has_coll_ ? static_cast<int64_t *>(d_gather_.ensure(sizeof(int64_t) * static_cast<size_t>(coll_P) * 3 * max_front)) : nullptr;
-    float *d_scores = static_cast<float *>(d_scores_.ensure(sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
-    float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
-    const int am_parts = kern::argmax_parts(std::max(1, n_cand));
-    const size_t am_cap = static_cast<size_t>(max_front) * std::max(am_parts, std::max(1, n_slots));   // greedy: one part per feature slot
-    float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * am_cap));
-    int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * am_cap));
-    int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
-    int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
-    {   // zero unless the last tree's publication handed these words back clean
-        const size_t need = sizeof(int64_t) * max_nodes * (D + 1);
-        if (!(leafacc_clean_ptr_ == d_leafacc && need <= leafacc_clean_bytes_))
-            hip_check(hipMemsetAsync(d_leafacc, 0, need, s), "memset leaf acc");
-        leafacc_clean_ptr_ = nullptr;     // dirty until the end of this tree
-        leafacc_clean_bytes_ = need;
-    }
+    // RL-sized steps on one GPU grow the whole tree in ONE launch (kern::small_grow, small_grow.hip): no level buffers, no partials,
+    // no row lists.  GBRL_HIP_NO_SMALL_GROW=1 (tests / measurement): the level loop below for every shape.
+    const bool l2_degenerate = !c.cosine && n_global < 2;
+    const bool no_small_grow = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_GROW"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const int small_G = (!has_coll_ && !no_small_grow && n_global == N && n_cand > 0 && !l2_degenerate && MD >= 1 && !(oblivious && device_levels_requested()) &&
+                         kern::small_grow_supported(N, D, NB, MD, n_slots, n_cand)) ? kern::small_grow_blocks(n_slots) : 0;
+    const bool use_small = small_G > 0;
     // per-step constants: slots, candidate weights / reference order / slot lookup
     const std::vector<int32_t> &cand_slot = *c.cand_slot;
     const size_t table_cap = c.prefix_cacheable ? static_cast<size_t>(std::max(c.cand_cap, n_cand)) : static_cast<size_t>(n_cand);
@@ -1109,6 +1078,46 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         stc.flush();
         if (c.const_cacheable) { step_const_.dev_base = stc.device_base(); step_const_.stage_bytes = stage_bytes; }
     }
+    int32_t *d_rows[2] = {static_cast<int32_t *>(d_rows_[0].ensure(sizeof(int32_t) * N)),
+                          static_cast<int32_t *>(d_rows_[1].ensure(sizeof(int32_t) * N))};
+    // A level is one balanced round of (chunks x feature groups) histogram blocks, one block per CU: 256 / n_groups chunks, at least
+    // 32 (few features => more, smaller chunks; the chunk length only has an upper bound, `chunk_rows`, from the fixed-point scale).
+    const int hist_chunk_budget = std::max(32, 256 / std::max(1, n_groups));
+    const int hist_max_chunks = std::max(hist_chunk_budget, (N + chunk_rows - 1) / chunk_rows) + 2 * (1 << MD) + 2;
+    int32_t *d_partials = static_cast<int32_t *>(d_hist_partials_.ensure(use_small ? 256 : sizeof(int32_t) * static_cast<size_t>(hist_max_chunks) * n_groups * n_acc));
+    const size_t hist_node_elems = static_cast<size_t>(Fp) * NB * (D + 1);
+    // two level buffers (current / previous) so that the larger child of every split can be derived as parent - sibling
+    int64_t *d_hist_lvl[2] = {static_cast<int64_t *>(d_hist_.ensure(use_small ? 256 : sizeof(int64_t) * max_front * hist_node_elems)),
+                              static_cast<int64_t *>(d_hist_prev_.ensure(use_small ? 256 : sizeof(int64_t) * max_front * hist_node_elems))};
+    // Row-sharded runs exchange the level histograms by FEATURE (SURVEY.md 8e): the local sums of the accumulated nodes are laid out
+    // [owner rank][node][feature of the rank's slice] and reduce-scattered, so every rank receives the GLOBAL sums of its own
+    // Fs = ceil(Fp / P) features only (half the bytes of an all-reduce on the xGMI ring), scores its own candidates, and the
+    // level's winner is agreed with ONE small all-reduce (kern::winner_pack / winner_adopt).
+    const int coll_P = has_coll_ ? std::max(1, coll_.world_size) : 1;
+    const int coll_Fs = (Fp + coll_P - 1) / coll_P;                          // features per rank slice
+    const int coll_lo = has_coll_ ? coll_.rank * coll_Fs : 0;                // first feature (= feature slot) of this rank
+    const int own_slots = has_coll_ ? std::max(0, std::min(n_slots, coll_lo + coll_Fs) - coll_lo) : n_slots;
+    const size_t feat_elems = static_cast<size_t>(NB) * (D + 1);
+    int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_P) * coll_Fs * feat_elems)) : nullptr;
+    int64_t *d_hist_recv = has_coll_ ? static_cast<int64_t *>(d_hist_recv_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_Fs) * feat_elems)) : nullptr;
+    int64_t *d_gather = has_coll_ ? static_cast<int64_t *>(d_gather_.ensure(sizeof(int64_t) * static_cast<size_t>(coll_P) * 3 * max_front)) : nullptr;
+    float *d_scores = static_cast<float *>(d_scores_.ensure(use_small ? 256 : sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
+    float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
+    const int am_parts = kern::argmax_parts(std::max(1, n_cand));
+    const size_t am_cap = static_cast<size_t>(max_front) * std::max(am_parts, std::max(1, n_slots));   // greedy: one part per feature slot
+    float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * am_cap));
+    int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * am_cap));
+    int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
+    int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
+    {   // zero unless the last tree's publication handed these words back clean
+        const size_t need = sizeof(int64_t) * max_nodes * (D + 1);
+        if (!use_small) {
+            if (!(leafacc_clean_ptr_ == d_leafacc && need <= leafacc_clean_bytes_))
+                hip_check(hipMemsetAsync(d_leafacc, 0, need, s), "memset leaf acc");
+            leafacc_clean_ptr_ = nullptr;     // dirty until the end of this tree
+            leafacc_clean_bytes_ = need;
+        }
+    }
     // result block read back once per level: [best_idx i32 x mf][best_score f32 x mf][counts i64 x 4 x mf]
     const size_t res_bytes = static_cast<size_t>(max_front) * (4 + 4 + 32) + 64;
     char *d_res = static_cast<char *>(d_results_.ensure(res_bytes));
@@ -1135,7 +1144,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // two lists by depth parity and keeps generating its own.)
     int32_t *const d_rows_b = d_rows[0];
     bool iota_root = false;
-    {
+    if (!use_small) {
         // the device-planned loop partitions INTO d_rows[depth parity]: it must never be handed the cached list (same latched flag as below)
         const char *e2 = std::getenv("GBRL_HIP_NO_IOTA_CACHE");   // measurement hook
         if (!(oblivious && device_levels_requested()) && !(e2 && e2[0] == '1')) {
@@ -1209,6 +1218,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         if (feat < 0 || feat >= Fc || cls < 1 || cls > cat_index_off[feat + 1] - cat_index_off[feat]) return -1;
         return cat_index[cat_index_off[feat] + cls - 1];
     };
+    const float *win_thr = nullptr;   // small-step kernel: the winners' threshold values travel with the level's result block
     auto digest_level = [&](const std::vector<int> &active, const char *hres) -> LevelOutcome {
         LevelOutcome out;
         const int n_act = static_cast<int>(active.size());
@@ -1259,7 +1269,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 c.cat_cand = cat_cand_of(c.feat_idx, q.bin);
             } else {
                 c.feat_idx = q.fslot;
-                c.value = h_thr[static_cast<size_t>(q.fslot) * B + q.bin];
+                c.value = win_thr ? win_thr[k] : h_thr[static_cast<size_t>(q.fslot) * B + q.bin];
                 c.cat_cand = -1;
             }
             const long long npar = nodes[id].n_global, nr = right_g[k], nl = npar - nr;
@@ -1295,7 +1305,69 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
 
     // L2 with ONE row: the reference's unbiased variance is 0/0 (math_ops.cpp:461-513), every standardised gradient and every
     // split score is NaN, no comparison succeeds and the tree stays a depth-0 leaf (fitter.cpp:357, :458)
-    const bool l2_degenerate = !c.cosine && n_global < 2;
+    // ---- RL-sized steps: ONE launch grows the tree, ONE wait, then the bookkeeping is replayed from the per-level result blocks -------
+    if (use_small) {
+        const size_t res_stride = kern::small_grow_res_stride(MD);
+        const size_t res_all = res_stride * MD;
+        const size_t acc_words = static_cast<size_t>(2u << MD) * (D + 1);
+        const size_t o_acc = (res_all + 255) & ~static_cast<size_t>(255), o_status = o_acc + sizeof(int64_t) * acc_words;
+        char *h_blk = static_cast<char *>(pin_res_all_.ensure(o_status + 64));
+        void *h_blk_dev = nullptr;
+        hip_check(hipHostGetDevicePointer(&h_blk_dev, h_blk, 0), "hipHostGetDevicePointer");
+        char *d_blk = static_cast<char *>(h_blk_dev);
+        volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(h_blk + o_status);
+        unsigned *d_sync = static_cast<unsigned *>(d_sg_sync_.ensure(256));
+        if (d_sync != sg_sync_ptr_) {
+            hip_check(hipMemsetAsync(d_sync, 0, 256, s), "memset barrier words");
+            sg_sync_ptr_ = d_sync;
+        }
+        kern::SmallGrowIO io{};
+        io.codes = d_codes; io.qg = d_qg; io.grads = dgrads; io.scales = d_scales; io.slots = d_slots; io.thr = d_thr; io.cand_w = d_cand_w; io.cand_ref = d_cand_ref;
+        io.N = N; io.D = D; io.B = B; io.n_slots = n_slots; io.NB = NB; io.MD = MD; io.min_data = md.min_data_in_leaf; io.cosine = cosine; io.oblivious = oblivious;
+        io.G = small_G;
+        io.bests = d_sg_bests_.ensure(kern::small_grow_bests_bytes(MD, small_G, oblivious));
+        io.sync = d_sync;
+        io.res = d_blk; io.acc = reinterpret_cast<int64_t *>(d_blk + o_acc); io.status = reinterpret_cast<uint32_t *>(d_blk + o_status);
+        uint32_t seq = ++level_seq_;
+        if (seq == 0) seq = ++level_seq_;
+        io.seq = seq;
+        h_status[0] = 0;
+        phase_begin();
+        if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
+        phase_end("small_grow");
+        spin_until_published(h_status, seq, s, "small-step tree");
+        hip_check(hipGetLastError(), "growth kernel");
+        if (h_status[3] != 0) {
+            sg_sync_ptr_ = nullptr;
+            throw HipError("small-step growth kernel gave up at a grid barrier (its blocks were not co-resident?)");
+        }
+        const int levels_written = static_cast<int>(h_status[1]);
+        for (int depth = 0; depth < MD; ++depth) {
+            std::vector<int> active;
+            for (int id : frontier)
+                if (oblivious || nodes[id].n_global > 0) active.push_back(id);
+            if (active.empty()) break;
+            if (depth >= levels_written) throw HipError("internal: the growth kernel wrote fewer levels than the replay needs");
+            const char *hres = h_blk + static_cast<size_t>(depth) * res_stride;
+            win_thr = reinterpret_cast<const float *>(hres + 40 * static_cast<size_t>(max_front));
+            LevelOutcome lvl = digest_level(active, hres);
+            if (lvl.stop) break;
+            if (lvl.splitting.empty()) { frontier.clear(); break; }
+            frontier = lvl.next;
+        }
+        win_thr = nullptr;
+        for (int id : frontier)
+            if (!nodes[id].leaf) nodes[id].leaf = true;
+        if (nodes.size() == 1) nodes[0].leaf = true;
+        if (nodes.size() != static_cast<size_t>(h_status[2])) throw HipError("internal: the growth kernel numbered " + std::to_string(h_status[2]) + " nodes, the replay " + std::to_string(nodes.size()));
+        const int64_t *h_acc = reinterpret_cast<const int64_t *>(h_blk + o_acc);
+        acc.assign(nodes.size() * (D + 1), 0);
+        for (size_t id = 0; id < nodes.size(); ++id)
+            if (nodes[id].left < 0) std::memcpy(&acc[id * (D + 1)], h_acc + id * (D + 1), sizeof(int64_t) * (D + 1));
+        if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
+        leaf_scale = c.h_scales->leaf_scale;
+        return;
+    }
     // ---- oblivious trees on one GPU, opt-in (GBRL_HIP_DEVICE_LEVELS=1): the whole tree is enqueued without a host round trip per level.
     // k_plan_oblivious builds every level's descriptors on the device from the previous level's resolved splits; the consumers run
     // on worst-case grids (unused chunk entries have len 0).  The host synchronises ONCE, reads all levels' result blocks and

@@ -296,6 +296,29 @@ void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *c
                     const Chunk *chunks, int n_chunks, const NodeSplit *splits, int32_t *cursors /*[n_nodes*2], zeroed*/,
                     hipStream_t s);
 
+// ---- RL-sized steps: the whole growth of one tree in ONE launch (small_grow.hip) ----
+// Per level: LDS histograms of the owned feature slots, scores, arg-max, ONE grid barrier, row routing; then the leaf sums.  The host reads
+// `status[0] == seq` (pinned), then MD result blocks of small_grow_res_stride(MD) bytes -- [best_idx i32 x mf][best_score f32 x mf]
+// [counts i64 x 4 x mf: total | right | - | -][winner threshold f32 x mf], mf = 2^(MD-1) -- and acc[node id][D+1] of every leaf.
+struct SmallGrowIO {
+    const uint16_t *codes; const int32_t *qg; const float *grads; const StepScales *scales;
+    const FeatureSlot *slots; const float *thr; const float *cand_w; const int32_t *cand_ref;
+    int N, D, B, n_slots, NB, MD, min_data;
+    bool cosine, oblivious;
+    int G;                 // blocks: small_grow_blocks(n_slots)
+    void *bests;           // device scratch, small_grow_bests_bytes(MD, G, oblivious)
+    unsigned *sync;        // device, 4 words, zero before the first launch (the kernel hands them back zeroed)
+    char *res;             // pinned, device-mapped
+    int64_t *acc;          // pinned, device-mapped, [2 << MD][D + 1]
+    uint32_t *status;      // pinned, device-mapped, 4 words: sequence word | levels | node count | error
+    uint32_t seq;
+};
+bool small_grow_supported(int N, int D, int NB, int MD, int n_slots, int n_cand);
+int small_grow_blocks(int n_slots);
+size_t small_grow_bests_bytes(int MD, int G, bool oblivious);
+size_t small_grow_res_stride(int MD);
+bool small_grow(const SmallGrowIO &io, hipStream_t s);   // false: nothing was launched
+
 // ---- leaf values (A11) ----
 void leaf_sums(const float *grads, int D, const int32_t *rows, const Chunk *chunks, int n_chunks, const StepScales *sc,
                int64_t *acc /*[n_leaves][D+1], zeroed*/, hipStream_t s);

@@ -8,6 +8,7 @@
 // rounded to fp32 once, then compared the way the reference compares them (fitter.cpp:332-341, 435-444).
 #include "kernels.h"
 #include "kernels_common.h"
+#include "score_common.h"
 
 #include <hip/hip_ext.h>
 
@@ -1031,59 +1032,6 @@ __global__ void k_winner_adopt(const int64_t *__restrict__ gather, int P, int n_
 // node's path (node.cpp:154-166) or a side has fewer than min_data_in_leaf rows (node.cpp:354).
 // Block (slot 0) also emits the node's parent score for greedy growth (split_candidate_generator.cpp:262-320).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double side_term(const int64_t *S, int D, int64_t n, double inv_scale) {
-    if (n <= 0) return 0.0;
-    double ss = 0.0;
-    for (int d = 0; d < D; ++d) {
-        const double v = static_cast<double>(S[d]) * inv_scale;
-        ss += v * v;
-    }
-    return ss / static_cast<double>(n);
-}
-
-// A8 oblivious: s_j = (sum over nodes, in node order, fp32) * w_j ; lowest index among maxima wins (fitter.cpp:411-457)
-struct Best { float v; int i; };
-__device__ __forceinline__ Best better(Best a, Best b) {
-    // strictly greater wins; on equality the lower reference index wins.  A -inf score never replaces the initial
-    // (-inf, none) state, exactly like "if (score > local_best_score)" with local_best = -inf (fitter.cpp:338, 441).
-    if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
-    return a;
-}
-// Inclusive scan over the 64 lanes of NINE 64-bit values at once (k_score's fields), every step as two DPP-fused adds per value:
-//   v_add_co_u32_dpp lo, vcc, lo, lo <ctrl>   ;  v_addc_co_u32_dpp hi, vcc, hi, hi, vcc <ctrl>
-// A lane whose source is outside its row (row_shr) or whose row is masked (row_bcast) is simply not written, i.e. keeps x -- no
-// zero-initialised temporary, no separate 64-bit add: 2 VALU instructions per value and step instead of 5 (the kernel is bound by its
-// VALU instruction count).  gfx9 hazard "VALU writes a VGPR, DPP reads it: 2 wait states": inside a step the nine values are
-// independent, and a value is touched again 16 instructions later; the s_nop covers whatever the compiler issued just before.
-#define GBRL_SCAN9_STEP(CTRL) \
-    asm volatile("s_nop 1\n" \
-                 "v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n v_addc_co_u32_dpp %9, vcc, %9, %9, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %1, vcc, %1, %1 " CTRL "\n v_addc_co_u32_dpp %10, vcc, %10, %10, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n v_addc_co_u32_dpp %11, vcc, %11, %11, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %3, vcc, %3, %3 " CTRL "\n v_addc_co_u32_dpp %12, vcc, %12, %12, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %4, vcc, %4, %4 " CTRL "\n v_addc_co_u32_dpp %13, vcc, %13, %13, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %5, vcc, %5, %5 " CTRL "\n v_addc_co_u32_dpp %14, vcc, %14, %14, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %6, vcc, %6, %6 " CTRL "\n v_addc_co_u32_dpp %15, vcc, %15, %15, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %7, vcc, %7, %7 " CTRL "\n v_addc_co_u32_dpp %16, vcc, %16, %16, vcc " CTRL "\n" \
-                 "v_add_co_u32_dpp %8, vcc, %8, %8 " CTRL "\n v_addc_co_u32_dpp %17, vcc, %17, %17, vcc " CTRL "\n" \
-                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), \
-                   "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]), "+v"(hi[8]) \
-                 : : "vcc")
-__device__ __forceinline__ void wave_scan9(long long (&v)[9]) {
-    unsigned int lo[9], hi[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) { lo[j] = static_cast<unsigned int>(v[j]); hi[j] = static_cast<unsigned int>(static_cast<unsigned long long>(v[j]) >> 32); }
-    GBRL_SCAN9_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
-    GBRL_SCAN9_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
-    GBRL_SCAN9_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
-    GBRL_SCAN9_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
-    GBRL_SCAN9_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");   // lane 15 of rows 0 / 2 -> rows 1 / 3
-    GBRL_SCAN9_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");   // lane 31 -> rows 2, 3
-#pragma unroll
-    for (int j = 0; j < 9; ++j) v[j] = static_cast<long long>((static_cast<unsigned long long>(hi[j]) << 32) | lo[j]);
-}
-#undef GBRL_SCAN9_STEP
-
 constexpr int kScoreLoads = 10;
 __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, const int64_t *__restrict__ hist_prev,
                                                const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib, int Fp, int NB, int D,
@@ -1259,22 +1207,9 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
         if (reject) {
             out = -INFINITY;
         } else {
-            // Same value, bit for bit, as sum_d ((double)S_d * inv_scale)^2 / n per side: inv_scale is a power of two, so it commutes
-            // with every rounding below (no under- / overflow: |S| < 2^53, inv_scale >= 2^-40) and is applied once, squared, at the end
-            // (sqrt: an even power of two); (double)(total - right) == (double)total - (double)right because all three are exact.
-            // k_score is bound by its VALU instruction count and this loop was 170 of them per candidate (now ~115).
-            double sr = 0.0, sl_ = 0.0;
-            for (int d = 0; d < D; ++d) {
-                const double vr = static_cast<double>(R[d]);
-                const double vl = total_f[d] - vr;
-                sr += vr * vr;
-                sl_ += vl * vl;
-            }
-            double x = 0.0;
-            if (n_l > 0) x += sl_ / static_cast<double>(n_l);
-            if (n_r > 0) x += sr / static_cast<double>(n_r);
-            x *= inv_scale * inv_scale;
-            out = static_cast<float>(cosine ? sqrt(x) : x);
+            // (score_common.h: the fused RL-sized growth kernel evaluates the same expression.)  k_score is bound by its VALU instruction
+            // count and this loop was 170 of them per candidate (now ~115).
+            out = candidate_score([&](int d) { return static_cast<double>(R[d]); }, total_f, D, n_l, n_r, cosine, inv_scale);
         }
         if (part_v) {
             const int j = sl.cand_base + k;
