@@ -1219,6 +1219,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         return cat_index[cat_index_off[feat] + cls - 1];
     };
     const float *win_thr = nullptr;   // small-step kernel: the winners' threshold values travel with the level's result block
+    bool counts_later = false;        // small-step kernel, oblivious trees: the node sizes are derived from the leaves' row counts after the replay
     auto digest_level = [&](const std::vector<int> &active, const char *hres) -> LevelOutcome {
         LevelOutcome out;
         const int n_act = static_cast<int>(active.size());
@@ -1257,7 +1258,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         std::vector<int> &next = out.next;
         for (int k : splitting) {
             const int id = active[k];
-            if (tot_g[k] != nodes[id].n_global) throw HipError("internal: histogram row count mismatch");
+            if (!counts_later && tot_g[k] != nodes[id].n_global) throw HipError("internal: histogram row count mismatch");
             const NodeSplit &q = sp[k];
             HCond c{};
             c.fslot = q.fslot;
@@ -1311,14 +1312,14 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         const size_t res_all = res_stride * MD;
         const size_t acc_words = static_cast<size_t>(2u << MD) * (D + 1);
         const size_t o_acc = (res_all + 255) & ~static_cast<size_t>(255), o_status = o_acc + sizeof(int64_t) * acc_words;
-        char *h_blk = static_cast<char *>(pin_res_all_.ensure(o_status + 64));
+        char *h_blk = static_cast<char *>(pin_res_all_.ensure(o_status + 64 + 64));
         void *h_blk_dev = nullptr;
         hip_check(hipHostGetDevicePointer(&h_blk_dev, h_blk, 0), "hipHostGetDevicePointer");
         char *d_blk = static_cast<char *>(h_blk_dev);
         volatile uint32_t *h_status = reinterpret_cast<volatile uint32_t *>(h_blk + o_status);
-        unsigned *d_sync = static_cast<unsigned *>(d_sg_sync_.ensure(256));
+        unsigned *d_sync = static_cast<unsigned *>(d_sg_sync_.ensure(4096));
         if (d_sync != sg_sync_ptr_) {
-            hip_check(hipMemsetAsync(d_sync, 0, 256, s), "memset barrier words");
+            hip_check(hipMemsetAsync(d_sync, 0, 4096, s), "memset barrier words");
             sg_sync_ptr_ = d_sync;
         }
         kern::SmallGrowIO io{};
@@ -1331,6 +1332,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         uint32_t seq = ++level_seq_;
         if (seq == 0) seq = ++level_seq_;
         io.seq = seq;
+        static const bool sg_prof = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_PROF"); return e && e[0] == '1'; }();   // measurement hook
+        if (sg_prof) io.prof = reinterpret_cast<uint32_t *>(d_blk + o_status + 64);
         h_status[0] = 0;
         phase_begin();
         if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
@@ -1341,7 +1344,15 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             sg_sync_ptr_ = nullptr;
             throw HipError("small-step growth kernel gave up at a grid barrier (its blocks were not co-resident?)");
         }
+        if (sg_prof) {
+            static const char *names[14] = {"codes", "zero", "accumulate", "scan", "carries", "score", "select", "slot_best", "barrier", "winners", "tables", "route", "level_end", "leaves"};
+            const volatile uint32_t *pw = reinterpret_cast<const volatile uint32_t *>(h_blk + o_status + 64);
+            std::string line = "[small_grow block 0, us]";
+            for (int i = 0; i < 14; ++i) line += std::string(" ") + names[i] + " " + std::to_string(pw[i] / 100.0).substr(0, 5);
+            fprintf(stderr, "%s\n", line.c_str());
+        }
         const int levels_written = static_cast<int>(h_status[1]);
+        counts_later = oblivious;
         for (int depth = 0; depth < MD; ++depth) {
             std::vector<int> active;
             for (int id : frontier)
@@ -1356,6 +1367,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             frontier = lvl.next;
         }
         win_thr = nullptr;
+        counts_later = false;
         for (int id : frontier)
             if (!nodes[id].leaf) nodes[id].leaf = true;
         if (nodes.size() == 1) nodes[0].leaf = true;
@@ -1364,6 +1376,23 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         acc.assign(nodes.size() * (D + 1), 0);
         for (size_t id = 0; id < nodes.size(); ++id)
             if (nodes[id].left < 0) std::memcpy(&acc[id * (D + 1)], h_acc + id * (D + 1), sizeof(int64_t) * (D + 1));
+        if (oblivious && nodes.size() > 1) {
+            // An oblivious level keeps both children of every node, so the kernel never counts them: a node's size is the sum of its leaves'
+            // row counts (bottom-up: children have higher ids than their parent), and the edge weights follow (node.cpp:131).
+            std::vector<long long> cnt(nodes.size(), 0);
+            for (size_t id = nodes.size(); id-- > 0;)
+                cnt[id] = nodes[id].left < 0 ? acc[id * (D + 1) + D] : cnt[nodes[id].left] + cnt[nodes[id].right];
+            if (cnt[0] != N) throw HipError("internal: the leaves of the grown tree hold " + std::to_string(cnt[0]) + " of " + std::to_string(N) + " rows");
+            for (size_t id = 0; id < nodes.size(); ++id) {
+                HNode &nd = nodes[id];
+                nd.n_global = cnt[id];
+                nd.n_local = static_cast<int>(cnt[id]);
+                if (id == 0) continue;
+                const HNode &par = nodes[nd.parent];
+                for (size_t q = 0; q + 1 < nd.path.size(); ++q) nd.path[q].edge_w = par.path[q].edge_w;
+                nd.path.back().edge_w = cnt[nd.parent] > 0 ? static_cast<float>(cnt[id]) / static_cast<float>(cnt[nd.parent]) : 0.0f;
+            }
+        }
         if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
         leaf_scale = c.h_scales->leaf_scale;
         return;

@@ -307,11 +307,12 @@ struct SmallGrowIO {
     bool cosine, oblivious;
     int G;                 // blocks: small_grow_blocks(n_slots)
     void *bests;           // device scratch, small_grow_bests_bytes(MD, G, oblivious)
-    unsigned *sync;        // device, 4 words, zero before the first launch (the kernel hands them back zeroed)
+    unsigned *sync;        // device, 4096 bytes, zero before the first launch (the kernel hands them back zeroed)
     char *res;             // pinned, device-mapped
     int64_t *acc;          // pinned, device-mapped, [2 << MD][D + 1]
     uint32_t *status;      // pinned, device-mapped, 4 words: sequence word | levels | node count | error
     uint32_t seq;
+    uint32_t *prof = nullptr;   // measurement: pinned, 16 words (block 0's time per phase, 10 ns units)
 };
 bool small_grow_supported(int N, int D, int NB, int MD, int n_slots, int n_cand);
 int small_grow_blocks(int n_slots);

@@ -67,16 +67,36 @@ __device__ __forceinline__ void wave_scan9(long long (&v)[9]) {
 }
 #undef GBRL_SCAN9_STEP
 
+// The same scan for nine 32-bit values (sums of at most 4096 fixed-point gradients fit 32 bits: the one-launch growth kernel's LDS histograms):
+// one DPP-fused add per value and step.
+#define GBRL_SCAN9I_STEP(CTRL) \
+    asm volatile("s_nop 1\n" \
+                 "v_add_u32_dpp %0, %0, %0 " CTRL "\n v_add_u32_dpp %1, %1, %1 " CTRL "\n v_add_u32_dpp %2, %2, %2 " CTRL "\n" \
+                 "v_add_u32_dpp %3, %3, %3 " CTRL "\n v_add_u32_dpp %4, %4, %4 " CTRL "\n v_add_u32_dpp %5, %5, %5 " CTRL "\n" \
+                 "v_add_u32_dpp %6, %6, %6 " CTRL "\n v_add_u32_dpp %7, %7, %7 " CTRL "\n v_add_u32_dpp %8, %8, %8 " CTRL "\n" \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]))
+__device__ __forceinline__ void wave_scan9(int32_t (&v)[9]) {
+    GBRL_SCAN9I_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9I_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9I_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9I_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
+    GBRL_SCAN9I_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    GBRL_SCAN9I_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+}
+#undef GBRL_SCAN9I_STEP
+
 
 // One candidate's score from its right-side sums R(d) (exact integers as doubles), the node totals (as doubles) and the side counts:
 //   L2: |S_L|^2/n_L + |S_R|^2/n_R (node.cpp:360-373);  Cosine: the square root of it (math_ops.h:538-575).
 // Same value, bit for bit, as sum_d ((double)S_d * inv_scale)^2 / n per side: inv_scale is a power of two, so it commutes with every rounding
 // (no under- / overflow: |S| < 2^53, inv_scale >= 2^-40) and is applied once, squared, at the end (sqrt: an even power of two);
 // (double)(total - right) == (double)total - (double)right because all three are exact.
-template <typename GetR>
-__device__ __forceinline__ float candidate_score(GetR R, const double *total_f, int D, long long n_l, long long n_r, int cosine, double inv_scale) {
+// (CNT: long long for k_score's row counts; int where they are known to fit -- the conversion to double is one instruction instead of five.)
+template <typename GetR, typename CNT>
+__device__ __forceinline__ float candidate_score(GetR R, const double *total_f, int D, CNT n_l, CNT n_r, int cosine, double inv_scale) {
     double sr = 0.0, sl_ = 0.0;
-    for (int d = 0; d < D; ++d) {
+#pragma unroll 4
+    for (int d = 0; d < D; ++d) {   // (unrolled so that the operand loads of four fields are issued together; the additions keep their order)
         const double vr = R(d);
         const double vl = total_f[d] - vr;
         sr += vr * vr;

@@ -41,8 +41,10 @@ namespace {
 constexpr int kSgThreads = 1024;
 constexpr int kSgWaves = kSgThreads / kWave;
 constexpr unsigned kLeafBit = 0x8000u;     // rownode: the row has reached a leaf; low 15 bits = node id
-constexpr unsigned kRightBit = 0x4000u;    // rownode, between the two routing passes: the row goes right
 
+// One candidate in the arg-max: gain / score, reference candidate index (ties: the lower wins), feature slot << 16 | bin (numeric: threshold
+// index; categorical: class), and -- greedy growth -- `pad` = the rows the candidate sends RIGHT in its node (known where the candidate is
+// scored; travels with the winner so that nobody has to count the children's rows).
 struct alignas(16) SgBest { float v; int32_t ref; uint32_t slotbin; uint32_t pad; };
 
 __device__ __forceinline__ SgBest sg_better(SgBest a, SgBest b) {
@@ -50,23 +52,74 @@ __device__ __forceinline__ SgBest sg_better(SgBest a, SgBest b) {
     if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.ref < a.ref)) return b;
     return a;
 }
+// Reduction over the 64 lanes with DPP moves (row_shr 1, 2, 4, 8, then row_bcast 15 / 31: lane 63 ends up with the best of all) and three
+// readlanes -- no LDS crossbar round trips (a __shfl_xor butterfly is 18 ds_bpermute with ~100 clocks of latency each, and these
+// reductions sit on the critical path of every level).  A lane without a source keeps its own value (update_dpp's `old`).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ SgBest sg_dpp_step(SgBest m) {
+    SgBest o;
+    o.v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m.v), __float_as_int(m.v), CTRL, ROW_MASK, 0xf, false));
+    o.ref = __builtin_amdgcn_update_dpp(m.ref, m.ref, CTRL, ROW_MASK, 0xf, false);
+    o.slotbin = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(m.slotbin), static_cast<int>(m.slotbin), CTRL, ROW_MASK, 0xf, false));
+    o.pad = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(m.pad), static_cast<int>(m.pad), CTRL, ROW_MASK, 0xf, false));
+    return sg_better(m, o);
+}
 __device__ __forceinline__ SgBest sg_wave_best(SgBest m) {
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        SgBest other;
-        other.v = __shfl_xor(m.v, o, kWave);
-        other.ref = __shfl_xor(m.ref, o, kWave);
-        other.slotbin = static_cast<uint32_t>(__shfl_xor(static_cast<int>(m.slotbin), o, kWave));
-        other.pad = 0;
-        m = sg_better(m, other);
-    }
-    return m;
+    m = sg_dpp_step<0x111, 0xf>(m);   // row_shr:1
+    m = sg_dpp_step<0x112, 0xf>(m);   // row_shr:2
+    m = sg_dpp_step<0x114, 0xf>(m);   // row_shr:4
+    m = sg_dpp_step<0x118, 0xf>(m);   // row_shr:8
+    m = sg_dpp_step<0x142, 0xa>(m);   // row_bcast:15 -> rows 1, 3
+    m = sg_dpp_step<0x143, 0xc>(m);   // row_bcast:31 -> rows 2, 3
+    SgBest r;
+    r.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.v), 63));
+    r.ref = __builtin_amdgcn_readlane(m.ref, 63);
+    r.slotbin = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m.slotbin), 63));
+    r.pad = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m.pad), 63));
+    return r;
 }
 
 __device__ __forceinline__ void sg_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void sg_add(long long *p, long long v) { atomicAdd(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(v)); }
 
+// hist[(node - k0) * NBe + class][0 .. D] += (qg[row][0 .. D) | 1) for the rows whose node is in the batch [k0, k0 + nbk).
+// V = 4 / 2 / 1 gradient words per load (D % 4 == 0, D % 2 == 0, any D): a lane reads its row's fields with 16- / 8- / 4-byte loads.
+template <typename ACC, int V>
+__device__ __forceinline__ void sg_accumulate_rows(const int32_t *__restrict__ qg, const uint32_t *rc, ACC *hist, int N, int D, int NBe, int k0, int nbk, int tid) {
+    typedef int sg_iv __attribute__((ext_vector_type(V)));
+    const int W = D + 1;
+    constexpr int R = 4;
+    for (int r0 = tid; r0 < N; r0 += kSgThreads * R) {
+        ACC *base[R];
+        const int32_t *src[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int r = r0 + u * kSgThreads, rr = min(r, N - 1);
+            const uint32_t rv = rc[rr];
+            const unsigned kb = (rv & 0xffffu) - static_cast<unsigned>(k0);
+            const bool okk = r < N && kb < static_cast<unsigned>(nbk);
+            base[u] = okk ? hist + (static_cast<size_t>(kb) * NBe + (rv >> 16)) * W : nullptr;
+            src[u] = qg + static_cast<size_t>(rr) * D;
+        }
+        for (int j0 = 0; j0 < D; j0 += V) {
+            sg_iv q[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) q[u] = *reinterpret_cast<const sg_iv *>(src[u] + j0);
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                if (base[u]) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) sg_add(base[u] + j0 + i, static_cast<ACC>(q[u][i]));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) if (base[u]) sg_add(base[u] + D, static_cast<ACC>(1));
+    }
+}
+
 struct SgLayout {     // byte offsets into the dynamic LDS block (host computes, kernel carves)
-    int rownode, scode, tn, tid, psb, pv, nright, split, cidx, cid, win, wcat, nbest, ssum, leafflag, ttot, total, totalf, ibest, wbest, lacc, hist;
+    int rc, sw, sref, tn, tid, psb, pv, split, cidx, cid, win, wcat, nbest, ssum, leafflag, ttot, total, totalf, ibest, wbest, lacc, hist;
     int total_bytes;
 };
 
@@ -83,24 +136,47 @@ struct SmallGrowArgs {
     int G, NC, nb_cap, Tmax, NIDS;
     uint32_t magicW;            // floor(2^32 / (D + 1)) + 1
     SgBest *bests;              // greedy [MD][NC][G], oblivious [MD][G]
-    unsigned *sync;             // [0] barrier arrivals, [1] finished blocks, [2] abort
+    unsigned *sync;             // [0] groups arrived, [1] finished blocks, [2] abort, [32 + 32 g] arrivals of group g (kSmallGrowSyncBytes)
     char *res;                  // pinned, device-mapped: MD result blocks of res_stride bytes
     int res_stride, max_front;
     int64_t *acc;               // pinned: [NIDS][D+1]
     uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] error
     uint32_t seq;
+    uint32_t *prof;             // nullable (GBRL_HIP_SMALL_GROW_PROF=1): block 0's time per phase, 10 ns units, 16 words, pinned
     SgLayout L;
 };
 
 // One barrier over the grid (all G blocks are resident: G <= CUs, one block per CU).  Monotonic arrival counter; a timeout (or another
 // block's abort) makes every block leave through the error exit instead of spinning forever.
+// NO fences: an agent-scope release / acquire fence is a write-back / invalidate of the XCD's whole L2 (buffer_wbl2 / buffer_inv), and with
+// 16 waves of 192 blocks executing one per level the first version spent 40 us per level behind them (and every block re-fetched its
+// gradients from HBM afterwards).  The only data that crosses blocks are the per-level bests: they are written and read with agent-scope
+// atomic accesses (sc1: written through to / fetched from the coherence point), the writers drain their stores (s_waitcnt vmcnt(0)) in
+// front of the block barrier that precedes the arrival, and the arrival itself is an agent-scope atomic.
+__device__ __forceinline__ void sg_store_best(SgBest *p, SgBest b) {
+    unsigned long long lo = (static_cast<unsigned long long>(static_cast<uint32_t>(b.ref)) << 32) | __float_as_uint(b.v);
+    unsigned long long hi = (static_cast<unsigned long long>(b.pad) << 32) | b.slotbin;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ SgBest sg_load_best(const SgBest *p) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return SgBest{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+}
+// Arrivals are counted per GROUP of 16 blocks (counters 128 bytes apart) and the last block of a group arrives at the top counter: 256
+// atomics on ONE word took ~7 us per barrier (a device-scope atomic unit retires ~30 same-address operations per microsecond).
+constexpr int kSgGroup = 16;
 __device__ __forceinline__ bool sg_grid_barrier(unsigned *sync, unsigned G, unsigned &epoch, int *s_abort) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         ++epoch;
-        __threadfence();
-        atomicAdd(&sync[0], 1u);
-        const unsigned target = epoch * G;
+        const unsigned grp = blockIdx.x / kSgGroup, n_grp = (G + kSgGroup - 1) / kSgGroup;
+        const unsigned gsize = min(static_cast<unsigned>(kSgGroup), G - grp * kSgGroup);
+        const unsigned old = __hip_atomic_fetch_add(&sync[32 + 32 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old + 1u) % gsize == 0u) __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * n_grp;
         const long long t0 = wall_clock64();
         unsigned spins = 0;
         int bad = 0;
@@ -116,10 +192,8 @@ __device__ __forceinline__ bool sg_grid_barrier(unsigned *sync, unsigned G, unsi
             }
         }
         if (bad) *s_abort = 1;
-        __threadfence();
     }
     __syncthreads();
-    __threadfence();   // every wave: nothing read below may come from a line cached before the barrier
     return *s_abort == 0;
 }
 
@@ -127,13 +201,14 @@ template <typename ACC>
 __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a) {
     extern __shared__ __align__(16) unsigned char sg_lds[];
     const SgLayout &L = a.L;
-    uint16_t *rownode = reinterpret_cast<uint16_t *>(sg_lds + L.rownode);
-    uint16_t *scode = reinterpret_cast<uint16_t *>(sg_lds + L.scode);
+    uint32_t *rc = reinterpret_cast<uint32_t *>(sg_lds + L.rc);         // [N] per row: class code of the loaded slot << 16 | node word
+    uint16_t *rc16 = reinterpret_cast<uint16_t *>(rc);                   //   node word = rc16[2 r]: index into the level's table, or kLeafBit | node id
+    float *sw = reinterpret_cast<float *>(sg_lds + L.sw);               // [NB] candidate weights of the loaded slot
+    int32_t *sref = reinterpret_cast<int32_t *>(sg_lds + L.sref);       // [NB] their reference indices
     int *tn_b = reinterpret_cast<int *>(sg_lds + L.tn);                 // [2][NC] rows of the level's nodes
     int *tid_b = reinterpret_cast<int *>(sg_lds + L.tid);               // [2][NC] their node ids (host numbering)
     uint32_t *psb_b = reinterpret_cast<uint32_t *>(sg_lds + L.psb);     // [2][NC][MD] path: slot << 16 | bin
     float *pv_b = reinterpret_cast<float *>(sg_lds + L.pv);             // [2][NC][MD] path: threshold value
-    int *nright = reinterpret_cast<int *>(sg_lds + L.nright);           // [NC]
     int *split = reinterpret_cast<int *>(sg_lds + L.split);             // [NC]
     int *cidx = reinterpret_cast<int *>(sg_lds + L.cidx);               // [NC][2] child's index in the next table, -1: not active
     int *cid = reinterpret_cast<int *>(sg_lds + L.cid);                 // [NC] left child's node id
@@ -142,7 +217,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     SgBest *nbest = reinterpret_cast<SgBest *>(sg_lds + L.nbest);       // [NC] greedy: this block's best per node
     float *ssum = reinterpret_cast<float *>(sg_lds + L.ssum);           // [NB] oblivious: per candidate, sum over nodes
     unsigned char *leafflag = sg_lds + L.leafflag;                      // [NIDS]
-    long long *ttot = reinterpret_cast<long long *>(sg_lds + L.ttot);   // [nb][T][W] tile totals, then carries
+    ACC *ttot = reinterpret_cast<ACC *>(sg_lds + L.ttot);               // [nb][T][W] tile totals, then carries
     long long *total = reinterpret_cast<long long *>(sg_lds + L.total); // [nb][W]
     double *total_f = reinterpret_cast<double *>(sg_lds + L.totalf);    // [nb][W]
     SgBest *ibest = reinterpret_cast<SgBest *>(sg_lds + L.ibest);       // [nb][T]
@@ -157,10 +232,15 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, blk = blockIdx.x;
     const double inv_scale = a.scales->inv_scale;
     const bool obl = a.oblivious != 0;
-    const int NW = N * W, ND = N * D;
     unsigned epoch = 0;
+    // measurement (a.prof): thread 0 of block 0 charges the time since the last mark to a phase (marks sit behind barriers)
+    long long pt = a.prof ? wall_clock64() : 0;
+    unsigned pacc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pacc[i] = 0;
+#define SG_MARK(i) do { if (a.prof && blk == 0 && tid == 0) { const long long n_ = wall_clock64(); pacc[i] += static_cast<unsigned>(n_ - pt); pt = n_; } } while (0)
 
-    for (int r = tid; r < N; r += kSgThreads) rownode[r] = 0;
+    for (int r = tid; r < N; r += kSgThreads) rc[r] = 0;
     for (int i = tid; i < a.NIDS; i += kSgThreads) leafflag[i] = 0;
     if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; }
     __syncthreads();
@@ -179,42 +259,40 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             const FeatureSlot sl = a.slots[fs];
             const int NBe = sl.n_cand + 1;                       // classes of this slot
             const int T = (NBe - 1 + kWave - 1) / kWave;         // 64-class tiles over the classes 1 .. NBe-1
-            if (fs != loaded_slot) {                             // the slot's class codes in row order
+            if (fs != loaded_slot) {                             // the slot's class codes in row order, its candidates' weights and reference indices
                 const uint16_t *cs = a.codes + (static_cast<size_t>(fs >> 4) * N) * kCodeGroup + (fs & (kCodeGroup - 1));
-                for (int r = tid; r < N; r += kSgThreads) scode[r] = cs[static_cast<size_t>(r) * kCodeGroup];
+                for (int r0 = tid; r0 < N; r0 += kSgThreads * 8) {
+                    uint16_t cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cv[u] = cs[static_cast<size_t>(min(r0 + u * kSgThreads, N - 1)) * kCodeGroup];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (r0 + u * kSgThreads < N) rc16[2 * (r0 + u * kSgThreads) + 1] = cv[u];
+                }
+                for (int k = tid; k < sl.n_cand; k += kSgThreads) { sw[k] = a.cand_w[sl.cand_base + k]; sref[k] = a.cand_ref[sl.cand_base + k]; }
                 loaded_slot = fs;
             }
+            SG_MARK(0);
             if (obl) for (int k = tid; k < sl.n_cand; k += kSgThreads) ssum[k] = 0.0f;
             for (int k0 = 0; k0 < n_act; k0 += a.nb_cap) {
                 const int nbk = min(a.nb_cap, n_act - k0);
                 const int hwords = nbk * NBe * W;
-                for (int i = tid; i < hwords; i += kSgThreads) hist[i] = 0;
-                __syncthreads();
-                // -- accumulate: element e = (row, field); loads first, atomics second
-                constexpr int U = 4;
-                for (int e0 = tid; e0 < NW; e0 += kSgThreads * U) {
-                    int rr[U], jj[U], qq[U];
-                    unsigned kk[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int e = e0 + u * kSgThreads;
-                        const int ee = min(e, NW - 1);
-                        rr[u] = static_cast<int>(__umulhi(static_cast<unsigned>(ee), a.magicW));
-                        jj[u] = ee - rr[u] * W;
-                        qq[u] = a.qg[min(ee - rr[u], ND - 1)];
-                        kk[u] = e < NW ? rownode[rr[u]] : 0xffffu;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const unsigned kb = kk[u] - static_cast<unsigned>(k0);
-                        if (kb < static_cast<unsigned>(nbk)) {
-                            const int c = scode[rr[u]];
-                            const int v = jj[u] < D ? qq[u] : 1;
-                            sg_add(&hist[(kb * NBe + c) * W + jj[u]], static_cast<ACC>(v));
-                        }
-                    }
+                {   // (16-byte stores; the region's capacity is a multiple of 16 bytes)
+                    typedef unsigned int sg_u4 __attribute__((ext_vector_type(4)));
+                    sg_u4 *hz = reinterpret_cast<sg_u4 *>(hist);
+                    const int n16 = static_cast<int>((static_cast<size_t>(hwords) * sizeof(ACC) + 15) / 16);
+                    for (int i = tid; i < n16; i += kSgThreads) hz[i] = sg_u4{0u, 0u, 0u, 0u};
                 }
                 __syncthreads();
+                SG_MARK(1);
+                // -- accumulate: one ROW per lane (four rows per thread and round).  The row's class word is read once, its histogram base
+                //    computed once, and every field is one ds_add with an immediate offset: ~2.5 VALU instructions per (row, field) -- the first
+                //    version (one lane per (row, field)) spent 40 on index arithmetic and was bound by them (10 us per level at 4096 x 9).  The
+                //    lanes of a wave hit random classes, which the LDS atomic unit absorbs at its issue rate (DESIGN, k_hist_build).
+                if ((D & 3) == 0) sg_accumulate_rows<ACC, 4>(a.qg, rc, hist, N, D, NBe, k0, nbk, tid);
+                else if ((D & 1) == 0) sg_accumulate_rows<ACC, 2>(a.qg, rc, hist, N, D, NBe, k0, nbk, tid);
+                else sg_accumulate_rows<ACC, 1>(a.qg, rc, hist, N, D, NBe, k0, nbk, tid);
+                __syncthreads();
+                SG_MARK(2);
                 // -- phase A: per (node, tile) suffix sums over the tile's classes (in place) and the tile totals
                 const int n_items = nbk * T;
                 for (int it = wave; it < n_items; it += kSgWaves) {
@@ -223,13 +301,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     const bool have = c >= 1;
                     ACC *hc = hist + (static_cast<size_t>(kb) * NBe + (have ? c : 0)) * W;
                     for (int w0 = 0; w0 < W; w0 += 9) {
-                        long long v[9];
+                        ACC v[9];
 #pragma unroll
-                        for (int j = 0; j < 9; ++j) v[j] = (have && w0 + j < W) ? static_cast<long long>(hc[min(w0 + j, W - 1)]) : 0;
+                        for (int j = 0; j < 9; ++j) v[j] = (have && w0 + j < W) ? hc[min(w0 + j, W - 1)] : 0;
                         wave_scan9(v);
                         if (!sl.is_cat) {
 #pragma unroll
-                            for (int j = 0; j < 9; ++j) if (have && w0 + j < W) hc[w0 + j] = static_cast<ACC>(v[j]);
+                            for (int j = 0; j < 9; ++j) if (have && w0 + j < W) hc[w0 + j] = v[j];
                         }
                         if (lane == kWave - 1) {
 #pragma unroll
@@ -238,14 +316,15 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     }
                 }
                 __syncthreads();
+                SG_MARK(3);
                 // -- carries (sum of the tiles above) and node totals (all tiles + class 0)
                 for (int i = tid; i < nbk * W; i += kSgThreads) {
                     const int kb = i / W, j = i - kb * W;
                     long long run = 0;
                     for (int t = 0; t < T; ++t) {
-                        long long *p = &ttot[(static_cast<size_t>(kb) * T + t) * W + j];
-                        const long long x = *p;
-                        *p = run;
+                        ACC *p = &ttot[(static_cast<size_t>(kb) * T + t) * W + j];
+                        const ACC x = *p;
+                        *p = static_cast<ACC>(run);     // (a sum over a subset of the node's rows: fits the accumulator type)
                         run += x;
                     }
                     run += static_cast<long long>(hist[(static_cast<size_t>(kb) * NBe) * W + j]);
@@ -253,6 +332,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     total_f[i] = static_cast<double>(run);
                 }
                 __syncthreads();
+                SG_MARK(4);
                 // -- phase B: one lane per candidate
                 for (int it = wave; it < n_items; it += kSgWaves) {
                     const int kb = it / T, t = it - kb * T;
@@ -267,11 +347,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     int np = 0;
                     for (int p = 0; p < level; ++p) np += (psb[k_abs * MD + p] >> 16) == static_cast<uint32_t>(fs) ? 1 : 0;
                     ACC *hc = hist + (static_cast<size_t>(kb) * NBe + (have ? c : 0)) * W;
-                    const long long *cy = ttot + (static_cast<size_t>(kb) * T + t) * W;
+                    const ACC *cy = ttot + (static_cast<size_t>(kb) * T + t) * W;
                     const bool scanned = !sl.is_cat;
                     float out = -INFINITY;
+                    int n_r = 0;
                     if (have) {
-                        const long long n_r = static_cast<long long>(hc[D]) + (scanned ? cy[D] : 0), n_l = n_tot - n_r;
+                        n_r = static_cast<int>(hc[D] + (scanned ? cy[D] : 0));   // (row counts: at most 8192)
+                        const int n_l = static_cast<int>(n_tot) - n_r;
                         bool reject = (n_l < a.min_data) || (n_r < a.min_data);
                         if (np > 0) {
                             const float tk = sl.is_cat ? 0.0f : a.thr[static_cast<size_t>(fs) * B + k];
@@ -282,9 +364,10 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                                 else reject |= pv[k_abs * MD + p] == tk;
                             }
                         }
-                        if (!reject)
-                            out = candidate_score([&](int d) { return static_cast<double>(static_cast<long long>(hc[d]) + (scanned ? cy[d] : 0)); }, totf, D, n_l, n_r,
-                                                  a.cosine, inv_scale);
+                        if (!reject) {
+                            if (scanned) out = candidate_score([&](int d) { return static_cast<double>(static_cast<ACC>(hc[d] + cy[d])); }, totf, D, n_l, n_r, a.cosine, inv_scale);
+                            else out = candidate_score([&](int d) { return static_cast<double>(hc[d]); }, totf, D, n_l, n_r, a.cosine, inv_scale);
+                        }
                     }
                     if (obl) {
                         if (have) hc[0] = static_cast<ACC>(__float_as_int(out));   // the score takes the place of a word nobody reads again
@@ -297,15 +380,15 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                         }
                         SgBest mine{-INFINITY, 0x7fffffff, 0u, 0u};
                         if (have) {
-                            const int j = sl.cand_base + k;
-                            mine = SgBest{fmaf(out, a.cand_w[j], -par_sub), a.cand_ref[j],
-                                          (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u};
+                            mine = SgBest{fmaf(out, sw[k], -par_sub), sref[k],
+                                          (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), static_cast<uint32_t>(n_r)};
                         }
                         mine = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, mine));
                         if (lane == 0) ibest[it] = mine;
                     }
                 }
                 __syncthreads();
+                SG_MARK(5);
                 // -- phase C
                 if (obl) {
                     for (int k = tid; k < sl.n_cand; k += kSgThreads) {   // fp32 sum over the level's nodes in node order (fitter.cpp:426-435)
@@ -321,37 +404,40 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     }
                 }
                 __syncthreads();
+                SG_MARK(6);
             }
             if (obl) {   // the slot's best candidate: (sum over nodes) * w, lowest reference index among maxima (fitter.cpp:435-444)
                 SgBest mine{-INFINITY, 0x7fffffff, 0u, 0u};
                 for (int k = tid; k < sl.n_cand; k += kSgThreads) {
-                    const int j = sl.cand_base + k;
-                    mine = sg_better(mine, SgBest{ssum[k] * a.cand_w[j], a.cand_ref[j], (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u});
+                    mine = sg_better(mine, SgBest{ssum[k] * sw[k], sref[k], (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u});
                 }
                 mine = sg_wave_best(mine);
                 if (lane == 0) wbest[wave] = mine;
                 __syncthreads();
-                if (tid == 0) {
-                    SgBest b = s_bbest;
-                    for (int q = 0; q < kSgWaves; ++q) b = sg_better(b, wbest[q]);
-                    s_bbest = b;
+                if (wave == 0) {     // (the next write of wbest sits behind the barriers of the next slot / level)
+                    SgBest b = lane < kSgWaves ? wbest[lane] : SgBest{-INFINITY, 0x7fffffff, 0u, 0u};
+                    b = sg_wave_best(b);
+                    if (lane == 0) s_bbest = sg_better(s_bbest, b);
                 }
-                __syncthreads();
             }
         }
         __syncthreads();
         // ---- publish this block's bests, ONE grid barrier, reduce to the winners -------------------------------------------------
+        SG_MARK(7);
         SgBest *lv = a.bests + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
-        if (obl) { if (tid == 0) lv[blk] = s_bbest; }
-        else for (int k = tid; k < n_act; k += kSgThreads) lv[static_cast<size_t>(k) * G + blk] = nbest[k];
+        if (obl) { if (tid == 0) sg_store_best(&lv[blk], s_bbest); }
+        else for (int k = tid; k < n_act; k += kSgThreads) sg_store_best(&lv[static_cast<size_t>(k) * G + blk], nbest[k]);
         if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; break; }
+        SG_MARK(8);
         const int n_win = obl ? 1 : n_act;
         for (int k = wave; k < n_win; k += kSgWaves) {
             SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
-            for (int q = lane; q < G; q += kWave) {
-                typedef unsigned int sg_u4 __attribute__((ext_vector_type(4)));
-                const sg_u4 raw = __builtin_nontemporal_load(reinterpret_cast<const sg_u4 *>(lv + static_cast<size_t>(k) * G + q));
-                m = sg_better(m, SgBest{__uint_as_float(raw.x), static_cast<int32_t>(raw.y), raw.z, 0u});
+            for (int q0 = lane; q0 < G; q0 += kWave * 4) {          // (G <= 256 blocks: one round of four loads in flight)
+                SgBest b4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b4[u] = sg_load_best(lv + static_cast<size_t>(k) * G + min(q0 + u * kWave, G - 1));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (q0 + u * kWave < G) m = sg_better(m, b4[u]);
             }
             m = sg_wave_best(m);
             if (lane == 0) {
@@ -359,41 +445,11 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 wcat[k] = m.ref == 0x7fffffff ? 0 : a.slots[m.slotbin >> 16].is_cat;
             }
         }
-        for (int k = tid; k < n_act; k += kSgThreads) nright[k] = 0;
         __syncthreads();
-        for (int k = tid; k < n_act; k += kSgThreads) {
-            const SgBest w = win[obl ? 0 : k];
-            // fitter.cpp:458 oblivious: grow while any candidate is finite; fitter.cpp:357 greedy: split iff best >= 0
-            split[k] = obl ? (w.v != -INFINITY ? 1 : 0) : (w.v >= 0.0f ? 1 : 0);
-        }
-        __syncthreads();
-        // ---- routing pass 1: which side every row of a splitting node takes; rows going right per node ---------------------------
-        const int rounds = (N + kSgThreads - 1) / kSgThreads;
-        for (int q = 0; q < rounds; ++q) {
-            const int r = q * kSgThreads + tid;
-            const unsigned v = r < N ? rownode[r] : 0xffffu;
-            const bool act = v < kLeafBit;
-            const int k = act ? static_cast<int>(v) : 0;
-            const bool sp = act && split[k] != 0;
-            bool right = false;
-            if (sp) {
-                const SgBest w = win[obl ? 0 : k];
-                const int slot = static_cast<int>(w.slotbin >> 16), bin = static_cast<int>(w.slotbin & 0xffffu);
-                const int code = a.codes[(static_cast<size_t>(slot >> 4) * N + r) * kCodeGroup + (slot & (kCodeGroup - 1))];
-                right = wcat[obl ? 0 : k] ? (code == bin) : (code > bin);
-                if (right) rownode[r] = static_cast<uint16_t>(v | kRightBit);
-            }
-            // (a wave whose rows all sit in one node -- the usual case near the root -- counts with one atomic)
-            const int k_first = __builtin_amdgcn_readfirstlane(act ? k : -1);
-            const unsigned long long m_right = __ballot(right);
-            if (__all(!right || k == k_first)) {
-                if (lane == 0 && m_right) atomicAdd(&nright[k_first], __popcll(m_right));
-            } else if (right) {
-                atomicAdd(&nright[k], 1);
-            }
-        }
-        __syncthreads();
-        // ---- children: node ids in the host's order (for k in splitting: left, right), next level's table ------------------------
+        SG_MARK(9);
+        // ---- children: node ids in the host's order (for k in splitting: left, right), next level's table.  The child sizes of a greedy
+        //      split travel with its winner (SgBest::pad); an oblivious level keeps both children of every node, empty or not, so its table
+        //      needs no sizes (the host derives them from the leaves' row counts afterwards).
         const bool last_level = level + 1 == MD;
         int *tn2 = tn_b + (cur ^ 1) * NC, *tid2 = tid_b + (cur ^ 1) * NC;
         uint32_t *psb2 = psb_b + static_cast<size_t>(cur ^ 1) * NC * MD;
@@ -402,17 +458,20 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             int run_split = 0, run_act = 0;
             const int next_id = s_nextid;
             const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (kWave - lane));
+            const float v0 = win[0].v;
             for (int base = 0; base < n_act; base += kWave) {
                 const int k = base + lane;
                 const bool valid = k < n_act;
-                const bool sp = valid && split[k] != 0;
+                // fitter.cpp:458 oblivious: grow while any candidate is finite; fitter.cpp:357 greedy: split iff best >= 0
+                const bool sp = valid && (obl ? (v0 != -INFINITY) : (win[k].v >= 0.0f));
                 const unsigned long long m = __ballot(sp);
                 const int my_id = next_id + 2 * (run_split + __popcll(m & lt));
-                const int nr = valid ? nright[k] : 0, nl = valid ? tn[k] - nr : 0;
+                const int nr = (valid && !obl) ? static_cast<int>(win[k].pad) : 0, nl = (valid && !obl) ? tn[k] - nr : 0;
                 const bool al = sp && !last_level && (obl || nl > 0), ar = sp && !last_level && (obl || nr > 0);
                 const unsigned long long ml = __ballot(al), mr = __ballot(ar);
                 const int il = run_act + __popcll(ml & lt) + __popcll(mr & lt), ir = il + (al ? 1 : 0);
                 if (valid) {
+                    split[k] = sp ? 1 : 0;
                     cid[k] = my_id;
                     cidx[2 * k] = al ? il : -1;
                     cidx[2 * k + 1] = ar ? ir : -1;
@@ -430,6 +489,38 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             if (lane == 0) { s_nextid = next_id + 2 * run_split; s_nact_next = run_act; s_stop = run_split == 0 ? 1 : 0; }
         }
         __syncthreads();
+        SG_MARK(10);
+        // ---- routing: every row of a splitting node moves to its child (its index in the next table, or the child's node id when the child
+        //      is a leaf); rows of a node that did not split stay with it as a leaf.  ONE pass: the children's places are known (above).
+        for (int r0 = tid; r0 < N; r0 += kSgThreads * 4) {       // four rows per thread and round: the code loads are issued together
+            unsigned nv[4];
+            int code[4], bin[4], wc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * kSgThreads;
+                nv[u] = r < N ? (rc[r] & 0xffffu) : 0xffffu;
+                const int k = nv[u] < kLeafBit ? static_cast<int>(nv[u]) : 0;
+                const SgBest w = win[obl ? 0 : k];
+                const int slot = static_cast<int>(w.slotbin >> 16);
+                bin[u] = static_cast<int>(w.slotbin & 0xffffu);
+                wc[u] = wcat[obl ? 0 : k];
+                code[u] = a.codes[(static_cast<size_t>(slot >> 4) * N + min(r, N - 1)) * kCodeGroup + (slot & (kCodeGroup - 1))];   // (unconditional: a load in a branch is waited for at once)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (nv[u] >= kLeafBit) continue;
+                const int r = r0 + u * kSgThreads;
+                const int k = static_cast<int>(nv[u]);
+                unsigned w2;
+                if (!split[k]) w2 = kLeafBit | static_cast<unsigned>(tidc[k]);
+                else {
+                    const int side = (wc[u] ? (code[u] == bin[u]) : (code[u] > bin[u])) ? 1 : 0;
+                    const int ci = cidx[2 * k + side];
+                    w2 = ci >= 0 ? static_cast<unsigned>(ci) : (kLeafBit | static_cast<unsigned>(cid[k] + side));
+                }
+                rc16[2 * r] = static_cast<uint16_t>(w2);
+            }
+        }
         // paths of the active children: the parent's, plus the new condition
         for (int i = tid; i < n_act * 2 * (level + 1); i += kSgThreads) {
             const int p = i % (level + 1), ks = i / (level + 1), k = ks >> 1, side = ks & 1;
@@ -453,31 +544,20 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             for (int k = tid; k < n_act; k += kSgThreads) {
                 const SgBest w = win[obl ? 0 : k];
                 if (!obl || k == 0) { r_idx[k] = w.ref == 0x7fffffff ? 0 : w.ref; r_score[k] = w.v; }
-                r_cnt[k] = tn[k];
-                r_cnt[static_cast<size_t>(a.max_front) + k] = nright[k];
+                r_cnt[k] = obl ? 0 : tn[k];                                            // (oblivious: the host derives the sizes from the leaves)
+                r_cnt[static_cast<size_t>(a.max_front) + k] = obl ? 0 : static_cast<int>(w.pad);
                 float tv = 0.0f;
                 if (w.ref != 0x7fffffff && !wcat[obl ? 0 : k]) tv = a.thr[static_cast<size_t>(w.slotbin >> 16) * B + (w.slotbin & 0xffffu)];
                 r_thr[k] = tv;
             }
         }
-        // ---- routing pass 2: rows move to their child (or stay with a node that has become a leaf) -------------------------------
-        for (int r = tid; r < N; r += kSgThreads) {
-            const unsigned v = rownode[r];
-            if (v & kLeafBit) continue;
-            const int k = static_cast<int>(v & 0x3fffu), side = (v & kRightBit) ? 1 : 0;
-            unsigned nv;
-            if (!split[k]) nv = kLeafBit | static_cast<unsigned>(tidc[k]);
-            else {
-                const int ci = cidx[2 * k + side];
-                nv = ci >= 0 ? static_cast<unsigned>(ci) : (kLeafBit | static_cast<unsigned>(cid[k] + side));
-            }
-            rownode[r] = static_cast<uint16_t>(nv);
-        }
         __syncthreads();
+        SG_MARK(11);
         const int stop = s_stop;
         if (tid == 0) s_nact = s_nact_next;
         cur ^= 1;
         __syncthreads();
+        SG_MARK(12);
         if (stop || last_level) { ++level; break; }
     }
     // Oblivious trees keep growing with EMPTY nodes in the table; whatever is still active when the loop ends is a leaf.
@@ -486,8 +566,8 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         const int *tidc = tid_b + cur * NC;
         for (int k = tid; k < n_act; k += kSgThreads) leafflag[tidc[k]] = 1;
         for (int r = tid; r < N; r += kSgThreads) {
-            const unsigned v = rownode[r];
-            if (!(v & kLeafBit)) rownode[r] = static_cast<uint16_t>(kLeafBit | static_cast<unsigned>(tidc[v & 0x3fffu]));
+            const unsigned v = rc16[2 * r];
+            if (!(v & kLeafBit)) rc16[2 * r] = static_cast<uint16_t>(kLeafBit | static_cast<unsigned>(tidc[v & 0x3fffu]));
         }
         __syncthreads();
         // ---- leaf sums of the RAW gradients (k_leaf_sums' arithmetic: int64 fixed point, exact), leaves dealt to the blocks -----------
@@ -504,7 +584,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 int cnt = 0;
                 const unsigned want = kLeafBit | static_cast<unsigned>(id);
                 for (int r = sub; r < N; r += per) {
-                    if (rownode[r] == want) {
+                    if (rc16[2 * r] == want) {
                         s += __double2ll_rn(static_cast<double>(a.grads[static_cast<size_t>(r) * D + d]) * leaf_scale);
                         ++cnt;
                     }
@@ -519,6 +599,12 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             __syncthreads();
         }
     }
+    SG_MARK(13);
+    if (a.prof && blk == 0 && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.prof[i] = pacc[i];
+    }
+#undef SG_MARK
     // ---- the last block to finish publishes the sequence word (and hands the counters back zeroed) --------------------------------
     __syncthreads();
     if (tid == 0) {
@@ -527,6 +613,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         if (atomicAdd(&a.sync[1], 1u) == static_cast<unsigned>(G) - 1u) {
             const unsigned aborted = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.sync[0] = 0u; a.sync[1] = 0u; a.sync[2] = 0u;
+            for (int g = 0; g * kSgGroup < G; ++g) a.sync[32 + 32 * g] = 0u;
             a.status[3] = aborted || !ok ? 1u : 0u;
             __threadfence_system();
             __hip_atomic_store(a.status, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -561,13 +648,13 @@ SgLayout sg_layout(int N, int D, int NB, int MD, int acc_bytes, int &nb_cap, int
     SgLayout L{};
     int off = 0;
     auto take = [&](int bytes) { const int o = off; off = align16(off + bytes); return o; };
-    L.rownode = take(2 * N);
-    L.scode = take(2 * N);
+    L.rc = take(4 * N);
+    L.sw = take(4 * NB);
+    L.sref = take(4 * NB);
     L.tn = take(4 * 2 * NC);
     L.tid = take(4 * 2 * NC);
     L.psb = take(4 * 2 * NC * MD);
     L.pv = take(4 * 2 * NC * MD);
-    L.nright = take(4 * NC);
     L.split = take(4 * NC);
     L.cidx = take(8 * NC);
     L.cid = take(4 * NC);
@@ -578,14 +665,15 @@ SgLayout sg_layout(int N, int D, int NB, int MD, int acc_bytes, int &nb_cap, int
     L.leafflag = take(NIDS);
     L.wbest = take(16 * kSgWaves);
     L.lacc = take(8 * W);
-    const int budget = 160 * 1024 - 1024 /* static __shared__ + slack */ - off;
-    const int per_node = NB * W * acc_bytes + Tmax * W * 8 + W * 16 + Tmax * 16 + 64;
+    const int budget = 160 * 1024 - 1024 /* static __shared__ + slack */ - off - 8 * kWave - 16;
+    const int per_node = NB * W * acc_bytes + Tmax * W * acc_bytes + W * 16 + Tmax * 16 + 64;
     nb_cap = budget > 0 ? std::min(NC, budget / per_node) : 0;
     if (nb_cap <= 0) { nb_cap = 0; return L; }
-    L.ttot = take(8 * nb_cap * Tmax * W);
+    L.ttot = take(acc_bytes * nb_cap * Tmax * W);
     L.total = take(8 * nb_cap * W);
     L.totalf = take(8 * nb_cap * W);
     L.ibest = take(16 * nb_cap * Tmax);
+    (void)take(acc_bytes * kWave);                      // the accumulate loop's per-lane sink words sit right in front of the histogram
     L.hist = take(acc_bytes * nb_cap * NB * W);
     L.total_bytes = off;
     return L;
@@ -609,7 +697,7 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.G = io.G; a.NC = 1 << std::max(0, io.MD - 1); a.NIDS = 2 << io.MD;
     a.magicW = static_cast<uint32_t>((1ull << 32) / static_cast<unsigned>(io.D + 1)) + 1u;
     a.bests = static_cast<SgBest *>(io.bests); a.sync = io.sync; a.res = io.res; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
-    a.acc = io.acc; a.status = io.status; a.seq = io.seq;
+    a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof;
     static PerDeviceOnce attr32, attr64;
     if (acc_bytes == 4) {
         if (attr32.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_grow<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) { (void)hipGetLastError(); attr32.done = 0; return false; }
