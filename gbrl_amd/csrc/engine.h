@@ -121,6 +121,7 @@ class Engine {
                                      std::vector<uint16_t> &h_catcodes, std::vector<int> &cat_classes);
     void numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
                             uint32_t *d_thrkeys, int pass1_chunks = 0, uint16_t *d_codes_out = nullptr, bool *codes_written = nullptr);
+    int64_t *quantile_cum_device(const std::vector<int64_t> &cum, long long n_global, int B);   // device copy of the quantile target ranks (cached)
     void phase_begin(bool key = false);
     void phase_end(const char *name, bool key = false);
     void phases_resolve();
@@ -180,6 +181,7 @@ class Engine {
     size_t leafacc_clean_bytes_ = 0;
     DevBuf d_sg_bests_, d_sg_sync_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
     const void *sg_sync_ptr_ = nullptr;
+    int prep_launches_ = 0;           // diagnostic of the last step(): 1 = kern::small_prep ran, 3 = the separate preparation launches
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;
     size_t ev_used_ = 0;

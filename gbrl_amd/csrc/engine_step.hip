@@ -781,6 +781,33 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
 // thresholds [F][B] of the rows in dobs (keys already transposed into d_kt): fixed ones (fit()), uniform (min/max + fma), or
 // exact quantiles (radix multi-select; sample-splitter selection and 32-pass bisection kept as cross-checks / fallbacks).
 // On return d_thr / d_thrkeys hold them on the device (the caller copies them to the host when it needs them there).
+// The quantile target ranks depend on (global row count, n_bins) only: uploaded when they change (an RL loop calls step() with the same
+// batch size over and over; the upload from pageable memory costs ~70 us of host time per call), through pinned memory.
+int64_t *Engine::quantile_cum_device(const std::vector<int64_t> &cum, long long n_global, int B) {
+    hipStream_t s = stream_;
+    const bool grown = d_cum_.capacity() < sizeof(int64_t) * static_cast<size_t>(B);
+    int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
+    if (grown || cum_cache_n_ != n_global || cum_cache_b_ != B) {
+        int64_t *h = static_cast<int64_t *>(pin_cum_.ensure(sizeof(int64_t) * B));
+        std::memcpy(h, cum.data(), sizeof(int64_t) * B);
+        hip_check(hipMemcpyAsync(d_cum, h, sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
+        hip_check(hipStreamSynchronize(s), "sync cum");   // the pinned block may be rewritten by the next call
+        cum_cache_n_ = n_global;
+        cum_cache_b_ = B;
+    }
+    return d_cum;
+}
+// split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1.  With fewer rows than buckets
+// the remainder loop still gives the first n_samples buckets one row each, so cum_i = min(i + 1, n_samples) >= 1: the ranks repeat at the
+// column maximum (the reference grows valid trees there).
+static std::vector<int64_t> quantile_target_ranks(long long n_global, int B) {
+    std::vector<int64_t> cum(B);
+    const long long per = n_global / (B + 1), rem = n_global % (B + 1);
+    long long run = 0;
+    for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
+    return cum;
+}
+
 void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long long n_global, const uint32_t *d_kt, float *d_thr,
                                 uint32_t *d_thrkeys, int pass1_chunks, uint16_t *d_codes_out, bool *codes_written) {
     if (codes_written) *codes_written = false;
@@ -790,19 +817,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
     bool fast_quantile = false;
     // The target ranks depend on (global row count, n_bins) only: uploaded when they change (an RL loop calls step() with the same
     // batch size over and over; the upload from pageable memory costs ~70 us of host time per call), through pinned memory.
-    auto upload_cum = [&](const std::vector<int64_t> &cum) -> int64_t * {
-        const bool grown = d_cum_.capacity() < sizeof(int64_t) * static_cast<size_t>(B);
-        int64_t *d_cum = static_cast<int64_t *>(d_cum_.ensure(sizeof(int64_t) * B));
-        if (grown || cum_cache_n_ != n_global || cum_cache_b_ != B) {
-            int64_t *h = static_cast<int64_t *>(pin_cum_.ensure(sizeof(int64_t) * B));
-            std::memcpy(h, cum.data(), sizeof(int64_t) * B);
-            hip_check(hipMemcpyAsync(d_cum, h, sizeof(int64_t) * B, hipMemcpyHostToDevice, s), "H2D cum");
-            hip_check(hipStreamSynchronize(s), "sync cum");   // the pinned block may be rewritten by the next call
-            cum_cache_n_ = n_global;
-            cum_cache_b_ = B;
-        }
-        return d_cum;
-    };
+    auto upload_cum = [&](const std::vector<int64_t> &cum) -> int64_t * { return quantile_cum_device(cum, n_global, B); };
     auto bisection_quantiles = [&](const std::vector<int64_t> &cum) {
         // exact but slow: 32 counting passes (also the multi-GPU path: only integer counts cross ranks)
         int64_t *d_cum = upload_cum(cum);
@@ -849,10 +864,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             // split_candidate_generator.cpp:216-249: n_bins+1 equal-count buckets, threshold i = value at rank cum_i - 1.  With
             // fewer rows than buckets the remainder loop still gives the first n_samples buckets one row each, so cum_i =
             // min(i + 1, n_samples) >= 1: the ranks repeat at the column maximum (the reference grows valid trees there).
-            cum.resize(B);
-            const long long per = n_global / (B + 1), rem = n_global % (B + 1);
-            long long run = 0;
-            for (int i = 0; i < B; ++i) { run += per + (i < rem ? 1 : 0); cum[i] = run; }
+            cum = quantile_target_ranks(n_global, B);
             bool floats_done = false;
             // sharded fast path needs a power-of-two world (union sample of world*4096 keys sorted in LDS)
             const bool coll_fast = has_coll_ && (coll_.world_size & (coll_.world_size - 1)) == 0 && coll_.world_size <= 8;
@@ -1854,7 +1866,17 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
     kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
     bool stats_fused = false;
-    {
+    int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
+    // RL-sized steps on one GPU: statistics, quantisation, split candidates and class codes in ONE launch (kern::small_prep, below, where the
+    // candidate buffers exist); GBRL_HIP_NO_SMALL_PREP=1 (tests / measurement): the separate launches
+    const bool no_small_prep = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_PREP"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool no_small_stats = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_STATS"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool no_sort_codes = [] { const char *e = std::getenv("GBRL_HIP_SORT_NO_CODES"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool uniform_gen = md.generator_type == GBRL_HIP_GEN_UNIFORM;
+    const bool prep_candidate = !has_coll_ && n_global == N && F > 0 && fixed_thr_.empty() && !candidates_only_ && !no_small_prep && !no_sort_codes &&
+                                !force_bisection_ && !force_sample_select_ && !force_radix_ && N <= (uniform_gen ? 8192 : kern::sort_quantiles_max_rows());
+    if (std::getenv("GBRL_HIP_DEBUG_PREP")) fprintf(stderr, "[small_prep] candidate %d: coll %d n_global %lld N %d F %d fixed %d cand_only %d hooks %d %d %d %d %d\n", prep_candidate ? 1 : 0, has_coll_ ? 1 : 0, n_global, N, F, fixed_thr_.empty() ? 0 : 1, candidates_only_ ? 1 : 0, no_small_prep ? 1 : 0, no_sort_codes ? 1 : 0, force_bisection_ ? 1 : 0, force_sample_select_ ? 1 : 0, force_radix_ ? 1 : 0);
+    auto run_stats = [&]() {
         // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
         // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
         // sums (fp64) and take the maxima (fp32, exact) over ranks between the kernels; the arithmetic stays on the device,
@@ -1869,9 +1891,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             kern::stats_unpack(d_smsg, D, world, st, s);
         };
         // RL-sized batch on one GPU: statistics and quantisation in ONE launch with the same reduction tree (kern::small_stats)
-        const bool no_small = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_STATS"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
-        int32_t *d_qg_small = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
-        if (!has_coll_ && !no_small && n_global == N && kern::small_stats(dgrads, N, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg_small, s)) {
+        if (!has_coll_ && !no_small_stats && n_global == N && kern::small_stats(dgrads, N, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg, s)) {
             stats_fused = true;
             if (!cosine) { d_mean = d_meanden; d_den = d_meanden + D; }
         } else {
@@ -1888,9 +1908,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             kern::stats_finish(d_stat, nullptr, n_global, D, chunk_rows, d_meanden, d_scales, s);
         }
         }
-    }
-    int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
-    if (!stats_fused) kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
+        if (!stats_fused) kern::quantize_grads(dgrads, n_el, D, d_mean, d_den, d_scales, d_qg, s);
+    };
+    if (!prep_candidate) run_stats();
     phase_end("grad_stats");
 
     // ---- 2. split candidates ----------------------------------------------------------------------------------------
@@ -1905,7 +1925,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     uint32_t *d_thrkeys = static_cast<uint32_t *>(d_thrkeys_.ensure(sizeof(uint32_t) * std::max<size_t>(1, n_thr)));
     uint32_t *d_kt = nullptr;
     int pass1_chunks = 0;
-    if (F > 0) {
+    if (F > 0 && !prep_candidate) {
         // order-preserving keys, feature-major: every later pass over the observations (selection, binning) streams columns
         d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
         // quantile candidates by radix selection (the branch numeric_thresholds will take): the first digit is counted while the keys
@@ -1929,8 +1949,25 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     if (Fc > 0 && (F + Fc) % kern::kCodeGroup != 0) hip_check(hipMemsetAsync(d_codes, 0, sizeof(uint16_t) * code_elems, s), "memset codes");
     bool codes_from_sort = false;
     root_le_ = nullptr;
-    if (F > 0) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);
+    bool prep_done = false;
+    int prep_launches = 3;   // (diagnostic, reported as a pseudo-phase at profiling level 2: 1 = the fused preparation kernel ran)
+    if (prep_candidate) {
+        const int64_t *d_cum = uniform_gen ? nullptr : quantile_cum_device(quantile_target_ranks(n_global, B), n_global, B);
+        bool stats_done = false;
+        prep_done = kern::small_prep(dobs, N, F, B, uniform_gen, d_cum, d_thr, d_thrkeys, d_codes, dgrads, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg,
+                                     !no_small_stats, &stats_done, s);
+        if (std::getenv("GBRL_HIP_DEBUG_PREP")) fprintf(stderr, "[small_prep] N %d F %d B %d D %d uniform %d -> done %d stats %d\n", N, F, B, D, uniform_gen ? 1 : 0, prep_done ? 1 : 0, stats_done ? 1 : 0);
+        if (prep_done) { codes_from_sort = true; last_quantile_fallback_ = false; prep_launches = 1; }
+        if (stats_done) stats_fused = true;
+        else run_stats();
+        if (!prep_done) {   // the shape did not qualify after all: the separate launches, keys first
+            d_kt = static_cast<uint32_t *>(d_kt_.ensure(sizeof(uint32_t) * static_cast<size_t>(N) * F));
+            kern::transpose_keys(dobs, N, F, d_kt, s);
+        }
+    }
+    if (F > 0 && !prep_done) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);
     phase_end("candidates");
+    prep_launches_ = F > 0 ? prep_launches : 0;
     // numeric class codes (3. below) before the host waits for the categorical scan
     phase_begin();
     if (F > 0 && !codes_from_sort) kern::bin_cols(d_kt, N, F, d_thrkeys, B, d_codes, s);

@@ -296,6 +296,14 @@ void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *c
                     const Chunk *chunks, int n_chunks, const NodeSplit *splits, int32_t *cursors /*[n_nodes*2], zeroed*/,
                     hipStream_t s);
 
+// ---- RL-sized steps: the whole preparation in ONE launch (small_prep.hip) ----
+// Split candidates (quantile: <= 4096 rows, `cum` = the device copy of the target ranks; uniform: <= 8192 rows) and class codes of every
+// numeric feature from the row-major matrix, and -- when `want_stats` and the shape qualifies (small_stats' limits) -- the gradient statistics,
+// scales and quantised gradients (*stats_done).  false: nothing was launched (the caller runs the separate kernels).
+bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64_t *cum, float *thr, uint32_t *thr_keys, uint16_t *codes,
+                const float *grads, int D, bool centred, int chunk_rows, double *stat, float *meanden, StepScales *sc, int32_t *qg,
+                bool want_stats, bool *stats_done, hipStream_t s);
+
 // ---- RL-sized steps: the whole growth of one tree in ONE launch (small_grow.hip) ----
 // Per level: LDS histograms of the owned feature slots, scores, arg-max, ONE grid barrier, row routing; then the leaf sums.  The host reads
 // `status[0] == seq` (pinned), then MD result blocks of small_grow_res_stride(MD) bytes -- [best_idx i32 x mf][best_score f32 x mf]

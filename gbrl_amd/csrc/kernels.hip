@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include "kernels_common.h"
 #include "score_common.h"
+#include "small_prep.h"
 
 #include <hip/hip_ext.h>
 
@@ -91,7 +92,6 @@ __global__ __launch_bounds__(256) void k_column_sums_final(const double *__restr
 __global__ __launch_bounds__(256) void k_stats_mean(const double *__restrict__ stat, long long n, int D, float *__restrict__ meanden) {
     for (int d = threadIdx.x; d < D; d += blockDim.x) meanden[d] = static_cast<float>(stat[d] / static_cast<double>(n));
 }
-__device__ __forceinline__ int ilog2_floor_dev(double x) { int e; (void)frexp(x, &e); return e - 1; }
 __global__ __launch_bounds__(256) void k_stats_finish(const double *__restrict__ stat_raw, const double *__restrict__ stat_centred,
                                                       long long n, int D, int chunk_rows, float *__restrict__ meanden,
                                                       StepScales *__restrict__ sc) {
@@ -134,144 +134,13 @@ __global__ __launch_bounds__(256) void k_stats_finish(const double *__restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// RL-sized batches (round 4): the whole statistics chain -- column sums, mean, centred squares, std / maxima / scales, quantisation --
-// in ONE block.  The chain above takes seven launches for an L2 step; at a few thousand rows each of them is pure launch latency.
-// The sums keep their BITS: the block replays the reduction tree of k_column_sums / k_column_sums_final on "virtual threads"
-// (virtual block b, thread t accumulates the elements b*bs + t + k*stride in order; per (block, column) the partials are added
-// in increasing t; the final kernel's 256-entry tree is run per output), so a step gives the same quantised gradients whichever
-// path it takes.  Host guarantees: n_blocks * bs <= kSmallStatsVirtual, D <= 16.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kSmallStatsVirtual = 8192;
-constexpr int kSmallStatsThreads = 1024;
+// RL-sized batches (round 4): the whole statistics chain in ONE block -- small_prep.h, small_stats_body (shared with the fused
+// preparation kernel of small_prep.hip).
 __global__ __launch_bounds__(kSmallStatsThreads) void k_small_stats(const float *__restrict__ g, int n, int D, int n_blocks, int bs, int centred /*L2: standardise*/,
                                                                     int chunk_rows, double *__restrict__ stat /*[4D]*/, float *__restrict__ meanden /*[2D]*/,
                                                                     StepScales *__restrict__ sc, int32_t *__restrict__ qg) {
     extern __shared__ double sd[];                       // [V] sums, [V] maxima, then [n_blocks][2D] partials
-    const int V = n_blocks * bs;
-    double *vacc = sd, *vmax = sd + V, *part = sd + 2 * V;
-    __shared__ float s_center[16], s_den[16];
-    __shared__ double s_stat[64];                        // the block's own copy of stat[4D] (D <= 16): no global round trip between phases
-    const size_t n_el = static_cast<size_t>(n) * D;
-    const size_t stride = static_cast<size_t>(V);
-    auto sums = [&](bool use_center, double *out /*[2D]*/) {
-        for (int v = threadIdx.x; v < V; v += kSmallStatsThreads) {
-            const int col = (v % bs) % D;
-            const float c = use_center ? s_center[col] : 0.0f;
-            double acc = 0.0;
-            float mx = 0.0f;
-            // (k_column_sums: the order of the plain grid-stride loop; eight loads in flight -- a virtual thread owns at most eight
-            // elements when the grid is sized like column_sums_blocks, so this is usually one batch)
-            for (size_t e0 = static_cast<size_t>(v); e0 < n_el; e0 += 8 * stride) {
-                float xs[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const size_t e = e0 + u * stride; xs[u] = e < n_el ? g[e] : 0.0f; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (e0 + u * stride < n_el) {
-                        if (use_center) {
-                            const float dv = xs[u] - c;
-                            acc += static_cast<double>(dv) * static_cast<double>(dv);
-                            mx = fmaxf(mx, fabsf(dv));
-                        } else {
-                            acc += static_cast<double>(xs[u]);
-                            mx = fmaxf(mx, fabsf(xs[u]));
-                        }
-                    }
-                }
-            }
-            vacc[v] = acc;
-            vmax[v] = static_cast<double>(mx);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < n_blocks * D; i += kSmallStatsThreads) {   // per (virtual block, column): increasing t
-            const int b = i / D, d = i % D;
-            double s2 = 0.0, m = 0.0;
-            for (int t = d; t < bs; t += D) { s2 += vacc[b * bs + t]; m = fmax(m, vmax[b * bs + t]); }
-            part[static_cast<size_t>(b) * 2 * D + d] = s2;
-            part[static_cast<size_t>(b) * 2 * D + D + d] = m;
-        }
-        __syncthreads();
-        // k_column_sums_final, output o (D sums, then D maxima): its 256 threads fold the partials b = x, x + 256, ... (here n_blocks <= 32:
-        // one term, 0.0 + partial) and run the 128 .. 1 tree.  Entries x >= n_blocks are +0.0 and no folded sum is ever -0.0, so the
-        // stages 128, 64 and 32 add exact zeros: the tree is replayed from stage 16 on 32 entries, by one thread per output, in registers
-        // (a block-wide replay cost ten barriers per four outputs: 33 us for 8 outputs, more than the launches it saved).
-        if (threadIdx.x < 2 * D) {
-            const int o = threadIdx.x;
-            const bool is_max = o >= D;
-            double t[32];
-#pragma unroll
-            for (int x = 0; x < 32; ++x) {
-                const double v2 = x < n_blocks ? part[static_cast<size_t>(x) * 2 * D + o] : 0.0;
-                t[x] = is_max ? fmax(0.0, v2) : 0.0 + v2;
-            }
-#pragma unroll
-            for (int w = 16; w > 0; w >>= 1) {
-#pragma unroll
-                for (int x = 0; x < 16; ++x)
-                    if (x < w) t[x] = is_max ? fmax(t[x], t[x + w]) : t[x] + t[x + w];
-            }
-            out[o] = t[0];
-            s_stat[(out - stat) + o] = t[0];
-        }
-        __syncthreads();
-    };
-    sums(false, stat);
-    __syncthreads();
-    if (centred) {
-        if (threadIdx.x < D) {   // k_stats_mean
-            const float m = static_cast<float>(s_stat[threadIdx.x] / static_cast<double>(static_cast<long long>(n)));
-            meanden[threadIdx.x] = m;
-            s_center[threadIdx.x] = m;
-        }
-        __syncthreads();
-        sums(true, stat + 2 * D);
-        __syncthreads();
-    }
-    // k_stats_finish (maxima: order-free)
-    __shared__ float s_h0, s_h1;
-    if (threadIdx.x == 0) {
-        const double *stat_raw = s_stat, *stat_centred = centred ? s_stat + 2 * D : nullptr;
-        float h0 = 0.0f, h1 = 0.0f;
-        const float recip = __fdiv_rn(1.0f, __fsub_rn(static_cast<float>(static_cast<long long>(n)), 1.0f));
-        for (int d = 0; d < D; ++d) {
-            h1 = fmaxf(h1, static_cast<float>(stat_raw[D + d]));
-            if (!(fabs(stat_raw[d]) < INFINITY)) h1 = INFINITY;
-            if (stat_centred && !(fabs(stat_centred[d]) < INFINITY)) h0 = INFINITY;
-            if (stat_centred) {
-                const float sdv = __fsqrt_rn(__fmul_rn(static_cast<float>(stat_centred[d]), recip));
-                const float den = __fadd_rn(sdv, 1e-8f);
-                meanden[D + d] = den;
-                s_den[d] = den;
-                h0 = fmaxf(h0, __fmul_rn(__fdiv_rn(static_cast<float>(stat_centred[D + d]), den), 1.0001f));
-            }
-        }
-        if (h0 != h0) h0 = INFINITY;
-        if (h1 != h1) h1 = INFINITY;
-        const float hraw = h1, hbuild = stat_centred ? h0 : h1;
-        int sbits = 20, lbits = 40;
-        if (hbuild > 0.f && hbuild < INFINITY) sbits = min(100, ilog2_floor_dev(2147483647.0 / (static_cast<double>(chunk_rows) * hbuild)) - 1);
-        if (hraw > 0.f && hraw < INFINITY) lbits = min(60, ilog2_floor_dev(4.0e18 / (static_cast<double>(static_cast<long long>(n)) * hraw)) - 1);
-        StepScales o{};
-        o.sbits = sbits; o.lbits = lbits;
-        o.scale = static_cast<float>(ldexp(1.0, sbits));
-        o.inv_scale = ldexp(1.0, -sbits);
-        o.leaf_scale = ldexp(1.0, lbits);
-        o.hmax_build = hbuild; o.hmax_raw = hraw;
-        *sc = o;
-        s_h0 = o.scale;
-    }
-    __syncthreads();
-    __threadfence_block();
-    const float scale = s_h0;
-    // k_quantize
-    for (size_t e = threadIdx.x; e < n_el; e += kSmallStatsThreads) {
-        const int col = static_cast<int>(e % D);
-        float v = g[e];
-        if (centred) v = (v - s_center[col]) / s_den[col];
-        qg[e] = __float2int_rn(v * scale);
-    }
-    (void)s_h1;
+    small_stats_body(g, n, D, n_blocks, bs, centred, chunk_rows, stat, meanden, sc, qg, sd);
 }
 
 __device__ __forceinline__ float standardise(float v, const float *mean, const float *denom, int col) {

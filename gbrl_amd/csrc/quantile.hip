@@ -14,6 +14,8 @@
 // Everything is exact; the sample only balances the classes.  If a list would overflow its budget the engine falls back
 // to the 32-pass bisection of kernels.hip (same results, slower).
 #include "kernels.h"
+#include "kernels_common.h"
+#include "small_prep.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -24,16 +26,8 @@ namespace kern {
 
 namespace {
 
-constexpr int kWave = 64;
 constexpr int kMaxSplit = 4095;
 constexpr int kClasses = 2 * (kMaxSplit + 1);  // 8192
-
-__device__ __forceinline__ uint32_t float_to_key(float x) {
-    uint32_t u = __float_as_uint(x);
-    if ((u << 1) == 0) u = 0;
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0u;   // NaN: below every threshold, like the float comparison `x > t` (false)
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
 
 // ---- 1. transpose + key ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_transpose_keys(const float *__restrict__ obs, int n, int F, uint32_t *__restrict__ kt) {
@@ -137,94 +131,12 @@ __global__ __launch_bounds__(1024) void k_sample_splitters(const uint32_t *__res
 // One block per feature: n <= S keys padded with the maximal key to S (a power of two <= 16384), bitonic sort in LDS,
 // thr_keys[f][k] = sorted[cum[k] - 1].  One launch instead of the eight of the radix multi-select, which are launch-bound at
 // these sizes.  Exact by construction (padding sorts last and no rank points into it).
-__device__ __forceinline__ float key_to_float_q(uint32_t k) {
-    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-// `codes` (nullable; round 4): the block also writes its feature's class codes -- codes[g][row][fl] = #{k : thr_key[f][k] < key(row, f)},
-// what k_bin_cols computes -- from the thresholds it has just selected (a binary search per row in LDS), so an RL-sized step needs no
-// separate binning launch.  The grid then covers the padding features of the last group of 16 too: their blocks write zeros.
+// (small_prep.h: sort_quantiles_body, shared with the fused preparation kernel of small_prep.hip)
 __global__ __launch_bounds__(1024) void k_sort_quantiles(const uint32_t *__restrict__ kt, int n, int S, const int64_t *__restrict__ cum, int B,
                                                          uint32_t *__restrict__ thr_keys, float *__restrict__ thr_floats, int F,
                                                          uint16_t *__restrict__ codes) {
     extern __shared__ uint32_t s[];   // [S] keys, then [B] selected thresholds
-    const int f = blockIdx.x;
-    if (f >= F) {                     // padding feature of the last code group (codes != nullptr only)
-        uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
-        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[static_cast<size_t>(i) * kCodeGroup] = 0;
-        return;
-    }
-    const uint32_t *col = kt + static_cast<size_t>(f) * n;
-    // Bitonic sort, four keys per thread (blockDim.x = S / 4, S >= 256): element i = 256 * wave + 4 * lane + r.  Compare-exchange
-    // distances 1 and 2 stay inside a thread's registers, 4 .. 128 are lane exchanges inside the wave (no LDS memory, no barrier), and
-    // only the distances >= 256 cross waves through LDS (10 of the 78 stages at S = 4096).  Round 3 kept every key in LDS and paid two
-    // dependent LDS round trips per stage: 31 us for 4096 keys, the largest kernel of an RL-sized step.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int base = wave * 256 + lane * 4;
-    uint32_t a[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = base + r < n ? col[base + r] : 0xffffffffu;
-    for (int k = 2; k <= S; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 256) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[base + r] = a[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = base + r;
-                    const uint32_t other = s[i ^ j];
-                    const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-                    a[r] = take_min ? min(a[r], other) : max(a[r], other);
-                }
-                __syncthreads();
-            } else if (j >= 4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = base + r;
-                    const uint32_t other = __shfl_xor(a[r], j >> 2, 64);
-                    const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-                    a[r] = take_min ? min(a[r], other) : max(a[r], other);
-                }
-            } else {
-                // (static register pairs: a dynamically indexed a[r | j] would be demoted to scratch)
-                auto cx = [&](uint32_t &x, uint32_t &y, int i) {
-                    const bool up = (i & k) == 0;
-                    const uint32_t lo = min(x, y), hi = max(x, y);
-                    x = up ? lo : hi;
-                    y = up ? hi : lo;
-                };
-                if (j == 2) { cx(a[0], a[2], base); cx(a[1], a[3], base + 1); }
-                else { cx(a[0], a[1], base); cx(a[2], a[3], base + 2); }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[base + r] = a[r];
-    __syncthreads();
-    // keys and floats at once (what k_keys_to_floats does for the other selections: a key in the NaN range is raised to -inf's key)
-    uint32_t *thr_s = s + S;
-    for (int k = threadIdx.x; k < B; k += blockDim.x) {
-        uint32_t key = s[cum[k] - 1];
-        if (key < 0x007fffffu) key = 0x007fffffu;
-        thr_keys[static_cast<size_t>(f) * B + k] = key;
-        thr_floats[static_cast<size_t>(f) * B + k] = key_to_float_q(key);
-        if (codes) thr_s[k] = key;
-    }
-    if (codes == nullptr) return;
-    __syncthreads();
-    int top = 1;
-    while (top <= B) top <<= 1;                      // 2^m > B: the descent can reach every count 0 .. B
-    uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t key = col[i];
-        int pos = 0;
-        for (int step = top >> 1; step > 0; step >>= 1) {
-            const int np = pos + step;
-            if (np <= B && thr_s[np - 1] < key) pos = np;   // thresholds are sorted: the predicate is monotone
-        }
-        dst[static_cast<size_t>(i) * kCodeGroup] = static_cast<uint16_t>(pos);
-    }
+    sort_quantiles_body<false>(kt, n, S, cum, B, thr_keys, thr_floats, F, static_cast<int>(blockIdx.x), codes, s);
 }
 
 // Sharded runs: sort the union of all ranks' samples ([F][SU] int64 after the exchange, SU a power of two <= 32768) and

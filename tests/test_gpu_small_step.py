@@ -7,6 +7,8 @@
 * `k_hist_build` stores the int64 histograms of single-chunk nodes itself (`GBRL_HIP_NO_DIRECT_HIST=1` = partials + `k_hist_reduce`).
 * round 5: `k_small_grow` grows the WHOLE tree of a step of at most 8192 rows in one launch (LDS histograms per feature slot, one grid
   barrier per level, leaf sums; `small_grow.hip`).  `GBRL_HIP_NO_SMALL_GROW=1` = the level-synchronous loop of kernels.
+* round 5: `k_small_prep` runs the whole preparation (statistics, quantisation, quantile or uniform candidates, class codes) as one launch
+  from the row-major matrix (`small_prep.hip`; the same device bodies as the separate kernels).  `GBRL_HIP_NO_SMALL_PREP=1` = the separate launches.
 The hooks are read per call (a latched hook would compare a path with itself).  All against the plain paths on batches of 2 .. 4096 rows, both policies and scores, 1 .. 16 outputs, feature counts with and without a
 partial last code group, categorical columns beside the numeric ones -- ensembles compared byte for byte.
 """
@@ -17,7 +19,7 @@ import cases as K
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ("GBRL_HIP_NO_SMALL_STATS", "GBRL_HIP_SORT_NO_CODES", "GBRL_HIP_NO_DIRECT_HIST", "GBRL_HIP_NO_SMALL_GROW")
+HOOKS = ("GBRL_HIP_NO_SMALL_STATS", "GBRL_HIP_SORT_NO_CODES", "GBRL_HIP_NO_DIRECT_HIST", "GBRL_HIP_NO_SMALL_GROW", "GBRL_HIP_NO_SMALL_PREP")
 
 
 def _grow(case, monkeypatch, env):
@@ -43,7 +45,8 @@ def test_fused_small_step_kernels_keep_every_bit(policy, score, gen, D, F, Fc, N
         del case["loop"]
     ref, pref = _grow(case, monkeypatch, {k: "1" for k in HOOKS})
     for env in ({}, {"GBRL_HIP_NO_SMALL_STATS": "1", "GBRL_HIP_NO_DIRECT_HIST": "1"}, {"GBRL_HIP_SORT_NO_CODES": "1"}, {"GBRL_HIP_NO_DIRECT_HIST": "1"},
-                {"GBRL_HIP_NO_SMALL_GROW": "1"}, {"GBRL_HIP_NO_SMALL_GROW": "1", "GBRL_HIP_NO_DIRECT_HIST": "1"}):
+                {"GBRL_HIP_NO_SMALL_GROW": "1"}, {"GBRL_HIP_NO_SMALL_GROW": "1", "GBRL_HIP_NO_DIRECT_HIST": "1"}, {"GBRL_HIP_NO_SMALL_PREP": "1"},
+                {"GBRL_HIP_NO_SMALL_PREP": "1", "GBRL_HIP_NO_SMALL_GROW": "1"}, {"GBRL_HIP_NO_SMALL_STATS": "1"}):
         got, pgot = _grow(case, monkeypatch, env)
         for k in ref:
             a, b = np.asarray(ref[k]), np.asarray(got[k])
@@ -73,6 +76,8 @@ def test_the_hooks_really_switch_paths(monkeypatch):
     assert "small_grow" in fused and "small_grow" not in plain and "score_select" in plain and "score_select" not in fused, (plain, fused)
     loop = launches({"GBRL_HIP_NO_SMALL_GROW": "1"})
     assert "small_grow" not in loop and "score_select" in loop and "hist_reduce" not in loop, loop
+    # the fused preparation really ran (Engine::last_step_launches counts the preparation's kernel launches: 1 fused, >= 3 separate)
+    assert fused["prep_launches"] == 1 and plain["prep_launches"] >= 3, (fused, plain)
 
 
 def _same_bytes(a, b, what):
@@ -104,10 +109,12 @@ def test_one_launch_growth_keeps_every_bit(shape, N, monkeypatch):
                 min_data_in_leaf=mdl, discrete_cols=[0] if F > 2 else [], constant_cols=[1] if F > 4 else [])
     if F > 0 and D == 1:
         case["loop"] = "rmse"
-    loop, ploop = _grow(case, monkeypatch, {"GBRL_HIP_NO_SMALL_GROW": "1"})
+    loop, ploop = _grow(case, monkeypatch, {"GBRL_HIP_NO_SMALL_GROW": "1", "GBRL_HIP_NO_SMALL_PREP": "1"})
     one, pone = _grow(case, monkeypatch, {})
     _same_bytes(loop, one, "small_grow")
     assert ploop.tobytes() == pone.tobytes()
+    sep, psep = _grow(case, monkeypatch, {"GBRL_HIP_NO_SMALL_PREP": "1"})     # the growth kernel behind the separate preparation launches
+    _same_bytes(loop, sep, "small_grow, separate preparation")
     # fewer blocks than slots (several slots per block, the codes reloaded per slot) must not matter either
     few, pfew = _grow(case, monkeypatch, {"GBRL_HIP_SMALL_GROW_BLOCKS": "3"})
     _same_bytes(loop, few, "small_grow, 3 blocks")
@@ -118,7 +125,7 @@ def test_golden_inputs_through_both_growth_paths(name, monkeypatch):
     """Every golden fixture of at most 8192 rows: the one-launch growth and the level loop give the same ensemble bytes (the fixtures
     themselves are checked against the default path by test_gpu_parity.py)."""
     case = K.BY_NAME[name]
-    loop, ploop = _grow(case, monkeypatch, {"GBRL_HIP_NO_SMALL_GROW": "1"})
+    loop, ploop = _grow(case, monkeypatch, {"GBRL_HIP_NO_SMALL_GROW": "1", "GBRL_HIP_NO_SMALL_PREP": "1"})
     one, pone = _grow(case, monkeypatch, {})
     _same_bytes(loop, one, name)
     assert ploop.tobytes() == pone.tobytes()
