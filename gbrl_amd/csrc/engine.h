@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <array>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -181,6 +182,7 @@ class Engine {
     size_t leafacc_clean_bytes_ = 0;
     DevBuf d_sg_bests_, d_sg_sync_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
     const void *sg_sync_ptr_ = nullptr;
+    std::chrono::steady_clock::time_point prof_step_entry_{};   // measurement (GBRL_HIP_SMALL_GROW_PROF)
     int prep_launches_ = 0;           // diagnostic of the last step(): 1 = kern::small_prep ran, 3 = the separate preparation launches
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
     std::vector<const char *> ev_names_;

@@ -71,6 +71,8 @@ struct GrowCtx {
     const std::vector<CatCandidate> *cat_cands;
     bool prefix_cacheable;     // mixed step: numeric table prefixes stay on the device, categorical tails are uploaded per step
     int n_num_cand, cand_cap;  // numeric candidates (= prefix length), capacity of the fixed table layout
+    char *pub_thr_dev, *pub_scales_dev; // device addresses of the pinned copies below (kern::publish_pair / the growth kernel write them)
+    size_t pub_thr_bytes;
     const float *h_thr;                 // pinned; valid once the stream has passed the copy enqueued behind the binning
     const kern::StepScales *h_scales;   // pinned, same
     const float *d_thr;
@@ -1318,6 +1320,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
 
     // L2 with ONE row: the reference's unbiased variance is 0/0 (math_ops.cpp:461-513), every standardised gradient and every
     // split score is NaN, no comparison succeeds and the tree stays a depth-0 leaf (fitter.cpp:357, :458)
+    if (!use_small) kern::publish_pair(d_thr, c.pub_thr_dev, c.pub_thr_bytes, d_scales, c.pub_scales_dev, sizeof(kern::StepScales), s);
     // ---- RL-sized steps: ONE launch grows the tree, ONE wait, then the bookkeeping is replayed from the per-level result blocks -------
     if (use_small) {
         const size_t res_stride = kern::small_grow_res_stride(MD);
@@ -1344,13 +1347,16 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         uint32_t seq = ++level_seq_;
         if (seq == 0) seq = ++level_seq_;
         io.seq = seq;
+        io.scales_out = reinterpret_cast<kern::StepScales *>(c.pub_scales_dev);
         static const bool sg_prof = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_PROF"); return e && e[0] == '1'; }();   // measurement hook
         if (sg_prof) io.prof = reinterpret_cast<uint32_t *>(d_blk + o_status + 64);
         h_status[0] = 0;
         phase_begin();
         if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
         phase_end("small_grow");
+        const auto t_launched = std::chrono::steady_clock::now();
         spin_until_published(h_status, seq, s, "small-step tree");
+        const auto t_seen = std::chrono::steady_clock::now();
         hip_check(hipGetLastError(), "growth kernel");
         if (h_status[3] != 0) {
             sg_sync_ptr_ = nullptr;
@@ -1363,6 +1369,12 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             for (int i = 0; i < 14; ++i) line += std::string(" ") + names[i] + " " + std::to_string(pw[i] / 100.0).substr(0, 5);
             fprintf(stderr, "%s\n", line.c_str());
         }
+        struct HostProf { bool on; std::chrono::steady_clock::time_point t0, t1, t2; ~HostProf() {
+            if (!on) return;
+            const auto t3 = std::chrono::steady_clock::now();
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "[small step host, us] entry->growth launched %.1f  wait %.1f  replay %.1f\n", us(t0, t1), us(t1, t2), us(t2, t3));
+        } } host_prof{sg_prof, prof_step_entry_, t_launched, t_seen};
         const int levels_written = static_cast<int>(h_status[1]);
         counts_later = oblivious;
         for (int depth = 0; depth < MD; ++depth) {
@@ -1791,6 +1803,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     if (md.max_depth > kern::kMaxPath) throw Unsupported("max_depth > 32 is not supported");
     if (md.n_bins < 1 || md.n_bins > 65534) throw Unsupported("n_bins must be in [1, 65534]");
     ensure_device();
+    prof_step_entry_ = std::chrono::steady_clock::now();
     ev_used_ = 0;
     ev_names_.clear();
     exch_bytes_ = 0;
@@ -2126,13 +2139,12 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         kern::scatter_cat_codes_grouped(d_cc2, N, Fc, F, d_codes, s);
     }
     if (Fc > 0) phase_end("cat_codes");
-    {   // thresholds and scales into the pinned block with ONE launch (device-written host memory) instead of two copy-engine transfers
-        static_assert(sizeof(kern::StepScales) % 4 == 0, "copied as 32-bit words");
-        void *pin_dev = nullptr;
-        hip_check(hipHostGetDevicePointer(&pin_dev, pin_ts, 0), "hipHostGetDevicePointer");
-        char *pd = static_cast<char *>(pin_dev);
-        kern::publish_pair(d_thr, pd, sizeof(float) * n_thr, d_scales, pd + (reinterpret_cast<char *>(h_scales_pin) - pin_ts), sizeof(kern::StepScales), s);
-    }
+    // thresholds and scales reach the pinned block through ONE launch (device-written host memory) instead of two copy-engine transfers:
+    // kern::publish_pair at the top of the level loop (grow_tree); the one-launch growth publishes the scales itself and hands the
+    // winners' thresholds over with its result blocks
+    static_assert(sizeof(kern::StepScales) % 4 == 0, "copied as 32-bit words");
+    void *pin_dev = nullptr;
+    hip_check(hipHostGetDevicePointer(&pin_dev, pin_ts, 0), "hipHostGetDevicePointer");
 
     // ---- 4. growth (level-synchronous; Engine::grow_tree) and 5. leaf sums --------------------------------------------------
     GrowCtx gc{};
@@ -2141,6 +2153,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     gc.slots = &slots; gc.cand_w = &cand_w; gc.cand_ref = &cand_ref; gc.ref_to_internal = &ref_to_internal; gc.cand_slot = &cand_slot;
     gc.const_cacheable = const_cacheable; gc.cat_cands = &cat_cands;
     gc.prefix_cacheable = prefix_cacheable; gc.n_num_cand = n_num_cand; gc.cand_cap = (F + Fc) * B;
+    gc.pub_thr_dev = static_cast<char *>(pin_dev); gc.pub_scales_dev = static_cast<char *>(pin_dev) + (reinterpret_cast<char *>(h_scales_pin) - pin_ts); gc.pub_thr_bytes = sizeof(float) * n_thr;
     gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.root_le = (Fc == 0 && !has_coll_) ? root_le_ : nullptr; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;

@@ -321,6 +321,7 @@ struct SmallGrowIO {
     uint32_t *status;      // pinned, device-mapped, 4 words: sequence word | levels | node count | error
     uint32_t seq;
     uint32_t *prof = nullptr;   // measurement: pinned, 16 words (block 0's time per phase, 10 ns units)
+    StepScales *scales_out = nullptr;   // pinned, device-mapped: the step's scales for the host (what publish_pair hands over in the level loop)
 };
 bool small_grow_supported(int N, int D, int NB, int MD, int n_slots, int n_cand);
 int small_grow_blocks(int n_slots);

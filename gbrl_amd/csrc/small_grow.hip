@@ -142,6 +142,7 @@ struct SmallGrowArgs {
     int64_t *acc;               // pinned: [NIDS][D+1]
     uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] error
     uint32_t seq;
+    StepScales *scales_out;     // pinned (nullable): block 0 mirrors the step's scales for the host
     uint32_t *prof;             // nullable (GBRL_HIP_SMALL_GROW_PROF=1): block 0's time per phase, 10 ns units, 16 words, pinned
     SgLayout L;
 };
@@ -608,7 +609,10 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     // ---- the last block to finish publishes the sequence word (and hands the counters back zeroed) --------------------------------
     __syncthreads();
     if (tid == 0) {
-        if (blk == 0) { a.status[1] = static_cast<uint32_t>(level); a.status[2] = static_cast<uint32_t>(s_nextid); }
+        if (blk == 0) {
+            a.status[1] = static_cast<uint32_t>(level); a.status[2] = static_cast<uint32_t>(s_nextid);
+            if (a.scales_out) *a.scales_out = *a.scales;
+        }
         __threadfence_system();
         if (atomicAdd(&a.sync[1], 1u) == static_cast<unsigned>(G) - 1u) {
             const unsigned aborted = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -697,7 +701,7 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.G = io.G; a.NC = 1 << std::max(0, io.MD - 1); a.NIDS = 2 << io.MD;
     a.magicW = static_cast<uint32_t>((1ull << 32) / static_cast<unsigned>(io.D + 1)) + 1u;
     a.bests = static_cast<SgBest *>(io.bests); a.sync = io.sync; a.res = io.res; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
-    a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof;
+    a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof; a.scales_out = io.scales_out;
     static PerDeviceOnce attr32, attr64;
     if (acc_bytes == 4) {
         if (attr32.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_grow<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) { (void)hipGetLastError(); attr32.done = 0; return false; }

@@ -158,6 +158,91 @@ __device__ __forceinline__ void small_stats_body(const float *__restrict__ g, in
 }
 
 
+// x of lane (lane ^ M), M = 1 .. 32, as VALU data movement: quad permutations (1, 2), mirrors composed (4 = half-mirror then quad reversal:
+// ^7 ^3; 8 = row mirror then half-mirror: ^15 ^7), v_permlane16_swap / v_permlane32_swap (gfx950) for 16 / 32.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x) {
+    const int v = static_cast<int>(x);
+    if constexpr (M == 1) return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true), 0x1B, 0xf, 0xf, true));
+    else if constexpr (M == 8) return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true), 0x141, 0xf, 0xf, true));
+    else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // r[0]: odd rows hold the even rows' values; r[1]: even rows hold the odd rows'
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0]: upper half holds the lower half's values; r[1]: the reverse
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+// out = mask bit of the lane ? if_set : if_clear -- one v_cndmask with the 64-bit lane mask in scalar registers
+__device__ __forceinline__ uint32_t select_by_lane_mask(uint32_t if_clear, uint32_t if_set, unsigned long long mask) {
+    uint32_t out;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return out;
+}
+// Lanes whose elements i = 256 * wave + 4 * lane + r have (i & V) == 0, V a power of two >= 4: a constant below 256 (a lane bit), the
+// whole wave or none of it from 256 on (a wave bit).
+template <int V>
+__device__ __forceinline__ unsigned long long bitonic_zero_mask(int wave_u) {
+    static_assert(V >= 4 && (V & (V - 1)) == 0, "a power of two >= 4");
+    if constexpr (V >= 256) return ((wave_u * 256) & V) == 0 ? ~0ull : 0ull;
+    else if constexpr (V == 4) return ~0xAAAAAAAAAAAAAAAAull;
+    else if constexpr (V == 8) return ~0xCCCCCCCCCCCCCCCCull;
+    else if constexpr (V == 16) return ~0xF0F0F0F0F0F0F0F0ull;
+    else if constexpr (V == 32) return ~0xFF00FF00FF00FF00ull;
+    else if constexpr (V == 64) return ~0xFFFF0000FFFF0000ull;
+    else return ~0xFFFFFFFF00000000ull;
+}
+// One compare-exchange stage of the bitonic network: run length K, distance J; four keys per thread (element i = 256 * wave + 4 * lane + r).
+//   J >= 256   partners sit in other waves: through LDS (two barriers); the whole wave takes minima or maxima
+//   4 .. 128   partners sit in other lanes: DPP / permlane moves (lane_xor), the lanes that keep the minimum are a constant 64-bit mask
+//              ((i & J) == 0) == ((i & K) == 0) -- one v_cndmask per key, no integer arithmetic on i
+//   1, 2       partners sit in the thread's own registers (static pairs)
+template <int K, int J>
+__device__ __forceinline__ void bitonic_stage(uint32_t (&a)[4], uint32_t *s, int base, bool act, int wave_u) {
+    if constexpr (J >= 256) {
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[base + r] = a[r];
+        }
+        __syncthreads();
+        const bool take_min = (((wave_u * 256) & J) == 0) == (((wave_u * 256) & K) == 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t other = act ? s[(base + r) ^ J] : 0u;
+            a[r] = take_min ? min(a[r], other) : max(a[r], other);
+        }
+        __syncthreads();
+    } else if constexpr (J >= 4) {
+        const unsigned long long tm = ~(bitonic_zero_mask<J>(wave_u) ^ bitonic_zero_mask<K>(wave_u));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t other = lane_xor<(J >> 2)>(a[r]);
+            a[r] = select_by_lane_mask(max(a[r], other), min(a[r], other), tm);
+        }
+    } else if constexpr (K >= 4) {
+        const unsigned long long up = bitonic_zero_mask<K>(wave_u);       // ascending where (i & K) == 0
+        auto cx = [&](uint32_t &x, uint32_t &y) {
+            const uint32_t lo = min(x, y), hi = max(x, y);
+            x = select_by_lane_mask(hi, lo, up);
+            y = select_by_lane_mask(lo, hi, up);
+        };
+        if constexpr (J == 2) { cx(a[0], a[2]); cx(a[1], a[3]); }
+        else { cx(a[0], a[1]); cx(a[2], a[3]); }
+    } else {   // K == 2, J == 1: (i & 2) == 0 for the pair (0, 1), != 0 for (2, 3)
+        const uint32_t lo0 = min(a[0], a[1]), hi0 = max(a[0], a[1]), lo1 = min(a[2], a[3]), hi1 = max(a[2], a[3]);
+        a[0] = lo0; a[1] = hi0; a[2] = hi1; a[3] = lo1;
+    }
+}
+// the stages from (K, J) to the end of the network for S keys, in order: J = K/2 .. 1 for K = 2, 4, .. S
+template <int S, int K, int J>
+__device__ __forceinline__ void bitonic_from(uint32_t (&a)[4], uint32_t *s, int base, bool act, int wave_u) {
+    bitonic_stage<K, J>(a, s, base, act, wave_u);
+    if constexpr (J > 1) bitonic_from<S, K, (J >> 1)>(a, s, base, act, wave_u);
+    else if constexpr (K < S) bitonic_from<S, K * 2, K>(a, s, base, act, wave_u);
+}
+
 // ---- small batches (RL-sized): the whole column fits in LDS -> sort it, read the ranks ---------------------------------------
 // One block per feature: n <= S keys padded with the maximal key to S (a power of two <= 16384), bitonic sort in LDS,
 // thr_keys[f][k] = sorted[cum[k] - 1].  One launch instead of the eight of the radix multi-select, which are launch-bound at
@@ -174,7 +259,10 @@ __device__ __forceinline__ float key_to_float_q(uint32_t k) {
 template <bool ROWMAJOR>
 __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src, int n, int S, const int64_t *__restrict__ cum, int B,
                                                     uint32_t *__restrict__ thr_keys, float *__restrict__ thr_floats, int F, int f,
-                                                    uint16_t *__restrict__ codes, uint32_t *s /*dynamic LDS: [S] keys, then [B] selected thresholds*/) {
+                                                    uint16_t *__restrict__ codes, uint32_t *s /*dynamic LDS: [S] keys, then [B] selected thresholds*/,
+                                                    uint32_t *prof = nullptr /*measurement: feature 0's time per stage, 10 ns units*/) {
+    long long pt = prof ? wall_clock64() : 0;
+    auto mark = [&](int i) { if (prof && f == 0 && threadIdx.x == 0) { const long long n_ = wall_clock64(); prof[i] = static_cast<uint32_t>(n_ - pt); pt = n_; } };
     if (f >= F) {                     // padding feature of the last code group (codes != nullptr only)
         uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
         for (int i = threadIdx.x; i < n; i += blockDim.x) dst[static_cast<size_t>(i) * kCodeGroup] = 0;
@@ -193,48 +281,23 @@ __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src
     uint32_t a[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = base + r < n ? key_at(base + r) : 0xffffffffu;
-    for (int k = 2; k <= S; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 256) {
-                if (act) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[base + r] = a[r];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = base + r;
-                    const uint32_t other = act ? s[i ^ j] : 0u;
-                    const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-                    a[r] = take_min ? min(a[r], other) : max(a[r], other);
-                }
-                __syncthreads();
-            } else if (j >= 4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = base + r;
-                    const uint32_t other = __shfl_xor(a[r], j >> 2, 64);
-                    const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-                    a[r] = take_min ? min(a[r], other) : max(a[r], other);
-                }
-            } else {
-                // (static register pairs: a dynamically indexed a[r | j] would be demoted to scratch)
-                auto cx = [&](uint32_t &x, uint32_t &y, int i) {
-                    const bool up = (i & k) == 0;
-                    const uint32_t lo = min(x, y), hi = max(x, y);
-                    x = up ? lo : hi;
-                    y = up ? hi : lo;
-                };
-                if (j == 2) { cx(a[0], a[2], base); cx(a[1], a[3], base + 1); }
-                else { cx(a[0], a[1], base); cx(a[2], a[3], base + 2); }
-            }
-        }
+    if (prof) { __syncthreads(); mark(0); }
+    // The 78 compare-exchange stages of a 4096-key sort, unrolled at compile time per S (bitonic_from): distances, directions and lane
+    // masks are constants, no loop counters and no branches between the stages.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    switch (S) {
+        case 256: bitonic_from<256, 2, 1>(a, s, base, act, wave_u); break;
+        case 512: bitonic_from<512, 2, 1>(a, s, base, act, wave_u); break;
+        case 1024: bitonic_from<1024, 2, 1>(a, s, base, act, wave_u); break;
+        case 2048: bitonic_from<2048, 2, 1>(a, s, base, act, wave_u); break;
+        default: bitonic_from<4096, 2, 1>(a, s, base, act, wave_u); break;
     }
     if (act) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[base + r] = a[r];
     }
     __syncthreads();
+    mark(1);
     // keys and floats at once (what k_keys_to_floats does for the other selections: a key in the NaN range is raised to -inf's key)
     uint32_t *thr_s = s + S;
     for (int k = threadIdx.x; k < B; k += blockDim.x) {
@@ -246,6 +309,7 @@ __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src
     }
     if (codes == nullptr) return;
     __syncthreads();
+    mark(2);
     int top = 1;
     while (top <= B) top <<= 1;                      // 2^m > B: the descent can reach every count 0 .. B
     uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
@@ -258,6 +322,7 @@ __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src
         }
         dst[static_cast<size_t>(i) * kCodeGroup] = static_cast<uint16_t>(pos);
     }
+    if (prof) { __syncthreads(); mark(3); }
 }
 
 

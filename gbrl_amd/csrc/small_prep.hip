@@ -16,6 +16,8 @@
 #include "small_prep.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace gbrl {
 namespace kern {
@@ -27,6 +29,7 @@ struct SmallPrepArgs {
     const int64_t *cum; float *thr; uint32_t *thr_keys; uint16_t *codes;
     const float *grads; int D, stat_blocks, stat_bs, centred, chunk_rows;
     double *stat; float *meanden; StepScales *sc; int32_t *qg;
+    uint32_t *prof;
 };
 
 __global__ __launch_bounds__(kSmallStatsThreads) void k_small_prep(const SmallPrepArgs a) {
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(kSmallStatsThreads) void k_small_prep(const SmallPr
         return;
     }
     if (a.uniform) uniform_thresholds_body(a.obs, a.N, a.F, b, a.B, a.thr, a.thr_keys, a.codes, reinterpret_cast<uint32_t *>(prep_lds));
-    else sort_quantiles_body<true>(a.obs, a.N, a.S, a.cum, a.B, a.thr_keys, a.thr, a.F, b, a.codes, reinterpret_cast<uint32_t *>(prep_lds));
+    else sort_quantiles_body<true>(a.obs, a.N, a.S, a.cum, a.B, a.thr_keys, a.thr, a.F, b, a.codes, reinterpret_cast<uint32_t *>(prep_lds), a.prof);
 }
 
 }  // namespace
@@ -86,6 +89,17 @@ bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64
     a.n_feat_blocks = ((F + kCodeGroup - 1) / kCodeGroup) * kCodeGroup;
     a.cum = cum; a.thr = thr; a.thr_keys = thr_keys; a.codes = codes;
     a.grads = grads; a.D = D; a.centred = centred ? 1 : 0; a.chunk_rows = chunk_rows; a.stat = stat; a.meanden = meanden; a.sc = sc; a.qg = qg;
+    {   // measurement hook: GBRL_HIP_SMALL_PREP_PROF=1 prints feature 0's stage times of the previous launch
+        static uint32_t *h_prof = nullptr;
+        static const bool on = [] { const char *e = std::getenv("GBRL_HIP_SMALL_PREP_PROF"); return e && e[0] == '1'; }();
+        if (on) {
+            if (!h_prof) { (void)hipHostMalloc(reinterpret_cast<void **>(&h_prof), 64, hipHostMallocCoherent | hipHostMallocMapped); for (int i = 0; i < 16; ++i) h_prof[i] = 0; }
+            else fprintf(stderr, "[small_prep feature 0, us] load %.2f sort %.2f thresholds %.2f codes %.2f\n", h_prof[0] / 100.0, h_prof[1] / 100.0, h_prof[2] / 100.0, h_prof[3] / 100.0);
+            void *dp = nullptr;
+            (void)hipHostGetDevicePointer(&dp, h_prof, 0);
+            a.prof = static_cast<uint32_t *>(dp);
+        }
+    }
     hipLaunchKernelGGL(k_small_prep, dim3(a.n_feat_blocks + (with_stats ? 1 : 0)), dim3(kSmallStatsThreads), lds, s, a);
     if (hipGetLastError() != hipSuccess) return false;
     *stats_done = with_stats;
