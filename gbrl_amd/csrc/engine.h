@@ -180,6 +180,7 @@ class Engine {
     const void *pub_done_ptr_ = nullptr;
     const void *leafacc_clean_ptr_ = nullptr;   // leaf accumulators known to be zero (handed back clean by the last publication)
     size_t leafacc_clean_bytes_ = 0;
+    DevBuf d_codes_fm_;               // feature-major copy of the numeric class codes (kern::small_prep -> kern::small_grow)
     DevBuf d_sg_bests_, d_sg_sync_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
     const void *sg_sync_ptr_ = nullptr;
     std::chrono::steady_clock::time_point prof_step_entry_{};   // measurement (GBRL_HIP_SMALL_GROW_PROF)

@@ -80,6 +80,7 @@ struct GrowCtx {
     const uint32_t *root_le;     // [F][B] #{keys <= threshold} from the radix selection (one GPU, numeric-only steps), else null
     const uint32_t *d_kt;        // [F][N] feature-major ordered keys of the observations (null when F == 0)
     const uint16_t *d_codes;
+    const uint16_t *d_codes_fm;  // [F][N] feature-major copy of the numeric codes (fused preparation only), else null
     const int32_t *d_qg;
     const float *dgrads;
     kern::StepScales *d_scales;
@@ -1338,12 +1339,12 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             sg_sync_ptr_ = d_sync;
         }
         kern::SmallGrowIO io{};
-        io.codes = d_codes; io.qg = d_qg; io.grads = dgrads; io.scales = d_scales; io.slots = d_slots; io.thr = d_thr; io.cand_w = d_cand_w; io.cand_ref = d_cand_ref;
+        io.codes = d_codes; io.codes_fm = c.d_codes_fm; io.n_fm = c.d_codes_fm ? F : 0; io.n_thr_slots = F; io.qg = d_qg; io.grads = dgrads; io.scales = d_scales; io.slots = d_slots; io.thr = d_thr; io.cand_w = d_cand_w; io.cand_ref = d_cand_ref;
         io.N = N; io.D = D; io.B = B; io.n_slots = n_slots; io.NB = NB; io.MD = MD; io.min_data = md.min_data_in_leaf; io.cosine = cosine; io.oblivious = oblivious;
         io.G = small_G;
         io.bests = d_sg_bests_.ensure(kern::small_grow_bests_bytes(MD, small_G, oblivious));
         io.sync = d_sync;
-        io.res = d_blk; io.acc = reinterpret_cast<int64_t *>(d_blk + o_acc); io.status = reinterpret_cast<uint32_t *>(d_blk + o_status);
+        io.res = d_blk; io.res_dev = static_cast<char *>(d_res_all_.ensure(res_all)); io.acc = reinterpret_cast<int64_t *>(d_blk + o_acc); io.status = reinterpret_cast<uint32_t *>(d_blk + o_status);
         uint32_t seq = ++level_seq_;
         if (seq == 0) seq = ++level_seq_;
         io.seq = seq;
@@ -1963,14 +1964,16 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     bool codes_from_sort = false;
     root_le_ = nullptr;
     bool prep_done = false;
+    const uint16_t *d_codes_fm = nullptr;   // feature-major copy of the numeric codes (kern::small_prep writes it for kern::small_grow)
     int prep_launches = 3;   // (diagnostic, reported as a pseudo-phase at profiling level 2: 1 = the fused preparation kernel ran)
     if (prep_candidate) {
         const int64_t *d_cum = uniform_gen ? nullptr : quantile_cum_device(quantile_target_ranks(n_global, B), n_global, B);
         bool stats_done = false;
-        prep_done = kern::small_prep(dobs, N, F, B, uniform_gen, d_cum, d_thr, d_thrkeys, d_codes, dgrads, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg,
+        uint16_t *d_fm = static_cast<uint16_t *>(d_codes_fm_.ensure(sizeof(uint16_t) * static_cast<size_t>(N) * F));
+        prep_done = kern::small_prep(dobs, N, F, B, uniform_gen, d_cum, d_thr, d_thrkeys, d_codes, d_fm, dgrads, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg,
                                      !no_small_stats, &stats_done, s);
         if (std::getenv("GBRL_HIP_DEBUG_PREP")) fprintf(stderr, "[small_prep] N %d F %d B %d D %d uniform %d -> done %d stats %d\n", N, F, B, D, uniform_gen ? 1 : 0, prep_done ? 1 : 0, stats_done ? 1 : 0);
-        if (prep_done) { codes_from_sort = true; last_quantile_fallback_ = false; prep_launches = 1; }
+        if (prep_done) { codes_from_sort = true; last_quantile_fallback_ = false; prep_launches = 1; d_codes_fm = d_fm; }
         if (stats_done) stats_fused = true;
         else run_stats();
         if (!prep_done) {   // the shape did not qualify after all: the separate launches, keys first
@@ -2154,7 +2157,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     gc.const_cacheable = const_cacheable; gc.cat_cands = &cat_cands;
     gc.prefix_cacheable = prefix_cacheable; gc.n_num_cand = n_num_cand; gc.cand_cap = (F + Fc) * B;
     gc.pub_thr_dev = static_cast<char *>(pin_dev); gc.pub_scales_dev = static_cast<char *>(pin_dev) + (reinterpret_cast<char *>(h_scales_pin) - pin_ts); gc.pub_thr_bytes = sizeof(float) * n_thr;
-    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.root_le = (Fc == 0 && !has_coll_) ? root_le_ : nullptr; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.root_le = (Fc == 0 && !has_coll_) ? root_le_ : nullptr; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_codes_fm = d_codes_fm; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;
     std::vector<int64_t> acc;

@@ -301,7 +301,7 @@ void partition_rows(const int32_t *rows_in, int32_t *rows_out, const uint16_t *c
 // numeric feature from the row-major matrix, and -- when `want_stats` and the shape qualifies (small_stats' limits) -- the gradient statistics,
 // scales and quantised gradients (*stats_done).  false: nothing was launched (the caller runs the separate kernels).
 bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64_t *cum, float *thr, uint32_t *thr_keys, uint16_t *codes,
-                const float *grads, int D, bool centred, int chunk_rows, double *stat, float *meanden, StepScales *sc, int32_t *qg,
+                uint16_t *codes_fm /*[F][N]: a second, feature-major copy of the numeric codes for kern::small_grow*/, const float *grads, int D, bool centred, int chunk_rows, double *stat, float *meanden, StepScales *sc, int32_t *qg,
                 bool want_stats, bool *stats_done, hipStream_t s);
 
 // ---- RL-sized steps: the whole growth of one tree in ONE launch (small_grow.hip) ----
@@ -310,6 +310,9 @@ bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64
 // [counts i64 x 4 x mf: total | right | - | -][winner threshold f32 x mf], mf = 2^(MD-1) -- and acc[node id][D+1] of every leaf.
 struct SmallGrowIO {
     const uint16_t *codes; const int32_t *qg; const float *grads; const StepScales *scales;
+    const uint16_t *codes_fm = nullptr;   // nullable: feature-major copy [n_fm][N] of the codes of the slots < n_fm (written by kern::small_prep)
+    int n_fm = 0;
+    int n_thr_slots = 0;                  // numeric slots (the rows of thr)
     const FeatureSlot *slots; const float *thr; const float *cand_w; const int32_t *cand_ref;
     int N, D, B, n_slots, NB, MD, min_data;
     bool cosine, oblivious;
@@ -317,6 +320,7 @@ struct SmallGrowIO {
     void *bests;           // device scratch, small_grow_bests_bytes(MD, G, oblivious)
     unsigned *sync;        // device, 4096 bytes, zero before the first launch (the kernel hands them back zeroed)
     char *res;             // pinned, device-mapped
+    char *res_dev;         // device staging of the result blocks, MD * small_grow_res_stride(MD) bytes
     int64_t *acc;          // pinned, device-mapped, [2 << MD][D + 1]
     uint32_t *status;      // pinned, device-mapped, 4 words: sequence word | levels | node count | error
     uint32_t seq;

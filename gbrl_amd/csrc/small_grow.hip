@@ -119,17 +119,20 @@ __device__ __forceinline__ void sg_accumulate_rows(const int32_t *__restrict__ q
 }
 
 struct SgLayout {     // byte offsets into the dynamic LDS block (host computes, kernel carves)
-    int rc, sw, sref, tn, tid, psb, pv, split, cidx, cid, win, wcat, nbest, ssum, leafflag, ttot, total, totalf, ibest, wbest, lacc, hist;
+    int rc, sw, sref, tn, tid, psb, pv, split, cidx, cid, win, wcat, wthr, nbest, ssum, leafflag, ttot, total, totalf, ibest, wbest, lacc, hist;
     int total_bytes;
 };
 
 struct SmallGrowArgs {
     const uint16_t *codes;      // [groups][N][16] class codes
+    const uint16_t *codes_fm;   // nullable: [n_fm][N] feature-major copy of the codes of the slots < n_fm (coalesced column loads and row routing)
+    int n_fm;
     const int32_t *qg;          // [N][D] fixed-point build gradients
     const float *grads;         // [N][D] raw gradients (leaf sums)
     const StepScales *scales;
     const FeatureSlot *slots;   // [n_slots]
     const float *thr;           // [F][B]
+    int n_thr_slots;            // F: the slots that have thresholds
     const float *cand_w;        // [n_cand]
     const int32_t *cand_ref;    // [n_cand]
     int N, D, B, n_slots, NB, MD, min_data, cosine, oblivious;
@@ -137,7 +140,8 @@ struct SmallGrowArgs {
     uint32_t magicW;            // floor(2^32 / (D + 1)) + 1
     SgBest *bests;              // greedy [MD][NC][G], oblivious [MD][G]
     unsigned *sync;             // [0] groups arrived, [1] finished blocks, [2] abort, [32 + 32 g] arrivals of group g (kSmallGrowSyncBytes)
-    char *res;                  // pinned, device-mapped: MD result blocks of res_stride bytes
+    char *res;                  // pinned, device-mapped: MD result blocks of res_stride bytes (block 0 copies them out of res_dev at the end)
+    char *res_dev;              // device staging of the same
     int res_stride, max_front;
     int64_t *acc;               // pinned: [NIDS][D+1]
     uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] error
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     int *cid = reinterpret_cast<int *>(sg_lds + L.cid);                 // [NC] left child's node id
     SgBest *win = reinterpret_cast<SgBest *>(sg_lds + L.win);           // [NC] the level's winners
     int *wcat = reinterpret_cast<int *>(sg_lds + L.wcat);               // [NC] winner slot is categorical
+    float *wthr = reinterpret_cast<float *>(sg_lds + L.wthr);           // [NC] winner's threshold value (+inf: categorical)
     SgBest *nbest = reinterpret_cast<SgBest *>(sg_lds + L.nbest);       // [NC] greedy: this block's best per node
     float *ssum = reinterpret_cast<float *>(sg_lds + L.ssum);           // [NB] oblivious: per candidate, sum over nodes
     unsigned char *leafflag = sg_lds + L.leafflag;                      // [NIDS]
@@ -261,11 +266,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             const int NBe = sl.n_cand + 1;                       // classes of this slot
             const int T = (NBe - 1 + kWave - 1) / kWave;         // 64-class tiles over the classes 1 .. NBe-1
             if (fs != loaded_slot) {                             // the slot's class codes in row order, its candidates' weights and reference indices
-                const uint16_t *cs = a.codes + (static_cast<size_t>(fs >> 4) * N) * kCodeGroup + (fs & (kCodeGroup - 1));
+                const bool fm = a.codes_fm != nullptr && fs < a.n_fm;
+                const uint16_t *cs = fm ? a.codes_fm + static_cast<size_t>(fs) * N : a.codes + (static_cast<size_t>(fs >> 4) * N) * kCodeGroup + (fs & (kCodeGroup - 1));
+                const int cstride = fm ? 1 : kCodeGroup;
                 for (int r0 = tid; r0 < N; r0 += kSgThreads * 8) {
                     uint16_t cv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) cv[u] = cs[static_cast<size_t>(min(r0 + u * kSgThreads, N - 1)) * kCodeGroup];
+                    for (int u = 0; u < 8; ++u) cv[u] = cs[static_cast<size_t>(min(r0 + u * kSgThreads, N - 1)) * cstride];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) if (r0 + u * kSgThreads < N) rc16[2 * (r0 + u * kSgThreads) + 1] = cv[u];
                 }
@@ -442,8 +449,15 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             }
             m = sg_wave_best(m);
             if (lane == 0) {
+                // the winner's kind and threshold value: both loads issued here, together (the paths of the children and the result block
+                // need the value; fetched there it was a second DRAM round trip behind the routing pass's)
+                const int wslot = m.ref == 0x7fffffff ? 0 : static_cast<int>(m.slotbin >> 16);
+                const int is_cat = a.slots[wslot].is_cat;
+                const int tslot = wslot < a.n_thr_slots ? wslot : 0;
+                const float tv = a.n_thr_slots > 0 ? a.thr[static_cast<size_t>(tslot) * B + min(static_cast<int>(m.slotbin & 0xffffu), B - 1)] : 0.0f;
                 win[k] = m;
-                wcat[k] = m.ref == 0x7fffffff ? 0 : a.slots[m.slotbin >> 16].is_cat;
+                wcat[k] = m.ref == 0x7fffffff ? 0 : is_cat;
+                wthr[k] = (m.ref == 0x7fffffff || is_cat) ? (is_cat ? INFINITY : 0.0f) : tv;
             }
         }
         __syncthreads();
@@ -493,9 +507,9 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         SG_MARK(10);
         // ---- routing: every row of a splitting node moves to its child (its index in the next table, or the child's node id when the child
         //      is a leaf); rows of a node that did not split stay with it as a leaf.  ONE pass: the children's places are known (above).
-        for (int r0 = tid; r0 < N; r0 += kSgThreads * 4) {       // four rows per thread and round: the code loads are issued together
+        for (int r0 = tid; r0 < N; r0 += kSgThreads * 4) {       // four rows per thread and round: everything is loaded before anything is decided
             unsigned nv[4];
-            int code[4], bin[4], wc[4];
+            int code[4], bin[4], wc[4], go[4][2], stay[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = r0 + u * kSgThreads;
@@ -505,20 +519,22 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 const int slot = static_cast<int>(w.slotbin >> 16);
                 bin[u] = static_cast<int>(w.slotbin & 0xffffu);
                 wc[u] = wcat[obl ? 0 : k];
-                code[u] = a.codes[(static_cast<size_t>(slot >> 4) * N + min(r, N - 1)) * kCodeGroup + (slot & (kCodeGroup - 1))];   // (unconditional: a load in a branch is waited for at once)
+                const int rr = min(r, N - 1);
+                const uint16_t *cp = (a.codes_fm != nullptr && slot < a.n_fm) ? a.codes_fm + static_cast<size_t>(slot) * N + rr
+                                                                              : a.codes + (static_cast<size_t>(slot >> 4) * N + rr) * kCodeGroup + (slot & (kCodeGroup - 1));
+                code[u] = *cp;   // (unconditional: a load in a branch is waited for at once)
+                // where the row goes for either outcome (read while the code is on its way)
+                const int c0 = cidx[2 * k], c1 = cidx[2 * k + 1], idl = cid[k];
+                go[u][0] = c0 >= 0 ? c0 : static_cast<int>(kLeafBit | static_cast<unsigned>(idl));
+                go[u][1] = c1 >= 0 ? c1 : static_cast<int>(kLeafBit | static_cast<unsigned>(idl + 1));
+                stay[u] = split[k] ? -1 : static_cast<int>(kLeafBit | static_cast<unsigned>(tidc[k]));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (nv[u] >= kLeafBit) continue;
                 const int r = r0 + u * kSgThreads;
-                const int k = static_cast<int>(nv[u]);
-                unsigned w2;
-                if (!split[k]) w2 = kLeafBit | static_cast<unsigned>(tidc[k]);
-                else {
-                    const int side = (wc[u] ? (code[u] == bin[u]) : (code[u] > bin[u])) ? 1 : 0;
-                    const int ci = cidx[2 * k + side];
-                    w2 = ci >= 0 ? static_cast<unsigned>(ci) : (kLeafBit | static_cast<unsigned>(cid[k] + side));
-                }
+                const bool right = wc[u] ? (code[u] == bin[u]) : (code[u] > bin[u]);
+                const int w2 = stay[u] >= 0 ? stay[u] : (right ? go[u][1] : go[u][0]);
                 rc16[2 * r] = static_cast<uint16_t>(w2);
             }
         }
@@ -530,14 +546,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             if (p < level) { psb2[dst * MD + p] = psb[k * MD + p]; pv2[dst * MD + p] = pv[k * MD + p]; }
             else {
                 const SgBest w = win[obl ? 0 : k];
-                const int slot = static_cast<int>(w.slotbin >> 16), bin = static_cast<int>(w.slotbin & 0xffffu);
                 psb2[dst * MD + p] = w.slotbin;
-                pv2[dst * MD + p] = wcat[obl ? 0 : k] ? INFINITY : a.thr[static_cast<size_t>(slot) * B + bin];
+                pv2[dst * MD + p] = wthr[obl ? 0 : k];
             }
         }
         // block 0: the level's result block for the host (the layout digest_level reads) + the winners' threshold values
-        if (blk == 0) {
-            char *res = a.res + static_cast<size_t>(level) * a.res_stride;
+        if (blk == 0) {   // (staged in device memory: a store to the host's pinned block is a PCIe round trip in front of the next block barrier)
+            char *res = a.res_dev + static_cast<size_t>(level) * a.res_stride;
             int32_t *r_idx = reinterpret_cast<int32_t *>(res);
             float *r_score = reinterpret_cast<float *>(res + 4 * static_cast<size_t>(a.max_front));
             int64_t *r_cnt = reinterpret_cast<int64_t *>(res + 8 * static_cast<size_t>(a.max_front));
@@ -547,9 +562,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 if (!obl || k == 0) { r_idx[k] = w.ref == 0x7fffffff ? 0 : w.ref; r_score[k] = w.v; }
                 r_cnt[k] = obl ? 0 : tn[k];                                            // (oblivious: the host derives the sizes from the leaves)
                 r_cnt[static_cast<size_t>(a.max_front) + k] = obl ? 0 : static_cast<int>(w.pad);
-                float tv = 0.0f;
-                if (w.ref != 0x7fffffff && !wcat[obl ? 0 : k]) tv = a.thr[static_cast<size_t>(w.slotbin >> 16) * B + (w.slotbin & 0xffffu)];
-                r_thr[k] = tv;
+                r_thr[k] = wcat[obl ? 0 : k] ? 0.0f : wthr[obl ? 0 : k];
             }
         }
         __syncthreads();
@@ -606,6 +619,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         for (int i = 0; i < 16; ++i) a.prof[i] = pacc[i];
     }
 #undef SG_MARK
+    if (blk == 0) {   // the levels' result blocks, written by this block's own threads: out to the host in one go
+        __syncthreads();
+        const int words = level * a.res_stride / 4;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.res_dev);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.res);
+        for (int i = tid; i < words; i += kSgThreads) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- the last block to finish publishes the sequence word (and hands the counters back zeroed) --------------------------------
     __syncthreads();
     if (tid == 0) {
@@ -664,6 +684,7 @@ SgLayout sg_layout(int N, int D, int NB, int MD, int acc_bytes, int &nb_cap, int
     L.cid = take(4 * NC);
     L.win = take(16 * NC);
     L.wcat = take(4 * NC);
+    L.wthr = take(4 * NC);
     L.nbest = take(16 * NC);
     L.ssum = take(4 * NB);
     L.leafflag = take(NIDS);
@@ -696,11 +717,11 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     SmallGrowArgs a{};
     a.L = sg_layout(io.N, io.D, io.NB, io.MD, acc_bytes, a.nb_cap, a.Tmax);
     if (a.nb_cap < 1) return false;
-    a.codes = io.codes; a.qg = io.qg; a.grads = io.grads; a.scales = io.scales; a.slots = io.slots; a.thr = io.thr; a.cand_w = io.cand_w; a.cand_ref = io.cand_ref;
+    a.codes = io.codes; a.codes_fm = io.codes_fm; a.n_fm = io.n_fm; a.qg = io.qg; a.grads = io.grads; a.scales = io.scales; a.slots = io.slots; a.thr = io.thr; a.n_thr_slots = io.n_thr_slots; a.cand_w = io.cand_w; a.cand_ref = io.cand_ref;
     a.N = io.N; a.D = io.D; a.B = io.B; a.n_slots = io.n_slots; a.NB = io.NB; a.MD = io.MD; a.min_data = io.min_data; a.cosine = io.cosine ? 1 : 0; a.oblivious = io.oblivious ? 1 : 0;
     a.G = io.G; a.NC = 1 << std::max(0, io.MD - 1); a.NIDS = 2 << io.MD;
     a.magicW = static_cast<uint32_t>((1ull << 32) / static_cast<unsigned>(io.D + 1)) + 1u;
-    a.bests = static_cast<SgBest *>(io.bests); a.sync = io.sync; a.res = io.res; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
+    a.bests = static_cast<SgBest *>(io.bests); a.sync = io.sync; a.res = io.res; a.res_dev = io.res_dev; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
     a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof; a.scales_out = io.scales_out;
     static PerDeviceOnce attr32, attr64;
     if (acc_bytes == 4) {

@@ -70,7 +70,17 @@ __device__ __forceinline__ void small_stats_body(const float *__restrict__ g, in
         for (int i = threadIdx.x; i < n_blocks * D; i += kSmallStatsThreads) {   // per (virtual block, column): increasing t
             const int b = i / D, d = i % D;
             double s2 = 0.0, m = 0.0;
-            for (int t = d; t < bs; t += D) { s2 += vacc[b * bs + t]; m = fmax(m, vmax[b * bs + t]); }
+            // (the additions keep their order; the operands of eight of them are loaded together -- with one output this loop is 256 dependent
+            // LDS round trips on two threads otherwise: 10 of the 17 us of the statistics)
+            int t = d;
+            for (; t + 7 * D < bs; t += 8 * D) {
+                double x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { x[u] = vacc[b * bs + t + u * D]; y[u] = vmax[b * bs + t + u * D]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s2 += x[u]; m = fmax(m, y[u]); }
+            }
+            for (; t < bs; t += D) { s2 += vacc[b * bs + t]; m = fmax(m, vmax[b * bs + t]); }
             part[static_cast<size_t>(b) * 2 * D + d] = s2;
             part[static_cast<size_t>(b) * 2 * D + D + d] = m;
         }
@@ -243,6 +253,17 @@ __device__ __forceinline__ void bitonic_from(uint32_t (&a)[4], uint32_t *s, int 
     else if constexpr (K < S) bitonic_from<S, K * 2, K>(a, s, base, act, wave_u);
 }
 
+// Class codes of one feature against thresholds staged in LDS (sorted ascending): code = #{k : thr_s[k] < key}, by the same descent as
+// sort_quantiles_body's.
+__device__ __forceinline__ int code_of_key(const uint32_t *thr_s, int B, int top, uint32_t key) {
+    int pos = 0;
+    for (int step = top >> 1; step > 0; step >>= 1) {
+        const int np = pos + step;
+        if (np <= B && thr_s[np - 1] < key) pos = np;
+    }
+    return pos;
+}
+
 // ---- small batches (RL-sized): the whole column fits in LDS -> sort it, read the ranks ---------------------------------------
 // One block per feature: n <= S keys padded with the maximal key to S (a power of two <= 16384), bitonic sort in LDS,
 // thr_keys[f][k] = sorted[cum[k] - 1].  One launch instead of the eight of the radix multi-select, which are launch-bound at
@@ -260,7 +281,9 @@ template <bool ROWMAJOR>
 __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src, int n, int S, const int64_t *__restrict__ cum, int B,
                                                     uint32_t *__restrict__ thr_keys, float *__restrict__ thr_floats, int F, int f,
                                                     uint16_t *__restrict__ codes, uint32_t *s /*dynamic LDS: [S] keys, then [B] selected thresholds*/,
-                                                    uint32_t *prof = nullptr /*measurement: feature 0's time per stage, 10 ns units*/) {
+                                                    uint32_t *prof = nullptr /*measurement: feature 0's time per stage, 10 ns units*/,
+                                                    uint16_t *__restrict__ codes_fm = nullptr /*nullable: a second, feature-major copy [F][n] of the codes
+                                                    (the one-launch growth kernel reads a slot's column and routes rows with coalesced loads)*/) {
     long long pt = prof ? wall_clock64() : 0;
     auto mark = [&](int i) { if (prof && f == 0 && threadIdx.x == 0) { const long long n_ = wall_clock64(); prof[i] = static_cast<uint32_t>(n_ - pt); pt = n_; } };
     if (f >= F) {                     // padding feature of the last code group (codes != nullptr only)
@@ -281,6 +304,7 @@ __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src
     uint32_t a[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = base + r < n ? key_at(base + r) : 0xffffffffu;
+    const uint32_t orig[4] = {a[0], a[1], a[2], a[3]};
     if (prof) { __syncthreads(); mark(0); }
     // The 78 compare-exchange stages of a 4096-key sort, unrolled at compile time per S (bitonic_from): distances, directions and lane
     // masks are constants, no loop counters and no branches between the stages.
@@ -313,35 +337,26 @@ __device__ __forceinline__ void sort_quantiles_body(const void *__restrict__ src
     int top = 1;
     while (top <= B) top <<= 1;                      // 2^m > B: the descent can reach every count 0 .. B
     uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t key = key_at(i);
-        int pos = 0;
-        for (int step = top >> 1; step > 0; step >>= 1) {
-            const int np = pos + step;
-            if (np <= B && thr_s[np - 1] < key) pos = np;   // thresholds are sorted: the predicate is monotone
+    // (the thread's own four keys, kept from the load: no second pass over the column)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = base + r;
+        if (i < n) {
+            const int pos = code_of_key(thr_s, B, top, orig[r]);
+            dst[static_cast<size_t>(i) * kCodeGroup] = static_cast<uint16_t>(pos);
+            if (codes_fm) codes_fm[static_cast<size_t>(f) * n + i] = static_cast<uint16_t>(pos);
         }
-        dst[static_cast<size_t>(i) * kCodeGroup] = static_cast<uint16_t>(pos);
     }
     if (prof) { __syncthreads(); mark(3); }
 }
 
 
-// Class codes of one feature against thresholds staged in LDS (sorted ascending): code = #{k : thr_s[k] < key}, by the same descent as
-// sort_quantiles_body's.
-__device__ __forceinline__ int code_of_key(const uint32_t *thr_s, int B, int top, uint32_t key) {
-    int pos = 0;
-    for (int step = top >> 1; step > 0; step >>= 1) {
-        const int np = pos + step;
-        if (np <= B && thr_s[np - 1] < key) pos = np;
-    }
-    return pos;
-}
-
 // A4 in one block per feature (uniform candidates, split_candidate_generator.cpp:59-76): column minimum / maximum of the finite keys (what
 // k_column_minmax finds), the thresholds min + b * step as ONE fma (k_uniform_thresholds, Q5), and the feature's class codes.
 // LDS: [n] keys, then [B] threshold keys, then 2 x 16 words of reduction scratch.
 __device__ __forceinline__ void uniform_thresholds_body(const float *__restrict__ obs, int n, int F, int f, int B, float *__restrict__ thr,
-                                                        uint32_t *__restrict__ thr_keys, uint16_t *__restrict__ codes, uint32_t *lds) {
+                                                        uint32_t *__restrict__ thr_keys, uint16_t *__restrict__ codes, uint32_t *lds,
+                                                        uint16_t *__restrict__ codes_fm = nullptr) {
     uint16_t *dst = codes + (static_cast<size_t>(f >> 4) * n) * kCodeGroup + (f & (kCodeGroup - 1));
     if (f >= F) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) dst[static_cast<size_t>(i) * kCodeGroup] = 0;
@@ -377,7 +392,11 @@ __device__ __forceinline__ void uniform_thresholds_body(const float *__restrict_
     __syncthreads();
     int top = 1;
     while (top <= B) top <<= 1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[static_cast<size_t>(i) * kCodeGroup] = static_cast<uint16_t>(code_of_key(thr_s, B, top, keys[i]));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint16_t cv = static_cast<uint16_t>(code_of_key(thr_s, B, top, keys[i]));
+        dst[static_cast<size_t>(i) * kCodeGroup] = cv;
+        if (codes_fm) codes_fm[static_cast<size_t>(f) * n + i] = cv;
+    }
 }
 
 }  // namespace

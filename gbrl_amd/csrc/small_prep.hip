@@ -26,7 +26,7 @@ namespace {
 
 struct SmallPrepArgs {
     const float *obs; int N, F, B, S, uniform, n_feat_blocks;
-    const int64_t *cum; float *thr; uint32_t *thr_keys; uint16_t *codes;
+    const int64_t *cum; float *thr; uint32_t *thr_keys; uint16_t *codes, *codes_fm;
     const float *grads; int D, stat_blocks, stat_bs, centred, chunk_rows;
     double *stat; float *meanden; StepScales *sc; int32_t *qg;
     uint32_t *prof;
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(kSmallStatsThreads) void k_small_prep(const SmallPr
         small_stats_body(a.grads, a.N, a.D, a.stat_blocks, a.stat_bs, a.centred, a.chunk_rows, a.stat, a.meanden, a.sc, a.qg, reinterpret_cast<double *>(prep_lds));
         return;
     }
-    if (a.uniform) uniform_thresholds_body(a.obs, a.N, a.F, b, a.B, a.thr, a.thr_keys, a.codes, reinterpret_cast<uint32_t *>(prep_lds));
-    else sort_quantiles_body<true>(a.obs, a.N, a.S, a.cum, a.B, a.thr_keys, a.thr, a.F, b, a.codes, reinterpret_cast<uint32_t *>(prep_lds), a.prof);
+    if (a.uniform) uniform_thresholds_body(a.obs, a.N, a.F, b, a.B, a.thr, a.thr_keys, a.codes, reinterpret_cast<uint32_t *>(prep_lds), a.codes_fm);
+    else sort_quantiles_body<true>(a.obs, a.N, a.S, a.cum, a.B, a.thr_keys, a.thr, a.F, b, a.codes, reinterpret_cast<uint32_t *>(prep_lds), a.prof, a.codes_fm);
 }
 
 }  // namespace
@@ -55,7 +55,7 @@ bool small_stats_shape(int n, int D, int *n_blocks, int *bs, size_t *lds) {
     return true;
 }
 
-bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64_t *cum, float *thr, uint32_t *thr_keys, uint16_t *codes,
+bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64_t *cum, float *thr, uint32_t *thr_keys, uint16_t *codes, uint16_t *codes_fm,
                 const float *grads, int D, bool centred, int chunk_rows, double *stat, float *meanden, StepScales *sc, int32_t *qg,
                 bool want_stats, bool *stats_done, hipStream_t s) {
     *stats_done = false;
@@ -87,7 +87,7 @@ bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64
     if (dev >= 0 && dev < 64 && ((unsupported >> dev) & 1ull)) return false;
     a.obs = obs; a.N = N; a.F = F; a.B = B; a.uniform = uniform ? 1 : 0;
     a.n_feat_blocks = ((F + kCodeGroup - 1) / kCodeGroup) * kCodeGroup;
-    a.cum = cum; a.thr = thr; a.thr_keys = thr_keys; a.codes = codes;
+    a.cum = cum; a.thr = thr; a.thr_keys = thr_keys; a.codes = codes; a.codes_fm = codes_fm;
     a.grads = grads; a.D = D; a.centred = centred ? 1 : 0; a.chunk_rows = chunk_rows; a.stat = stat; a.meanden = meanden; a.sc = sc; a.qg = qg;
     {   // measurement hook: GBRL_HIP_SMALL_PREP_PROF=1 prints feature 0's stage times of the previous launch
         static uint32_t *h_prof = nullptr;
