@@ -1234,6 +1234,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         return cat_index[cat_index_off[feat] + cls - 1];
     };
     const float *win_thr = nullptr;   // small-step kernel: the winners' threshold values travel with the level's result block
+    bool lazy_paths = false;          // small-step kernel: children do not copy their parent's path (in_cond[id] = the condition into node id)
+    std::vector<HCond> in_cond;
     bool counts_later = false;        // small-step kernel, oblivious trees: the node sizes are derived from the leaves' row counts after the replay
     auto digest_level = [&](const std::vector<int> &active, const char *hres) -> LevelOutcome {
         LevelOutcome out;
@@ -1292,15 +1294,21 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             HNode l, r;
             l.depth = r.depth = nodes[id].depth + 1;
             l.parent = r.parent = id;
-            l.path = nodes[id].path;
-            r.path = nodes[id].path;
             HCond cl = c, cr = c;
             cl.dir = false;
             cl.edge_w = npar > 0 ? static_cast<float>(nl) / static_cast<float>(npar) : 0.0f;  // node.cpp:131
             cr.dir = true;
             cr.edge_w = npar > 0 ? static_cast<float>(nr) / static_cast<float>(npar) : 0.0f;
-            l.path.push_back(cl);
-            r.path.push_back(cr);
+            if (lazy_paths) {   // (one-launch growth: only the leaves' paths are ever read -- built once, at the end, from the conditions that lead INTO the nodes)
+                in_cond.resize(nodes.size() + 2);
+                in_cond[nodes.size()] = cl;
+                in_cond[nodes.size() + 1] = cr;
+            } else {
+                l.path = nodes[id].path;
+                r.path = nodes[id].path;
+                l.path.push_back(cl);
+                r.path.push_back(cr);
+            }
             const int nl_local = static_cast<int>(nodes[id].n_local - right_l[k]);
             l.seg_start = nodes[id].seg_start;
             l.n_local = nl_local;
@@ -1378,6 +1386,9 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         } } host_prof{sg_prof, prof_step_entry_, t_launched, t_seen};
         const int levels_written = static_cast<int>(h_status[1]);
         counts_later = oblivious;
+        lazy_paths = true;
+        in_cond.assign(1, HCond{});
+        in_cond.reserve(static_cast<size_t>(2) << MD);
         for (int depth = 0; depth < MD; ++depth) {
             std::vector<int> active;
             for (int id : frontier)
@@ -1393,6 +1404,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         }
         win_thr = nullptr;
         counts_later = false;
+        lazy_paths = false;
+        in_cond.resize(nodes.size());
         for (int id : frontier)
             if (!nodes[id].leaf) nodes[id].leaf = true;
         if (nodes.size() == 1) nodes[0].leaf = true;
@@ -1412,11 +1425,15 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 HNode &nd = nodes[id];
                 nd.n_global = cnt[id];
                 nd.n_local = static_cast<int>(cnt[id]);
-                if (id == 0) continue;
-                const HNode &par = nodes[nd.parent];
-                for (size_t q = 0; q + 1 < nd.path.size(); ++q) nd.path[q].edge_w = par.path[q].edge_w;
-                nd.path.back().edge_w = cnt[nd.parent] > 0 ? static_cast<float>(cnt[id]) / static_cast<float>(cnt[nd.parent]) : 0.0f;
+                if (id > 0) in_cond[id].edge_w = cnt[nd.parent] > 0 ? static_cast<float>(cnt[id]) / static_cast<float>(cnt[nd.parent]) : 0.0f;
             }
+        }
+        for (size_t id = 0; id < nodes.size(); ++id) {   // the leaves' paths (what append_tree writes into the model), root first
+            HNode &nd = nodes[id];
+            if (nd.left >= 0 || nd.depth == 0) continue;
+            nd.path.resize(nd.depth);
+            int at = static_cast<int>(id);
+            for (int d = nd.depth - 1; d >= 0; --d) { nd.path[d] = in_cond[at]; at = nodes[at].parent; }
         }
         if (!std::isfinite(c.h_scales->hmax_build) || !std::isfinite(c.h_scales->hmax_raw)) throw InvalidArgument("non-finite gradients");
         leaf_scale = c.h_scales->leaf_scale;
