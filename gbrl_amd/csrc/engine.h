@@ -183,6 +183,7 @@ class Engine {
     DevBuf d_codes_fm_;               // feature-major copy of the numeric class codes (kern::small_prep -> kern::small_grow)
     DevBuf d_sg_bests_, d_sg_sync_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
     const void *sg_sync_ptr_ = nullptr;
+    std::chrono::steady_clock::time_point prof_marks_[4]{};
     std::chrono::steady_clock::time_point prof_step_entry_{};   // measurement (GBRL_HIP_SMALL_GROW_PROF)
     int prep_launches_ = 0;           // diagnostic of the last step(): 1 = kern::small_prep ran, 3 = the separate preparation launches
     uint32_t level_seq_ = 0;          // sequence number of the last published level result block (0 is never published)
@@ -246,6 +247,9 @@ class Engine {
     const uint64_t *sdict_hash_ = nullptr, *sdict_words_ = nullptr;
     int cat_log2_hint_ = 20;                            // log2 of the per-feature table size the next step starts with (20: the full size)
     int cat_publish_guess_ = 256;                       // records the next step publishes with its header (the last count + 25 %)
+    void verify_pending_categories();
+    std::vector<std::pair<int, const char *>> cat_pending_;   // (item, published cell) pairs whose bytes are still to be compared this step
+    bool cat_clash_ = false;
     std::vector<detail::CatItem> cat_items_;            // every distinct (feature, cell) met so far
     std::vector<uint64_t> cat_tab_key_;                 // (raw hash, feature) -> head of the chain through CatItem::next: open-addressed
     std::vector<int32_t> cat_tab_id_;                   //   table (keys | item ids, -1 = empty), at most half full

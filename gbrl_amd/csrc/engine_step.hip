@@ -472,6 +472,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     const int32_t *h_hdr = nullptr, *lfeat = nullptr, *lfirst = nullptr;
     const uint64_t *lhash = nullptr;
     const char *names = nullptr;
+    bool names_in_pinned = false;
     auto publish = [&](int cap, bool launch, bool collect) {
         const size_t bytes = 64 + static_cast<size_t>(cap) * (8 + 4 + 4 + kCat);
         char *h = static_cast<char *>(pin_cat_.ensure(bytes));
@@ -491,8 +492,12 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         spin_until_published(flag, cat_pub_seq_, s, "the batch's distinct categorical cells");   // the publish only: kernels enqueued behind it keep running
         // the device wrote these lines over PCIe, so every first touch by the host misses its caches: ONE sequential pass (prefetcher
         // friendly) into ordinary memory, sized by the published count, instead of the replay's scattered reads (3x slower measured)
+        // (Round 5: the 128-byte cells -- 260 KiB of the 290 at configs[4] -- are NOT copied on one GPU: a cell the engine has met before is
+        // recognised by its 64-bit hash and feature, and its bytes are compared with the remembered ones later, while the device grows the
+        // tree (verify_pending_categories); only new cells are read here.)
+        const bool copy_names = has_coll_;
         const int n_pub = std::max(0, std::min(reinterpret_cast<const int32_t *>(h)[3], cap));
-        cat_host_.resize(64 + static_cast<size_t>(n_pub) * (8 + 4 + 4 + kCat));
+        cat_host_.resize(64 + static_cast<size_t>(n_pub) * (8 + 4 + 4 + (copy_names ? kCat : 0)));
         char *c = cat_host_.data();
         std::memcpy(c, h, 64);
         const size_t c_hash = 64, c_feat = c_hash + 8 * static_cast<size_t>(n_pub), c_first = c_feat + 4 * static_cast<size_t>(n_pub),
@@ -500,12 +505,13 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         std::memcpy(c + c_hash, h + o_hash, 8 * static_cast<size_t>(n_pub));
         std::memcpy(c + c_feat, h + o_feat, 4 * static_cast<size_t>(n_pub));
         std::memcpy(c + c_first, h + o_first, 4 * static_cast<size_t>(n_pub));
-        std::memcpy(c + c_names, h + o_names, static_cast<size_t>(kCat) * n_pub);
+        if (copy_names) std::memcpy(c + c_names, h + o_names, static_cast<size_t>(kCat) * n_pub);
         h_hdr = reinterpret_cast<const int32_t *>(c);
         lhash = reinterpret_cast<const uint64_t *>(c + c_hash);
         lfeat = reinterpret_cast<const int32_t *>(c + c_feat);
         lfirst = reinterpret_cast<const int32_t *>(c + c_first);
-        names = c + c_names;
+        names = copy_names ? c + c_names : h + o_names;
+        names_in_pinned = !copy_names;
     };
     for (bool first = true;; first = false) {
         const size_t slots = static_cast<size_t>(Fc) << log2_cap;
@@ -534,6 +540,9 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         if (h_hdr[0] != 0 && log2_cap < full_log2) { log2_cap = full_log2; continue; }   // a table (or the list) overflowed: once more at full size
         break;
     }
+    static const bool cat_prof = [] { const char *e = std::getenv("GBRL_HIP_CAT_PROF"); return e && e[0] == '1'; }();   // measurement hook
+    std::chrono::steady_clock::time_point cp[6];
+    if (cat_prof) cp[0] = std::chrono::steady_clock::now();
     int n_distinct = h_hdr[2];
     bool declined = h_hdr[0] != 0 || h_hdr[1] != 0 || n_distinct > keep;
     if (has_coll_) {   // every rank must take the same path
@@ -622,6 +631,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return lfeat[a] < lfeat[b2]; });
     }
+    if (cat_prof) cp[1] = std::chrono::steady_clock::now();
     // Replay of the reference's candidate container (std::unordered_map<std::string, ...> keyed by cell + "_" + feature, filled in
     // the order above, split_candidate_generator.cpp:117-130): its ITERATION order is the candidate order (Q8).  The order of a
     // libstdc++ hash table is a function of the keys' hash values and of the insertion sequence only, so the replay inserts small
@@ -648,10 +658,21 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
             if (oi[i] >= 0) { const size_t j = tab_slot(ok[i]); cat_tab_key_[j] = ok[i]; cat_tab_id_[j] = oi[i]; }
     };
     tab_reserve(cat_items_.size() + static_cast<size_t>(n_distinct));
+    const bool defer_compare = names_in_pinned;
+    cat_pending_.clear();
+    std::vector<int> item_of_q(static_cast<size_t>(std::max(1, n_distinct)), -1);
     auto item_of = [&](int feat, uint64_t h, const char *cell) -> int {
         const uint64_t key = h * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(feat);
         const size_t slot = tab_slot(key);
         const int head = cat_tab_id_[slot];
+        if (defer_compare) {
+            // exactly one remembered cell with this (feature, hash): take it and compare the bytes later (verify_pending_categories);
+            // several (two different cells that share a 64-bit hash have been met): compare now
+            int hit = -1, hits = 0;
+            for (int id = head; id >= 0; id = cat_items_[id].next)
+                if (cat_items_[id].feat == feat && cat_items_[id].lhash == h) { hit = id; ++hits; }
+            if (hits == 1) { cat_pending_.emplace_back(hit, cell); return hit; }
+        }
         for (int id = head; id >= 0; id = cat_items_[id].next) {
             const detail::CatItem &ci = cat_items_[id];
             if (ci.feat == feat && std::memcmp(ci.name, cell, kCat) == 0) return id;
@@ -681,13 +702,16 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         if (tag == 0) { std::fill(cat_seen_.begin(), cat_seen_.end(), 0u); cat_seen_tag_ = 1; }
         for (int q : order) {
             const int id = item_of(lfeat[q], lhash[q], names + static_cast<size_t>(q) * kCat);
+            item_of_q[q] = id;
             if (static_cast<size_t>(id) >= cat_seen_.size()) cat_seen_.resize(std::max<size_t>(2 * cat_seen_.size(), static_cast<size_t>(id) + 1), 0);
             if (cat_seen_[id] == cat_seen_tag_) continue;      // key already in the container (row-sharded lists): emplace() finds it, inserts nothing
             cat_seen_[id] = cat_seen_tag_;
             hcode.push_back(cat_items_[id].std_hash);
             node_q.push_back(q);
         }
+        if (cat_prof) cp[2] = std::chrono::steady_clock::now();
         for (int k : libstdcxx_unique_insert_order(hcode)) cand_item.push_back(node_q[k]);   // the container's iteration order (Q8)
+        if (cat_prof) cp[3] = std::chrono::steady_clock::now();
     }
     // The replay leans on libstdc++ internals.  Production processes check it against the real container on their FIRST categorical
     // steps (eight of them: the early ones have the fewest rehashes) and then trust it; GBRL_HIP_CAT_CHECK=1 (the test suite) checks
@@ -722,7 +746,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
             const int f = lfeat[q];
             const int cls = ++cat_classes[f];
             if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
-            cat_cands.emplace_back(f, names + static_cast<size_t>(q) * kCat, cls);
+            cat_cands.emplace_back(f, cat_items_[item_of_q[q]].name, cls);   // (the remembered bytes: equal to the published cell's, verified below / later)
             hc[q] = cls;
         }
         int32_t *dc = static_cast<int32_t *>(d_cat_clsq_.ensure(sizeof(int32_t) * static_cast<size_t>(std::max(1, n_distinct))));
@@ -732,6 +756,11 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         fs.n = 1; fs.dst[0] = dc; fs.src[0] = hc_dev; fs.words[0] = static_cast<uint32_t>(std::max(1, n_distinct));
         kern::fetch_segments(fs, s);
         cat_table_.valid = true; cat_table_.keys = d_keys; cat_table_.slot_q = d_slotq; cat_table_.cls_of_q = dc; cat_table_.log2_cap = log2_cap;
+        if (cat_prof) {
+            cp[4] = std::chrono::steady_clock::now();
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "[cat host, us] %d distinct: insertion order %.1f  items %.1f  container order %.1f  candidates + classes %.1f\n", n_distinct, us(cp[0], cp[1]), us(cp[1], cp[2]), us(cp[2], cp[3]), us(cp[3], cp[4]));
+        }
         return true;
     }
     struct DictE { uint64_t h; int cls; int item; };
@@ -746,7 +775,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
             const int f = lfeat[q];
             const int cls = ++cat_classes[f];
             if (cls > 65534) throw Unsupported("more than 65534 candidate categories in one feature");
-            cat_cands.emplace_back(f, names + static_cast<size_t>(q) * kCat, cls);
+            cat_cands.emplace_back(f, cat_items_[item_of_q[q]].name, cls);
             ent[cur[f]++] = {lhash[q], cls, q};
         }
     }
@@ -778,6 +807,17 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     sdict_off_ = reinterpret_cast<const int32_t *>(dd + o_off);
     sdict_cls_ = reinterpret_cast<const int32_t *>(dd + o_cls);
     return true;
+}
+
+// A categorical cell that device_categorical_candidates recognised by (feature, 64-bit hash) alone: its 128 bytes, still in the pinned block
+// the device published them to, are compared with the remembered ones HERE -- called while the device grows the tree, so the 260 KiB of
+// PCIe-written lines are read off the critical path.  A difference means two categories share a 64-bit hash: the step is refused (nothing has
+// joined the model yet) instead of continuing with the wrong category's name and candidate order.
+void Engine::verify_pending_categories() {
+    bool clash = false;
+    for (const auto &pq : cat_pending_) clash = clash || std::memcmp(cat_items_[pq.first].name, pq.second, kCat) != 0;
+    cat_pending_.clear();
+    if (clash) cat_clash_ = true;
 }
 
 // ---- A3/A4: numeric split candidates ------------------------------------------------------------------------------------
@@ -1364,6 +1404,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
         phase_end("small_grow");
         const auto t_launched = std::chrono::steady_clock::now();
+        verify_pending_categories();   // (host work hidden behind the kernel)
         spin_until_published(h_status, seq, s, "small-step tree");
         const auto t_seen = std::chrono::steady_clock::now();
         hip_check(hipGetLastError(), "growth kernel");
@@ -1384,6 +1425,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
             fprintf(stderr, "[small step host, us] entry->growth launched %.1f  wait %.1f  replay %.1f\n", us(t0, t1), us(t1, t2), us(t2, t3));
         } } host_prof{sg_prof, prof_step_entry_, t_launched, t_seen};
+        if (sg_prof) {
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "[small step host, us] inputs+cat launch %.1f  preparation enqueued %.1f  categorical candidates (host) %.1f  tables + cat codes %.1f  grow_tree to launch %.1f\n",
+                    us(prof_step_entry_, prof_marks_[0]), us(prof_marks_[0], prof_marks_[1]), us(prof_marks_[1], prof_marks_[2]), us(prof_marks_[2], prof_marks_[3]), us(prof_marks_[3], t_launched));
+        }
         const int levels_written = static_cast<int>(h_status[1]);
         counts_later = oblivious;
         lazy_paths = true;
@@ -1732,6 +1778,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 }
             } else {
                 // poll the sequence word; now and then ask the stream for errors (a faulted kernel would never publish)
+                verify_pending_categories();   // (first level only does work: hidden behind the level's kernels)
                 spin_until_published(h_flag, seq, s, "level results");
             }
         }
@@ -1869,6 +1916,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         dcells = t;
     }
     phase_end("inputs");
+    prof_marks_[0] = std::chrono::steady_clock::now();
     // the scan for the batch's distinct categorical cells goes first: its result is read by the HOST (device_categorical_candidates)
     const bool cat_early = Fc > 0 && !fixed_cat_valid_ && (has_coll_ || !force_host_categorical_);
     cat_launched_ = false;   // (a step that threw between the two stages must not be resumed)
@@ -2000,6 +2048,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     }
     if (F > 0 && !prep_done) numeric_thresholds(dobs, N, F, B, n_global, d_kt, d_thr, d_thrkeys, pass1_chunks, d_codes, &codes_from_sort);
     phase_end("candidates");
+    prof_marks_[1] = std::chrono::steady_clock::now();
     prep_launches_ = F > 0 ? prep_launches : 0;
     // numeric class codes (3. below) before the host waits for the categorical scan
     phase_begin();
@@ -2044,11 +2093,14 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         }
     }
 
+    prof_marks_[2] = std::chrono::steady_clock::now();
     if (candidates_only_) {   // fit(): only the candidates of this (whole) data set are wanted
         if (n_thr) hip_check(hipMemcpyAsync(h_thr, d_thr, sizeof(float) * n_thr, hipMemcpyDeviceToHost, s), "D2H thr");
         hip_check(hipStreamSynchronize(s), "sync");
         fixed_thr_.assign(h_thr, h_thr + n_thr);
         if (Fc > 0) {
+            verify_pending_categories();
+            if (cat_clash_) { cat_clash_ = false; cat_items_.clear(); cat_tab_key_.clear(); cat_tab_id_.clear(); throw HipError("two different categories of one feature share a 64-bit hash: fit() refused"); }
             if (!cat_codes_on_device)
                 throw Unsupported("fit(): the data set holds more distinct categories than Fc * n_bins (mean-gradient ranking of the whole data set is not implemented)");
             fixed_cat_cands_ = cat_cands;
@@ -2166,6 +2218,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     void *pin_dev = nullptr;
     hip_check(hipHostGetDevicePointer(&pin_dev, pin_ts, 0), "hipHostGetDevicePointer");
 
+    prof_marks_[3] = std::chrono::steady_clock::now();
     // ---- 4. growth (level-synchronous; Engine::grow_tree) and 5. leaf sums --------------------------------------------------
     GrowCtx gc{};
     gc.N = N; gc.F = F; gc.Fc = Fc; gc.D = D; gc.B = B; gc.MD = MD; gc.NB = NB; gc.FG = FG; gc.Fp = Fp; gc.n_groups = n_groups;
@@ -2180,6 +2233,12 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     std::vector<int64_t> acc;
     double leaf_scale = 1.0;
     grow_tree(gc, nodes, frontier, acc, leaf_scale);
+    verify_pending_categories();
+    if (cat_clash_) {
+        cat_clash_ = false;
+        cat_items_.clear(); cat_tab_key_.clear(); cat_tab_id_.clear(); std::fill(cat_seen_.begin(), cat_seen_.end(), 0u);
+        throw HipError("two different categories of one feature share a 64-bit hash: step refused (GBRL_HIP_HOST_CATEGORICAL=1 scans the cells on the host)");
+    }
     append_tree(model, nodes, frontier, acc, leaf_scale, cat_cands);
     (void)world;
     hip_check(hipGetLastError(), "step kernels");
