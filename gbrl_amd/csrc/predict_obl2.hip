@@ -636,12 +636,12 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
     const int n_tiles = (n + R - 1) / R;
     if constexpr (!CAT) {
         // small ensemble over a large batch: persistent blocks that prefetch their next row tile (the HBM-bound regime)
-        static const bool no_persist = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_PERSIST"); return e && e[0] == '1'; }();   // measurement hook
+        const bool no_persist = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_PERSIST"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
         // (with <= 16 trees of <= 2 KiB of values each, two 8-tree value buffers hold the whole ensemble: staged once per block)
         int resident_vals = 0;
         {
             const size_t vtb = (static_cast<size_t>(1) << MAXD) * (DMAX * sizeof(float) + (GREEDY ? 16 : 0));
-            static const bool no_res = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_RESIDENT"); return e && e[0] == '1'; }();   // measurement hook
+            const bool no_res = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_RESIDENT"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
             // (a 256-thread block stages kObl2MaxVec float4 per thread = 16 KiB per group: an 8-tree group must fit that, i.e. <= 2 KiB
             // of values per tree -- depth 7-8 trees with 4 outputs, 4 KiB each, keep the regular plan)
             if (!no_res && !GREEDY && pl.RG == 1 && trees <= 16 && DMAX <= 8 && 8 * vtb <= static_cast<size_t>(kObl2MaxVec) * 256 * 16) {

@@ -1,7 +1,8 @@
 """Randomised sweep of the register-tile predict kernels (predict_reg.hip) against the general kernel, bit for bit (GPU box; not part of
 the test suite; prints a summary and exits non-zero on the first mismatch).
     python scripts/predict_reg_sweep.py [n_cases] [first_seed]
-Every case: a random oblivious ensemble (1-70 trees grown by step() on a small batch: depth 1-6, 1-16 outputs, 1-300 numeric features,
+Every case: a random oblivious ensemble (1-70 trees grown by step() on a small batch: depth 1-8 (7 and 8: the shapes the register-tile
+kernels decline, swept at large n through the older kernels' persistent / resident modes too), 1-16 outputs, 1-300 numeric features,
 0-9 categorical columns, both generators, optional feature weights / bias / two optimisers), a random batch (1 .. 70 000 rows with NaN,
 infinities, signed zeros and unseen categories), random tree ranges -- predicted through the default dispatch with the row threshold
 lowered to 1 (fp32 register tiles where they apply, packed codes otherwise), through the forced grouped shape, and by the general kernel."""
@@ -26,7 +27,7 @@ for i in range(n_cases):
     Fc = int(rng.choice([0, 0, 0, 1, 3, 9]))
     F = int(rng.choice([1, 4, 8, 17, 40, 64, 128, 130, 200, 300])) if Fc == 0 or rng.random() < 0.8 else 0
     D = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 12, 16]))
-    case = dict(name="prs%d" % i, seed=seed0 + i, N=int(rng.choice([200, 800, 2000])), F=F, Fc=Fc, D=D, depth=int(rng.choice([1, 2, 3, 4, 5, 6])),
+    case = dict(name="prs%d" % i, seed=seed0 + i, N=int(rng.choice([200, 800, 2000])), F=F, Fc=Fc, D=D, depth=int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8])),
                 n_bins=int(rng.choice([7, 32, 100, 256])), score=str(rng.choice(["L2", "Cosine"])), gen=str(rng.choice(["Quantile", "Uniform"])),
                 policy="oblivious", trees=int(rng.choice([1, 2, 5, 16, 33, 70])), n_tokens=int(rng.choice([3, 8, 32])))
     if case["N"] < case["n_bins"] + 1: case["n_bins"] = 32
