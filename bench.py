@@ -197,6 +197,48 @@ def cpu_predict_baseline(np, model_path, n_feat, rows, budget_s=8.0):
             "kind": "reference", "what": "Predictor::predict_cpu of oracle/_ref on the model file the product saved"}
 
 
+def leg_collective(torch, np, gbrl_amd, workload, X, G, F, D, depth, B, steps, plain_ms):
+    """The row-sharded code path on ONE GPU over a world-size-1 native RCCL communicator (gbrl_amd.dist.install_rccl_single): every exchange of a
+    sharded step -- row count, gradient statistics, the selection's digit counts, the per-level histogram reduce-scatter and winner
+    all-reduce, the leaf sums -- is enqueued on the model's stream and executed by RCCL, but no byte crosses xGMI.  What it costs over the
+    plain one-GPU step is the fixed price of the multi-GPU path; the 1/2/4/8 curve needs a multi-GPU node."""
+    import ctypes
+    from gbrl_amd.dist import install_rccl_single
+    # RCCL prints a version banner on C stdout when its first communicator comes up: this process's stdout carries ONE JSON line, so file
+    # descriptor 1 points at stderr while the leg runs (and C stdio is flushed before it is restored)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        m = make_model(gbrl_amd, np, workload, F, 0, D, depth, B, "bench_collective")
+        install_rccl_single(m)
+        tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+        xo, go = tup(X), tup(G)
+        for _ in range(3):
+            m.step(xo, None, go)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.step(xo, None, go)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        m.set_profiling(2)
+        m.step(xo, None, go)
+        ph = dict(m.last_phase_times())
+        del m
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+    return {"phases_ms": {k: v for k, v in sorted(ph.items()) if not k.startswith("exchange_")},"world_size": 1, "transport": "rccl (native: collectives enqueued on the model's stream)", "steps": steps, "ms_per_step": ms,
+            "plain_ms_per_step": plain_ms, "overhead_vs_plain": ms / plain_ms if plain_ms > 0 else None,
+            "exchanges": ph.get("exchange_calls"), "payload_mb": ph.get("exchange_payload_mb"),
+            "note": "one GPU, no xGMI traffic: the fixed cost of the row-sharded path; multi-GPU scaling is measured by the driver's --gpus N runs"}
+
+
 def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
     """BASELINE configs[0], the reference's own CPU-runnable case (tests/test_gbt_single.py:46-61): single-output MultiRMSE loop --
     predict, gradient = prediction - target, step -- 4096 rows x 16 features, greedy / L2 / quantile, depth 4, 30 trees.  The product
@@ -624,6 +666,10 @@ def main():
 
     extra = {}
     if world == 1 and not args.no_extra_legs and not args.force_collective:
+        try:   # (a leg is reporting only; never let it hide the timed measurement)
+            extra["collective"] = leg_collective(torch, np, gbrl_amd, args.workload, X, G, F, D, depth, B, args.steps, dt / args.steps * 1e3)
+        except Exception as e:
+            extra["collective"] = {"error": repr(e)}
         del m
         torch.cuda.empty_cache()
         if args.workload != "cfg3":
@@ -686,7 +732,8 @@ def main():
             "predict_large_ensemble": large,
             "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"), "cfg1": extra.get("cfg1"),
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
-            "collective": ({"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)} if coll is not None else None),
+            "collective": (extra.get("collective") if coll is None else
+                           {"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)}),
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,
             "roofline": {"bound": "hbm", "kernel": "k_hist_build (split-score histogram build), %d launches per tree" % depth,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -935,6 +935,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 if (has_coll_) {
                     comm.ctx = this;
                     comm.allreduce_sum_i64 = &Engine::radix_exchange_trampoline;
+                    comm.stream_ordered = rccl_comm_ != nullptr;
                     comm.gbuf = static_cast<int64_t *>(d_counts_.ensure(sizeof(int64_t) * kern::radix_exchange_words(F)));
                     comm.partial_global = static_cast<uint32_t *>(d_radix_global_.ensure(kern::radix_global_partial_bytes(F)));
                 }
@@ -1748,19 +1749,18 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
             const int n_win = oblivious ? 1 : n_act;
             const size_t gwords = static_cast<size_t>(coll_P) * (n_win + 2 * n_act);
-            hip_check(hipMemsetAsync(d_gather, 0, sizeof(int64_t) * gwords, s), "memset");
-            kern::winner_pack(d_best_idx, d_best_score, d_counts4, max_front, n_win, n_act, coll_.rank, d_gather, s);
+            kern::winner_pack(d_best_idx, d_best_score, d_counts4, max_front, n_win, n_act, coll_.rank, d_gather, s, coll_P);
             exchange(Red::SumI64, d_gather, gwords);
             kern::winner_adopt(d_gather, coll_P, n_win, n_act, oblivious, d_ref_to_internal, d_cand_slot, d_slots, d_seg_starts, c.d_thrkeys, B, d_best_idx, d_best_score,
                                d_counts4, max_front, d_resolved, d_cursors, s);
-            int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);
-            hip_check(hipMemsetAsync(d_right_local, 0, sizeof(int64_t) * max_front, s), "memset");
+            int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);   // (cleared by winner_adopt)
             if (!count_chunks.empty())
                 kern::count_right(d_rows[cur], d_codes, c.d_kt, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
-            kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);   // global left sizes -> this rank's
+            // global left sizes -> this rank's, and the completed result block to the host: one launch
+            if (event_results) kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);
+            else kern::localize_publish(d_resolved, d_n_locals, d_right_local, n_act, d_res, h_res_dev, res_bytes, d_flag, seq, s);
         }
         if (event_results) hip_check(hipMemcpyAsync(h_res, d_res, res_bytes, hipMemcpyDeviceToHost, s), "D2H level results");
-        else if (!publish_in_resolve) kern::publish_block(d_res, h_res_dev, res_bytes, d_flag, seq, s);   // row-sharded: later kernels complete the block
         phase_end("score_select");
         {
             if (event_results) hip_check(hipEventRecord(ev_level_, s), "hipEventRecord");

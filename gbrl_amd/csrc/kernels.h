@@ -167,7 +167,9 @@ size_t radix_list_bytes(int n, int F);
 // same thresholds.  Returns 0, or non-zero when a HIP call (1) / the all-reduce (2) failed.
 struct RadixComm {
     void *ctx;
-    int (*allreduce_sum_i64)(void *ctx, int64_t *dev_buf, size_t count);   // called with the stream synchronised
+    int (*allreduce_sum_i64)(void *ctx, int64_t *dev_buf, size_t count);   // called with the stream synchronised unless stream_ordered
+    bool stream_ordered;        // the all-reduce is enqueued on the stream (native RCCL): radix_select never waits for the device -- the messages are
+                                // sized by their upper bound (B slot rows per feature) instead of the slot counts read back after every pass
     int64_t *gbuf;              // radix_exchange_words(F) int64
     uint32_t *partial_global;   // radix_global_partial_bytes(F)
 };
@@ -223,7 +225,7 @@ void fill_f32(float *p, size_t n, float v, hipStream_t s);
 // lowest index, the order of the single-GPU arg-max) and rebuilds best_idx / best_score / counts4 / the NodeSplit descriptors from
 // the owning rank's counts.  n_win = 1 (oblivious: one condition per level) or n_act (greedy).
 void winner_pack(const int32_t *best_idx, const float *best_score, const int64_t *counts4, int max_front, int n_win, int n_act, int rank,
-                 int64_t *gather /*[P][n_win + 2 * n_act], zeroed*/, hipStream_t s);
+                 int64_t *gather /*[P][n_win + 2 * n_act]: the kernel clears the other ranks' rows*/, hipStream_t s, int P);
 void winner_adopt(const int64_t *gather, int P, int n_win, int n_act, bool oblivious, const int32_t *ref_to_internal, const int32_t *cand_slot,
                   const FeatureSlot *slots, const int32_t *seg_start, const uint32_t *thr_keys, int B, int32_t *best_idx, float *best_score,
                   int64_t *counts4, int max_front, NodeSplit *out, int32_t *cursors, hipStream_t s);
@@ -264,6 +266,8 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);
+void localize_publish(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, void *d_src, void *h_dst_mapped, size_t bytes,
+                      uint32_t *flag_mapped, uint32_t seq, hipStream_t s);   // localize_splits + publish_block in one launch
 void hist_place(const int64_t *src, int64_t *dst, const int32_t *slot_map, int n, size_t node_elems, hipStream_t s);
 void count_right(const int32_t *rows, const uint16_t *codes, const uint32_t *kt /*nullable: feature-major keys*/, int n_rows, const Chunk *chunks, int n_chunks, const NodeSplit *splits,
                  int64_t *n_right /*[n_nodes], zeroed*/, hipStream_t s);

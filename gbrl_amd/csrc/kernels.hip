@@ -841,7 +841,11 @@ __global__ void k_fill_f32(float *__restrict__ p, size_t n, float v) {
 }
 // see kernels.h: winner_pack / winner_adopt
 __global__ void k_winner_pack(const int32_t *__restrict__ best_idx, const float *__restrict__ best_score, const int64_t *__restrict__ counts4,
-                              int max_front, int n_win, int n_act, int rank, int64_t *__restrict__ gather) {
+                              int max_front, int n_win, int n_act, int rank, int64_t *__restrict__ gather, int P) {
+    // (the other ranks' rows are cleared here: the sum over ranks is a gather; round 5: no memset launch in front of this one)
+    const size_t stride = static_cast<size_t>(n_win) + 2 * n_act;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < stride * P; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        if (i / stride != static_cast<size_t>(rank)) gather[i] = 0;
     int64_t *row = gather + static_cast<size_t>(rank) * (n_win + 2 * n_act);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_win) {
@@ -874,6 +878,7 @@ __global__ void k_winner_adopt(const int64_t *__restrict__ gather, int P, int n_
     if (k == w || !oblivious) { best_idx[w] = idx; best_score[w] = score; }
     counts4[k] = tot;
     counts4[static_cast<size_t>(max_front) + k] = right;
+    counts4[2 * static_cast<size_t>(max_front) + k] = 0;   // this rank's rows going right: counted next (k_count_right adds into it)
     const int j = ref_to_internal[idx];
     const int fs = cand_slot[j];
     const FeatureSlot sl = slots[fs];
@@ -1744,8 +1749,8 @@ void fill_f32(float *p, size_t n, float v, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p, n, v);
 }
 void winner_pack(const int32_t *best_idx, const float *best_score, const int64_t *counts4, int max_front, int n_win, int n_act, int rank,
-                 int64_t *gather, hipStream_t s) {
-    hipLaunchKernelGGL(k_winner_pack, dim3((n_act + 63) / 64), dim3(64), 0, s, best_idx, best_score, counts4, max_front, n_win, n_act, rank, gather);
+                 int64_t *gather, hipStream_t s, int P) {
+    hipLaunchKernelGGL(k_winner_pack, dim3((n_act + 63) / 64), dim3(64), 0, s, best_idx, best_score, counts4, max_front, n_win, n_act, rank, gather, P);
 }
 void winner_adopt(const int64_t *gather, int P, int n_win, int n_act, bool oblivious, const int32_t *ref_to_internal, const int32_t *cand_slot,
                   const FeatureSlot *slots, const int32_t *seg_start, const uint32_t *thr_keys, int B, int32_t *best_idx, float *best_score,
@@ -1798,6 +1803,20 @@ __global__ void k_localize_splits(NodeSplit *__restrict__ splits, const int32_t 
 }
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s) {
     hipLaunchKernelGGL(k_localize_splits, dim3((n_nodes + 63) / 64), dim3(64), 0, s, splits, n_local, right_local, n_nodes);
+}
+// the two in one launch (row-sharded levels: global left sizes -> this rank's, then the level's result block goes to the host)
+__global__ __launch_bounds__(256) void k_localize_publish(NodeSplit *__restrict__ splits, const int32_t *__restrict__ n_local, const int64_t *__restrict__ right_local,
+                                                          int n_nodes, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int words, uint32_t *flag, uint32_t seq) {
+    for (int k = threadIdx.x; k < n_nodes; k += 256) splits[k].n_left = n_local[k] - static_cast<int32_t>(right_local[k]);
+    for (int i = threadIdx.x; i < words; i += 256) __builtin_nontemporal_store(src[i], &dst[i]);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void localize_publish(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, void *d_src, void *h_dst_mapped, size_t bytes,
+                      uint32_t *flag_mapped, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_localize_publish, dim3(1), dim3(256), 0, s, splits, n_local, right_local, n_nodes, static_cast<const uint32_t *>(d_src),
+                       static_cast<uint32_t *>(h_dst_mapped), static_cast<int>(bytes / 4), flag_mapped, seq);
 }
 // Copies `n` contiguous node histograms into their level slots (dst slot = slot_map[k]).
 __global__ void k_hist_place(const int64_t *__restrict__ src, int64_t *__restrict__ dst, const int32_t *__restrict__ slot_map,

@@ -538,14 +538,20 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
             int rows = 1;
             hipLaunchKernelGGL(k_radix_globalize, dim3(1024), dim3(256), 0, s, pass, partial, n_chunks_pass, F, st, comm->gbuf, p1_u16);
             p1_u16 = 0;   // the summed counts come back as uint32
-            if (pass >= 2) {
-                h_slots.resize(static_cast<size_t>(F) * 4);
-                if (hipMemcpyAsync(h_slots.data(), st.n_slots, sizeof(uint32_t) * h_slots.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
-            }
-            if (hipStreamSynchronize(s) != hipSuccess) return 1;
-            if (pass >= 2) {
-                rows = 0;
-                for (int f2 = 0; f2 < F; ++f2) rows = std::max(rows, static_cast<int>(h_slots[f2 * 4 + (pass - 2)]));
+            if (comm->stream_ordered) {
+                // (round 5) no read-back, no synchronisation: a feature has at most one slot per target, so B slot rows bound every message
+                // (rows nobody filled are summed and ignored: k_radix_unpack / k_radix_targets stop at the feature's own slot count)
+                if (pass >= 2) rows = std::min(B, kMaxTargets);
+            } else {
+                if (pass >= 2) {
+                    h_slots.resize(static_cast<size_t>(F) * 4);
+                    if (hipMemcpyAsync(h_slots.data(), st.n_slots, sizeof(uint32_t) * h_slots.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+                }
+                if (hipStreamSynchronize(s) != hipSuccess) return 1;
+                if (pass >= 2) {
+                    rows = 0;
+                    for (int f2 = 0; f2 < F; ++f2) rows = std::max(rows, static_cast<int>(h_slots[f2 * 4 + (pass - 2)]));
+                }
             }
             const size_t words = static_cast<size_t>(rows) * F * (radix_bins(pass) / 2);
             if (comm->allreduce_sum_i64(comm->ctx, comm->gbuf, words) != 0) return 2;

@@ -132,3 +132,34 @@ def install_rccl(model, device, group=None) -> None:
     if not all_ok(ok):
         lib.gbrl_hip_set_collective(C.c_void_p(model._handle()), None)   # drop a communicator that only some ranks hold
         raise RuntimeError("gbrl_hip_set_rccl failed on some rank: " + (lib.gbrl_hip_last_error() or b"").decode())
+
+
+def install_rccl_single(model) -> None:
+    """A world-size-1 RCCL communicator of the model's own, without torch.distributed: the row-sharded code path (statistics / selection
+    count / histogram reduce-scatter / winner / leaf-sum exchanges, all enqueued on the model's stream) on ONE GPU.  `bench.py` uses it to
+    report what that path costs before any byte crosses xGMI.  The engine drops a world-size-1 communicator unless
+    GBRL_HIP_FORCE_COLLECTIVE=1 is set while this call runs (it is set and restored here)."""
+    import os
+    from . import LIB_PATH
+    lib = C.CDLL(LIB_PATH)
+    lib.gbrl_hip_rccl_available.restype = C.c_int
+    lib.gbrl_hip_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.gbrl_hip_rccl_unique_id.restype = C.c_int
+    lib.gbrl_hip_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.gbrl_hip_set_rccl.restype = C.c_int
+    lib.gbrl_hip_last_error.restype = C.c_char_p
+    if lib.gbrl_hip_rccl_available() != 1:
+        raise RuntimeError("RCCL is not available: " + (lib.gbrl_hip_last_error() or b"").decode())
+    buf = (C.c_char * 128)()
+    if lib.gbrl_hip_rccl_unique_id(buf) != 0:
+        raise RuntimeError("ncclGetUniqueId failed: " + (lib.gbrl_hip_last_error() or b"").decode())
+    old = os.environ.get("GBRL_HIP_FORCE_COLLECTIVE")
+    os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = "1"
+    try:
+        if lib.gbrl_hip_set_rccl(C.c_void_p(model._handle()), buf, 1, 0) != 0:
+            raise RuntimeError("gbrl_hip_set_rccl failed: " + (lib.gbrl_hip_last_error() or b"").decode())
+    finally:
+        if old is None:
+            os.environ.pop("GBRL_HIP_FORCE_COLLECTIVE", None)
+        else:
+            os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = old
