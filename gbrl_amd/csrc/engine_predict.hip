@@ -67,9 +67,9 @@ void Engine::sync_model_to_device() {
             void *st_dev = nullptr;
             hip_check(hipHostGetDevicePointer(&st_dev, st, 0), "hipHostGetDevicePointer");
             size_t off = 0;
-            for (size_t i = 0; i < segs.size(); i += 16) {
+            for (size_t i = 0; i < segs.size(); i += kern::kStageSegments) {
                 kern::StageSegments ss{};
-                for (size_t k = i; k < segs.size() && k < i + 16; ++k) {
+                for (size_t k = i; k < segs.size() && k < i + kern::kStageSegments; ++k) {
                     std::memcpy(st + off, segs[k].src, segs[k].bytes);
                     ss.dst[ss.n] = segs[k].dst; ss.src_off[ss.n] = static_cast<uint32_t>(off); ss.bytes[ss.n] = static_cast<uint32_t>(segs[k].bytes);
                     ++ss.n;

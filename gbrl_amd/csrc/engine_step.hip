@@ -568,6 +568,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         int l2 = 8;
         while ((1 << l2) < 4 * mx && l2 < 20) ++l2;
         cat_log2_hint_ = l2;                       // table size the next step starts with
+        if (n_distinct > (1 << 21)) throw Unsupported("more than 2^21 distinct categorical cells in one step");   // (the list index rides in the key's low 21 bits; Fc * n_bins <= 2^20 above)
         std::vector<uint64_t> ka(n_distinct), kb(n_distinct);
         for (int q = 0; q < n_distinct; ++q)
             ka[q] = ((static_cast<uint64_t>(lfeat[q]) * static_cast<uint64_t>(N) + static_cast<uint64_t>(lfirst[q])) << 21) | static_cast<uint64_t>(q);
@@ -914,7 +915,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
             const bool radix_ok = !force_sample_select_ && B <= kern::radix_max_targets() && n_global < (1ll << 32);
             if (force_bisection_ || (has_coll_ && !coll_fast && !radix_ok)) {
                 bisection_quantiles(cum);
-            } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && N <= kern::sort_quantiles_max_rows()) {
+            } else if (!has_coll_ && !force_sample_select_ && !force_radix_ && kern::sort_quantiles_fits(N, B)) {
                 // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
                 int64_t *d_cum = upload_cum(cum);
                 // (the sort kernel also writes the class codes of its feature: no separate binning launch)

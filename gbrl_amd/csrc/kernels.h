@@ -119,7 +119,8 @@ struct FetchSegments { void *dst[8]; const void *src[8]; uint32_t words[8]; int 
 void fetch_segments(const FetchSegments &fs, hipStream_t s);
 // up to 16 byte ranges out of one mapped pinned staging block by ONE launch (the model's device mirror after a step: a dozen appended slices
 // of a few hundred bytes each; a hipMemcpyAsync per slice from pageable memory cost ~10 us apiece).  Ranges need no alignment.
-struct StageSegments { void *dst[16]; uint32_t src_off[16]; uint32_t bytes[16]; int n; };
+constexpr int kStageSegments = 32;   // (a greedy model appends 17-18 slices per tree: one launch, not two)
+struct StageSegments { void *dst[kStageSegments]; uint32_t src_off[kStageSegments]; uint32_t bytes[kStageSegments]; int n; };
 void stage_copy(const StageSegments &ss, const void *stage_mapped, hipStream_t s);
 // up to four regions filled with a 32-bit pattern each by ONE launch (an RL-sized step pays 4-5 us per hipMemsetAsync)
 struct FillSegments { void *dst[4]; uint32_t words[4]; uint32_t value[4]; int n; };
@@ -157,6 +158,7 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
 // codes[(slot/16)*n*16 + row*16 + slot%16] (u16) = #{k : thr_key[f][k] < key(row, f)}
 // small batches: one LDS sort per column (n <= sort_quantiles_max_rows()); thr_keys[f][k] = key of 1-based rank cum[k]
 int sort_quantiles_max_rows();
+bool sort_quantiles_fits(int n, int B);   // the LDS sort takes (S + B) * 4 bytes, S = n rounded up to a power of two: <= 64 KiB
 void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats /*the same thresholds as floats*/, hipStream_t s, uint16_t *codes = nullptr /* also write the class codes (k_bin_cols' output) */);
 // radix_select.hip: exact order statistics by MSD radix counting (one GPU)
 size_t radix_state_bytes(int F, int B);

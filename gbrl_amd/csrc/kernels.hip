@@ -1424,13 +1424,21 @@ bool small_stats(const float *g, int n, int D, bool centred, int chunk_rows, dou
     const int bs = D <= 256 ? (256 / D) * D : D;
     if (D > 16 || n_blocks * bs > kSmallStatsVirtual || n_blocks > 32 || n < 2) return false;
     const size_t lds = sizeof(double) * (2 * static_cast<size_t>(n_blocks) * bs + static_cast<size_t>(n_blocks) * 2 * D);
-    static PerDeviceOnce attr;
-    if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
     if (lds > 156 * 1024) return false;
+    // A device that refuses the LDS opt-in (or the launch) is remembered: every later call answers "nothing was launched" and the
+    // caller runs the seven-kernel chain (the first version reported the failure on the first call only).
+    static PerDeviceOnce attr;
+    static uint64_t unsupported = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0;
+    if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) != hipSuccess) {
+        (void)hipGetLastError();
+        unsupported |= bit;
+    }
+    if (unsupported & bit) return false;
     hipLaunchKernelGGL(k_small_stats, dim3(1), dim3(kSmallStatsThreads), lds, s, g, n, D, n_blocks, bs, centred ? 1 : 0, chunk_rows, stat, meanden, sc, qg);
+    if (hipGetLastError() != hipSuccess) { unsupported |= bit; return false; }
     return true;
 }
 

@@ -771,12 +771,14 @@ void quantile_select(const uint32_t *lists, const uint32_t *tgt_off, const uint3
     hipLaunchKernelGGL(k_select, dim3((n_targets + 3) / 4), dim3(256), 0, s, lists, tgt_off, tgt_len, tgt_rank, n_targets, thr_keys);
 }
 
-int sort_quantiles_max_rows() { return 4096; }   // beyond this the bitonic sort (O(n log^2 n) in one block per feature) loses to the radix passes
+int sort_quantiles_max_rows() { return 4096; }
+bool sort_quantiles_fits(int n, int B) { int S = 256; while (S < n) S <<= 1; return n <= sort_quantiles_max_rows() && (static_cast<size_t>(S) + B) * sizeof(uint32_t) <= 64 * 1024; }   // beyond this the bitonic sort (O(n log^2 n) in one block per feature) loses to the radix passes
 void sort_quantiles(const uint32_t *kt, int n, int F, const int64_t *cum, int B, uint32_t *thr_keys, float *thr_floats, hipStream_t s, uint16_t *codes) {
     int S = 256;   // four keys per thread, whole waves: 256 keys per wave
     while (S < n) S <<= 1;
     static PerDeviceOnce attr;
     if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_quantiles), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }
+    // ((S + B) * 4 bytes of LDS: the engine takes this path only while that stays within 64 KiB -- sort_quantiles_fits)
     const int blocks = codes ? ((F + kCodeGroup - 1) / kCodeGroup) * kCodeGroup : F;   // with codes: the padding features of the last group too
     hipLaunchKernelGGL(k_sort_quantiles, dim3(blocks), dim3(S / 4), (static_cast<size_t>(S) + B) * sizeof(uint32_t), s, kt, n, S, cum, B, thr_keys, thr_floats, F, codes);
 }
