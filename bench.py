@@ -459,6 +459,9 @@ def main():
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0: grow the CPU sample while the leg stays within ~20 s on this host")
+    ap.add_argument("--cpu-full-tree", action="store_true",
+                    help="opt-in (minutes of CPU time): ALSO time ONE tree of the reference's CPU path at the full batch (2^20 x 128 on this host's cores, "
+                         "SURVEY 8d) and report it as cpu_baseline.full_tree -- no extrapolation")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the row-sharded code path (collective hooks through RCCL) on ONE GPU")
     ap.add_argument("--exchange", choices=["rccl", "hooks"], default="rccl",
@@ -709,7 +712,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj["bytes_per_launch"]
-                traffic_src = "%s (PMC passes of commit %s, %s)" % (tj.get("source", "profiles/hist_traffic.json"), tj.get("commit", "?"), tj.get("taken", "?"))
+                traffic_src = "profiles/hist_traffic.json = the builder's rocprofv3 PMC passes (%s; %s, taken %s)" % (tj.get("method", "2*FETCH_SIZE + WRITE_SIZE"), tj.get("commit", "?"), tj.get("taken", "?"))
             except Exception:
                 traffic = None
         try:
@@ -737,7 +740,9 @@ def main():
             "phases_note": "diagnostic pass of %d extra steps after the timed region (events around every phase)" % diag_steps,
             "roofline": {"bound": "hbm", "kernel": "k_hist_build (split-score histogram build), %d launches per tree" % depth,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg / depth,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_by": ("builder, not by this run: committed PMC summary profiles/hist_traffic.json" if traffic is not None else None),
+                         "algorithmic_bytes_per_launch": alg / depth,
                          "avg_launch_us": build_ms * 1e3 / depth, "launches_per_tree": depth,
                          "launches_timed": (("%d of the %d launches of the timed region (one in seven carries the HIP event pair, every tree level in turn)"
                                              % (int(n_samp), steps * depth)) if n_samp > 0 else "every launch"),
@@ -751,6 +756,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(F, D, depth, B, 1 << 20, args.cpu_sample_rows)
             except Exception as e:  # the baseline is reporting only; never let it hide the measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            if args.cpu_full_tree:
+                try:
+                    ft = cpu_baseline(F, D, depth, B, 1 << 20, 1 << 20)
+                    out["cpu_baseline"]["full_tree"] = {"trees_per_s": ft["value"], "seconds_per_tree": ft["sample_seconds"], "rows": 1 << 20, "cores": ft["cores"],
+                                                        "kind": ft["kind"], "what": "ONE tree of the reference's CPU path at the full batch, no extrapolation"}
+                except Exception as e:
+                    out["cpu_baseline"]["full_tree"] = {"error": repr(e)}
             try:   # the reference's predict_cpu on the ensembles the bench grew (rows/s on this host's cores)
                 import numpy as _np
                 if "small" in model_files:

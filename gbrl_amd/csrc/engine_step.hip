@@ -1955,7 +1955,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const bool uniform_gen = md.generator_type == GBRL_HIP_GEN_UNIFORM;
     const bool prep_candidate = !has_coll_ && n_global == N && F > 0 && fixed_thr_.empty() && !candidates_only_ && !no_small_prep && !no_sort_codes &&
                                 !force_bisection_ && !force_sample_select_ && !force_radix_ && N <= (uniform_gen ? 8192 : kern::sort_quantiles_max_rows());
-    if (std::getenv("GBRL_HIP_DEBUG_PREP")) fprintf(stderr, "[small_prep] candidate %d: coll %d n_global %lld N %d F %d fixed %d cand_only %d hooks %d %d %d %d %d\n", prep_candidate ? 1 : 0, has_coll_ ? 1 : 0, n_global, N, F, fixed_thr_.empty() ? 0 : 1, candidates_only_ ? 1 : 0, no_small_prep ? 1 : 0, no_sort_codes ? 1 : 0, force_bisection_ ? 1 : 0, force_sample_select_ ? 1 : 0, force_radix_ ? 1 : 0);
     auto run_stats = [&]() {
         // sums -> mean -> centred squares -> std, maxima, scales: all on the device (k_stats_mean / k_stats_finish); the host
         // reads the scales together with the thresholds (one synchronisation for both).  Row-sharded runs sum the column
@@ -2038,7 +2037,6 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         uint16_t *d_fm = static_cast<uint16_t *>(d_codes_fm_.ensure(sizeof(uint16_t) * static_cast<size_t>(N) * F));
         prep_done = kern::small_prep(dobs, N, F, B, uniform_gen, d_cum, d_thr, d_thrkeys, d_codes, d_fm, dgrads, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg,
                                      !no_small_stats, &stats_done, s);
-        if (std::getenv("GBRL_HIP_DEBUG_PREP")) fprintf(stderr, "[small_prep] N %d F %d B %d D %d uniform %d -> done %d stats %d\n", N, F, B, D, uniform_gen ? 1 : 0, prep_done ? 1 : 0, stats_done ? 1 : 0);
         if (prep_done) { codes_from_sort = true; last_quantile_fallback_ = false; prep_launches = 1; d_codes_fm = d_fm; }
         if (stats_done) stats_fused = true;
         else run_stats();

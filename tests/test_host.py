@@ -324,3 +324,20 @@ def test_register_tile_asm_header_is_current_and_the_compiler_keeps_out_of_the_b
         limit = base["k_predict_pc"] if "k_predict_pc" in k else base["k_predict_reg"]
         assert 0 <= top[k] < limit, (k, top[k], limit)
         assert seen[k]["ScratchSize"] == 0 and seen[k]["NumVgprs"] <= 256 and seen[k]["Occupancy"] >= 2, (k, seen[k])
+
+
+def test_every_environment_hook_the_product_reads_is_listed_in_integration_md():
+    """INTEGRATION.md section 5 is the one place that lists every `GBRL_HIP_*` hook with its status (supported / test / measurement):
+    a hook read by the product sources but missing from the table fails here."""
+    src = os.path.join(ROOT, "gbrl_amd", "csrc")
+    read = set()
+    for name in os.listdir(src):
+        if name.endswith((".hip", ".cpp", ".h")):
+            read |= set(re.findall(r'getenv\("(GBRL_HIP_[A-Z0-9_]+)"\)', open(os.path.join(src, name)).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    listed = set(re.findall(r"GBRL_HIP_[A-Z0-9_]+", doc))
+    # families written as `GBRL_HIP_PREDICT_RG / _TT / _NB` in the table
+    for fam in re.findall(r"`(GBRL_HIP_[A-Z0-9_]+?)_([A-Z0-9]+) / (_[A-Z0-9]+(?: / _[A-Z0-9]+)*)", doc):
+        for suffix in fam[2].split(" / "):
+            listed.add(fam[0] + suffix)
+    assert len(read) > 30 and not (read - listed), sorted(read - listed)
