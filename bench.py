@@ -239,6 +239,36 @@ def leg_collective(torch, np, gbrl_amd, workload, X, G, F, D, depth, B, steps, p
             "note": "one GPU, no xGMI traffic: the fixed cost of the row-sharded path; multi-GPU scaling is measured by the driver's --gpus N runs"}
 
 
+def leg_predict_deep(torch, np, gbrl_amd, dev, X, D, B, depth=8, trees=1000, mini=4096):
+    """predict() over 1000 oblivious trees of max_depth 8 on the bench's 2^20 x 128 rows (the reference has no depth limit,
+    predictor.cpp:231-265; the register-tile kernels stop at depth 6, so this leg runs the LDS-tile kernel).  The trees are grown on
+    4096-row minibatches of the same matrix (the one-launch growth: a second per 1000 trees)."""
+    N, F = X.shape
+    m = make_model(gbrl_amd, np, "cfg2", F, 0, D, depth, B, "bench_deep")
+    tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    W = torch.randn((8, D), device=dev, generator=gen)
+    m.set_profiling(0)
+    t0 = time.perf_counter()
+    for i in range(trees):
+        o = (i * mini) % (N - mini + 1)
+        xs = X[o:o + mini]
+        g = (torch.tanh(xs[:, :8] @ W) + 0.5 * torch.randn((mini, D), device=dev, generator=gen)).contiguous()
+        m.step(tup(xs), None, tup(g))
+    torch.cuda.synchronize()
+    grow_s = time.perf_counter() - t0
+    m.set_profiling(1)
+    xo = tup(X)
+    dt = time_predict(torch, m, xo, None, 5)
+    T = m.get_num_trees()
+    depths = np.asarray(m.get_ensemble_data()["depths"])
+    return {"workload": "oblivious, max_depth %d, %d trees grown on %d-row minibatches; predict on %d x %d rows" % (depth, T, mini, N, F),
+            "trees": T, "mean_depth": float(depths.mean()), "ms_per_call": dt * 1e3, "kernel_ms": m.last_phase_times().get("predict", 0.0),
+            "rows_per_s": N / dt, "row_trees_per_s": N * T / dt, "grown": "%d steps in %.2f s (%.2f ms/step)" % (T, grow_s, grow_s * 1e3 / max(1, T)),
+            "roofline_hbm_frac": (N * (F * 4 + D * 4)) / dt / 1e9 / HBM_PEAK_GBS}
+
+
 def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
     """BASELINE configs[0], the reference's own CPU-runnable case (tests/test_gbt_single.py:46-61): single-output MultiRMSE loop --
     predict, gradient = prediction - target, step -- 4096 rows x 16 features, greedy / L2 / quantile, depth 4, 30 trees.  The product
@@ -680,6 +710,10 @@ def main():
                 extra["cfg3"] = leg_cfg3(torch, np, gbrl_amd, dev, X, G, D, depth, B)
             except Exception as e:   # a leg is reporting only; never let it hide the timed measurement
                 extra["cfg3"] = {"error": repr(e)}
+        try:
+            extra["predict_depth8"] = leg_predict_deep(torch, np, gbrl_amd, dev, X, D, B)
+        except Exception as e:
+            extra["predict_depth8"] = {"error": repr(e)}
         del X, G
         torch.cuda.empty_cache()
         try:
@@ -733,7 +767,7 @@ def main():
             "predict": {"rows_per_s": world * N / dtp, "trees": n_trees, "ms_per_call": dtp * 1e3, "kernel_ms": pk,
                         "row_trees_per_s": world * N * n_trees / dtp, "roofline": predict_roofline(N, F, D, n_trees, depth, dtp)},
             "predict_large_ensemble": large,
-            "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"), "cfg1": extra.get("cfg1"),
+            "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"), "predict_depth8": extra.get("predict_depth8"), "cfg1": extra.get("cfg1"),
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
             "collective": (extra.get("collective") if coll is None else
                            {"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)}),

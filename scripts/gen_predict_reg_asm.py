@@ -277,6 +277,115 @@ class VariantPC:
         return L
 
 
+
+# ======================================================================================================================
+# Deep fp32 variant (round 5): 7 and 8 tree levels.  Two trees per step need 4 * maxd record dwords and 4 * maxd mask registers; with the
+# records double-buffered (class Variant) 8 levels would need 124 scalar registers.  This variant keeps ONE record buffer and TWO value
+# sets, with VariantPC's pipeline: every iteration waits once, issues the value reads of the previous step, the compares of this one, the
+# record loads of the next (into the buffer the compares have just read), the leaf sums, and the multiply-adds of the step before last.
+# Register map = class Variant's (bank v88 .. v215, leaves v216 / v217, values from v218: 4 * dmax registers).
+class VariantDeep:
+    def __init__(self, maxd, dmax):
+        self.maxd, self.dmax = maxd, dmax
+        self.dw = dmax // 4
+        self.ls = 1 << maxd
+        self.rec = self.ls * dmax * 4
+        self.slice = self.ls * self.dw * 4
+        self.tree_dw = 2 * maxd
+        self.step_dw = 2 * self.tree_dw
+        self.step_bytes = 4 * self.step_dw
+        self.r0 = 28
+        self.m0 = self.r0 + self.step_dw
+        self.s_end = self.m0 + 4 * maxd
+        assert self.s_end <= 100, (maxd, self.s_end)
+        self.v_end = V0 + 4 * dmax
+        assert self.v_end <= 256
+        assert 2 * self.rec + 3 * self.slice < 65536      # ds_read offsets are 16 bits
+        self.sfx = f"D{maxd}O{dmax}"
+
+    def loads(self, off, dw=None):
+        out, dw, r, o = [], (self.step_dw if dw is None else dw), self.r0, off
+        for width in (16, 8, 4, 2, 1):
+            while dw >= width:
+                out.append(f"s_load_dword{'x%d' % width if width > 1 else ''} {sreg(r, width)}, s[26:27], {hex(o)}")
+                dw -= width; r += width; o += 4 * width
+        assert dw == 0
+        return out
+
+    def cmps(self, trees=2):
+        out, first = [], True
+        for t in range(trees):
+            for d in range(self.maxd):
+                f = self.r0 + 2 * (t * self.maxd + d)
+                m = self.m0 + 2 * (t * self.maxd + d)
+                out.append(f"s_set_gpr_idx_on {sreg(f)}, gpr_idx(SRC0)" if first else f"s_set_gpr_idx_idx {sreg(f)}")
+                first = False
+                out.append(f"v_cmp_gt_f32_e64 {sreg(m, 2)}, {vreg(TB)}, {sreg(f + 1)}")
+        out.append("s_set_gpr_idx_off")
+        return out
+
+    def addcs(self, trees=2):
+        out = []
+        regs = [LA, LB][:trees]
+        for d in range(self.maxd):
+            for t, l in enumerate(regs):
+                m = self.m0 + 2 * (t * self.maxd + d)
+                src = "0, 0" if d == 0 else f"{vreg(l)}, {vreg(l)}"
+                out.append(f"v_addc_co_u32_e64 {vreg(l)}, vcc, {src}, {sreg(m, 2)}")
+        return out
+
+    def dsreads(self, vset, trees=2):
+        out = []
+        sh = {1: 2, 2: 3}[self.dw]
+        regs = [LA, LB][:trees]
+        for l in regs:
+            out.append(f"v_lshl_add_u32 {vreg(l)}, {vreg(l)}, {sh}, %[vb]")
+        for t, l in enumerate(regs):
+            base = V0 + vset * 2 * self.dmax + t * self.dmax
+            for sl in range(4):
+                off = t * self.rec + sl * self.slice
+                width = {1: "b32", 2: "b64"}[self.dw]
+                out.append(f"ds_read_{width} {vreg(base + self.dw * sl, self.dw)}, {vreg(l)} offset:{off}")
+        out.append(f"s_add_u32 %[vb], %[vb], {trees * self.rec}")
+        return out
+
+    def fmas(self, vset, trees=2):
+        out = []
+        for t in range(trees):
+            base = V0 + vset * 2 * self.dmax + t * self.dmax
+            for pr in range(self.dmax // 2):
+                out.append(f"v_pk_fma_f32 %[p{pr}], %[n{pr}], {vreg(base + 2 * pr, 2)}, %[p{pr}]")
+        return out
+
+    def walk_steps(self):
+        """n >= 1 steps; the schedule of VariantPC.walk_steps."""
+        sb = self.step_bytes
+        adv = [f"s_add_u32 s26, s26, {sb}", "s_addc_u32 s27, s27, 0"]
+        def it(s_par, with_ds, with_fma):
+            L = ["s_waitcnt lgkmcnt(0)"]
+            if with_ds:
+                L += self.dsreads((s_par + 1) % 2)
+            L += self.cmps() + adv + self.loads(0) + self.addcs()
+            if with_fma:
+                L += self.fmas(s_par)
+            return L
+        dec = ["s_sub_u32 %[n], %[n], 1", "s_cmp_eq_u32 %[n], 0"]
+        L = ["s_mov_b32 s26, %[cpl]", "s_mov_b32 s27, %[cph]"] + self.loads(0)
+        L += it(0, False, False) + dec + ["s_cbranch_scc1 4f"]
+        L += it(1, True, False) + dec + ["s_cbranch_scc1 5f"]
+        L += ["1:"] + it(0, True, True) + dec + ["s_cbranch_scc1 6f"]
+        L += it(1, True, True) + ["s_sub_u32 %[n], %[n], 1", "s_cmp_lg_u32 %[n], 0", "s_cbranch_scc1 1b"]
+        L += ["5:"] + self.dsreads(1) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(0) + self.fmas(1) + ["s_branch 9f"]
+        L += ["6:"] + self.dsreads(0) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(1) + self.fmas(0) + ["s_branch 9f"]
+        L += ["4:"] + self.dsreads(0) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(0) + ["9:"]
+        return L
+
+    def walk_one(self):
+        L = ["s_mov_b32 s26, %[cpl]", "s_mov_b32 s27, %[cph]"] + self.loads(0, self.tree_dw) + ["s_waitcnt lgkmcnt(0)"]
+        L += self.cmps(1) + self.addcs(1) + self.dsreads(0, 1) + ["s_waitcnt lgkmcnt(0)"] + self.fmas(0, 1)
+        return L
+
+
 def load_tile_pc():
     L = ["s_getpc_b64 s[26:27]", "s_add_u32 s26, s26, %[skip]", "s_addc_u32 s27, s27, 0", "s_setpc_b64 s[26:27]"]
     for piece in range(PC_NF // 4 - 1, -1, -1):
@@ -321,6 +430,13 @@ def generate():
         out.append(f"// ---- {maxd} levels, {dmax} padded outputs: {v.rec} bytes of values per tree, {v.step_bytes} bytes of records per step")
         out.append(f"#define PR_CLOB_TEMPS_{v.sfx} \\\n    " + clob("v", LA, v.v_end))
         out.append(f"#define PR_CLOB_SGPR_{v.sfx} \\\n    " + clob("s", 26, max(v.s_end, 101 if PREFETCH_STEPS else 0)))
+        out.append(f"#define PR_ASM_WALK_STEPS_{v.sfx} \\\n" + cstr(v.walk_steps()))
+        out.append(f"#define PR_ASM_WALK_ONE_{v.sfx} \\\n" + cstr(v.walk_one()))
+    for maxd, dmax in ((8, 8), (8, 4)):
+        v = VariantDeep(maxd, dmax)
+        out.append(f"// ---- {maxd} levels (single record buffer, two value sets), {dmax} padded outputs: {v.rec} bytes of values per tree, {v.step_bytes} bytes of records per step")
+        out.append(f"#define PR_CLOB_TEMPS_{v.sfx} \\\n    " + clob("v", LA, v.v_end))
+        out.append(f"#define PR_CLOB_SGPR_{v.sfx} \\\n    " + clob("s", 26, v.s_end))
         out.append(f"#define PR_ASM_WALK_STEPS_{v.sfx} \\\n" + cstr(v.walk_steps()))
         out.append(f"#define PR_ASM_WALK_ONE_{v.sfx} \\\n" + cstr(v.walk_one()))
     out.append("// ==== packed-code variant (rows wider than the fp32 bank, categorical columns): see VariantPC in the generator")

@@ -54,7 +54,8 @@ for i in range(n_cases):
     ranges = [(a, b) for a, b in ranges if (a, b) == (0, 0) or b > a]
     env({"GBRL_HIP_PREDICT_GENERIC": "1"})
     want = [np.asarray(m.predict(Xn, Cn, a, b)) for a, b in ranges]
-    covered = case["depth"] <= 6 and (D <= 8 or (Fc == 0 and F <= 128 and F % 4 == 0)) and (F + 1) // 2 + 0 <= 160
+    fp32_rows = Fc == 0 and 0 < F <= 128 and F % 4 == 0
+    covered = (case["depth"] <= 6 and (D <= 8 or fp32_rows) and (F + 1) // 2 + 0 <= 160) or (case["depth"] in (7, 8) and D <= 8 and fp32_rows)
     for mode in ({"GBRL_HIP_PREDICT_REG_MIN_ROWS": "1"}, {"GBRL_HIP_PREDICT_REG_MIN_ROWS": "1", "GBRL_HIP_PREDICT_REG_GROUPED": str(int(rng.choice([1, 3, 8])))}):
         env(dict(mode, **({"GBRL_HIP_PREDICT_REG_ONLY": "1"} if covered and Fc == 0 else {})))
         try:

@@ -63,10 +63,11 @@ MODES = (("reg", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_MIN_RO
          ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"}))
 
 
-@pytest.mark.parametrize("depth", [1, 3, 4, 5, 6])
+@pytest.mark.parametrize("depth", [1, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("D,F", [(8, 128), (3, 12), (4, 64), (7, 20), (1, 4), (5, 100), (12, 40), (16, 128)])
 def test_register_tile_kernel_equals_the_general_kernel(depth, D, F, monkeypatch):
-    """Every compiled variant (4 / 6 levels x 4 / 8 / 16 padded outputs; the packed-code kernels stop at 8 outputs), row widths below the register bank (the computed jump of the
+    """Every compiled variant (4 / 6 levels x 4 / 8 / 16 padded outputs; round 5: 8 levels x 4 / 8 padded outputs, the single-record-buffer
+    pipeline; the packed-code kernels stop at 6 levels and 8 outputs), row widths below the register bank (the computed jump of the
     tile load), output counts below the padded width, batches that end inside a 64-row tile, tree ranges that start and stop at odd
     and even trees (the pipelined pair loop + the single-tree tail), both launch shapes and groups that end inside the range."""
     n_trees = 27
@@ -78,6 +79,8 @@ def test_register_tile_kernel_equals_the_general_kernel(depth, D, F, monkeypatch
     m, _ = _grow(case)
     ranges = ((0, 0), (0, 1), (0, 2), (3, 20), (4, 21), (11, 12), (16, 27), (26, 27))
     modes = [mm for mm in MODES if D <= 8 or mm[0] != "packed"]
+    if depth > 6:   # 7-8 levels: fp32 register tiles up to 8 outputs, no packed-code variant; wider outputs stay on the older kernels
+        modes = [mm for mm in modes if mm[0] != "packed" and (D <= 8 or mm[0] in ("gen2", "generic"))]
     for n in (1, 63, 64, 65, 1000, 4133):
         Xp = _batch(case, n, seed=n)
         outs = {}
@@ -87,7 +90,7 @@ def test_register_tile_kernel_equals_the_general_kernel(depth, D, F, monkeypatch
         for mode, _ in modes:
             for r, a, b in zip(ranges, outs[mode], outs["generic"]):
                 assert a.shape == b.shape and np.array_equal(a, b), (mode, n, r)
-        assert np.abs(outs["reg"][0]).max() > 0
+        assert np.abs(outs["generic"][0]).max() > 0
 
 
 def test_register_tile_kernel_on_a_large_batch_and_a_large_ensemble(monkeypatch):
@@ -111,9 +114,32 @@ def test_register_tile_kernel_on_a_large_batch_and_a_large_ensemble(monkeypatch)
             assert np.array_equal(a, b), (mode, r)
 
 
+@pytest.mark.parametrize("depth,D", [(8, 8), (7, 8), (8, 3)])
+def test_deep_register_tile_kernel_on_a_large_batch(depth, D, monkeypatch):
+    """max_depth 7 and 8 at the shapes the variant exists for: 2^17 rows x 128 features; 10 trees (resident values: 8 KiB per tree at 8
+    outputs), 19 (the most that stay resident), 45 (grouped: groups of 8 trees, the last one partial; an odd count takes the single-tree
+    tail) -- default dispatch, bitwise equal to the general kernel and to the second-generation kernel."""
+    n_trees = 45
+    case = dict(name="prl8", seed=4300 + depth + D, N=3000, F=128, Fc=0, D=D, depth=depth, n_bins=64, score="L2", gen="Quantile", policy="oblivious", trees=n_trees)
+    m, _ = _grow(case)
+    assert int(np.asarray(m.get_ensemble_data()["depths"]).max()) == depth
+    Xp = _batch(case, (1 << 17) + 77, seed=6)
+    ranges = ((0, 10), (1, 20), (0, 19), (0, 0), (3, 45), (0, 44), (40, 45))
+    outs = {}
+    for mode, env in (("reg", {"GBRL_HIP_PREDICT_REG_ONLY": "1"}), ("reg_groups_of_3", {"GBRL_HIP_PREDICT_REG_ONLY": "1", "GBRL_HIP_PREDICT_REG_GROUPED": "3"}),
+                      ("gen2", {"GBRL_HIP_PREDICT_NO_REG": "1", "GBRL_HIP_PREDICT_NO_PC": "1"}), ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"})):
+        _set(monkeypatch, env)
+        outs[mode] = [np.asarray(m.predict(Xp, None, a, b)) for a, b in ranges]
+    for mode in ("reg", "reg_groups_of_3", "gen2"):
+        for r, a, b in zip(ranges, outs[mode], outs["generic"]):
+            assert np.array_equal(a, b), (mode, r)
+    assert np.abs(outs["reg"][0]).max() > 0
+
+
 def test_register_tile_kernel_takes_device_inputs_and_declines_what_it_does_not_cover(monkeypatch):
     """Device-resident inputs (the bench's path) through DLPack; a feature count that is not a multiple of four goes to the
-    packed-code kernel; trees deeper than six levels are declined by both (REG_ONLY raises) and predicted by the older kernels."""
+    packed-code kernel; seven levels go to the round-5 deep variant; trees deeper than eight levels are declined by both (REG_ONLY raises)
+    and predicted by the older kernels."""
     import torch
     import gbrl_amd
     case = dict(name="prd", seed=77, N=2000, F=24, Fc=0, D=4, depth=4, n_bins=32, score="L2", gen="Uniform", policy="oblivious", trees=9)
@@ -129,7 +155,7 @@ def test_register_tile_kernel_takes_device_inputs_and_declines_what_it_does_not_
     _set(monkeypatch, {"GBRL_HIP_PREDICT_REG_ONLY": "1"})
     got = torch.from_dlpack(md.predict((t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda"), None, 0, 0)).cpu().numpy()
     assert np.array_equal(got, want)
-    for variant, taken in ((dict(case, F=23, name="prd_odd"), True), (dict(case, depth=7, name="prd_deep"), False)):
+    for variant, taken in ((dict(case, F=23, name="prd_odd"), True), (dict(case, depth=7, name="prd_deep7"), True), (dict(case, depth=9, name="prd_deep9"), False)):
         _set(monkeypatch, {})
         mo, _ = _grow(variant)
         Xo = _batch(variant, 40000, seed=2)
