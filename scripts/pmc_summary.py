@@ -44,6 +44,6 @@ open(out_txt, "w").write("\n".join(lines) + "\n")
 hb = [v for k, v in summary.items() if "k_hist_build" in k]
 if hb:
     json.dump({"kernel": "k_hist_build", "bytes_per_launch": hb[0]["corrected_bytes_per_call"], "launches_per_tree": 6,
-               "source": out_txt, "commit": COMMIT, "taken": time.strftime("%Y-%m-%d %H:%M"), "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; traffic = 2*FETCH + WRITE (gfx950 correction)"},
+               "source": "profiles/rNN_pmc_traffic.txt (scripts/collect_evidence.sh writes it as gpurun_out/evidence/" + os.path.basename(out_txt) + "; copied into profiles/ under the round's name)", "commit": COMMIT, "taken": time.strftime("%Y-%m-%d %H:%M"), "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; traffic = 2*FETCH + WRITE (gfx950 correction)"},
               open(out_json, "w"), indent=1)
 print("\n".join(lines[:14]))
