@@ -426,6 +426,15 @@ int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float
     return n;
 }
 
+int gbrl_hip_replay_scores(const float *grads, const uint8_t *in_node, const uint8_t *goes_right, int n_rows, int output_dim,
+                           const float *meanden, int cosine, int min_data_in_leaf, float *out_scores) {
+    if (!grads || !in_node || !goes_right || !out_scores || n_rows < 1 || output_dim < 1) return GBRL_HIP_E_INVALID;
+    return guarded([&] {
+        if (!gbrl::kern::near_tie_selftest(grads, in_node, goes_right, n_rows, output_dim, meanden, cosine != 0, min_data_in_leaf, out_scores))
+            throw gbrl::Unsupported("near-tie replay: shape not supported (n_rows <= 65536, output_dim <= 2048) or no HIP device");
+    });
+}
+
 int gbrl_hip_set_profiling(gbrl_hip_model *m, int enabled) {
     if (!m) return GBRL_HIP_E_INVALID;
     m->engine.set_profiling(enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled));

@@ -256,6 +256,10 @@ void Engine::phases_resolve() {
     ev_used_ = 0;
     ev_names_.clear();
     if (profiling_ >= 2 && prep_launches_ > 0) phases_.emplace_back("prep_launches", static_cast<float>(prep_launches_));   // not a time: 1 = the fused preparation kernel ran
+    if (profiling_ >= 2) {   // not times: counters since the engine was created (near-tie replay, neartie.hip)
+        phases_.emplace_back("near_replays", static_cast<float>(near_replays_));
+        phases_.emplace_back("near_bailouts", static_cast<float>(near_bailouts_));
+    }
     if (has_coll_) {   // not times: what this call handed to the transport (all-reduce payload; a reduce-scatter counts half its send buffer)
         phases_.emplace_back("exchange_payload_mb", static_cast<float>(exch_bytes_ / 1e6));
         phases_.emplace_back("exchange_calls", static_cast<float>(exch_calls_));

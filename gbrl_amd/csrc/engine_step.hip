@@ -83,6 +83,7 @@ struct GrowCtx {
     const uint16_t *d_codes_fm;  // [F][N] feature-major copy of the numeric codes (fused preparation only), else null
     const int32_t *d_qg;
     const float *dgrads;
+    const float *d_meanden;      // L2: [D] mean | [D] std + 1e-8f of the build gradients' standardisation; null for Cosine (raw gradients)
     kern::StepScales *d_scales;
 };
 
@@ -1073,7 +1074,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const bool no_small_grow = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_GROW"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     const int small_G = (!has_coll_ && !no_small_grow && n_global == N && n_cand > 0 && !l2_degenerate && MD >= 1 && !(oblivious && device_levels_requested()) &&
                          kern::small_grow_supported(N, D, NB, MD, n_slots, n_cand)) ? kern::small_grow_blocks(n_slots) : 0;
-    const bool use_small = small_G > 0;
+    const bool use_small = small_G > 0 && !force_level_loop_;
     // per-step constants: slots, candidate weights / reference order / slot lookup
     const std::vector<int32_t> &cand_slot = *c.cand_slot;
     const size_t table_cap = c.prefix_cacheable ? static_cast<size_t>(std::max(c.cand_cap, n_cand)) : static_cast<size_t>(n_cand);
@@ -1164,6 +1165,13 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const size_t am_cap = static_cast<size_t>(max_front) * std::max(am_parts, std::max(1, n_slots));   // greedy: one part per feature slot
     float *d_am_v = static_cast<float *>(d_am_v_.ensure(sizeof(float) * am_cap));
     int32_t *d_am_i = static_cast<int32_t *>(d_am_i_.ensure(sizeof(int32_t) * am_cap));
+    // Near-tie replay (neartie.hip; one GPU, batches of <= 65 536 rows): the selection also tracks the best DISTINCT runner-up; a node whose
+    // runner-up is within `near_rel` of the winner (or whose winning gain is that close to zero) has the candidates in the window re-scored
+    // in the reference's float32 sequence.  GBRL_HIP_NO_NEARTIE_REPLAY=1: the exact arg-max decides everywhere (rounds 1-4).
+    const bool no_near = [] { const char *e = std::getenv("GBRL_HIP_NO_NEARTIE_REPLAY"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const float near_rel = [] { const char *e = std::getenv("GBRL_HIP_NEARTIE_REL"); return e ? static_cast<float>(std::atof(e)) : 9.5367431640625e-07f; }();   // 2^-20; measurement hook
+    const bool near_on = !no_near && !has_coll_ && n_global == N && n_cand > 0 && kern::near_tie_supported(N, D);
+    float *d_am_s = (near_on && !use_small) ? static_cast<float *>(d_am_s_.ensure(sizeof(float) * am_cap)) : nullptr;
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
     {   // zero unless the last tree's publication handed these words back clean
@@ -1399,6 +1407,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         if (seq == 0) seq = ++level_seq_;
         io.seq = seq;
         io.scales_out = reinterpret_cast<kern::StepScales *>(c.pub_scales_dev);
+        io.near_rel = near_on ? near_rel : 0.0f;
         static const bool sg_prof = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_PROF"); return e && e[0] == '1'; }();   // measurement hook
         if (sg_prof) io.prof = reinterpret_cast<uint32_t *>(d_blk + o_status + 64);
         h_status[0] = 0;
@@ -1410,6 +1419,14 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         spin_until_published(h_status, seq, s, "small-step tree");
         const auto t_seen = std::chrono::steady_clock::now();
         hip_check(hipGetLastError(), "growth kernel");
+        if (h_status[3] == 2) {
+            // a level of this tree has a near-tie: the level loop grows it, with the candidates in the window re-scored in the reference's order
+            ++near_bailouts_;
+            struct Reset { bool &f; ~Reset() { f = false; } } reset{force_level_loop_};
+            force_level_loop_ = true;
+            grow_tree(c, nodes, frontier, acc, leaf_scale);
+            return;
+        }
         if (h_status[3] != 0) {
             sg_sync_ptr_ = nullptr;
             throw HipError("small-step growth kernel gave up at a grid barrier (its blocks were not co-resident?)");
@@ -1730,11 +1747,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         if (own_slots > 0)
             kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                    d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
-                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0, !drop_derived);
+                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0, !drop_derived, oblivious ? nullptr : d_am_s);
         // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
         // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
         if (oblivious)
-            kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s);
+            kern::argmax(d_scores, n_act, n_cand, d_cand_w, d_cand_ref, d_parent, d_isroot, oblivious, d_am_v, d_am_i, d_best_idx, d_best_score, s, d_am_s);
         // counts4 = [total | right] from the (global) histogram; sharded runs add [right_local] counted from the local rows
         // (one GPU: the kernel itself mirrors the result block into the pinned host copy and its last block publishes the sequence word)
         uint32_t seq = 0;
@@ -1743,9 +1760,11 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             seq = ++level_seq_;
             if (seq == 0) seq = ++level_seq_;
         }
+        const bool near_level = d_am_s != nullptr && publish_in_resolve;
+        const kern::NearDetect near_detect{d_am_s, near_rel, d_parent, d_isroot, cosine ? 1 : 0, N};
         kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
                              d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, publish_in_resolve ? h_res_dev : nullptr, d_flag, seq, d_pub_done,
-                             drop_derived ? d_hist_prev : nullptr, drop_derived ? d_sub_par : nullptr, drop_derived ? d_sub_sib : nullptr);
+                             drop_derived ? d_hist_prev : nullptr, drop_derived ? d_sub_par : nullptr, drop_derived ? d_sub_sib : nullptr, near_level ? &near_detect : nullptr);
         if (has_coll_) {
             // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
             const int n_win = oblivious ? 1 : n_act;
@@ -1784,6 +1803,52 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             }
         }
         hip_check(hipGetLastError(), "growth kernels");
+        if (near_level) {
+            // flags of the level (k_resolve_splits): any -> the candidates in the window are scored once more, the reference's way, the final
+            // arg-max stage runs on their outcome and the partition -- already enqueued from the exact decision, its input list is intact -- runs again
+            const int64_t *near_h = reinterpret_cast<const int64_t *>(h_res + 8 * static_cast<size_t>(max_front)) + 2 * static_cast<size_t>(max_front);
+            bool any = false;
+            for (int k = 0; k < (oblivious ? 1 : n_act); ++k) any = any || near_h[k] != 0;
+            static const bool near_debug = [] { const char *e = std::getenv("GBRL_HIP_NEARTIE_DEBUG"); return e && e[0] == '1'; }();   // measurement hook
+            if (any && near_debug) {
+                const float *bs = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
+                for (int k = 0; k < (oblivious ? 1 : n_act); ++k)
+                    if (near_h[k]) {
+                        const int32_t sb = static_cast<int32_t>(near_h[max_front + k]);
+                        float sec; std::memcpy(&sec, &sb, 4);
+                        fprintf(stderr, "[near-tie] depth %d node %d of %d (%d rows): best gain %.9g (candidate %d), runner-up %.9g, difference %.3g\n", depth, k, n_act, nodes[active[k]].n_local,
+                                bs[k], reinterpret_cast<const int32_t *>(h_res)[k], sec, bs[k] - sec);
+                    }
+            }
+            if (any) {
+                ++near_replays_;
+                phase_begin();
+                if (!oblivious)   // every candidate's exact score (the greedy selection kept the per-slot bests only)
+                    kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
+                                           d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot, nullptr, d_am_i, s, 0, !drop_derived);
+                kern::NearTieIO io{};
+                io.rows = d_rows[cur]; io.seg_start = d_seg_starts; io.n_rows = d_n_locals; io.codes = d_codes; io.N = N; io.D = D; io.grads = dgrads; io.meanden = c.d_meanden;
+                io.cosine = cosine ? 1 : 0; io.oblivious = oblivious ? 1 : 0; io.min_data = md.min_data_in_leaf; io.slots = d_slots; io.cand_slot = d_cand_slot; io.cand_w = d_cand_w; io.cand_ref = d_cand_ref;
+                io.n_cand = n_cand; io.scores = d_scores; io.parent = d_parent; io.is_root = d_isroot; io.best_score = d_best_score; io.near = d_counts4 + 2 * static_cast<size_t>(max_front);
+                io.rel = near_rel; io.n_act = n_act;
+                int32_t *lists = static_cast<int32_t *>(d_near_list_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * (kern::kNearCands + 1)));
+                io.list = lists; io.list_n = lists + static_cast<size_t>(max_front) * kern::kNearCands;
+                io.ent = static_cast<int32_t *>(d_near_ent_.ensure(sizeof(int32_t) * static_cast<size_t>(kern::kNearCands + 1) * N));
+                io.rep = static_cast<float *>(d_near_rep_.ensure(sizeof(float) * static_cast<size_t>(max_front) * (kern::kNearCands + 1)));
+                io.part_v = d_am_v; io.part_i = d_am_i; io.n_parts = oblivious ? am_parts : own_slots;
+                kern::near_tie_replay(io, s);
+                seq = ++level_seq_;
+                if (seq == 0) seq = ++level_seq_;
+                kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+                                     d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, h_res_dev, d_flag, seq, d_pub_done,
+                                     drop_derived ? d_hist_prev : nullptr, drop_derived ? d_sub_par : nullptr, drop_derived ? d_sub_sib : nullptr, nullptr);
+                if (!part_chunks.empty())
+                    kern::partition_rows(d_rows[cur], d_rows[cur ^ 1], d_codes, c.d_kt, N, d_part_chunks, static_cast<int>(part_chunks.size()), d_resolved, d_cursors, s);
+                phase_end("near_tie_replay");
+                spin_until_published(h_flag, seq, s, "level results after the near-tie replay");
+                hip_check(hipGetLastError(), "near-tie replay kernels");
+            }
+        }
         LevelOutcome lvl = digest_level(active, h_res);
         if (lvl.stop) break;
         std::vector<int> &splitting = lvl.splitting, &new_leaves = lvl.new_leaves, &next = lvl.next;
@@ -2226,7 +2291,7 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     gc.const_cacheable = const_cacheable; gc.cat_cands = &cat_cands;
     gc.prefix_cacheable = prefix_cacheable; gc.n_num_cand = n_num_cand; gc.cand_cap = (F + Fc) * B;
     gc.pub_thr_dev = static_cast<char *>(pin_dev); gc.pub_scales_dev = static_cast<char *>(pin_dev) + (reinterpret_cast<char *>(h_scales_pin) - pin_ts); gc.pub_thr_bytes = sizeof(float) * n_thr;
-    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.root_le = (Fc == 0 && !has_coll_) ? root_le_ : nullptr; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_codes_fm = d_codes_fm; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_scales = d_scales;
+    gc.h_thr = h_thr; gc.h_scales = h_scales_pin; gc.d_thr = d_thr; gc.d_thrkeys = d_thrkeys; gc.root_le = (Fc == 0 && !has_coll_) ? root_le_ : nullptr; gc.d_kt = d_kt; gc.d_codes = d_codes; gc.d_codes_fm = d_codes_fm; gc.d_qg = d_qg; gc.dgrads = dgrads; gc.d_meanden = cosine ? nullptr : d_meanden; gc.d_scales = d_scales;
     std::vector<HNode> nodes;
     std::vector<int> frontier;
     std::vector<int64_t> acc;

@@ -244,13 +244,18 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       float *part_v /*nullable.  greedy: [n_nodes][n_slots] best gain per feature -- arg-max stage 1 fused, scores not written*/,
                       int32_t *part_i, hipStream_t s, int slot0 = 0 /* first feature slot scored (n_slots of them): feature-parallel scoring */,
                       bool keep_derived = true /* false (last level only): derived slices are scored but not written back; resolve_splits
-                      must then be given hist_prev / sub_par / sub_sib */);
+                      must then be given hist_prev / sub_par / sub_sib */,
+                      float *part_s = nullptr /* greedy, nullable: [n_nodes][n_slots] the best gain strictly below part_v (near-tie detection) */);
 // best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
 // result (sum over nodes); greedy: one per node.  part_v/part_i: scratch of n_nodes * argmax_parts(n_cand).
 int argmax_parts(int n_cand);
 void argmax(const float *scores, int n_nodes, int n_cand, const float *cand_weight, const int32_t *cand_ref, const float *parent,
             const int32_t *is_root, bool oblivious, float *part_v, int32_t *part_i, int32_t *best_idx, float *best_score,
-            hipStream_t s);
+            hipStream_t s, float *part_s = nullptr /* nullable: per block the best score strictly below part_v */);
+
+// near-tie detection inside resolve_splits (one GPU): counts4[2 * max_front + node] = 1 when the best DISTINCT runner-up is within
+// rel * (magnitude of the scores) of the winner, or (greedy) the winning gain is that close to zero
+struct NearDetect { const float *part_s; float rel; const float *parent; const int32_t *is_root; int cosine; long long rows; /* of the batch (oblivious levels) */ };
 
 // winner -> (feature slot, class) and the child sizes it induces, per active node (one read-back per level)
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*argmax stage-1 output; the final stage runs here*/,
@@ -264,7 +269,46 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
                     uint32_t *pub_flag = nullptr /*... the last block stores pub_seq here (system scope)*/, uint32_t pub_seq = 0,
                     unsigned *pub_done = nullptr /*device counter, zero between launches*/,
                     const int64_t *hist_prev = nullptr, const int32_t *sub_par = nullptr /*non-null: derived nodes' counts = hist_prev[par] - hist_local[sib]*/,
-                    const int32_t *sub_sib = nullptr);
+                    const int32_t *sub_sib = nullptr, const NearDetect *near = nullptr);
+
+// ---- near-tie replay (neartie.hip): the candidates inside the window of a flagged node are re-scored in the reference's float32
+// sequence, and the arg-max input of resolve_splits (part_v / part_i) is rewritten with the reference's comparison of them.
+constexpr int kNearCands = 16;         // distinct gains replayed per node (the closest ones)
+constexpr int kNearMaxRows = 65536;    // batches up to this many rows are replayed (a bit per row in LDS)
+constexpr int kNearMaxD = 2048;
+struct NearTieIO {
+    const int32_t *rows;        // the level's row list
+    const int32_t *seg_start;   // [n_act] first position of every active node's segment
+    const int32_t *n_rows;      // [n_act] its length
+    const uint16_t *codes;      // [group][row][16] class codes
+    int N, D;
+    const float *grads;         // [N][D] raw gradients
+    const float *meanden;       // L2: [D] mean | [D] std + 1e-8f of the step; nullptr: raw gradients (Cosine)
+    int cosine, oblivious, min_data;
+    const FeatureSlot *slots;
+    const int32_t *cand_slot;   // internal candidate -> feature slot
+    const float *cand_w;        // [n_cand] feature weight of every internal candidate
+    const int32_t *cand_ref;    // [n_cand] reference index of every internal candidate
+    int n_cand;
+    const float *scores;        // [n_act][n_cand] exact scores (score_candidates without part_v)
+    const float *parent;        // [n_act] exact parent scores
+    const int32_t *is_root;     // [n_act]
+    const float *best_score;    // [n_act] exact best gain (oblivious: [0])
+    const int64_t *near;        // [n_act] flags (oblivious: [0])
+    float rel;
+    int n_act;
+    int32_t *list;              // scratch [n_act][kNearCands]
+    int32_t *list_n;            // scratch [n_act]
+    int32_t *ent;               // scratch [(kNearCands + 1) * N]: ordered row lists
+    float *rep;                 // scratch [n_act][kNearCands + 1]: replayed scores, [kNearCands] = the parent's
+    float *part_v;              // arg-max stage-1 arrays of the level: rewritten for the replayed nodes
+    int32_t *part_i;
+    int n_parts;
+};
+bool near_tie_supported(int N, int D);
+void near_tie_replay(const NearTieIO &io, hipStream_t s);
+// diagnostics (gbrl_hip_replay_scores): one node given by per-row flags, host pointers; out[0] = split score, out[1] = parent score
+bool near_tie_selftest(const float *grads, const uint8_t *in_node, const uint8_t *goes_right, int n_rows, int D, const float *meanden, bool cosine, int min_data, float *out);
 
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);
@@ -332,6 +376,8 @@ struct SmallGrowIO {
     uint32_t seq;
     uint32_t *prof = nullptr;   // measurement: pinned, 16 words (block 0's time per phase, 10 ns units)
     StepScales *scales_out = nullptr;   // pinned, device-mapped: the step's scales for the host (what publish_pair hands over in the level loop)
+    float near_rel = 0.0f;      // > 0: near-tie detection -- the kernel gives the tree up (status word 3 = 2) at the first level whose runner-up
+                                // is within near_rel of the winner; the level loop then grows it with the replay (neartie.hip)
 };
 bool small_grow_supported(int N, int D, int NB, int MD, int n_slots, int n_cand);
 int small_grow_blocks(int n_slots);

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
                                                float *__restrict__ scores, float *__restrict__ parent,
                                                const float *__restrict__ cand_w, const int32_t *__restrict__ cand_ref,
                                                const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i, int slot0,
-                                               int keep_derived) {
+                                               int keep_derived, float *__restrict__ part_s /*nullable: second-best DISTINCT gain per block (near-tie detection)*/) {
     extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
     const double inv_scale = scp->inv_scale;
     const int node = blockIdx.y, fs = slot0 + blockIdx.x;
@@ -1065,6 +1065,7 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
     // root parent = 0, lowest reference index among maxima)
     const float par_sub = (part_v && is_root[node]) ? 0.0f : par_score;
     Best mine{-INFINITY, 0x7fffffff};
+    float second = -INFINITY;     // the best gain strictly below mine.v (candidates with EQUAL gains split the node's rows identically)
     const int np = s_np;
     for (int k = threadIdx.x; k < sl.n_cand; k += blockDim.x) {
         const int64_t *R = sh64 + (k + 1) * W;
@@ -1087,7 +1088,9 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
         }
         if (part_v) {
             const int j = sl.cand_base + k;
-            mine = better(mine, Best{fmaf(out, cand_w[j], -par_sub), cand_ref[j]});
+            const float gain = fmaf(out, cand_w[j], -par_sub);
+            second = second_distinct(mine.v, second, gain, -INFINITY);
+            mine = better(mine, Best{gain, cand_ref[j]});
         } else {
             scores[static_cast<size_t>(node) * n_cand + sl.cand_base + k] = out;
         }
@@ -1095,17 +1098,20 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
     if (part_v) {
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const Best other{__shfl_xor(mine.v, o, kWave), __shfl_xor(mine.i, o, kWave)};
+            if (part_s) second = second_distinct(mine.v, second, other.v, __shfl_xor(second, o, kWave));
             mine = better(mine, other);
         }
-        __shared__ float bv[4];
+        __shared__ float bv[4], b2[4];
         __shared__ int bi[4];
-        if (lane == 0) { bv[wave] = mine.v; bi[wave] = mine.i; }
+        if (lane == 0) { bv[wave] = mine.v; bi[wave] = mine.i; b2[wave] = second; }
         __syncthreads();
         if (threadIdx.x == 0) {
             Best b{bv[0], bi[0]};
-            for (int q = 1; q < 4; ++q) b = better(b, Best{bv[q], bi[q]});
+            float s2 = b2[0];
+            for (int q = 1; q < 4; ++q) { s2 = second_distinct(b.v, s2, bv[q], b2[q]); b = better(b, Best{bv[q], bi[q]}); }
             part_v[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.v;
             part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.i;
+            if (part_s) part_s[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = s2;
         }
     }
 }
@@ -1115,7 +1121,8 @@ constexpr int kArgmaxThreads = 256;
 __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *__restrict__ scores, int n_nodes, int n_cand,
                                                                   const float *__restrict__ w, const int32_t *__restrict__ ref,
                                                                   const float *__restrict__ parent, const int32_t *__restrict__ is_root,
-                                                                  int oblivious, float *__restrict__ part_v, int32_t *__restrict__ part_i) {
+                                                                  int oblivious, float *__restrict__ part_v, int32_t *__restrict__ part_i,
+                                                                  float *__restrict__ part_s /*nullable: second-best distinct score per block*/) {
     const int j = blockIdx.x * kArgmaxThreads + threadIdx.x;
     const int node = blockIdx.y;
     Best mine{-INFINITY, 0x7fffffff};
@@ -1139,14 +1146,16 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *_
         }
         mine = better(mine, Best{sc, ref[j]});
     }
-    __shared__ float sv[kArgmaxThreads];
+    __shared__ float sv[kArgmaxThreads], s2[kArgmaxThreads];
     __shared__ int si[kArgmaxThreads];
     sv[threadIdx.x] = mine.v;
     si[threadIdx.x] = mine.i;
+    s2[threadIdx.x] = -INFINITY;
     __syncthreads();
     for (int o = kArgmaxThreads / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             Best a2{sv[threadIdx.x], si[threadIdx.x]}, b2{sv[threadIdx.x + o], si[threadIdx.x + o]};
+            s2[threadIdx.x] = second_distinct(a2.v, s2[threadIdx.x], b2.v, s2[threadIdx.x + o]);
             a2 = better(a2, b2);
             sv[threadIdx.x] = a2.v;
             si[threadIdx.x] = a2.i;
@@ -1156,6 +1165,7 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax_stage1(const float *_
     if (threadIdx.x == 0) {
         part_v[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = sv[0];
         part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = si[0];
+        if (part_s) part_s[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = s2[0];
     }
 }
 // Child sizes of the selected split of every active node, straight from the histograms (one wave per node), so that the
@@ -1170,7 +1180,9 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                                                        const int32_t *__restrict__ seg_start /*nullable*/, int32_t *__restrict__ cursors,
                                                        const uint32_t *__restrict__ thr_keys, int B, char *pub, uint32_t *pub_flag,
                                                        uint32_t pub_seq, unsigned *pub_done, const int64_t *__restrict__ hist_prev,
-                                                       const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib) {
+                                                       const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib,
+                                                       const float *__restrict__ part_s, float near_rel, const float *__restrict__ parent,
+                                                       const int32_t *__restrict__ is_root, int cosine_score, long long near_rows) {
     const int node = blockIdx.x;
     // pub != nullptr: the result block [best_idx | best_score | counts4] is mirrored into pinned, device-mapped host memory of the same
     // layout and the LAST block to finish stores pub_seq to pub_flag (system scope) -- the host polls it (no publishing launch)
@@ -1181,14 +1193,26 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     // reduces the per-block bests of its node (oblivious: of the level); the owner block publishes them for the host
     const int src_node = oblivious ? 0 : node;
     Best mine{-INFINITY, 0x7fffffff};
-    for (int q = threadIdx.x; q < n_parts; q += kWave)
-        mine = better(mine, Best{part_v[static_cast<size_t>(src_node) * n_parts + q], part_i[static_cast<size_t>(src_node) * n_parts + q]});
+    float second = -INFINITY;
+    for (int q = threadIdx.x; q < n_parts; q += kWave) {
+        const Best other{part_v[static_cast<size_t>(src_node) * n_parts + q], part_i[static_cast<size_t>(src_node) * n_parts + q]};
+        if (part_s) second = second_distinct(mine.v, second, other.v, part_s[static_cast<size_t>(src_node) * n_parts + q]);
+        mine = better(mine, other);
+    }
     for (int o = kWave / 2; o > 0; o >>= 1) {
         const Best other{__shfl_xor(mine.v, o, kWave), __shfl_xor(mine.i, o, kWave)};
+        if (part_s) second = second_distinct(mine.v, second, other.v, __shfl_xor(second, o, kWave));
         mine = better(mine, other);
     }
     const int best = mine.i == 0x7fffffff ? 0 : mine.i;
     const float best_v = mine.v;
+    // near-tie flag (one GPU, counts4's third array is free there): the runner-up -- the best DISTINCT gain -- is within near_rel of the
+    // winner, relative to the scores' magnitude, or (greedy) the winning gain is that close to zero, where "split" and "leaf" part
+    // (fitter.cpp:357).  The host then has the few candidates in the window re-scored in the reference's float32 order (neartie.hip).
+    if (threadIdx.x == 0 && node == src_node && !hist_global) {
+        counts4[3 * static_cast<size_t>(max_front) + node] = __float_as_int(second);   // (diagnostics: GBRL_HIP_NEARTIE_DEBUG prints it)
+        if (pub) pub_counts[3 * static_cast<size_t>(max_front) + node] = __float_as_int(second);
+    }
     if (threadIdx.x == 0 && node == src_node) {
         best_idx[node] = best; best_score[node] = best_v;
         if (pub) { pub_idx[node] = best; pub_score[node] = best_v; }
@@ -1236,6 +1260,25 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                 pub_counts[(2 * pass + 1) * static_cast<size_t>(max_front) + node] = right;
             }
             if (pass == 0) n_left = static_cast<int>(tot - right);
+            if (pass == 0 && node == src_node && !hist_global) {
+                // near-tie flag (one GPU: counts4's third array is free there): the runner-up -- the best DISTINCT gain -- is within the window of
+                // the winner, relative to the scores' magnitude, or (greedy) the winning gain is that close to zero, where "split" and "leaf"
+                // part (fitter.cpp:357).  The host then has the candidates in the window re-scored in the reference's float32 order (neartie.hip).
+                // A zero gain needs no replay under L2 when the winner sends every row to ONE side: the reference's split score is then its
+                // parent score operation for operation (node.cpp:321-376 against split_candidate_generator.cpp:293-320) and its gain is exactly
+                // 0 as well.  (Cosine divides by sqrtf in one and by a double sqrt in the other: there the last bit decides, and is replayed.)
+                long long near = 0;
+                if (part_s && best_v != -INFINITY) {
+                    float mag;
+                    if (oblivious) mag = fabsf(best_v);
+                    else { const float par = is_root[node] ? 0.0f : parent[node]; mag = fmaxf(fabsf(best_v + par), fabsf(par)); }
+                    const float win = near_window_rel(near_rel, oblivious ? near_rows : tot) * mag;
+                    if (second != -INFINITY && best_v - second <= win) near = 1;
+                    if (!oblivious && !is_root[node] && fabsf(best_v) <= win && !(cosine_score == 0 && (right == 0 || right == tot))) near = 1;
+                }
+                counts4[2 * static_cast<size_t>(max_front) + node] = near;
+                if (pub) pub_counts[2 * static_cast<size_t>(max_front) + node] = near;
+            }
         }
     }
     if (threadIdx.x == 0) {
@@ -1772,7 +1815,7 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
-                      int32_t *part_i, hipStream_t s, int slot0, bool keep_derived) {
+                      int32_t *part_i, hipStream_t s, int slot0, bool keep_derived, float *part_s) {
     const size_t lds = static_cast<size_t>(NB + 2) * (D + 1) * sizeof(int64_t);   // class sums, the totals, the totals as doubles
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
@@ -1780,27 +1823,28 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
                        cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i, slot0,
-                       keep_derived ? 1 : 0);
+                       keep_derived ? 1 : 0, part_s);
 }
 
 int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }
 void argmax(const float *scores, int n_nodes, int n_cand, const float *w, const int32_t *ref, const float *parent,
             const int32_t *is_root, bool oblivious, float *part_v, int32_t *part_i, int32_t *best_idx, float *best_score,
-            hipStream_t s) {
+            hipStream_t s, float *part_s) {
     const int parts = argmax_parts(n_cand);
     const int out_nodes = oblivious ? 1 : n_nodes;
     hipLaunchKernelGGL(k_argmax_stage1, dim3(parts, out_nodes), dim3(kArgmaxThreads), 0, s, scores, n_nodes, n_cand, w, ref, parent,
-                       is_root, oblivious ? 1 : 0, part_v, part_i);
+                       is_root, oblivious ? 1 : 0, part_v, part_i, part_s);
     (void)best_idx; (void)best_score;   // published by k_resolve_splits, which runs the last reduction stage itself
 }
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int32_t *best_idx, float *best_score, bool oblivious, int n_nodes, const int32_t *ref_to_internal, const int32_t *cand_slot,
                     const FeatureSlot *slots, const int64_t *hist_local, const int64_t *hist_global, int Fp, int NB, int D,
                     NodeSplit *out, int64_t *counts4, int max_front, const int32_t *seg_start, int32_t *cursors, const uint32_t *thr_keys,
                     int B, hipStream_t s, void *pub, uint32_t *pub_flag, uint32_t pub_seq, unsigned *pub_done, const int64_t *hist_prev,
-                    const int32_t *sub_par, const int32_t *sub_sib) {
+                    const int32_t *sub_par, const int32_t *sub_sib, const NearDetect *near) {
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, part_v, part_i, n_parts, best_idx, best_score, oblivious ? 1 : 0,
                        ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors, thr_keys, B,
-                       static_cast<char *>(pub), pub_flag, pub_seq, pub_done, hist_prev, sub_par, sub_sib);
+                       static_cast<char *>(pub), pub_flag, pub_seq, pub_done, hist_prev, sub_par, sub_sib,
+                       near ? near->part_s : nullptr, near ? near->rel : 0.0f, near ? near->parent : nullptr, near ? near->is_root : nullptr, near ? near->cosine : 1, near ? near->rows : 0);
 }
 
 // Row-sharded runs: k_resolve_splits wrote GLOBAL left sizes; the partition needs this rank's.

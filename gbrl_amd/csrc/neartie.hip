@@ -1,0 +1,348 @@
+// neartie.hip -- near-tie replay: when the exact arg-max of a level has a runner-up within a relative 2^-20 (or a zero gain decides between
+// "split" and "leaf"), the few candidates in that window are scored ONCE MORE the way the reference scores them -- float32, its rows in
+// ascending order, its operation sequence -- and the winner of THAT comparison is taken, so the tree has the reference's structure even
+// where the reference's own rounding noise decided (SURVEY hard part 1; fitter.cpp:318-357 greedy, :411-459 oblivious).
+//
+// What "the reference's sequence" is (node.cpp:187-251 Cosine, :321-376 L2; math_ops.h:432-449, 476-485, 538-575), as compiled by GCC -O3
+// for an AVX2 + FMA target (the reference's release flags; oracle/_ref) -- pinned bit for bit by tests/test_oracle.py against the reference's
+// own functions on 6000 random nodes:
+//   * per side and output column a float32 sum over the node's rows in ascending row order; mean = sum * (1.0f / count);
+//   * sum_{row, col} g[row][col] * mean[col] and sum_col mean[col]^2 are IN-ORDER float32 reductions (`omp simd` without a reduction
+//     clause: GCC keeps the order) whose vectorised part rounds the product before the add and whose scalar remainder -- the last
+//     n_cols % 4 columns -- is contracted to a fused multiply-add;
+//   * Cosine: (num_right + num_left) / sqrtf(fma(norm_right, n_right, norm_left * n_left)), 0 when the denominator is 0;
+//     L2: fma(n_left, norm_left, n_right * norm_right);
+//   * parent score (greedy, split_candidate_generator.cpp:262-320): the same reductions over all rows of the node; Cosine divides in
+//     double: (float)((double)dot / sqrt((double)(norm * n))); L2: norm * n;
+//   * gain = fma(score, feature weight, -parent) (greedy; root: parent = 0); oblivious: (sum over the level's nodes in node order) * weight.
+// L2 scores are taken on the standardised gradients (g - mean) / (std + 1e-8f), recomputed here from the step's statistics.
+//
+// The replay is rare (1-3 % of random trees have such a node) and serial by nature -- a float32 sum in a fixed order is a dependent chain --
+// so it is written for clarity, not speed: one block per (node, candidate); the two sides' chains run in two waves.
+#include "kernels.h"
+#include "kernels_common.h"
+#include "score_common.h"
+
+#include <algorithm>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace gbrl {
+namespace kern {
+namespace {
+
+constexpr int kNearThreads = 256;
+constexpr int kNearBatch = 2048;          // products staged per wave and batch
+
+
+__device__ __forceinline__ float near_gain(const NearTieIO &a, int node, int j) {
+    const float sc = a.scores[static_cast<size_t>(node) * a.n_cand + j];
+    if (a.oblivious) return sc;   // (per-node term; the level sum is formed by the caller)
+    const float par = a.is_root[node] ? 0.0f : a.parent[node];
+    return fmaf(sc, a.cand_w[j], -par);
+}
+// the exact level score of candidate j the way k_argmax_stage1 forms it (fp32 sum in node order, then * w)
+__device__ __forceinline__ float near_level_score(const NearTieIO &a, int j) {
+    float sc = 0.0f;
+    for (int nd = 0; nd < a.n_act; ++nd) sc += a.scores[static_cast<size_t>(nd) * a.n_cand + j];
+    return sc * a.cand_w[j];
+}
+
+// The distinct gain values inside the window, best first, each represented by its lowest reference index (candidates with the same exact
+// gain induce the same partition of the node -- thresholds between the same two rows -- and the reference scores them identically).
+__global__ __launch_bounds__(kNearThreads) void k_near_list(NearTieIO a) {
+    const int node = blockIdx.x;
+    if (a.near[node] == 0) { if (threadIdx.x == 0) a.list_n[node] = 0; return; }
+    __shared__ float sv[kNearThreads];
+    __shared__ int si[kNearThreads], sj[kNearThreads];
+    const float b1 = a.best_score[node];
+    float mag;
+    if (a.oblivious) mag = fabsf(b1);
+    else { const float par = a.is_root[node] ? 0.0f : a.parent[node]; mag = fmaxf(fabsf(b1 + par), fabsf(par)); }
+    const float lo = b1 - near_window_rel(a.rel, a.oblivious ? a.N : a.n_rows[node]) * mag;
+    float prev = INFINITY;
+    int count = 0;
+    for (; count < kNearCands; ++count) {
+        float bv = -INFINITY; int bi = 0x7fffffff, bj = -1;
+        for (int j = threadIdx.x; j < a.n_cand; j += kNearThreads) {
+            const float g = a.oblivious ? near_level_score(a, j) : near_gain(a, node, j);
+            if (!(g >= lo) || !(g < prev)) continue;
+            const int r = a.cand_ref[j];
+            if (g > bv || (g == bv && r < bi)) { bv = g; bi = r; bj = j; }
+        }
+        sv[threadIdx.x] = bv; si[threadIdx.x] = bi; sj[threadIdx.x] = bj;
+        __syncthreads();
+        for (int o = kNearThreads / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                const float ov = sv[threadIdx.x + o]; const int oi = si[threadIdx.x + o];
+                if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; sj[threadIdx.x] = sj[threadIdx.x + o]; }
+            }
+            __syncthreads();
+        }
+        const float got = sv[0]; const int got_j = sj[0];
+        __syncthreads();
+        if (got_j < 0) break;
+        if (threadIdx.x == 0) a.list[static_cast<size_t>(node) * kNearCands + count] = got_j;
+        prev = got;
+    }
+    if (threadIdx.x == 0) a.list_n[node] = count;
+}
+
+__device__ __forceinline__ float near_grad(const NearTieIO &a, int row, int c) {
+    const float g = a.grads[static_cast<size_t>(row) * a.D + c];
+    if (a.meanden == nullptr) return g;
+    return (g - a.meanden[c]) / a.meanden[a.D + c];     // fitter.cpp:58-63 -> math_ops.cpp:498,94: what k_quantize standardises
+}
+
+// sum_{row in list, col} g[row][col] * vec[col], in order (math_ops.h:432-449 as compiled: see the head of this file).  One wave; lane 0
+// carries the chain, all lanes stage the products.
+__device__ float near_dot_chain(const NearTieIO &a, const int32_t *list, int m, int stride /*+1 / -1*/, const float *vec /*LDS [D]*/, float *buf /*LDS [kNearBatch]*/) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int D = a.D, D4 = D & ~3;
+    float s = 0.0f;
+    const int rows_per = max(1, kNearBatch / D);
+    if (D > kNearBatch) {   // (very wide outputs: no staging)
+        if (lane == 0)
+            for (int r = 0; r < m; ++r) {
+                const int row = list[static_cast<ptrdiff_t>(r) * stride];
+                for (int c = 0; c < D4; ++c) { const float p = near_grad(a, row, c) * vec[c]; s = s + p; }
+                for (int c = D4; c < D; ++c) s = fmaf(near_grad(a, row, c), vec[c], s);
+            }
+        return __shfl(s, 0, kWave);
+    }
+    for (int r0 = 0; r0 < m; r0 += rows_per) {
+        const int nr = min(rows_per, m - r0), tot = nr * D;
+        for (int e = lane; e < tot; e += kWave) {
+            const int r = e / D, c = e - r * D;
+            const float g = near_grad(a, list[static_cast<ptrdiff_t>(r0 + r) * stride], c);
+            buf[e] = c < D4 ? g * vec[c] : g;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
+        if (lane == 0) {
+            for (int r = 0; r < nr; ++r) {
+                const float *b = buf + r * D;
+                for (int c = 0; c < D4; ++c) s = s + b[c];
+                for (int c = D4; c < D; ++c) s = fmaf(b[c], vec[c], s);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return __shfl(s, 0, kWave);
+}
+__device__ __forceinline__ float near_sqnorm(const float *v, int D) {   // math_ops.h:476-485 as compiled
+    const int D4 = D & ~3;
+    float s = 0.0f;
+    for (int c = 0; c < D4; ++c) { const float p = v[c] * v[c]; s = s + p; }
+    for (int c = D4; c < D; ++c) s = fmaf(v[c], v[c], s);
+    return s;
+}
+
+// grid (kNearCands + 1, n_act): block (i, node) replays the node's i-th listed candidate; block (kNearCands, node) the parent score.
+__global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
+    const int node = blockIdx.y, i = blockIdx.x;
+    const int lnode = a.oblivious ? 0 : node;
+    if (a.near[lnode] == 0) return;
+    const bool is_parent = i == kNearCands;
+    if (is_parent ? (a.oblivious || a.is_root[node]) : (i >= a.list_n[lnode])) return;
+    extern __shared__ uint32_t lds[];
+    uint32_t *in_map = lds;                         // [2048] bit per row: in the node
+    uint32_t *right_map = lds + 2048;               // [2048] bit per row: goes right
+    float *mean = reinterpret_cast<float *>(lds + 4096);       // [2][D] right | left
+    float *buf = mean + 2 * a.D;                               // [2][kNearBatch]
+    __shared__ int s_cnt[kNearThreads][2];
+    __shared__ float s_num[2];
+    const int n = a.n_rows[node], seg = a.seg_start[node];
+    const int D = a.D;
+    float *out = a.rep + static_cast<size_t>(node) * (kNearCands + 1) + i;
+    // the candidate's test (what k_partition applies)
+    int fs = 0, bin = -1, is_cat = 0;
+    if (!is_parent) {
+        const int j = a.list[static_cast<size_t>(lnode) * kNearCands + i];
+        fs = a.cand_slot[j];
+        const FeatureSlot sl = a.slots[fs];
+        is_cat = sl.is_cat;
+        bin = is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
+    }
+    const uint16_t *cbase = a.codes + (static_cast<size_t>(fs >> 4) * a.N) * 16 + (fs & 15);
+    for (int w = threadIdx.x; w < 4096; w += kNearThreads) lds[w] = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += kNearThreads) {
+        const int row = a.rows[seg + p];
+        atomicOr(&in_map[row >> 5], 1u << (row & 31));
+        if (!is_parent) {
+            const int code = cbase[static_cast<size_t>(row) * 16];
+            if (is_cat ? (code == bin) : (code > bin)) atomicOr(&right_map[row >> 5], 1u << (row & 31));
+        }
+    }
+    __syncthreads();
+    // ordered lists: right rows ascending from the front of the region, left rows ascending from its back (read with stride -1)
+    int32_t *ent = a.ent + static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+    const int n_words = (a.N + 31) >> 5, per = (n_words + kNearThreads - 1) / kNearThreads;
+    const int w0 = threadIdx.x * per, w1 = min(n_words, w0 + per);
+    int cr = 0, cl = 0;
+    for (int w = w0; w < w1; ++w) { cr += __popc(in_map[w] & right_map[w]); cl += __popc(in_map[w] & ~right_map[w]); }
+    s_cnt[threadIdx.x][0] = cr; s_cnt[threadIdx.x][1] = cl;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int run = 0;
+        for (int t = 0; t < kNearThreads; ++t) { const int c = s_cnt[t][threadIdx.x]; s_cnt[t][threadIdx.x] = run; run += c; }
+    }
+    __syncthreads();
+    {
+        int pr = s_cnt[threadIdx.x][0], pl = s_cnt[threadIdx.x][1];
+        for (int w = w0; w < w1; ++w) {
+            uint32_t m = in_map[w];
+            const uint32_t rm = right_map[w];
+            while (m) {
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                const int row = (w << 5) + b;
+                if ((rm >> b) & 1u) ent[pr++] = row; else ent[n - 1 - (pl++)] = row;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    int n_r = 0, n_l = 0;
+    {   // totals: the last thread's prefix + its own counts
+        n_r = s_cnt[kNearThreads - 1][0]; n_l = s_cnt[kNearThreads - 1][1];
+        const int lw0 = (kNearThreads - 1) * per, lw1 = min(n_words, lw0 + per);
+        for (int w = lw0; w < lw1; ++w) { n_r += __popc(in_map[w] & right_map[w]); n_l += __popc(in_map[w] & ~right_map[w]); }
+    }
+    if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { if (threadIdx.x == 0) *out = -INFINITY; return; }   // node.cpp:354
+    const float nrf = static_cast<float>(n_r), nlf = static_cast<float>(n_l);
+    const float rrec = n_r > 0 ? 1.0f / nrf : 0.0f, lrec = n_l > 0 ? 1.0f / nlf : 0.0f;
+    // side sums: one thread per (side, column), rows in order
+    for (int t = threadIdx.x; t < 2 * D; t += kNearThreads) {
+        const int side = t / D, c = t - side * D;   // 0 right, 1 left
+        const int m = side ? n_l : n_r;
+        float s = 0.0f;
+        for (int r = 0; r < m; ++r) s += near_grad(a, side ? ent[n - 1 - r] : ent[r], c);
+        mean[t] = s * (side ? lrec : rrec);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x / kWave;
+    if (a.cosine && wave < 2) {
+        const int m = wave ? n_l : n_r;
+        float num = 0.0f;
+        if (m > 0) num = near_dot_chain(a, wave ? ent + (n - 1) : ent, m, wave ? -1 : 1, mean + wave * D, buf + wave * kNearBatch);
+        if ((threadIdx.x & (kWave - 1)) == 0) s_num[wave] = num;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float res;
+        if (is_parent) {       // every row is on the "left" side here
+            if (a.cosine) {
+                const float den = near_sqnorm(mean + D, D) * nlf;
+                res = (n_l == 0 || den == 0.0f) ? 0.0f : static_cast<float>(static_cast<double>(s_num[1]) / sqrt(static_cast<double>(den)));
+            } else {
+                res = near_sqnorm(mean + D, D) * nlf;
+            }
+        } else if (a.cosine) {
+            const float tn = near_sqnorm(mean, D), fn = near_sqnorm(mean + D, D);
+            const float fden = fn * nlf;
+            const float den = fmaf(tn, nrf, fden);
+            const float num = s_num[0] + s_num[1];
+            res = den == 0.0f ? 0.0f : num / sqrtf(den);
+        } else {
+            const float ln = near_sqnorm(mean + D, D), rn = near_sqnorm(mean, D);
+            const float rp = nrf * rn;
+            res = fmaf(nlf, ln, rp);
+        }
+        *out = res;
+    }
+}
+
+// The reference's comparison over the replayed candidates (fitter.cpp:332-357 / 426-459: highest score, first index among equals), written
+// where the final arg-max stage reads its input, so that k_resolve_splits (run once more) derives everything else.
+__global__ __launch_bounds__(kWave) void k_near_apply(NearTieIO a) {
+    const int node = blockIdx.x;
+    if (a.near[node] == 0) return;
+    const int cnt = a.list_n[node];
+    if (cnt <= 0) return;
+    if (threadIdx.x == 0) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = 0; i < cnt; ++i) {
+            const int j = a.list[static_cast<size_t>(node) * kNearCands + i];
+            float g;
+            if (a.oblivious) {
+                float sc = 0.0f;
+                for (int nd = 0; nd < a.n_act; ++nd) sc += a.rep[static_cast<size_t>(nd) * (kNearCands + 1) + i];
+                g = sc * a.cand_w[j];
+            } else {
+                const float par = a.is_root[node] ? 0.0f : a.rep[static_cast<size_t>(node) * (kNearCands + 1) + kNearCands];
+                g = fmaf(a.rep[static_cast<size_t>(node) * (kNearCands + 1) + i], a.cand_w[j], -par);
+            }
+            const int r = a.cand_ref[j];
+            if (g > bv || (g == bv && r < bi)) { bv = g; bi = r; }
+        }
+        a.part_v[static_cast<size_t>(node) * a.n_parts] = bv;
+        a.part_i[static_cast<size_t>(node) * a.n_parts] = bi;
+    }
+    for (int p = 1 + threadIdx.x; p < a.n_parts; p += kWave) {
+        a.part_v[static_cast<size_t>(node) * a.n_parts + p] = -INFINITY;
+        a.part_i[static_cast<size_t>(node) * a.n_parts + p] = 0x7fffffff;
+    }
+}
+
+}  // namespace
+
+bool near_tie_supported(int N, int D) { return N >= 1 && N <= kNearMaxRows && D >= 1 && D <= kNearMaxD; }
+
+void near_tie_replay(const NearTieIO &io, hipStream_t s) {
+    const int n_list = io.oblivious ? 1 : io.n_act;
+    hipLaunchKernelGGL(k_near_list, dim3(n_list), dim3(kNearThreads), 0, s, io);
+    const size_t lds = sizeof(uint32_t) * 4096 + sizeof(float) * (2 * static_cast<size_t>(io.D) + 2 * kNearBatch);
+    hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
+    hipLaunchKernelGGL(k_near_apply, dim3(n_list), dim3(kWave), 0, s, io);
+}
+
+bool near_tie_selftest(const float *grads, const uint8_t *in_node, const uint8_t *goes_right, int n_rows, int D, const float *meanden, bool cosine, int min_data, float *out) {
+    if (!near_tie_supported(n_rows, D)) return false;
+    // the node as the level loop would hand it over: its rows in SCRAMBLED order (the kernel has to restore the ascending order), one
+    // numeric feature slot with one threshold, class code 1 = "goes right"
+    std::vector<int32_t> rows;
+    for (int r = n_rows - 1; r >= 0; --r) if (in_node[r]) rows.push_back(r);
+    for (size_t i = 0; i + 2 < rows.size(); i += 3) std::swap(rows[i], rows[i + 2]);
+    std::vector<uint16_t> codes(static_cast<size_t>(n_rows) * 16, 0);
+    for (int r = 0; r < n_rows; ++r) codes[static_cast<size_t>(r) * 16] = goes_right[r] ? 1 : 0;
+    const FeatureSlot slot{0, 1, 0, 0};
+    const int32_t zero = 0, one = 1, n_node = static_cast<int32_t>(rows.size());
+    const int64_t flag = 1;
+    const float w = 1.0f;
+    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } };
+    auto up = [](Dev &d, const void *src, size_t bytes) {
+        if (hipMalloc(&d.p, std::max<size_t>(bytes, 16)) != hipSuccess) return false;
+        return bytes == 0 || hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    Dev d_rows, d_codes, d_grads, d_md, d_slot, d_zero, d_one, d_n, d_flag, d_w, d_ent, d_rep, d_list;
+    bool ok = up(d_rows, rows.data(), rows.size() * 4) && up(d_codes, codes.data(), codes.size() * 2) && up(d_grads, grads, sizeof(float) * n_rows * D) &&
+              (!meanden || up(d_md, meanden, sizeof(float) * 2 * D)) && up(d_slot, &slot, sizeof(slot)) && up(d_zero, &zero, 4) && up(d_one, &one, 4) && up(d_n, &n_node, 4) &&
+              up(d_flag, &flag, 8) && up(d_w, &w, 4) && up(d_ent, nullptr, 0) && up(d_rep, nullptr, 0) && up(d_list, nullptr, 0);
+    if (!ok) { (void)hipGetLastError(); return false; }
+    (void)hipFree(d_ent.p); d_ent.p = nullptr;
+    (void)hipFree(d_rep.p); d_rep.p = nullptr;
+    (void)hipFree(d_list.p); d_list.p = nullptr;
+    if (hipMalloc(&d_ent.p, sizeof(int32_t) * static_cast<size_t>(kNearCands + 1) * n_rows) != hipSuccess || hipMalloc(&d_rep.p, sizeof(float) * (kNearCands + 1)) != hipSuccess ||
+        hipMalloc(&d_list.p, sizeof(int32_t) * (kNearCands + 1)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    NearTieIO io{};
+    io.rows = static_cast<int32_t *>(d_rows.p); io.seg_start = static_cast<int32_t *>(d_zero.p); io.n_rows = static_cast<int32_t *>(d_n.p); io.codes = static_cast<uint16_t *>(d_codes.p);
+    io.N = n_rows; io.D = D; io.grads = static_cast<float *>(d_grads.p); io.meanden = meanden ? static_cast<float *>(d_md.p) : nullptr; io.cosine = cosine ? 1 : 0; io.oblivious = 0; io.min_data = min_data;
+    io.slots = static_cast<FeatureSlot *>(d_slot.p); io.cand_slot = static_cast<int32_t *>(d_zero.p); io.cand_w = static_cast<float *>(d_w.p); io.cand_ref = static_cast<int32_t *>(d_zero.p); io.n_cand = 1;
+    io.is_root = static_cast<int32_t *>(d_zero.p); io.near = static_cast<int64_t *>(d_flag.p); io.n_act = 1;
+    io.list = static_cast<int32_t *>(d_list.p); io.list_n = static_cast<int32_t *>(d_one.p);   // the one candidate, internal index 0
+    io.ent = static_cast<int32_t *>(d_ent.p); io.rep = static_cast<float *>(d_rep.p);
+    if (hipMemset(d_list.p, 0, sizeof(int32_t) * (kNearCands + 1)) != hipSuccess) return false;
+    const size_t lds = sizeof(uint32_t) * 4096 + sizeof(float) * (2 * static_cast<size_t>(D) + 2 * kNearBatch);
+    hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, 1), dim3(kNearThreads), lds, nullptr, io);
+    float rep[kNearCands + 1];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(rep, d_rep.p, sizeof(rep), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    out[0] = rep[0];
+    out[1] = rep[kNearCands];
+    return true;
+}
+
+}  // namespace kern
+}  // namespace gbrl

@@ -32,6 +32,20 @@ __device__ __forceinline__ Best better(Best a, Best b) {
     if (b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i)) return b;
     return a;
 }
+// Near-tie detection: (best, second) pairs, `second` = the best value STRICTLY below `best` (candidates with equal exact gains split the
+// node's rows identically -- thresholds between the same two rows -- and are not a tie to resolve).  Returns the merged pair's second.
+__device__ __forceinline__ float second_distinct(float a1, float a2, float c1, float c2) {
+    const float hi = fmaxf(a1, c1), lo = fminf(a1, c1);
+    float s = fmaxf(a2, c2);
+    if (lo < hi) s = fmaxf(s, lo);
+    return s;
+}
+// The window of the near-tie replay, relative to the scores' magnitude: `rel` (2^-20) for nodes of up to 8192 rows -- the RL-sized range, where
+// a replay costs as much as the tree -- and the reference's own summation noise eps32 * sqrt(rows) beyond (tests/neartie.py explains a
+// difference within 4x that).
+__device__ __forceinline__ float near_window_rel(float rel, long long rows) {
+    return rows > 8192 ? fmaxf(rel, 1.1920929e-07f * sqrtf(static_cast<float>(rows))) : rel;
+}
 // Inclusive scan over the 64 lanes of NINE 64-bit values at once (k_score's fields), every step as two DPP-fused adds per value:
 //   v_add_co_u32_dpp lo, vcc, lo, lo <ctrl>   ;  v_addc_co_u32_dpp hi, vcc, hi, hi, vcc <ctrl>
 // A lane whose source is outside its row (row_shr) or whose row is masked (row_bcast) is simply not written, i.e. keeps x -- no

@@ -79,6 +79,25 @@ __device__ __forceinline__ SgBest sg_wave_best(SgBest m) {
     return r;
 }
 
+// Near-tie detection (score_common.h second_distinct): the pair (best value, best value strictly below it) reduced over the wave with the
+// same DPP steps; returns the wave's second.  A lane without a source merges with itself, which changes nothing.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void sg_dpp_second_step(float &v, float &sec) {
+    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    const float os = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sec), __float_as_int(sec), CTRL, ROW_MASK, 0xf, false));
+    sec = second_distinct(v, sec, ov, os);
+    v = fmaxf(v, ov);
+}
+__device__ __forceinline__ float sg_wave_second(float v, float sec) {
+    sg_dpp_second_step<0x111, 0xf>(v, sec);
+    sg_dpp_second_step<0x112, 0xf>(v, sec);
+    sg_dpp_second_step<0x114, 0xf>(v, sec);
+    sg_dpp_second_step<0x118, 0xf>(v, sec);
+    sg_dpp_second_step<0x142, 0xa>(v, sec);
+    sg_dpp_second_step<0x143, 0xc>(v, sec);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sec), 63));
+}
+
 __device__ __forceinline__ void sg_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void sg_add(long long *p, long long v) { atomicAdd(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(v)); }
 
@@ -119,7 +138,7 @@ __device__ __forceinline__ void sg_accumulate_rows(const int32_t *__restrict__ q
 }
 
 struct SgLayout {     // byte offsets into the dynamic LDS block (host computes, kernel carves)
-    int rc, sw, sref, tn, tid, psb, pv, split, cidx, cid, win, wcat, wthr, nbest, ssum, leafflag, ttot, total, totalf, ibest, wbest, lacc, hist;
+    int rc, sw, sref, tn, tid, psb, pv, split, cidx, cid, win, wcat, wthr, nbest, nbest2, npar, ssum, leafflag, ttot, total, totalf, ibest, ibest2, wbest, wbest2, lacc, hist;
     int total_bytes;
 };
 
@@ -139,12 +158,15 @@ struct SmallGrowArgs {
     int G, NC, nb_cap, Tmax, NIDS;
     uint32_t magicW;            // floor(2^32 / (D + 1)) + 1
     SgBest *bests;              // greedy [MD][NC][G], oblivious [MD][G]
+    float2 *seconds;            // same shape: (best gain strictly below the block's best, the node's parent score) -- near-tie detection
+    float near_rel;             // 0: no detection
+    int tiny_words;             // 32-bit words of the histogram region every wave may use as scratch (sg_tiny_zero_gain)
     unsigned *sync;             // [0] groups arrived, [1] finished blocks, [2] abort, [32 + 32 g] arrivals of group g (kSmallGrowSyncBytes)
     char *res;                  // pinned, device-mapped: MD result blocks of res_stride bytes (block 0 copies them out of res_dev at the end)
     char *res_dev;              // device staging of the same
     int res_stride, max_front;
     int64_t *acc;               // pinned: [NIDS][D+1]
-    uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] error
+    uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] 1 = error, 2 = a near-tie was met (the level loop grows this tree)
     uint32_t seq;
     StepScales *scales_out;     // pinned (nullable): block 0 mirrors the step's scales for the host
     uint32_t *prof;             // nullable (GBRL_HIP_SMALL_GROW_PROF=1): block 0's time per phase, 10 ns units, 16 words, pinned
@@ -168,6 +190,14 @@ __device__ __forceinline__ SgBest sg_load_best(const SgBest *p) {
     const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return SgBest{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+}
+__device__ __forceinline__ void sg_store_second(float2 *p, float sec, float par) {
+    const unsigned long long w = (static_cast<unsigned long long>(__float_as_uint(par)) << 32) | __float_as_uint(sec);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 sg_load_second(const float2 *p) {
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return float2{__uint_as_float(static_cast<uint32_t>(w)), __uint_as_float(static_cast<uint32_t>(w >> 32))};
 }
 // Arrivals are counted per GROUP of 16 blocks (counters 128 bytes apart) and the last block of a group arrives at the top counter: 256
 // atomics on ONE word took ~7 us per barrier (a device-scope atomic unit retires ~30 same-address operations per microsecond).
@@ -202,6 +232,56 @@ __device__ __forceinline__ bool sg_grid_barrier(unsigned *sync, unsigned G, unsi
     return *s_abort == 0;
 }
 
+// Near-tie replay inside the kernel for the one case that is frequent in RL-sized trees: a node of a few rows (an outlier split off by the
+// levels above) whose best candidate sends every row to one side.  Its exact gain is 0; the reference's is score - parent, the SAME float32
+// sums divided by sqrtf in one (math_ops.h:538-575) and by a double sqrt in the other (:504-524) -- the last bit decides between "split"
+// and "leaf" (fitter.cpp:357).  One wave evaluates both from the node's rows in ascending order, operation for operation what
+// k_near_replay (neartie.hip) does for this node in the level loop; returns fma(score, w, -parent).  Cosine only (under L2 both are the same
+// operations and the gain is exactly 0).  scratch: this wave's slice of the (idle) histogram region, sg_tiny_words(n, D) words.
+constexpr int kSgTinyRows = 16;
+__device__ __forceinline__ int sg_tiny_words(int n, int D) { return kSgTinyRows + D + n * D; }   // scratch: rows | mean | the rows' gradients
+__device__ float sg_tiny_zero_gain(const uint16_t *rc16, int N, int k, int n, const float *__restrict__ grads, int D, float w, uint32_t *scratch) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & (kWave - 1);
+    int *rows = reinterpret_cast<int *>(scratch);
+    float *mean = reinterpret_cast<float *>(scratch + kSgTinyRows), *g = mean + D;
+    int found = 0;
+    for (int r0 = 0; r0 < N && found < n; r0 += kWave) {
+        const int r = r0 + lane;
+        const bool in = r < N && rc16[2 * r] == static_cast<uint16_t>(k);
+        const unsigned long long m = __ballot(in);
+        if (in) { const int pos = found + __popcll(m & ((1ull << lane) - 1ull)); if (pos < kSgTinyRows) rows[pos] = r; }
+        found += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < n * D; e += kWave) { const int i = e / D; g[e] = grads[static_cast<size_t>(rows[i]) * D + (e - i * D)]; }   // one round trip for all of them
+    __builtin_amdgcn_wave_barrier();
+    const float nf = static_cast<float>(n), rec = 1.0f / nf;
+    for (int d = lane; d < D; d += kWave) {
+        float sum = 0.0f;
+        for (int i = 0; i < n; ++i) sum += g[i * D + d];
+        mean[d] = sum * rec;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float gain = 0.0f;
+    if (lane == 0) {
+        const int D4 = D & ~3;
+        float num = 0.0f, norm = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            const float *gi = g + i * D;
+            for (int c = 0; c < D4; ++c) { const float pr = gi[c] * mean[c]; num = num + pr; }
+            for (int c = D4; c < D; ++c) num = fmaf(gi[c], mean[c], num);
+        }
+        for (int c = 0; c < D4; ++c) { const float pr = mean[c] * mean[c]; norm = norm + pr; }
+        for (int c = D4; c < D; ++c) norm = fmaf(mean[c], mean[c], norm);
+        const float den = norm * nf;
+        const float score = den == 0.0f ? 0.0f : num / sqrtf(den);
+        const float parent = den == 0.0f ? 0.0f : static_cast<float>(static_cast<double>(num) / sqrt(static_cast<double>(den)));
+        gain = fmaf(score, w, -parent);
+    }
+    return __shfl(gain, 0, kWave);
+}
+
 template <typename ACC>
 __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a) {
     extern __shared__ __align__(16) unsigned char sg_lds[];
@@ -221,23 +301,29 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     int *wcat = reinterpret_cast<int *>(sg_lds + L.wcat);               // [NC] winner slot is categorical
     float *wthr = reinterpret_cast<float *>(sg_lds + L.wthr);           // [NC] winner's threshold value (+inf: categorical)
     SgBest *nbest = reinterpret_cast<SgBest *>(sg_lds + L.nbest);       // [NC] greedy: this block's best per node
+    float *nbest2 = reinterpret_cast<float *>(sg_lds + L.nbest2);       // [NC] ... and the best gain strictly below it
+    float *npar = reinterpret_cast<float *>(sg_lds + L.npar);           // [NC] the node's parent score
     float *ssum = reinterpret_cast<float *>(sg_lds + L.ssum);           // [NB] oblivious: per candidate, sum over nodes
     unsigned char *leafflag = sg_lds + L.leafflag;                      // [NIDS]
     ACC *ttot = reinterpret_cast<ACC *>(sg_lds + L.ttot);               // [nb][T][W] tile totals, then carries
     long long *total = reinterpret_cast<long long *>(sg_lds + L.total); // [nb][W]
     double *total_f = reinterpret_cast<double *>(sg_lds + L.totalf);    // [nb][W]
     SgBest *ibest = reinterpret_cast<SgBest *>(sg_lds + L.ibest);       // [nb][T]
+    float *ibest2 = reinterpret_cast<float *>(sg_lds + L.ibest2);       // [nb][T]
     SgBest *wbest = reinterpret_cast<SgBest *>(sg_lds + L.wbest);       // [16]
+    float *wbest2 = reinterpret_cast<float *>(sg_lds + L.wbest2);       // [16]
     unsigned long long *lacc = reinterpret_cast<unsigned long long *>(sg_lds + L.lacc);   // [W]
     ACC *hist = reinterpret_cast<ACC *>(sg_lds + L.hist);               // [nb][NBe][W]
 
-    __shared__ int s_abort, s_nact, s_nextid, s_nact_next, s_stop;
+    __shared__ int s_abort, s_nact, s_nextid, s_nact_next, s_stop, s_near;
     __shared__ SgBest s_bbest;
+    __shared__ float s_bbest2;
 
     const int N = a.N, D = a.D, W = a.D + 1, B = a.B, MD = a.MD, NC = a.NC, G = a.G;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, blk = blockIdx.x;
     const double inv_scale = a.scales->inv_scale;
     const bool obl = a.oblivious != 0;
+    const bool detect = a.near_rel > 0.0f;
     unsigned epoch = 0;
     // measurement (a.prof): thread 0 of block 0 charges the time since the last mark to a phase (marks sit behind barriers)
     long long pt = a.prof ? wall_clock64() : 0;
@@ -248,19 +334,19 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
 
     for (int r = tid; r < N; r += kSgThreads) rc[r] = 0;
     for (int i = tid; i < a.NIDS; i += kSgThreads) leafflag[i] = 0;
-    if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; }
+    if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; s_near = 0; }
     __syncthreads();
 
     int cur = 0, level = 0, loaded_slot = -1;
-    bool ok = true;
+    bool ok = true, near_exit = false;
     for (; level < MD; ++level) {
         const int n_act = s_nact;
         int *tn = tn_b + cur * NC, *tidc = tid_b + cur * NC;
         uint32_t *psb = psb_b + static_cast<size_t>(cur) * NC * MD;
         float *pv = pv_b + static_cast<size_t>(cur) * NC * MD;
         // ---- this block's slots ------------------------------------------------------------------------------------------------
-        if (obl) { if (tid == 0) s_bbest = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; }
-        else for (int k = tid; k < n_act; k += kSgThreads) nbest[k] = SgBest{-INFINITY, 0x7fffffff, 0u, 0u};
+        if (obl) { if (tid == 0) { s_bbest = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; s_bbest2 = -INFINITY; } }
+        else for (int k = tid; k < n_act; k += kSgThreads) { nbest[k] = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; nbest2[k] = -INFINITY; npar[k] = 0.0f; }
         for (int fs = blk; fs < a.n_slots; fs += G) {
             const FeatureSlot sl = a.slots[fs];
             const int NBe = sl.n_cand + 1;                       // classes of this slot
@@ -391,8 +477,9 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                             mine = SgBest{fmaf(out, sw[k], -par_sub), sref[k],
                                           (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), static_cast<uint32_t>(n_r)};
                         }
+                        const float sec = detect ? sg_wave_second(mine.v, -INFINITY) : -INFINITY;
                         mine = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, mine));
-                        if (lane == 0) ibest[it] = mine;
+                        if (lane == 0) { ibest[it] = mine; ibest2[it] = sec; if (t == 0) npar[k_abs] = par_sub; }
                     }
                 }
                 __syncthreads();
@@ -407,8 +494,10 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 } else {
                     for (int kb = tid; kb < nbk; kb += kSgThreads) {
                         SgBest b = nbest[k0 + kb];
-                        for (int t = 0; t < T; ++t) b = sg_better(b, ibest[kb * T + t]);
+                        float b2 = nbest2[k0 + kb];
+                        for (int t = 0; t < T; ++t) { b2 = second_distinct(b.v, b2, ibest[kb * T + t].v, ibest2[kb * T + t]); b = sg_better(b, ibest[kb * T + t]); }
                         nbest[k0 + kb] = b;
+                        nbest2[k0 + kb] = b2;
                     }
                 }
                 __syncthreads();
@@ -416,16 +505,22 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             }
             if (obl) {   // the slot's best candidate: (sum over nodes) * w, lowest reference index among maxima (fitter.cpp:435-444)
                 SgBest mine{-INFINITY, 0x7fffffff, 0u, 0u};
+                float sec = -INFINITY;
                 for (int k = tid; k < sl.n_cand; k += kSgThreads) {
-                    mine = sg_better(mine, SgBest{ssum[k] * sw[k], sref[k], (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u});
+                    const float sc = ssum[k] * sw[k];
+                    sec = second_distinct(mine.v, sec, sc, -INFINITY);
+                    mine = sg_better(mine, SgBest{sc, sref[k], (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u});
                 }
+                if (detect) sec = sg_wave_second(mine.v, sec);
                 mine = sg_wave_best(mine);
-                if (lane == 0) wbest[wave] = mine;
+                if (lane == 0) { wbest[wave] = mine; wbest2[wave] = sec; }
                 __syncthreads();
                 if (wave == 0) {     // (the next write of wbest sits behind the barriers of the next slot / level)
                     SgBest b = lane < kSgWaves ? wbest[lane] : SgBest{-INFINITY, 0x7fffffff, 0u, 0u};
+                    float b2 = lane < kSgWaves ? wbest2[lane] : -INFINITY;
+                    if (detect) b2 = sg_wave_second(b.v, b2);
                     b = sg_wave_best(b);
-                    if (lane == 0) s_bbest = sg_better(s_bbest, b);
+                    if (lane == 0) { s_bbest2 = second_distinct(s_bbest.v, s_bbest2, b.v, b2); s_bbest = sg_better(s_bbest, b); }
                 }
             }
         }
@@ -433,21 +528,64 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         // ---- publish this block's bests, ONE grid barrier, reduce to the winners -------------------------------------------------
         SG_MARK(7);
         SgBest *lv = a.bests + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
-        if (obl) { if (tid == 0) sg_store_best(&lv[blk], s_bbest); }
-        else for (int k = tid; k < n_act; k += kSgThreads) sg_store_best(&lv[static_cast<size_t>(k) * G + blk], nbest[k]);
+        float2 *lv2 = a.seconds + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
+        if (obl) { if (tid == 0) { sg_store_best(&lv[blk], s_bbest); if (detect) sg_store_second(&lv2[blk], s_bbest2, 0.0f); } }
+        else for (int k = tid; k < n_act; k += kSgThreads) {
+            sg_store_best(&lv[static_cast<size_t>(k) * G + blk], nbest[k]);
+            if (detect) sg_store_second(&lv2[static_cast<size_t>(k) * G + blk], nbest2[k], npar[k]);
+        }
         if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; break; }
         SG_MARK(8);
         const int n_win = obl ? 1 : n_act;
         for (int k = wave; k < n_win; k += kSgWaves) {
             SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
+            float m2 = -INFINITY, mpar = 0.0f;
             for (int q0 = lane; q0 < G; q0 += kWave * 4) {          // (G <= 256 blocks: one round of four loads in flight)
                 SgBest b4[4];
+                float2 s4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) b4[u] = sg_load_best(lv + static_cast<size_t>(k) * G + min(q0 + u * kWave, G - 1));
+                if (detect) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (q0 + u * kWave < G) m = sg_better(m, b4[u]);
+                    for (int u = 0; u < 4; ++u) s4[u] = sg_load_second(lv2 + static_cast<size_t>(k) * G + min(q0 + u * kWave, G - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (q0 + u * kWave < G) {
+                    if (detect) { m2 = second_distinct(m.v, m2, b4[u].v, s4[u].x); mpar = s4[u].y; }
+                    m = sg_better(m, b4[u]);
+                }
+            }
+            float par = 0.0f;
+            if (detect) {
+                m2 = sg_wave_second(m.v, m2);
+                par = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mpar)));   // (every block stored the same parent score)
             }
             m = sg_wave_best(m);
+            int tiny_k = 0;
+            if (lane == 0 && detect && m.v != -INFINITY) {
+                // the same test as k_resolve_splits: the runner-up within near_rel of the winner (relative to the scores' magnitude), or a greedy
+                // gain that close to zero -- except, under L2, a zero gain whose winner sends every row to one side (exactly 0 in the reference
+                // too).  Every block evaluates it on the same records, so all of them leave together.
+                const float mag = obl ? fabsf(m.v) : fmaxf(fabsf(m.v + par), fabsf(par));
+                const float win_w = a.near_rel * mag;
+                bool near = m2 != -INFINITY && m.v - m2 <= win_w;
+                int tiny = 0;
+                if (!obl && level > 0 && fabsf(m.v) <= win_w) {
+                    const int nr = static_cast<int>(m.pad), nn = tn[k];
+                    const bool one_sided = nr == 0 || nr == nn;
+                    if (!one_sided) near = true;
+                    else if (a.cosine) { if (nn <= kSgTinyRows && sg_tiny_words(nn, D) <= a.tiny_words) tiny = 1; else near = true; }
+                }
+                if (near) s_near = 1;
+                else if (tiny) tiny_k = 1;
+            }
+            tiny_k = __builtin_amdgcn_readfirstlane(tiny_k);
+            if (tiny_k) {     // (wave-uniform) the zero gain of a node of a few rows, settled here: this wave's slice of the idle histogram region is its scratch
+                const int wslot = static_cast<int>(m.slotbin >> 16), wbin = static_cast<int>(m.slotbin & 0xffffu);
+                const FeatureSlot wsl = a.slots[wslot];
+                const float wgt = a.cand_w[wsl.cand_base + (wsl.is_cat ? wbin - 1 : wbin)];
+                m.v = sg_tiny_zero_gain(rc16, N, k, tn[k], a.grads, D, wgt, reinterpret_cast<uint32_t *>(hist) + static_cast<size_t>(wave) * a.tiny_words);
+            }
             if (lane == 0) {
                 // the winner's kind and threshold value: both loads issued here, together (the paths of the children and the result block
                 // need the value; fetched there it was a second DRAM round trip behind the routing pass's)
@@ -462,6 +600,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         }
         __syncthreads();
         SG_MARK(9);
+        if (s_near) { near_exit = true; break; }
         // ---- children: node ids in the host's order (for k in splitting: left, right), next level's table.  The child sizes of a greedy
         //      split travel with its winner (SgBest::pad); an oblivious level keeps both children of every node, empty or not, so its table
         //      needs no sizes (the host derives them from the leaves' row counts afterwards).
@@ -575,7 +714,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         if (stop || last_level) { ++level; break; }
     }
     // Oblivious trees keep growing with EMPTY nodes in the table; whatever is still active when the loop ends is a leaf.
-    if (ok) {
+    if (ok && !near_exit) {
         const int n_act = s_nact;
         const int *tidc = tid_b + cur * NC;
         for (int k = tid; k < n_act; k += kSgThreads) leafflag[tidc[k]] = 1;
@@ -638,7 +777,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             const unsigned aborted = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.sync[0] = 0u; a.sync[1] = 0u; a.sync[2] = 0u;
             for (int g = 0; g * kSgGroup < G; ++g) a.sync[32 + 32 * g] = 0u;
-            a.status[3] = aborted || !ok ? 1u : 0u;
+            a.status[3] = aborted || !ok ? 1u : (near_exit ? 2u : 0u);
             __threadfence_system();
             __hip_atomic_store(a.status, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -651,9 +790,9 @@ int align16(int x) { return (x + 15) & ~15; }
 
 // ---------------------------------------------------------------------------------------------------- host side
 
-size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {
+size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {   // the bests, then the (second, parent) pairs of the near-tie detection
     const int NC = 1 << std::max(0, MD - 1);
-    return sizeof(SgBest) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
+    return (sizeof(SgBest) + sizeof(float2)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
 }
 size_t small_grow_res_stride(int MD) { return static_cast<size_t>(1 << std::max(0, MD - 1)) * 44 + 64; }
 
@@ -686,18 +825,22 @@ SgLayout sg_layout(int N, int D, int NB, int MD, int acc_bytes, int &nb_cap, int
     L.wcat = take(4 * NC);
     L.wthr = take(4 * NC);
     L.nbest = take(16 * NC);
+    L.nbest2 = take(4 * NC);
+    L.npar = take(4 * NC);
     L.ssum = take(4 * NB);
     L.leafflag = take(NIDS);
     L.wbest = take(16 * kSgWaves);
+    L.wbest2 = take(4 * kSgWaves);
     L.lacc = take(8 * W);
     const int budget = 160 * 1024 - 1024 /* static __shared__ + slack */ - off - 8 * kWave - 16;
-    const int per_node = NB * W * acc_bytes + Tmax * W * acc_bytes + W * 16 + Tmax * 16 + 64;
+    const int per_node = NB * W * acc_bytes + Tmax * W * acc_bytes + W * 16 + Tmax * 20 + 80;
     nb_cap = budget > 0 ? std::min(NC, budget / per_node) : 0;
     if (nb_cap <= 0) { nb_cap = 0; return L; }
     L.ttot = take(acc_bytes * nb_cap * Tmax * W);
     L.total = take(8 * nb_cap * W);
     L.totalf = take(8 * nb_cap * W);
     L.ibest = take(16 * nb_cap * Tmax);
+    L.ibest2 = take(4 * nb_cap * Tmax);
     (void)take(acc_bytes * kWave);                      // the accumulate loop's per-lane sink words sit right in front of the histogram
     L.hist = take(acc_bytes * nb_cap * NB * W);
     L.total_bytes = off;
@@ -721,7 +864,11 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.N = io.N; a.D = io.D; a.B = io.B; a.n_slots = io.n_slots; a.NB = io.NB; a.MD = io.MD; a.min_data = io.min_data; a.cosine = io.cosine ? 1 : 0; a.oblivious = io.oblivious ? 1 : 0;
     a.G = io.G; a.NC = 1 << std::max(0, io.MD - 1); a.NIDS = 2 << io.MD;
     a.magicW = static_cast<uint32_t>((1ull << 32) / static_cast<unsigned>(io.D + 1)) + 1u;
-    a.bests = static_cast<SgBest *>(io.bests); a.sync = io.sync; a.res = io.res; a.res_dev = io.res_dev; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
+    a.bests = static_cast<SgBest *>(io.bests);
+    a.seconds = reinterpret_cast<float2 *>(static_cast<SgBest *>(io.bests) + static_cast<size_t>(io.MD) * (io.oblivious ? 1 : a.NC) * io.G);
+    a.near_rel = io.near_rel;
+    a.tiny_words = static_cast<int>((static_cast<size_t>(acc_bytes) * a.nb_cap * io.NB * (io.D + 1) / 4 / kSgWaves) & ~static_cast<size_t>(3));
+    a.sync = io.sync; a.res = io.res; a.res_dev = io.res_dev; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
     a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof; a.scales_out = io.scales_out;
     static PerDeviceOnce attr32, attr64;
     if (acc_bytes == 4) {

@@ -211,6 +211,13 @@ int gbrl_hip_last_phase_times(const gbrl_hip_model *m, const char **names, float
  * predict()) are timed -- step(): the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL events), free for a timed region.  2: every phase is bracketed
  * (diagnostic: each record costs a few microseconds of stream bubble, ~60 records per step). */
 int gbrl_hip_set_profiling(gbrl_hip_model *m, int level);
+/* Diagnostics (tests): the near-tie replay kernel (csrc/neartie.hip) on ONE node given explicitly -- the float32 score the reference's
+ * TreeNode::splitScoreCosine / splitScoreL2 (node.cpp:187-251, 321-376) gives the split {rows with goes_right} | {the others} of the rows
+ * with in_node set, and the node's parent score (scoreCosine / scoreL2, split_candidate_generator.cpp:262-320).  Host pointers: grads
+ * [n_rows][output_dim]; in_node, goes_right [n_rows] bytes; meanden nullable [2 * output_dim] (L2: column means | std + 1e-8f, the
+ * standardisation applied to grads before scoring); out_scores[2] = split score | parent score.  n_rows <= 65536. */
+int gbrl_hip_replay_scores(const float *grads, const uint8_t *in_node, const uint8_t *goes_right, int n_rows, int output_dim,
+                           const float *meanden, int cosine, int min_data_in_leaf, float *out_scores);
 
 /* ---- device / stream contract (new; the reference pins everything to device 0 and the null stream, cuda_types.cu:32-106) -- */
 /* The device the model computes on: the ordinal given at creation, or -- for -1 -- the calling thread's current device at the

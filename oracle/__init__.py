@@ -201,3 +201,52 @@ def load_ref(native: bool = False):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+# ---- the reference's per-candidate float32 score as an explicit operation sequence (replay_sequence.cpp) and the reference's own
+# ---- functions behind a C shim (oracle/_ref/ref_score_probe.so): what the product's near-tie replay is tested against
+def replay_scores(obs, grads, rows, feature, value, min_data, cosine):
+    """(split score, parent score) of the numeric candidate obs[:, feature] > value on the node `rows` (ascending), restated sequence."""
+    lib = _lib()
+    obs = np.ascontiguousarray(obs, np.float32)
+    grads = np.ascontiguousarray(grads, np.float32)
+    rows = np.ascontiguousarray(rows, np.int32)
+    n, F, D = len(rows), obs.shape[1], grads.shape[1]
+    sp = lib.oracle_replay_split_cosine if cosine else lib.oracle_replay_split_l2
+    pa = lib.oracle_replay_parent_cosine if cosine else lib.oracle_replay_parent_l2
+    sp.restype = pa.restype = C.c_float
+    sp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    pa.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    s = sp(obs.ctypes.data, grads.ctypes.data, rows.ctypes.data, n, F, D, int(feature), float(value), int(min_data))
+    p = pa(grads.ctypes.data, rows.ctypes.data, n, D) if n else 0.0
+    return np.float32(s), np.float32(p)
+
+
+_PROBE = None
+
+
+def ref_score_probe():
+    """ctypes handle onto TreeNode::splitScoreCosine / splitScoreL2 / scoreCosine / scoreL2 of oracle/_ref, or None when it is not built."""
+    global _PROBE
+    if _PROBE is None:
+        path = os.path.join(_HERE, "_ref", "ref_score_probe.so")
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        lib.ref_split_score.restype = lib.ref_parent_score.restype = C.c_float
+        lib.ref_split_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
+        lib.ref_parent_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _PROBE = lib
+    return _PROBE
+
+
+def ref_scores(obs, grads, rows, feature, value, min_data, cosine):
+    """The same pair from the reference's own functions."""
+    lib = ref_score_probe()
+    obs = np.ascontiguousarray(obs, np.float32)
+    grads = np.ascontiguousarray(grads, np.float32)
+    rows = np.ascontiguousarray(rows, np.int32)
+    n, F, D = len(rows), obs.shape[1], grads.shape[1]
+    s = lib.ref_split_score(obs.ctypes.data, grads.ctypes.data, rows.ctypes.data, n, F, D, int(feature), float(value), int(min_data), 1 if cosine else 0)
+    p = lib.ref_parent_score(grads.ctypes.data, rows.ctypes.data, n, D, 1 if cosine else 0) if n else 0.0
+    return np.float32(s), np.float32(p)

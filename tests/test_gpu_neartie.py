@@ -1,0 +1,155 @@
+"""Near-tie replay (round 5, gbrl_amd/csrc/neartie.hip).
+
+Where the exact arg-max of a node has a runner-up within 2^-20 relative (or a greedy gain that close to zero), the product re-scores the
+candidates in the window in the reference's float32 operation sequence and takes the reference's comparison of them, so that the tree has
+the reference's structure even where the reference's own rounding decided.
+
+* the replay kernel against the restated sequence (oracle/replay_sequence.cpp, pinned to the reference's own functions by
+  tests/test_oracle.py) and, where oracle/_ref is present, against those functions themselves -- bit for bit;
+* the near-tie specimen of the golden fixtures becomes exact, and is the explained near-tie of rounds 1-4 with the hook
+  GBRL_HIP_NO_NEARTIE_REPLAY=1;
+* the one-launch growth kernel (which hands a tree with a near-tie to the level loop) and the level loop give the same bytes;
+* random cases against the reference build / the restatement: fewer structural differences with the replay than without, none unexplained.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import cases as K
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+HOOKS = ("GBRL_HIP_NO_NEARTIE_REPLAY", "GBRL_HIP_NO_SMALL_GROW", "GBRL_HIP_NO_SMALL_PREP", "GBRL_HIP_NEARTIE_REL")
+
+
+def _lib():
+    import gbrl_amd
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(gbrl_amd.__file__), "libgbrl_hip.so"))
+    lib.gbrl_hip_replay_scores.restype = ctypes.c_int
+    lib.gbrl_hip_replay_scores.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.gbrl_hip_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def _device_scores(lib, g, in_node, right, meanden, cosine, min_data):
+    out = np.zeros(2, np.float32)
+    g = np.ascontiguousarray(g, np.float32)
+    in_node = np.ascontiguousarray(in_node, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    md = None if meanden is None else np.ascontiguousarray(meanden, np.float32)
+    rc = lib.gbrl_hip_replay_scores(g.ctypes.data, in_node.ctypes.data, right.ctypes.data, g.shape[0], g.shape[1],
+                                    None if md is None else md.ctypes.data, 1 if cosine else 0, min_data, out.ctypes.data)
+    assert rc == 0, lib.gbrl_hip_last_error()
+    return out
+
+
+@pytest.mark.parametrize("cosine", [True, False])
+def test_replay_kernel_is_the_reference_sequence_bit_for_bit(cosine):
+    import oracle
+    lib = _lib()
+    probe = oracle.ref_score_probe()
+    rng = np.random.default_rng(11 if cosine else 12)
+    shapes = [(1, 1), (2, 3), (5, 4), (64, 7), (65, 8), (300, 1), (300, 33), (1000, 9), (4096, 16), (4097, 5), (20000, 2), (65536, 3), (700, 130), (50, 520)]
+    for rep in range(60):
+        N, D = shapes[rep % len(shapes)]
+        sc = np.exp(rng.standard_normal() * 2)
+        g = (rng.standard_normal((N, D)) * sc + (0.4 * sc if rep % 3 else 0)).astype(np.float32)
+        x = rng.standard_normal((N, 1)).astype(np.float32)
+        in_node = (rng.integers(0, 4, N) > 0) if rep % 4 else np.ones(N, bool)
+        if rep % 9 == 8:
+            in_node[:] = False
+            in_node[rng.integers(0, N, 2)] = True        # one- and two-row nodes
+        thr = float(np.float32(rng.standard_normal() * (2.5 if rep % 5 == 4 else 0.6)))   # (now and then every row on one side)
+        right = x[:, 0] > thr
+        rows = np.flatnonzero(in_node).astype(np.int32)
+        md = 0 if rep % 6 else int(rng.integers(1, 4))
+        meanden = None
+        gs = g
+        if not cosine:   # L2 scores the standardised gradients: (g - mean) / (std + 1e-8f), float32 operation by operation
+            mean = g.mean(axis=0).astype(np.float32)
+            den = (g.std(axis=0).astype(np.float32) + np.float32(1e-8)).astype(np.float32)
+            meanden = np.concatenate([mean, den])
+            gs = ((g - mean[None, :]) / den[None, :]).astype(np.float32)
+        got = _device_scores(lib, g, in_node, right, meanden, cosine, md)
+        want = oracle.replay_scores(x, gs, rows, 0, thr, md, cosine)
+        assert got[0].tobytes() == want[0].tobytes(), ("split score", rep, N, D, len(rows), got, want)
+        assert got[1].tobytes() == want[1].tobytes(), ("parent score", rep, N, D, len(rows), got, want)
+        if probe is not None:
+            ref = oracle.ref_scores(x, gs, rows, 0, thr, md, cosine)
+            assert got[0].tobytes() == ref[0].tobytes() and got[1].tobytes() == ref[1].tobytes(), ("reference functions", rep, got, ref)
+
+
+def _grow(case, inputs, monkeypatch, env, counters=False):
+    import gbrl_amd
+    for k in HOOKS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    X, Xc, G, y = inputs
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    m.set_profiling(2)
+    pred = K.drive(m, case, X, Xc, G, y)
+    e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+    if not counters:
+        return e, np.asarray(pred)
+    m.step(X, Xc, np.ascontiguousarray(G if G is not None else np.zeros((len(X), case["D"]), np.float32)))
+    return e, np.asarray(pred), dict(m.last_phase_times())
+
+
+def test_near_tie_specimen_is_exact_with_the_replay_and_explained_without(monkeypatch):
+    import neartie
+    case, g, inputs = load_golden("grd_cos_q_ac_d6_neartie")
+    e, _ = _grow(case, inputs, monkeypatch, {})
+    assert neartie.first_mismatch(g, e, case["policy"]) is None, "the replay should reproduce the reference's choice at the 547-row node"
+    e_loop, _ = _grow(case, inputs, monkeypatch, {"GBRL_HIP_NO_SMALL_GROW": "1", "GBRL_HIP_NO_SMALL_PREP": "1"})
+    assert neartie.first_mismatch(g, e_loop, case["policy"]) is None
+    e_off, _ = _grow(case, inputs, monkeypatch, {"GBRL_HIP_NO_NEARTIE_REPLAY": "1"})
+    mm = neartie.first_mismatch(g, e_off, case["policy"])
+    assert mm is not None, "without the replay the product keeps the float64 maximum here (rounds 1-4)"
+    info = neartie.explain_first_mismatch(case, inputs[0], inputs[1], inputs[2], g, e_off)
+    assert info["explained"] and info["product_is_true_max"], info
+
+
+def _sweep_case(seed):
+    rng = np.random.default_rng(seed)
+    policy = ["greedy", "oblivious"][int(rng.integers(0, 2))] if seed % 3 == 0 else "greedy"
+    return dict(name="nt%d" % seed, seed=seed, N=int(rng.choice([300, 1000, 3000, 6000, 9000])), F=int(rng.choice([1, 3, 8, 17])), Fc=int(rng.choice([0, 0, 1])),
+                D=int(rng.choice([1, 2, 3, 8, 11, 33])), depth=int(rng.choice([3, 4, 5])), n_bins=int(rng.choice([7, 64, 256])), score="Cosine",
+                gen=["Quantile", "Uniform"][int(rng.integers(0, 2))], policy=policy, trees=int(rng.choice([1, 2, 4])), min_data_in_leaf=int(rng.choice([0, 0, 5])))
+
+
+def test_replay_matches_the_reference_where_the_exact_argmax_does_not(monkeypatch):
+    """Cosine cases against the reference build (the restatement where oracle/_ref is absent).  The replay may only ever turn a structural
+    difference into agreement: every case that agrees without it agrees with it, both growth paths give the same bytes, and over the
+    set there are fewer differences with the replay than without."""
+    import neartie
+    import oracle
+    ref_mod = oracle.load_ref()
+    diffs_on = diffs_off = replays = 0
+    for seed in range(31000, 31060):
+        case = _sweep_case(seed)
+        inputs = K.make_inputs(case)
+        r = ref_mod.GBRL(**K.ctor_kwargs(case)) if ref_mod is not None else oracle.OracleGBRL(**K.ctor_kwargs(case))
+        K.drive(r, case, *inputs)
+        g = {k: np.asarray(v) for k, v in r.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
+        e_on, p_on, ph = _grow(case, inputs, monkeypatch, {}, counters=True)
+        e_off, _ = _grow(case, inputs, monkeypatch, {"GBRL_HIP_NO_NEARTIE_REPLAY": "1"})
+        e_loop, p_loop = _grow(case, inputs, monkeypatch, {"GBRL_HIP_NO_SMALL_GROW": "1"})
+        for k in e_on:
+            assert e_on[k].shape == e_loop[k].shape and e_on[k].tobytes() == e_loop[k].tobytes(), (case, k, "one-launch growth vs level loop")
+        assert p_on.tobytes() == p_loop.tobytes(), case
+        replays += ph.get("near_replays", 0)
+        m_on, m_off = neartie.first_mismatch(g, e_on, case["policy"]), neartie.first_mismatch(g, e_off, case["policy"])
+        diffs_on += m_on is not None
+        diffs_off += m_off is not None
+        if m_off is None:
+            assert m_on is None, ("the replay broke a case that agreed without it", case)
+        if m_on is not None:
+            info = neartie.explain_first_mismatch(case, inputs[0], inputs[1], inputs[2], g, e_on)
+            assert info["explained"], (case, info)
+    print("near-tie sweep: %d cases, differences without the replay %d, with it %d, levels replayed %d" % (60, diffs_off, diffs_on, replays))
+    assert diffs_on <= diffs_off
+    assert replays > 0, "no level of 60 cases was replayed: the detection never fired"

@@ -114,3 +114,32 @@ def test_fullsize_checker_agrees_with_the_reference_build(policy, score):
         leaves = [0, len(e["values"]) - 1]
         recs = fullsize.check_greedy_nodes(X, G, e, B, score, leaves, [0, int(e["depths"][leaves[1]]) - 1], rel_tol=tol)
     assert all(r["exact"] for r in recs), recs
+
+
+def _random_node(rng, rep):
+    D = int(rng.integers(1, 41)) if rep % 7 else int(rng.integers(1, 131))
+    N = int(rng.integers(1, 600))
+    F = int(rng.integers(1, 6))
+    obs = rng.standard_normal((N, F)).astype(np.float32)
+    sc = np.exp(rng.standard_normal() * 3)
+    g = (rng.standard_normal((N, D)) * sc + (0.3 * sc if rep % 3 else 0)).astype(np.float32)
+    rows = np.flatnonzero(rng.integers(0, 4, N) > 0).astype(np.int32)
+    if rep % 11 == 0:
+        rows = rows[:int(rng.integers(1, 4))]
+    return obs, g, rows, int(rng.integers(0, F)), float(np.float32(rng.standard_normal() * 0.7))
+
+
+@pytest.mark.parametrize("cosine", [True, False])
+def test_replay_sequence_is_the_reference_functions_bit_for_bit(cosine):
+    """oracle/replay_sequence.cpp (explicit fmaf / rounded products, built without contraction) against TreeNode::splitScoreCosine /
+    splitScoreL2 and scoreCosine / scoreL2 of the reference build on random nodes: every output width 1..130, nodes of 0..600 rows,
+    gradient scales over six decades.  This pins the operation sequence the product's near-tie replay implements."""
+    if oracle.ref_score_probe() is None:
+        pytest.skip("oracle/_ref/ref_score_probe.so not built (needs /root/reference)")
+    rng = np.random.default_rng(5 if cosine else 6)
+    for rep in range(3000):
+        obs, g, rows, f, v = _random_node(rng, rep)
+        md = 0 if rep % 5 else int(rng.integers(0, 4))
+        a = oracle.ref_scores(obs, g, rows, f, v, md, cosine)
+        b = oracle.replay_scores(obs, g, rows, f, v, md, cosine)
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes(), (rep, a, b, g.shape, len(rows))
