@@ -1171,7 +1171,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const bool no_near = [] { const char *e = std::getenv("GBRL_HIP_NO_NEARTIE_REPLAY"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     const float near_rel = [] { const char *e = std::getenv("GBRL_HIP_NEARTIE_REL"); return e ? static_cast<float>(std::atof(e)) : 9.5367431640625e-07f; }();   // 2^-20; measurement hook
     const bool near_on = !no_near && !has_coll_ && n_global == N && n_cand > 0 && kern::near_tie_supported(N, D);
-    float *d_am_s = (near_on && !use_small) ? static_cast<float *>(d_am_s_.ensure(sizeof(float) * am_cap)) : nullptr;
+    float *d_am_s = (near_on && !use_small) ? static_cast<float *>(d_am_s_.ensure(sizeof(float) * am_cap * 2)) : nullptr;
+    int32_t *d_am_n = d_am_s ? reinterpret_cast<int32_t *>(d_am_s + am_cap) : nullptr;
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
     {   // zero unless the last tree's publication handed these words back clean
@@ -1747,7 +1748,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         if (own_slots > 0)
             kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                    d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
-                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0, !drop_derived, oblivious ? nullptr : d_am_s);
+                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0, !drop_derived, oblivious ? nullptr : d_am_s, oblivious ? nullptr : d_am_n);
         // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
         // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
         if (oblivious)
@@ -1761,7 +1762,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (seq == 0) seq = ++level_seq_;
         }
         const bool near_level = d_am_s != nullptr && publish_in_resolve;
-        const kern::NearDetect near_detect{d_am_s, near_rel, d_parent, d_isroot, cosine ? 1 : 0, N};
+        const kern::NearDetect near_detect{d_am_s, oblivious ? nullptr : d_am_n, near_rel, d_parent, d_isroot, cosine ? 1 : 0, N};
         kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
                              d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, publish_in_resolve ? h_res_dev : nullptr, d_flag, seq, d_pub_done,
                              drop_derived ? d_hist_prev : nullptr, drop_derived ? d_sub_par : nullptr, drop_derived ? d_sub_sib : nullptr, near_level ? &near_detect : nullptr);
@@ -1823,13 +1824,14 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (any) {
                 ++near_replays_;
                 phase_begin();
-                if (!oblivious)   // every candidate's exact score (the greedy selection kept the per-slot bests only)
+                int32_t *d_cand_nr = oblivious ? nullptr : static_cast<int32_t *>(d_near_nr_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
+                if (!oblivious)   // every candidate's exact score and child sizes (the greedy selection kept the per-slot bests only)
                     kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
-                                           d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot, nullptr, d_am_i, s, 0, !drop_derived);
+                                           d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot, nullptr, d_am_i, s, 0, !drop_derived, nullptr, nullptr, d_cand_nr);
                 kern::NearTieIO io{};
                 io.rows = d_rows[cur]; io.seg_start = d_seg_starts; io.n_rows = d_n_locals; io.codes = d_codes; io.N = N; io.D = D; io.grads = dgrads; io.meanden = c.d_meanden;
                 io.cosine = cosine ? 1 : 0; io.oblivious = oblivious ? 1 : 0; io.min_data = md.min_data_in_leaf; io.slots = d_slots; io.cand_slot = d_cand_slot; io.cand_w = d_cand_w; io.cand_ref = d_cand_ref;
-                io.n_cand = n_cand; io.scores = d_scores; io.parent = d_parent; io.is_root = d_isroot; io.best_score = d_best_score; io.near = d_counts4 + 2 * static_cast<size_t>(max_front);
+                io.n_cand = n_cand; io.scores = d_scores; io.cand_nr = d_cand_nr; io.parent = d_parent; io.is_root = d_isroot; io.best_score = d_best_score; io.near = d_counts4 + 2 * static_cast<size_t>(max_front);
                 io.rel = near_rel; io.n_act = n_act;
                 int32_t *lists = static_cast<int32_t *>(d_near_list_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * (kern::kNearCands + 1)));
                 io.list = lists; io.list_n = lists + static_cast<size_t>(max_front) * kern::kNearCands;

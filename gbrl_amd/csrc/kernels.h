@@ -245,7 +245,9 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       int32_t *part_i, hipStream_t s, int slot0 = 0 /* first feature slot scored (n_slots of them): feature-parallel scoring */,
                       bool keep_derived = true /* false (last level only): derived slices are scored but not written back; resolve_splits
                       must then be given hist_prev / sub_par / sub_sib */,
-                      float *part_s = nullptr /* greedy, nullable: [n_nodes][n_slots] the best gain strictly below part_v (near-tie detection) */);
+                      float *part_s = nullptr /* greedy, nullable: [n_nodes][n_slots] the best gain of another candidate class than part_v's (near-tie detection) */,
+                      int32_t *part_n = nullptr /* with part_s: rows the slot's best sends right (0 when it sends all of them: one class with 'none') */,
+                      int32_t *cand_nr = nullptr /* nullable, scores mode (part_v == nullptr): [n_nodes][n_cand] rows every candidate sends right */);
 // best_idx holds REFERENCE candidate indices (cand_ref[j]); ties go to the lowest reference index.  oblivious: one
 // result (sum over nodes); greedy: one per node.  part_v/part_i: scratch of n_nodes * argmax_parts(n_cand).
 int argmax_parts(int n_cand);
@@ -255,7 +257,7 @@ void argmax(const float *scores, int n_nodes, int n_cand, const float *cand_weig
 
 // near-tie detection inside resolve_splits (one GPU): counts4[2 * max_front + node] = 1 when the best DISTINCT runner-up is within
 // rel * (magnitude of the scores) of the winner, or (greedy) the winning gain is that close to zero
-struct NearDetect { const float *part_s; float rel; const float *parent; const int32_t *is_root; int cosine; long long rows; /* of the batch (oblivious levels) */ };
+struct NearDetect { const float *part_s; const int32_t *part_n /* nullable: oblivious */; float rel; const float *parent; const int32_t *is_root; int cosine; long long rows; /* of the batch (oblivious levels) */ };
 
 // winner -> (feature slot, class) and the child sizes it induces, per active node (one read-back per level)
 void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*argmax stage-1 output; the final stage runs here*/,
@@ -291,6 +293,7 @@ struct NearTieIO {
     const int32_t *cand_ref;    // [n_cand] reference index of every internal candidate
     int n_cand;
     const float *scores;        // [n_act][n_cand] exact scores (score_candidates without part_v)
+    const int32_t *cand_nr;     // greedy: [n_act][n_cand] rows every candidate sends right (same launch); nullptr: oblivious
     const float *parent;        // [n_act] exact parent scores
     const int32_t *is_root;     // [n_act]
     const float *best_score;    // [n_act] exact best gain (oblivious: [0])

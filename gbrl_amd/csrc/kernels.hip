@@ -916,7 +916,9 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
                                                float *__restrict__ scores, float *__restrict__ parent,
                                                const float *__restrict__ cand_w, const int32_t *__restrict__ cand_ref,
                                                const int32_t *__restrict__ is_root, float *__restrict__ part_v, int32_t *__restrict__ part_i, int slot0,
-                                               int keep_derived, float *__restrict__ part_s /*nullable: second-best DISTINCT gain per block (near-tie detection)*/) {
+                                               int keep_derived, float *__restrict__ part_s /*nullable: second-best DISTINCT gain per block (near-tie detection)*/,
+                                               int32_t *__restrict__ part_n /*with part_s: rows the block's best sends right*/,
+                                               int32_t *__restrict__ cand_nr /*nullable, scores mode: [n_nodes][n_cand] rows every candidate sends right*/) {
     extern __shared__ int64_t sh64[];  // [NB][D+1] suffix sums (numeric) or raw classes (categorical)
     const double inv_scale = scp->inv_scale;
     const int node = blockIdx.y, fs = slot0 + blockIdx.x;
@@ -1065,7 +1067,8 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
     // root parent = 0, lowest reference index among maxima)
     const float par_sub = (part_v && is_root[node]) ? 0.0f : par_score;
     Best mine{-INFINITY, 0x7fffffff};
-    float second = -INFINITY;     // the best gain strictly below mine.v (candidates with EQUAL gains split the node's rows identically)
+    float second = -INFINITY;     // the best gain of a candidate of another class (score_common.h second_merge)
+    int mine_nr = -1;             // rows the block's best sends right
     const int np = s_np;
     for (int k = threadIdx.x; k < sl.n_cand; k += blockDim.x) {
         const int64_t *R = sh64 + (k + 1) * W;
@@ -1089,29 +1092,41 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
         if (part_v) {
             const int j = sl.cand_base + k;
             const float gain = fmaf(out, cand_w[j], -par_sub);
-            second = second_distinct(mine.v, second, gain, -INFINITY);
-            mine = better(mine, Best{gain, cand_ref[j]});
+            const Best cb{gain, cand_ref[j]};
+            const int cls = near_class(n_r, n_tot);
+            second = second_merge(mine.v, mine_nr, second, gain, cls, -INFINITY);
+            if (better_takes_second(mine, cb)) { mine = cb; mine_nr = cls; }
         } else {
             scores[static_cast<size_t>(node) * n_cand + sl.cand_base + k] = out;
+            if (cand_nr) cand_nr[static_cast<size_t>(node) * n_cand + sl.cand_base + k] = near_class(n_r, n_tot);
         }
     }
     if (part_v) {
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const Best other{__shfl_xor(mine.v, o, kWave), __shfl_xor(mine.i, o, kWave)};
-            if (part_s) second = second_distinct(mine.v, second, other.v, __shfl_xor(second, o, kWave));
+            if (part_s) {
+                const int onr = __shfl_xor(mine_nr, o, kWave);
+                second = second_merge(mine.v, mine_nr, second, other.v, onr, __shfl_xor(second, o, kWave));
+                if (better_takes_second(mine, other)) mine_nr = onr;
+            }
             mine = better(mine, other);
         }
         __shared__ float bv[4], b2[4];
-        __shared__ int bi[4];
-        if (lane == 0) { bv[wave] = mine.v; bi[wave] = mine.i; b2[wave] = second; }
+        __shared__ int bi[4], bn[4];
+        if (lane == 0) { bv[wave] = mine.v; bi[wave] = mine.i; b2[wave] = second; bn[wave] = mine_nr; }
         __syncthreads();
         if (threadIdx.x == 0) {
             Best b{bv[0], bi[0]};
             float s2 = b2[0];
-            for (int q = 1; q < 4; ++q) { s2 = second_distinct(b.v, s2, bv[q], b2[q]); b = better(b, Best{bv[q], bi[q]}); }
+            int nr = bn[0];
+            for (int q = 1; q < 4; ++q) {
+                const Best o{bv[q], bi[q]};
+                s2 = second_merge(b.v, nr, s2, o.v, bn[q], b2[q]);
+                if (better_takes_second(b, o)) { b = o; nr = bn[q]; }
+            }
             part_v[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.v;
             part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.i;
-            if (part_s) part_s[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = s2;
+            if (part_s) { part_s[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = s2; part_n[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = nr; }
         }
     }
 }
@@ -1181,7 +1196,7 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                                                        const uint32_t *__restrict__ thr_keys, int B, char *pub, uint32_t *pub_flag,
                                                        uint32_t pub_seq, unsigned *pub_done, const int64_t *__restrict__ hist_prev,
                                                        const int32_t *__restrict__ sub_par, const int32_t *__restrict__ sub_sib,
-                                                       const float *__restrict__ part_s, float near_rel, const float *__restrict__ parent,
+                                                       const float *__restrict__ part_s, const int32_t *__restrict__ part_n /*nullable: oblivious levels*/, float near_rel, const float *__restrict__ parent,
                                                        const int32_t *__restrict__ is_root, int cosine_score, long long near_rows) {
     const int node = blockIdx.x;
     // pub != nullptr: the result block [best_idx | best_score | counts4] is mirrored into pinned, device-mapped host memory of the same
@@ -1194,14 +1209,23 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
     const int src_node = oblivious ? 0 : node;
     Best mine{-INFINITY, 0x7fffffff};
     float second = -INFINITY;
+    int mine_nr = 0;          // (oblivious levels carry no child sizes: every candidate's is 0 and only the gains tell classes apart)
     for (int q = threadIdx.x; q < n_parts; q += kWave) {
         const Best other{part_v[static_cast<size_t>(src_node) * n_parts + q], part_i[static_cast<size_t>(src_node) * n_parts + q]};
-        if (part_s) second = second_distinct(mine.v, second, other.v, part_s[static_cast<size_t>(src_node) * n_parts + q]);
+        if (part_s) {
+            const int onr = part_n ? part_n[static_cast<size_t>(src_node) * n_parts + q] : 0;
+            second = second_merge(mine.v, mine_nr, second, other.v, onr, part_s[static_cast<size_t>(src_node) * n_parts + q]);
+            if (better_takes_second(mine, other)) mine_nr = onr;
+        }
         mine = better(mine, other);
     }
     for (int o = kWave / 2; o > 0; o >>= 1) {
         const Best other{__shfl_xor(mine.v, o, kWave), __shfl_xor(mine.i, o, kWave)};
-        if (part_s) second = second_distinct(mine.v, second, other.v, __shfl_xor(second, o, kWave));
+        if (part_s) {
+            const int onr = __shfl_xor(mine_nr, o, kWave);
+            second = second_merge(mine.v, mine_nr, second, other.v, onr, __shfl_xor(second, o, kWave));
+            if (better_takes_second(mine, other)) mine_nr = onr;
+        }
         mine = better(mine, other);
     }
     const int best = mine.i == 0x7fffffff ? 0 : mine.i;
@@ -1815,7 +1839,7 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
                       const float *thr, int B, int n_cand, int min_data, int cosine, const StepScales *sc,
                       const int32_t *path_len, const int32_t *path_slot, const float *path_val, const int32_t *path_bin,
                       float *scores, float *parent, const float *cand_w, const int32_t *cand_ref, const int32_t *is_root, float *part_v,
-                      int32_t *part_i, hipStream_t s, int slot0, bool keep_derived, float *part_s) {
+                      int32_t *part_i, hipStream_t s, int slot0, bool keep_derived, float *part_s, int32_t *part_n, int32_t *cand_nr) {
     const size_t lds = static_cast<size_t>(NB + 2) * (D + 1) * sizeof(int64_t);   // class sums, the totals, the totals as doubles
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
@@ -1823,7 +1847,7 @@ void score_candidates(int64_t *hist, const int64_t *hist_prev, const int32_t *su
     }
     hipLaunchKernelGGL(k_score, dim3(n_slots, n_nodes), dim3(256), lds, s, hist, hist_prev, sub_par, sub_sib, Fp, NB, D, slots, thr, B, n_cand, min_data,
                        cosine, sc, path_len, path_slot, path_val, path_bin, scores, parent, cand_w, cand_ref, is_root, part_v, part_i, slot0,
-                       keep_derived ? 1 : 0, part_s);
+                       keep_derived ? 1 : 0, part_s, part_n, cand_nr);
 }
 
 int argmax_parts(int n_cand) { return (n_cand + kArgmaxThreads - 1) / kArgmaxThreads; }
@@ -1844,7 +1868,7 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts, int
     hipLaunchKernelGGL(k_resolve_splits, dim3(n_nodes), dim3(64), 0, s, part_v, part_i, n_parts, best_idx, best_score, oblivious ? 1 : 0,
                        ref_to_internal, cand_slot, slots, hist_local, hist_global, Fp, NB, D, out, counts4, max_front, seg_start, cursors, thr_keys, B,
                        static_cast<char *>(pub), pub_flag, pub_seq, pub_done, hist_prev, sub_par, sub_sib,
-                       near ? near->part_s : nullptr, near ? near->rel : 0.0f, near ? near->parent : nullptr, near ? near->is_root : nullptr, near ? near->cosine : 1, near ? near->rows : 0);
+                       near ? near->part_s : nullptr, near ? near->part_n : nullptr, near ? near->rel : 0.0f, near ? near->parent : nullptr, near ? near->is_root : nullptr, near ? near->cosine : 1, near ? near->rows : 0);
 }
 
 // Row-sharded runs: k_resolve_splits wrote GLOBAL left sizes; the partition needs this rank's.

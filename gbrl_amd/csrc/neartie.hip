@@ -49,42 +49,47 @@ __device__ __forceinline__ float near_level_score(const NearTieIO &a, int j) {
     return sc * a.cand_w[j];
 }
 
-// The distinct gain values inside the window, best first, each represented by its lowest reference index (candidates with the same exact
-// gain induce the same partition of the node -- thresholds between the same two rows -- and the reference scores them identically).
+// The candidate CLASSES inside the window, best first, each represented by its lowest reference index.  A class = (gain, rows going right):
+// candidates with the same exact gain and the same child sizes induce the same partition of the node -- thresholds between the same two
+// rows -- and the reference scores them identically; the same gain with other child sizes is another partition (score_common.h second_merge).
 __global__ __launch_bounds__(kNearThreads) void k_near_list(NearTieIO a) {
     const int node = blockIdx.x;
     if (a.near[node] == 0) { if (threadIdx.x == 0) a.list_n[node] = 0; return; }
     __shared__ float sv[kNearThreads];
-    __shared__ int si[kNearThreads], sj[kNearThreads];
+    __shared__ int si[kNearThreads], sj[kNearThreads], sn[kNearThreads];
     const float b1 = a.best_score[node];
     float mag;
     if (a.oblivious) mag = fabsf(b1);
     else { const float par = a.is_root[node] ? 0.0f : a.parent[node]; mag = fmaxf(fabsf(b1 + par), fabsf(par)); }
     const float lo = b1 - near_window_rel(a.rel, a.oblivious ? a.N : a.n_rows[node]) * mag;
     float prev = INFINITY;
+    int prev_n = 0x7fffffff;
     int count = 0;
     for (; count < kNearCands; ++count) {
-        float bv = -INFINITY; int bi = 0x7fffffff, bj = -1;
+        float bv = -INFINITY; int bi = 0x7fffffff, bj = -1, bn = 0x7fffffff;
         for (int j = threadIdx.x; j < a.n_cand; j += kNearThreads) {
             const float g = a.oblivious ? near_level_score(a, j) : near_gain(a, node, j);
-            if (!(g >= lo) || !(g < prev)) continue;
+            const int n = a.cand_nr ? a.cand_nr[static_cast<size_t>(node) * a.n_cand + j] : 0;
+            if (!(g >= lo) || !(g < prev || (g == prev && n > prev_n))) continue;
             const int r = a.cand_ref[j];
-            if (g > bv || (g == bv && r < bi)) { bv = g; bi = r; bj = j; }
+            if (g > bv || (g == bv && (n < bn || (n == bn && r < bi)))) { bv = g; bi = r; bj = j; bn = n; }
         }
-        sv[threadIdx.x] = bv; si[threadIdx.x] = bi; sj[threadIdx.x] = bj;
+        sv[threadIdx.x] = bv; si[threadIdx.x] = bi; sj[threadIdx.x] = bj; sn[threadIdx.x] = bn;
         __syncthreads();
         for (int o = kNearThreads / 2; o > 0; o >>= 1) {
             if (threadIdx.x < o) {
-                const float ov = sv[threadIdx.x + o]; const int oi = si[threadIdx.x + o];
-                if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; sj[threadIdx.x] = sj[threadIdx.x + o]; }
+                const float ov = sv[threadIdx.x + o]; const int oi = si[threadIdx.x + o], on = sn[threadIdx.x + o];
+                const float mv = sv[threadIdx.x]; const int mi = si[threadIdx.x], mn = sn[threadIdx.x];
+                if (ov > mv || (ov == mv && (on < mn || (on == mn && oi < mi)))) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; sj[threadIdx.x] = sj[threadIdx.x + o]; sn[threadIdx.x] = on; }
             }
             __syncthreads();
         }
-        const float got = sv[0]; const int got_j = sj[0];
+        const float got = sv[0]; const int got_j = sj[0], got_n = sn[0];
         __syncthreads();
         if (got_j < 0) break;
         if (threadIdx.x == 0) a.list[static_cast<size_t>(node) * kNearCands + count] = got_j;
         prev = got;
+        prev_n = got_n;
     }
     if (threadIdx.x == 0) a.list_n[node] = count;
 }

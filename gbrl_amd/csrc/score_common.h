@@ -40,6 +40,20 @@ __device__ __forceinline__ float second_distinct(float a1, float a2, float c1, f
     if (lo < hi) s = fmaxf(s, lo);
     return s;
 }
+// The same with the candidates' identity taken from (gain, rows going right): two candidates with the SAME float32 gain and the same child
+// sizes split the node's rows identically (thresholds between the same two rows); the same gain with different child sizes is a tie between
+// DIFFERENT partitions -- mirrored ones, or scores closer than float32 resolves -- and counts as a runner-up at distance 0.
+__device__ __forceinline__ float second_merge(float v1, int nr1, float s1, float v2, int nr2, float s2) {
+    float s = fmaxf(s1, s2);
+    if (v1 == v2) { if (nr1 != nr2 && v1 > -INFINITY) s = v1; }
+    else s = fmaxf(s, fminf(v1, v2));
+    return s;
+}
+// The class of a candidate that sends n_right of its node's n_node rows right.  Every row on one side -- either side -- is ONE class (the
+// reference scores both the same, operation for operation).  Nodes of up to 8192 rows (the RL-sized range) tell classes apart by the gain
+// alone: mirror-image partitions of a few rows tie exactly all the time there, and re-scoring them would cost more than the tree.
+__device__ __forceinline__ int near_class(long long n_right, long long n_node) { return (n_node <= 8192 || n_right == n_node) ? 0 : static_cast<int>(n_right); }
+__device__ __forceinline__ bool better_takes_second(Best a, Best b) { return b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i); }
 // The window of the near-tie replay, relative to the scores' magnitude: `rel` (2^-20) for nodes of up to 8192 rows -- the RL-sized range, where
 // a replay costs as much as the tree -- and the reference's own summation noise eps32 * sqrt(rows) beyond (tests/neartie.py explains a
 // difference within 4x that).

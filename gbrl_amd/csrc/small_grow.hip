@@ -79,23 +79,22 @@ __device__ __forceinline__ SgBest sg_wave_best(SgBest m) {
     return r;
 }
 
-// Near-tie detection (score_common.h second_distinct): the pair (best value, best value strictly below it) reduced over the wave with the
-// same DPP steps; returns the wave's second.  A lane without a source merges with itself, which changes nothing.
+// Near-tie detection: the wave's best value STRICTLY below `top` (the wave's maximum, already known to every lane) over the lanes' (v, sec)
+// pairs -- sec = a lane's own best below its v.  A plain maximum with the same DPP steps (one v_max_f32 with a DPP operand per step).  The
+// kernel takes batches of <= 8192 rows, where candidates are told apart by their gain alone (score_common.h near_class).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void sg_dpp_second_step(float &v, float &sec) {
-    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-    const float os = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sec), __float_as_int(sec), CTRL, ROW_MASK, 0xf, false));
-    sec = second_distinct(v, sec, ov, os);
-    v = fmaxf(v, ov);
+__device__ __forceinline__ float sg_dpp_max_step(float x) {
+    return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false)));
 }
-__device__ __forceinline__ float sg_wave_second(float v, float sec) {
-    sg_dpp_second_step<0x111, 0xf>(v, sec);
-    sg_dpp_second_step<0x112, 0xf>(v, sec);
-    sg_dpp_second_step<0x114, 0xf>(v, sec);
-    sg_dpp_second_step<0x118, 0xf>(v, sec);
-    sg_dpp_second_step<0x142, 0xa>(v, sec);
-    sg_dpp_second_step<0x143, 0xc>(v, sec);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sec), 63));
+__device__ __forceinline__ float sg_wave_second(float v, float sec, float top) {
+    float x = v < top ? fmaxf(v, sec) : sec;
+    x = sg_dpp_max_step<0x111, 0xf>(x);
+    x = sg_dpp_max_step<0x112, 0xf>(x);
+    x = sg_dpp_max_step<0x114, 0xf>(x);
+    x = sg_dpp_max_step<0x118, 0xf>(x);
+    x = sg_dpp_max_step<0x142, 0xa>(x);
+    x = sg_dpp_max_step<0x143, 0xc>(x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
 __device__ __forceinline__ void sg_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
@@ -158,7 +157,7 @@ struct SmallGrowArgs {
     int G, NC, nb_cap, Tmax, NIDS;
     uint32_t magicW;            // floor(2^32 / (D + 1)) + 1
     SgBest *bests;              // greedy [MD][NC][G], oblivious [MD][G]
-    float2 *seconds;            // same shape: (best gain strictly below the block's best, the node's parent score) -- near-tie detection
+    float *seconds;             // same shape: the best gain strictly below the block's best -- near-tie detection
     float near_rel;             // 0: no detection
     int tiny_words;             // 32-bit words of the histogram region every wave may use as scratch (sg_tiny_zero_gain)
     unsigned *sync;             // [0] groups arrived, [1] finished blocks, [2] abort, [32 + 32 g] arrivals of group g (kSmallGrowSyncBytes)
@@ -191,14 +190,8 @@ __device__ __forceinline__ SgBest sg_load_best(const SgBest *p) {
     const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return SgBest{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
 }
-__device__ __forceinline__ void sg_store_second(float2 *p, float sec, float par) {
-    const unsigned long long w = (static_cast<unsigned long long>(__float_as_uint(par)) << 32) | __float_as_uint(sec);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 sg_load_second(const float2 *p) {
-    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return float2{__uint_as_float(static_cast<uint32_t>(w)), __uint_as_float(static_cast<uint32_t>(w >> 32))};
-}
+__device__ __forceinline__ void sg_store_second(float *p, float sec) { __hip_atomic_store(p, sec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sg_load_second(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Arrivals are counted per GROUP of 16 blocks (counters 128 bytes apart) and the last block of a group arrives at the top counter: 256
 // atomics on ONE word took ~7 us per barrier (a device-scope atomic unit retires ~30 same-address operations per microsecond).
 constexpr int kSgGroup = 16;
@@ -477,8 +470,9 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                             mine = SgBest{fmaf(out, sw[k], -par_sub), sref[k],
                                           (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), static_cast<uint32_t>(n_r)};
                         }
-                        const float sec = detect ? sg_wave_second(mine.v, -INFINITY) : -INFINITY;
+                        const float own = mine.v;
                         mine = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, mine));
+                        const float sec = detect ? sg_wave_second(own, -INFINITY, mine.v) : -INFINITY;
                         if (lane == 0) { ibest[it] = mine; ibest2[it] = sec; if (t == 0) npar[k_abs] = par_sub; }
                     }
                 }
@@ -511,15 +505,17 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     sec = second_distinct(mine.v, sec, sc, -INFINITY);
                     mine = sg_better(mine, SgBest{sc, sref[k], (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u});
                 }
-                if (detect) sec = sg_wave_second(mine.v, sec);
+                const float own = mine.v;
                 mine = sg_wave_best(mine);
+                if (detect) sec = sg_wave_second(own, sec, mine.v);
                 if (lane == 0) { wbest[wave] = mine; wbest2[wave] = sec; }
                 __syncthreads();
                 if (wave == 0) {     // (the next write of wbest sits behind the barriers of the next slot / level)
                     SgBest b = lane < kSgWaves ? wbest[lane] : SgBest{-INFINITY, 0x7fffffff, 0u, 0u};
                     float b2 = lane < kSgWaves ? wbest2[lane] : -INFINITY;
-                    if (detect) b2 = sg_wave_second(b.v, b2);
+                    const float own = b.v;
                     b = sg_wave_best(b);
+                    if (detect) b2 = sg_wave_second(own, b2, b.v);
                     if (lane == 0) { s_bbest2 = second_distinct(s_bbest.v, s_bbest2, b.v, b2); s_bbest = sg_better(s_bbest, b); }
                 }
             }
@@ -528,21 +524,21 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         // ---- publish this block's bests, ONE grid barrier, reduce to the winners -------------------------------------------------
         SG_MARK(7);
         SgBest *lv = a.bests + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
-        float2 *lv2 = a.seconds + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
-        if (obl) { if (tid == 0) { sg_store_best(&lv[blk], s_bbest); if (detect) sg_store_second(&lv2[blk], s_bbest2, 0.0f); } }
+        float *lv2 = a.seconds + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
+        if (obl) { if (tid == 0) { sg_store_best(&lv[blk], s_bbest); if (detect) sg_store_second(&lv2[blk], s_bbest2); } }
         else for (int k = tid; k < n_act; k += kSgThreads) {
             sg_store_best(&lv[static_cast<size_t>(k) * G + blk], nbest[k]);
-            if (detect) sg_store_second(&lv2[static_cast<size_t>(k) * G + blk], nbest2[k], npar[k]);
+            if (detect) sg_store_second(&lv2[static_cast<size_t>(k) * G + blk], nbest2[k]);
         }
         if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; break; }
         SG_MARK(8);
         const int n_win = obl ? 1 : n_act;
         for (int k = wave; k < n_win; k += kSgWaves) {
             SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
-            float m2 = -INFINITY, mpar = 0.0f;
+            float m2 = -INFINITY;
             for (int q0 = lane; q0 < G; q0 += kWave * 4) {          // (G <= 256 blocks: one round of four loads in flight)
                 SgBest b4[4];
-                float2 s4[4];
+                float s4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) b4[u] = sg_load_best(lv + static_cast<size_t>(k) * G + min(q0 + u * kWave, G - 1));
                 if (detect) {
@@ -551,16 +547,14 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (q0 + u * kWave < G) {
-                    if (detect) { m2 = second_distinct(m.v, m2, b4[u].v, s4[u].x); mpar = s4[u].y; }
+                    if (detect) m2 = second_distinct(m.v, m2, b4[u].v, s4[u]);
                     m = sg_better(m, b4[u]);
                 }
             }
-            float par = 0.0f;
-            if (detect) {
-                m2 = sg_wave_second(m.v, m2);
-                par = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mpar)));   // (every block stored the same parent score)
-            }
+            const float own = m.v;
             m = sg_wave_best(m);
+            if (detect) m2 = sg_wave_second(own, m2, m.v);
+            const float par = (detect && !obl) ? npar[k] : 0.0f;       // (every block derives the same parent score from the node's totals)
             int tiny_k = 0;
             if (lane == 0 && detect && m.v != -INFINITY) {
                 // the same test as k_resolve_splits: the runner-up within near_rel of the winner (relative to the scores' magnitude), or a greedy
@@ -792,7 +786,7 @@ int align16(int x) { return (x + 15) & ~15; }
 
 size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {   // the bests, then the (second, parent) pairs of the near-tie detection
     const int NC = 1 << std::max(0, MD - 1);
-    return (sizeof(SgBest) + sizeof(float2)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
+    return (sizeof(SgBest) + sizeof(float)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
 }
 size_t small_grow_res_stride(int MD) { return static_cast<size_t>(1 << std::max(0, MD - 1)) * 44 + 64; }
 
@@ -865,7 +859,7 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.G = io.G; a.NC = 1 << std::max(0, io.MD - 1); a.NIDS = 2 << io.MD;
     a.magicW = static_cast<uint32_t>((1ull << 32) / static_cast<unsigned>(io.D + 1)) + 1u;
     a.bests = static_cast<SgBest *>(io.bests);
-    a.seconds = reinterpret_cast<float2 *>(static_cast<SgBest *>(io.bests) + static_cast<size_t>(io.MD) * (io.oblivious ? 1 : a.NC) * io.G);
+    a.seconds = reinterpret_cast<float *>(static_cast<SgBest *>(io.bests) + static_cast<size_t>(io.MD) * (io.oblivious ? 1 : a.NC) * io.G);
     a.near_rel = io.near_rel;
     a.tiny_words = static_cast<int>((static_cast<size_t>(acc_bytes) * a.nb_cap * io.NB * (io.D + 1) / 4 / kSgWaves) & ~static_cast<size_t>(3));
     a.sync = io.sync; a.res = io.res; a.res_dev = io.res_dev; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;

@@ -24,11 +24,13 @@ def run(env):
     m.set_feature_weights(np.ones(F, np.float32)); m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
     m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
     for i in range(20): m.step(tup(X), None, tup(Gs[i % 32]))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for i in range(steps): m.step(tup(X), None, tup(Gs[i % 32]))
-    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / steps
+    ms = 1e9
+    for _ in range(5):     # (best of five passes over the same gradients: the replays are part of every pass)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps): m.step(tup(X), None, tup(Gs[i % 32]))
+        torch.cuda.synchronize(); ms = min(ms, (time.perf_counter() - t0) * 1e3 / steps)
     m.set_profiling(2); m.step(tup(X), None, tup(Gs[0])); ph = dict(m.last_phase_times())
     return ms, ph.get("near_replays", 0), ph.get("near_bailouts", 0)
 for env in ({"GBRL_HIP_NO_NEARTIE_REPLAY": "1"}, {}, {"GBRL_HIP_NEARTIE_REL": "7.6e-6"}):
     ms, rp, bo = run(env)
-    print("%-40s %dx%d D=%d depth %d %s %s: %.4f ms/step, levels replayed %d, trees handed to the level loop %d of %d" % (env or "default (2^-20)", N, F, D, depth, policy, score, ms, rp, bo, steps + 21))
+    print("%-40s %dx%d D=%d depth %d %s %s: %.4f ms/step, levels replayed %d, trees handed to the level loop %d of %d" % (env or "default (2^-20)", N, F, D, depth, policy, score, ms, rp, bo, 5 * steps + 21))
