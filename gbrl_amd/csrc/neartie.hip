@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "kernels_common.h"
 #include "score_common.h"
+#include "neartie_core.h"
 
 #include <algorithm>
 #include <vector>
@@ -33,7 +34,6 @@ namespace kern {
 namespace {
 
 constexpr int kNearThreads = 256;
-constexpr int kNearBatch = 2048;          // products staged per wave and batch
 
 
 __device__ __forceinline__ float near_gain(const NearTieIO &a, int node, int j) {
@@ -94,57 +94,10 @@ __global__ __launch_bounds__(kNearThreads) void k_near_list(NearTieIO a) {
     if (threadIdx.x == 0) a.list_n[node] = count;
 }
 
-__device__ __forceinline__ float near_grad(const NearTieIO &a, int row, int c) {
-    const float g = a.grads[static_cast<size_t>(row) * a.D + c];
-    if (a.meanden == nullptr) return g;
-    return (g - a.meanden[c]) / a.meanden[a.D + c];     // fitter.cpp:58-63 -> math_ops.cpp:498,94: what k_quantize standardises
-}
-
-// sum_{row in list, col} g[row][col] * vec[col], in order (math_ops.h:432-449 as compiled: see the head of this file).  One wave; lane 0
-// carries the chain, all lanes stage the products.
-__device__ float near_dot_chain(const NearTieIO &a, const int32_t *list, int m, int stride /*+1 / -1*/, const float *vec /*LDS [D]*/, float *buf /*LDS [kNearBatch]*/) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int D = a.D, D4 = D & ~3;
-    float s = 0.0f;
-    const int rows_per = max(1, kNearBatch / D);
-    if (D > kNearBatch) {   // (very wide outputs: no staging)
-        if (lane == 0)
-            for (int r = 0; r < m; ++r) {
-                const int row = list[static_cast<ptrdiff_t>(r) * stride];
-                for (int c = 0; c < D4; ++c) { const float p = near_grad(a, row, c) * vec[c]; s = s + p; }
-                for (int c = D4; c < D; ++c) s = fmaf(near_grad(a, row, c), vec[c], s);
-            }
-        return __shfl(s, 0, kWave);
-    }
-    for (int r0 = 0; r0 < m; r0 += rows_per) {
-        const int nr = min(rows_per, m - r0), tot = nr * D;
-        for (int e = lane; e < tot; e += kWave) {
-            const int r = e / D, c = e - r * D;
-            const float g = near_grad(a, list[static_cast<ptrdiff_t>(r0 + r) * stride], c);
-            buf[e] = c < D4 ? g * vec[c] : g;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
-        if (lane == 0) {
-            for (int r = 0; r < nr; ++r) {
-                const float *b = buf + r * D;
-                for (int c = 0; c < D4; ++c) s = s + b[c];
-                for (int c = D4; c < D; ++c) s = fmaf(b[c], vec[c], s);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    return __shfl(s, 0, kWave);
-}
-__device__ __forceinline__ float near_sqnorm(const float *v, int D) {   // math_ops.h:476-485 as compiled
-    const int D4 = D & ~3;
-    float s = 0.0f;
-    for (int c = 0; c < D4; ++c) { const float p = v[c] * v[c]; s = s + p; }
-    for (int c = D4; c < D; ++c) s = fmaf(v[c], v[c], s);
-    return s;
-}
-
 // grid (kNearCands + 1, n_act): block (i, node) replays the node's i-th listed candidate; block (kNearCands, node) the parent score.
+// Two passes over the node's rows in ascending order, a tile of kNearTile floats at a time, staged in LDS by all threads (one memory round
+// trip per tile): pass 1 the per-side column sums (thread c adds column c's entries in order), pass 2 -- Cosine -- the two in-order dot
+// chains, one lane each (waves 0 and 1), over products the staging has already rounded.
 __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
     const int node = blockIdx.y, i = blockIdx.x;
     const int lnode = a.oblivious ? 0 : node;
@@ -154,12 +107,8 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
     extern __shared__ uint32_t lds[];
     uint32_t *in_map = lds;                         // [2048] bit per row: in the node
     uint32_t *right_map = lds + 2048;               // [2048] bit per row: goes right
-    float *mean = reinterpret_cast<float *>(lds + 4096);       // [2][D] right | left
-    float *buf = mean + 2 * a.D;                               // [2][kNearBatch]
-    __shared__ int s_cnt[kNearThreads][2];
-    __shared__ float s_num[2];
+    __shared__ int s_cnt[kNearThreads];
     const int n = a.n_rows[node], seg = a.seg_start[node];
-    const int D = a.D;
     float *out = a.rep + static_cast<size_t>(node) * (kNearCands + 1) + i;
     // the candidate's test (what k_partition applies)
     int fs = 0, bin = -1, is_cat = 0;
@@ -182,82 +131,42 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         }
     }
     __syncthreads();
-    // ordered lists: right rows ascending from the front of the region, left rows ascending from its back (read with stride -1)
+    // the node's rows in ascending order, bit 31 = goes right (the partition above leaves a node's segment in no particular order)
     int32_t *ent = a.ent + static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
     const int n_words = (a.N + 31) >> 5, per = (n_words + kNearThreads - 1) / kNearThreads;
-    const int w0 = threadIdx.x * per, w1 = min(n_words, w0 + per);
-    int cr = 0, cl = 0;
-    for (int w = w0; w < w1; ++w) { cr += __popc(in_map[w] & right_map[w]); cl += __popc(in_map[w] & ~right_map[w]); }
-    s_cnt[threadIdx.x][0] = cr; s_cnt[threadIdx.x][1] = cl;
+    const int w0 = min(n_words, static_cast<int>(threadIdx.x) * per), w1 = min(n_words, w0 + per);
+    int cnt = 0, cr = 0;
+    for (int w = w0; w < w1; ++w) { cnt += __popc(in_map[w]); cr += __popc(in_map[w] & right_map[w]); }
+    s_cnt[threadIdx.x] = cnt;
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x == 0) {
         int run = 0;
-        for (int t = 0; t < kNearThreads; ++t) { const int c = s_cnt[t][threadIdx.x]; s_cnt[t][threadIdx.x] = run; run += c; }
+        for (int t = 0; t < kNearThreads; ++t) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
     }
     __syncthreads();
     {
-        int pr = s_cnt[threadIdx.x][0], pl = s_cnt[threadIdx.x][1];
+        int pos = s_cnt[threadIdx.x];
         for (int w = w0; w < w1; ++w) {
             uint32_t m = in_map[w];
             const uint32_t rm = right_map[w];
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                const int row = (w << 5) + b;
-                if ((rm >> b) & 1u) ent[pr++] = row; else ent[n - 1 - (pl++)] = row;
+                ent[pos++] = ((w << 5) + b) | static_cast<int32_t>(((rm >> b) & 1u) << 31);
             }
         }
     }
-    __threadfence_block();
+    // rows going right: a block-wide sum of the per-thread counts
     __syncthreads();
-    int n_r = 0, n_l = 0;
-    {   // totals: the last thread's prefix + its own counts
-        n_r = s_cnt[kNearThreads - 1][0]; n_l = s_cnt[kNearThreads - 1][1];
-        const int lw0 = (kNearThreads - 1) * per, lw1 = min(n_words, lw0 + per);
-        for (int w = lw0; w < lw1; ++w) { n_r += __popc(in_map[w] & right_map[w]); n_l += __popc(in_map[w] & ~right_map[w]); }
-    }
+    s_cnt[threadIdx.x] = cr;
+    __syncthreads();
+    for (int o = kNearThreads / 2; o > 0; o >>= 1) { if (static_cast<int>(threadIdx.x) < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
+    const int n_r = s_cnt[0], n_l = n - n_r;
+    __syncthreads();
     if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { if (threadIdx.x == 0) *out = -INFINITY; return; }   // node.cpp:354
-    const float nrf = static_cast<float>(n_r), nlf = static_cast<float>(n_l);
-    const float rrec = n_r > 0 ? 1.0f / nrf : 0.0f, lrec = n_l > 0 ? 1.0f / nlf : 0.0f;
-    // side sums: one thread per (side, column), rows in order
-    for (int t = threadIdx.x; t < 2 * D; t += kNearThreads) {
-        const int side = t / D, c = t - side * D;   // 0 right, 1 left
-        const int m = side ? n_l : n_r;
-        float s = 0.0f;
-        for (int r = 0; r < m; ++r) s += near_grad(a, side ? ent[n - 1 - r] : ent[r], c);
-        mean[t] = s * (side ? lrec : rrec);
-    }
-    __syncthreads();
-    const int wave = threadIdx.x / kWave;
-    if (a.cosine && wave < 2) {
-        const int m = wave ? n_l : n_r;
-        float num = 0.0f;
-        if (m > 0) num = near_dot_chain(a, wave ? ent + (n - 1) : ent, m, wave ? -1 : 1, mean + wave * D, buf + wave * kNearBatch);
-        if ((threadIdx.x & (kWave - 1)) == 0) s_num[wave] = num;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float res;
-        if (is_parent) {       // every row is on the "left" side here
-            if (a.cosine) {
-                const float den = near_sqnorm(mean + D, D) * nlf;
-                res = (n_l == 0 || den == 0.0f) ? 0.0f : static_cast<float>(static_cast<double>(s_num[1]) / sqrt(static_cast<double>(den)));
-            } else {
-                res = near_sqnorm(mean + D, D) * nlf;
-            }
-        } else if (a.cosine) {
-            const float tn = near_sqnorm(mean, D), fn = near_sqnorm(mean + D, D);
-            const float fden = fn * nlf;
-            const float den = fmaf(tn, nrf, fden);
-            const float num = s_num[0] + s_num[1];
-            res = den == 0.0f ? 0.0f : num / sqrtf(den);
-        } else {
-            const float ln = near_sqnorm(mean + D, D), rn = near_sqnorm(mean, D);
-            const float rp = nrf * rn;
-            res = fmaf(nlf, ln, rp);
-        }
-        *out = res;
-    }
+    const NearGrads ng{a.grads, a.meanden, a.D};
+    const float res = near_replay_core(ent, n, n_r, ng, a.cosine != 0, is_parent, reinterpret_cast<uint32_t *>(lds + 4096));
+    if (threadIdx.x == 0) *out = res;
 }
 
 // The reference's comparison over the replayed candidates (fitter.cpp:332-357 / 426-459: highest score, first index among equals), written
@@ -299,7 +208,7 @@ bool near_tie_supported(int N, int D) { return N >= 1 && N <= kNearMaxRows && D 
 void near_tie_replay(const NearTieIO &io, hipStream_t s) {
     const int n_list = io.oblivious ? 1 : io.n_act;
     hipLaunchKernelGGL(k_near_list, dim3(n_list), dim3(kNearThreads), 0, s, io);
-    const size_t lds = sizeof(uint32_t) * 4096 + sizeof(float) * (2 * static_cast<size_t>(io.D) + 2 * kNearBatch);
+    const size_t lds = sizeof(uint32_t) * (4096 + static_cast<size_t>(near_core_words(io.D)));
     hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
     hipLaunchKernelGGL(k_near_apply, dim3(n_list), dim3(kWave), 0, s, io);
 }
@@ -340,7 +249,7 @@ bool near_tie_selftest(const float *grads, const uint8_t *in_node, const uint8_t
     io.list = static_cast<int32_t *>(d_list.p); io.list_n = static_cast<int32_t *>(d_one.p);   // the one candidate, internal index 0
     io.ent = static_cast<int32_t *>(d_ent.p); io.rep = static_cast<float *>(d_rep.p);
     if (hipMemset(d_list.p, 0, sizeof(int32_t) * (kNearCands + 1)) != hipSuccess) return false;
-    const size_t lds = sizeof(uint32_t) * 4096 + sizeof(float) * (2 * static_cast<size_t>(D) + 2 * kNearBatch);
+    const size_t lds = sizeof(uint32_t) * (4096 + static_cast<size_t>(near_core_words(D)));
     hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, 1), dim3(kNearThreads), lds, nullptr, io);
     float rep[kNearCands + 1];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(rep, d_rep.p, sizeof(rep), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
