@@ -183,8 +183,8 @@ class Engine {
     DevBuf d_codes_fm_;               // feature-major copy of the numeric class codes (kern::small_prep -> kern::small_grow)
     DevBuf d_am_s_, d_near_list_, d_near_ent_, d_near_rep_, d_near_nr_;   // near-tie replay (kern::near_tie_replay): runner-up per arg-max block, candidate lists, ordered row lists, replayed scores
     bool force_level_loop_ = false;   // grow_tree: the one-launch kernel met a near-tie and handed the tree to the level loop
-    long long near_replays_ = 0, near_bailouts_ = 0;   // levels replayed / one-launch trees handed over (diagnostics: phases at profiling level 2)
-    DevBuf d_sg_bests_, d_sg_sync_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
+    long long near_replays_ = 0, near_bailouts_ = 0, near_in_kernel_ = 0;   // levels replayed / one-launch trees handed over (diagnostics: phases at profiling level 2)
+    DevBuf d_sg_bests_, d_sg_sync_, d_sg_near_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
     const void *sg_sync_ptr_ = nullptr;
     std::chrono::steady_clock::time_point prof_marks_[4]{};
     std::chrono::steady_clock::time_point prof_step_entry_{};   // measurement (GBRL_HIP_SMALL_GROW_PROF)

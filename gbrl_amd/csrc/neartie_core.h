@@ -11,7 +11,7 @@ namespace {
 
 constexpr int kNearTile = 4096, kNearTileRows = 1024;
 // 32-bit words of LDS scratch near_replay_core needs (16-byte aligned)
-__host__ __device__ inline int near_core_words(int D) { return ((2 * D + 3) & ~3) + kNearTile + kNearTileRows / 2 + 4; }
+__host__ __device__ inline int near_core_words(int D, int tile_floats = kNearTile) { return ((2 * D + 3) & ~3) + tile_floats + kNearTileRows / 2 + 4; }
 
 struct NearGrads { const float *grads; const float *meanden; int D; };
 __device__ __forceinline__ float near_grad(const NearGrads &a, int row, int c) {
@@ -34,13 +34,14 @@ __device__ __forceinline__ float near_sqnorm(const float *v, int D) {   // math_
 // Two passes over the rows, a tile of kNearTile floats at a time, staged in LDS by all threads (one memory round trip per tile): pass 1 the
 // per-side column sums (one thread per (side, column) adds its column's entries in order), pass 2 -- Cosine -- the two in-order dot chains, one
 // lane each (waves 0 and 1), over products the staging has already rounded.
-__device__ float near_replay_core(const int32_t *__restrict__ ent, int n, int n_r, const NearGrads a, bool cosine, bool is_parent, uint32_t *scratch) {
+__device__ float near_replay_core(const int32_t *__restrict__ ent, int n, int n_r, const NearGrads a, bool cosine, bool is_parent, uint32_t *scratch,
+                                  int tile_floats = kNearTile /* a multiple of 4, at least 4 * ((D + 3) & ~3) */) {
 #pragma clang fp contract(off)
     const int D = a.D, n_l = n - n_r;
     const int n_threads = blockDim.x, half = n_threads / 2;
     float *mean = reinterpret_cast<float *>(scratch);                 // [2][D] right | left
-    float *tile = mean + ((2 * D + 3) & ~3);                          // [kNearTile] gradients / products of a batch of rows (16-byte aligned: read as float4)
-    uint16_t *tpos = reinterpret_cast<uint16_t *>(tile + kNearTile);  // [kNearTileRows] a row's place among the batch's rows of its side | side << 15
+    float *tile = mean + ((2 * D + 3) & ~3);                          // [tile_floats] gradients / products of a batch of rows (16-byte aligned: read as float4)
+    uint16_t *tpos = reinterpret_cast<uint16_t *>(tile + tile_floats);  // [kNearTileRows] a row's place among the batch's rows of its side | side << 15
     int *s_nrb_p = reinterpret_cast<int *>(tpos + kNearTileRows);     // rows of the batch that go right
     float *s_num = reinterpret_cast<float *>(s_nrb_p + 1);            // [2]
     const float nrf = static_cast<float>(n_r), nlf = static_cast<float>(n_l);
@@ -49,7 +50,7 @@ __device__ float near_replay_core(const int32_t *__restrict__ ent, int n, int n_
     // row every Dp = D rounded up to 4 floats -- so that the serial loops below walk contiguous memory with nothing to decide per row (a flag
     // test and a dependent LDS read per row cost ~100 clocks each; the first version spent 0.8 ms on a 4096-row node that way).
     const int Dp = (D + 3) & ~3, D4 = D & ~3;
-    const int rows_per = max(1, min(kNearTileRows, kNearTile / Dp));
+    const int rows_per = max(1, min(kNearTileRows, tile_floats / Dp));
     auto stage_places = [&](int r0, int nr) {     // wave 0: the places (ballot ranks), and how many of the batch's rows go right
         if (threadIdx.x < kWave) {
             int base_r = 0, base_l = 0;

@@ -29,6 +29,7 @@
 #include "kernels.h"
 #include "kernels_common.h"
 #include "score_common.h"
+#include "neartie_core.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -136,6 +137,17 @@ __device__ __forceinline__ void sg_accumulate_rows(const int32_t *__restrict__ q
     }
 }
 
+// In-kernel near-tie replay (greedy trees, one flagged node per level): a candidate inside the window, as the blocks exchange it
+struct alignas(16) SgCand { float gain; int32_t ref; uint32_t slotbin; uint32_t nr; };
+constexpr int kSgCandCap = 32;        // per block (distinct neighbours inside the window)
+constexpr int kSgMergeCap = 64;       // over all blocks
+struct SgNearScratch {                // device memory, small_grow_near_bytes(G, N)
+    uint32_t *count;                  // [G] candidates every block collected (0xffff: too many)
+    SgCand *list;                     // [G][kSgCandCap]
+    float *rep;                       // [kNearCands + 1] replayed scores, [kNearCands] = the parent's
+    int32_t *ent;                     // [G][N] ordered row lists, one region per block
+};
+
 struct SgLayout {     // byte offsets into the dynamic LDS block (host computes, kernel carves)
     int rc, sw, sref, tn, tid, psb, pv, split, cidx, cid, win, wcat, wthr, nbest, nbest2, npar, ssum, leafflag, ttot, total, totalf, ibest, ibest2, wbest, wbest2, lacc, hist;
     int total_bytes;
@@ -159,13 +171,17 @@ struct SmallGrowArgs {
     SgBest *bests;              // greedy [MD][NC][G], oblivious [MD][G]
     float *seconds;             // same shape: the best gain strictly below the block's best -- near-tie detection
     float near_rel;             // 0: no detection
+    SgNearScratch nt;           // in-kernel replay
+    int near_in_kernel;         // the idle histogram region holds the replay's scratch (else a flagged tree goes to the level loop)
+    int near_tile;              // floats of that scratch the replay stages a batch of rows in
+    const float *meanden;       // L2: the step's standardisation (mean | std + 1e-8f), nullptr for Cosine
     int tiny_words;             // 32-bit words of the histogram region every wave may use as scratch (sg_tiny_zero_gain)
     unsigned *sync;             // [0] groups arrived, [1] finished blocks, [2] abort, [32 + 32 g] arrivals of group g (kSmallGrowSyncBytes)
     char *res;                  // pinned, device-mapped: MD result blocks of res_stride bytes (block 0 copies them out of res_dev at the end)
     char *res_dev;              // device staging of the same
     int res_stride, max_front;
     int64_t *acc;               // pinned: [NIDS][D+1]
-    uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] 1 = error, 2 = a near-tie was met (the level loop grows this tree)
+    uint32_t *status;           // pinned: [0] sequence word, [1] levels written, [2] node count, [3] 1 = error, 2 = a near-tie was met (the level loop grows this tree), [4] levels replayed in here
     uint32_t seq;
     StepScales *scales_out;     // pinned (nullable): block 0 mirrors the step's scales for the host
     uint32_t *prof;             // nullable (GBRL_HIP_SMALL_GROW_PROF=1): block 0's time per phase, 10 ns units, 16 words, pinned
@@ -308,7 +324,9 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     unsigned long long *lacc = reinterpret_cast<unsigned long long *>(sg_lds + L.lacc);   // [W]
     ACC *hist = reinterpret_cast<ACC *>(sg_lds + L.hist);               // [nb][NBe][W]
 
-    __shared__ int s_abort, s_nact, s_nextid, s_nact_next, s_stop, s_near;
+    __shared__ int s_abort, s_nact, s_nextid, s_nact_next, s_stop, s_near, s_kf, s_ccount, s_cover;
+    __shared__ float s_lo;
+    __shared__ SgCand s_clist[kSgCandCap];
     __shared__ SgBest s_bbest;
     __shared__ float s_bbest2;
 
@@ -327,19 +345,28 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
 
     for (int r = tid; r < N; r += kSgThreads) rc[r] = 0;
     for (int i = tid; i < a.NIDS; i += kSgThreads) leafflag[i] = 0;
-    if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; s_near = 0; }
+    if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; s_near = 0; s_kf = 0; s_ccount = 0; s_cover = 0; s_lo = 0.0f; }
     __syncthreads();
 
     int cur = 0, level = 0, loaded_slot = -1;
     bool ok = true, near_exit = false;
+    unsigned n_replayed = 0;      // levels whose near-tie this launch replayed itself
     for (; level < MD; ++level) {
         const int n_act = s_nact;
         int *tn = tn_b + cur * NC, *tidc = tid_b + cur * NC;
         uint32_t *psb = psb_b + static_cast<size_t>(cur) * NC * MD;
         float *pv = pv_b + static_cast<size_t>(cur) * NC * MD;
         // ---- this block's slots ------------------------------------------------------------------------------------------------
-        if (obl) { if (tid == 0) { s_bbest = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; s_bbest2 = -INFINITY; } }
+        // (pass 1 only when the selection flags a near-tie at ONE node of a greedy level: the node's candidates are scored once more, those
+        //  inside the window collected, re-scored in the reference's float32 order by the blocks, and the winner replaced -- below)
+        bool leave = false;
+        for (int pass = 0; pass < 2 && !leave; ++pass) {
+        const bool redo = pass == 1;
+        if (redo) { if (tid == 0) { s_ccount = 0; s_cover = 0; } }
+        else if (obl) { if (tid == 0) { s_bbest = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; s_bbest2 = -INFINITY; } }
         else for (int k = tid; k < n_act; k += kSgThreads) { nbest[k] = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; nbest2[k] = -INFINITY; npar[k] = 0.0f; }
+        __syncthreads();
+        const int k_begin = redo ? s_kf : 0, k_end = redo ? s_kf + 1 : n_act;
         for (int fs = blk; fs < a.n_slots; fs += G) {
             const FeatureSlot sl = a.slots[fs];
             const int NBe = sl.n_cand + 1;                       // classes of this slot
@@ -360,8 +387,8 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             }
             SG_MARK(0);
             if (obl) for (int k = tid; k < sl.n_cand; k += kSgThreads) ssum[k] = 0.0f;
-            for (int k0 = 0; k0 < n_act; k0 += a.nb_cap) {
-                const int nbk = min(a.nb_cap, n_act - k0);
+            for (int k0 = k_begin; k0 < k_end; k0 += a.nb_cap) {
+                const int nbk = min(a.nb_cap, k_end - k0);
                 const int hwords = nbk * NBe * W;
                 {   // (16-byte stores; the region's capacity is a multiple of 16 bytes)
                     typedef unsigned int sg_u4 __attribute__((ext_vector_type(4)));
@@ -470,6 +497,24 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                             mine = SgBest{fmaf(out, sw[k], -par_sub), sref[k],
                                           (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), static_cast<uint32_t>(n_r)};
                         }
+                        if (redo) {
+                            // collect the candidates inside the window; of a run of neighbours with the same gain (thresholds between the same
+                            // two rows of the node) only the lowest reference index -- the last lane of the run
+                            const float below = __shfl_down(mine.v, 1, kWave);
+                            const bool keep = have && mine.v >= s_lo && (lane == kWave - 1 || below != mine.v);
+                            const unsigned long long mk = __ballot(keep);
+                            if (mk) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(&s_ccount, __popcll(mk));
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                if (keep) {
+                                    const int at = base + __popcll(mk & ((1ull << lane) - 1ull));
+                                    if (at < kSgCandCap) s_clist[at] = SgCand{mine.v, mine.ref, mine.slotbin, mine.pad};
+                                    else s_cover = 1;
+                                }
+                            }
+                            continue;
+                        }
                         const float own = mine.v;
                         mine = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, mine));
                         const float sec = detect ? sg_wave_second(own, -INFINITY, mine.v) : -INFINITY;
@@ -485,7 +530,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                         for (int kb = 0; kb < nbk; ++kb) s += __int_as_float(static_cast<int>(hist[(static_cast<size_t>(kb) * NBe + k + 1) * W]));
                         ssum[k] = s;
                     }
-                } else {
+                } else if (!redo) {
                     for (int kb = tid; kb < nbk; kb += kSgThreads) {
                         SgBest b = nbest[k0 + kb];
                         float b2 = nbest2[k0 + kb];
@@ -521,6 +566,132 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             }
         }
         __syncthreads();
+        if (redo) {
+            // ---- in-kernel near-tie replay of node s_kf (neartie.hip states the sequence; tests/test_gpu_neartie.py compares both paths) ----
+            const int kf = s_kf;
+            const int my_n = s_cover ? 0xffff : min(s_ccount, kSgCandCap);
+            if (tid < kSgCandCap && tid < (my_n & 0x7fff) && my_n != 0xffff) {
+                const SgCand cnd = s_clist[tid];
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(&a.nt.list[static_cast<size_t>(blk) * kSgCandCap + tid]);
+                __hip_atomic_store(dst, (static_cast<unsigned long long>(static_cast<uint32_t>(cnd.ref)) << 32) | __float_as_uint(cnd.gain), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, (static_cast<unsigned long long>(cnd.nr) << 32) | cnd.slotbin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) __hip_atomic_store(&a.nt.count[blk], static_cast<uint32_t>(my_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; leave = true; break; }
+            // the idle histogram region: [replay core scratch | 1024 prefix words | merged list | final list | flags]
+            uint32_t *scr = reinterpret_cast<uint32_t *>(hist);
+            uint32_t *pre = scr + near_core_words(D, a.near_tile);
+            SgCand *mlist = reinterpret_cast<SgCand *>(pre + 64);
+            SgCand *fin = mlist + kSgMergeCap;
+            int *st = reinterpret_cast<int *>(fin + kNearCands);     // [0] merged count (-1: too many), [1] classes
+            if (wave == 0) {
+                int total = 0;
+                bool over = false;
+                for (int b0 = 0; b0 < G; b0 += kWave) {
+                    const int b = b0 + lane;
+                    const uint32_t cnt = b < G ? __hip_atomic_load(&a.nt.count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    over = over || __any(cnt == 0xffffu);
+                    int incl = static_cast<int>(cnt == 0xffffu ? 0u : cnt);
+                    for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o, kWave); if (lane >= o) incl += up; }
+                    const int mine_n = static_cast<int>(cnt == 0xffffu ? 0u : cnt), off = total + incl - mine_n;
+                    for (int e = 0; e < mine_n; ++e) {
+                        if (off + e >= kSgMergeCap) { over = true; break; }
+                        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&a.nt.list[static_cast<size_t>(b) * kSgCandCap + e]);
+                        const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mlist[off + e] = SgCand{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+                    }
+                    total += __shfl(incl, kWave - 1, kWave);
+                    over = __any(over);
+                }
+                if (total > kSgMergeCap) over = true;
+                __builtin_amdgcn_wave_barrier();
+                // classes = distinct gains, each by its lowest reference index, best first (what k_near_list does in the level loop)
+                int n_cls = 0;
+                if (!over) {
+                    SgCand me{-INFINITY, 0x7fffffff, 0u, 0u};
+                    bool uniq = false;
+                    if (lane < total) {
+                        me = mlist[lane];
+                        uniq = true;
+                        for (int j = 0; j < total; ++j) { const SgCand o = mlist[j]; if (o.gain == me.gain && o.ref < me.ref) uniq = false; }
+                    }
+                    int pos = 0;
+                    for (int j = 0; j < total; ++j) {
+                        const SgCand o = mlist[j];
+                        bool ou = true;
+                        for (int q = 0; q < total; ++q) { const SgCand o2 = mlist[q]; if (o2.gain == o.gain && o2.ref < o.ref) ou = false; }
+                        if (ou && o.gain > me.gain) ++pos;
+                    }
+                    if (uniq && pos < kNearCands) fin[pos] = me;
+                    n_cls = min(kNearCands, static_cast<int>(__popcll(__ballot(uniq))));
+                }
+                if (lane == 0) { st[0] = over ? -1 : total; st[1] = n_cls; }
+            }
+            __syncthreads();
+            if (st[0] <= 0) { near_exit = true; leave = true; break; }      // too many candidates (or none): the level loop takes the tree
+            const int n_cls = st[1];
+            const int n_items = n_cls + (level > 0 ? 1 : 0);
+            const NearGrads ng{a.grads, a.meanden, D};
+            for (int item = blk; item < n_items; item += G) {
+                const bool is_parent = item == n_cls;
+                const SgCand cnd = is_parent ? SgCand{0.0f, 0, 0u, 0u} : fin[item];
+                const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
+                const int ccat = is_parent ? 0 : a.slots[cslot].is_cat;
+                const bool fm = a.codes_fm != nullptr && cslot < a.n_fm;
+                const uint16_t *cs = fm ? a.codes_fm + static_cast<size_t>(cslot) * N : a.codes + (static_cast<size_t>(cslot >> 4) * N) * kCodeGroup + (cslot & (kCodeGroup - 1));
+                const int cstride = fm ? 1 : kCodeGroup;
+                // the node's rows in ascending order, bit 31 = goes right: thread t owns the rows [t * per, (t + 1) * per)
+                int32_t *ent = a.nt.ent + static_cast<size_t>(blk) * N;
+                const int per = (N + kSgThreads - 1) / kSgThreads, r_lo = min(N, tid * per), r_hi = min(N, r_lo + per);
+                int cnt = 0;
+                for (int r = r_lo; r < r_hi; ++r) cnt += rc16[2 * r] == static_cast<uint16_t>(kf) ? 1 : 0;
+                int incl = cnt;
+                for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o, kWave); if (lane >= o) incl += up; }
+                if (lane == kWave - 1) pre[wave] = static_cast<uint32_t>(incl);
+                __syncthreads();
+                int base = incl - cnt;
+                for (int w = 0; w < wave; ++w) base += static_cast<int>(pre[w]);
+                for (int r = r_lo; r < r_hi; ++r) {
+                    if (rc16[2 * r] != static_cast<uint16_t>(kf)) continue;
+                    bool right = false;
+                    if (!is_parent) { const int code = cs[static_cast<size_t>(r) * cstride]; right = ccat ? (code == cbin) : (code > cbin); }
+                    ent[base++] = r | static_cast<int32_t>(right ? 0x80000000u : 0u);
+                }
+                __threadfence_block();
+                __syncthreads();
+                const float res = near_replay_core(ent, tn[kf], is_parent ? 0 : static_cast<int>(cnd.nr), ng, a.cosine != 0, is_parent, scr, a.near_tile);
+                if (tid == 0) __hip_atomic_store(&a.nt.rep[is_parent ? kNearCands : item], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+            }
+            if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; leave = true; break; }
+            // the reference's comparison of the replayed candidates (fitter.cpp:332-357): highest gain, first index among equals
+            if (wave == 0) {
+                SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
+                const float par = level > 0 ? __hip_atomic_load(&a.nt.rep[kNearCands], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                if (lane < n_cls) {
+                    const SgCand cnd = fin[lane];
+                    const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
+                    const FeatureSlot csl = a.slots[cslot];
+                    const float wgt = a.cand_w[csl.cand_base + (csl.is_cat ? cbin - 1 : cbin)];
+                    const float sc = __hip_atomic_load(&a.nt.rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m = SgBest{fmaf(sc, wgt, -par), cnd.ref, cnd.slotbin, cnd.nr};
+                }
+                m = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, m));
+                if (lane == 0) {
+                    const int wslot = m.ref == 0x7fffffff ? 0 : static_cast<int>(m.slotbin >> 16);
+                    const int is_cat = a.slots[wslot].is_cat;
+                    const int tslot = wslot < a.n_thr_slots ? wslot : 0;
+                    const float tv = a.n_thr_slots > 0 ? a.thr[static_cast<size_t>(tslot) * B + min(static_cast<int>(m.slotbin & 0xffffu), B - 1)] : 0.0f;
+                    win[kf] = m;
+                    wcat[kf] = m.ref == 0x7fffffff ? 0 : is_cat;
+                    wthr[kf] = (m.ref == 0x7fffffff || is_cat) ? (is_cat ? INFINITY : 0.0f) : tv;
+                    s_near = 0;
+                }
+            }
+            ++n_replayed;
+            __syncthreads();
+            break;
+        }
         // ---- publish this block's bests, ONE grid barrier, reduce to the winners -------------------------------------------------
         SG_MARK(7);
         SgBest *lv = a.bests + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
@@ -530,7 +701,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             sg_store_best(&lv[static_cast<size_t>(k) * G + blk], nbest[k]);
             if (detect) sg_store_second(&lv2[static_cast<size_t>(k) * G + blk], nbest2[k]);
         }
-        if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; break; }
+        if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; leave = true; break; }
         SG_MARK(8);
         const int n_win = obl ? 1 : n_act;
         for (int k = wave; k < n_win; k += kSgWaves) {
@@ -570,7 +741,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     if (!one_sided) near = true;
                     else if (a.cosine) { if (nn <= kSgTinyRows && sg_tiny_words(nn, D) <= a.tiny_words) tiny = 1; else near = true; }
                 }
-                if (near) s_near = 1;
+                if (near) { atomicAdd(&s_near, 1); s_kf = k; s_lo = m.v - win_w; }
                 else if (tiny) tiny_k = 1;
             }
             tiny_k = __builtin_amdgcn_readfirstlane(tiny_k);
@@ -594,7 +765,10 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         }
         __syncthreads();
         SG_MARK(9);
-        if (s_near) { near_exit = true; break; }
+        if (s_near == 0) break;                                        // (the usual case: no second pass)
+        if (s_near != 1 || obl || !a.near_in_kernel) { near_exit = true; leave = true; break; }   // more than one node, or no room: the level loop takes the tree
+        }   // passes
+        if (leave) break;
         // ---- children: node ids in the host's order (for k in splitting: left, right), next level's table.  The child sizes of a greedy
         //      split travel with its winner (SgBest::pad); an oblivious level keeps both children of every node, empty or not, so its table
         //      needs no sizes (the host derives them from the leaves' row counts afterwards).
@@ -763,7 +937,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     __syncthreads();
     if (tid == 0) {
         if (blk == 0) {
-            a.status[1] = static_cast<uint32_t>(level); a.status[2] = static_cast<uint32_t>(s_nextid);
+            a.status[1] = static_cast<uint32_t>(level); a.status[2] = static_cast<uint32_t>(s_nextid); a.status[4] = n_replayed;
             if (a.scales_out) *a.scales_out = *a.scales;
         }
         __threadfence_system();
@@ -787,6 +961,9 @@ int align16(int x) { return (x + 15) & ~15; }
 size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {   // the bests, then the (second, parent) pairs of the near-tie detection
     const int NC = 1 << std::max(0, MD - 1);
     return (sizeof(SgBest) + sizeof(float)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
+}
+size_t small_grow_near_bytes(int G, int N) {   // SgNearScratch: counts | candidate lists | replayed scores | ordered row lists
+    return 256 * ((sizeof(uint32_t) * G + 255) / 256) + sizeof(SgCand) * static_cast<size_t>(G) * kSgCandCap + 256 + sizeof(int32_t) * static_cast<size_t>(G) * N;
 }
 size_t small_grow_res_stride(int MD) { return static_cast<size_t>(1 << std::max(0, MD - 1)) * 44 + 64; }
 
@@ -861,6 +1038,21 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.bests = static_cast<SgBest *>(io.bests);
     a.seconds = reinterpret_cast<float *>(static_cast<SgBest *>(io.bests) + static_cast<size_t>(io.MD) * (io.oblivious ? 1 : a.NC) * io.G);
     a.near_rel = io.near_rel;
+    a.meanden = io.meanden;
+    {
+        char *base = static_cast<char *>(io.near_scratch);
+        const size_t o_list = 256 * ((sizeof(uint32_t) * io.G + 255) / 256), o_rep = o_list + sizeof(SgCand) * static_cast<size_t>(io.G) * kSgCandCap, o_ent = o_rep + 256;
+        a.nt.count = reinterpret_cast<uint32_t *>(base);
+        a.nt.list = reinterpret_cast<SgCand *>(base + o_list);
+        a.nt.rep = reinterpret_cast<float *>(base + o_rep);
+        a.nt.ent = reinterpret_cast<int32_t *>(base + o_ent);
+        const size_t hist_bytes = static_cast<size_t>(acc_bytes) * a.nb_cap * io.NB * (io.D + 1);
+        const size_t fixed = sizeof(uint32_t) * (static_cast<size_t>(near_core_words(io.D, 0)) + 64) + sizeof(SgCand) * (kSgMergeCap + kNearCands) + 64;
+        const int Dp = (io.D + 3) & ~3;
+        a.near_tile = hist_bytes > fixed ? static_cast<int>(std::min<size_t>(kNearTile, ((hist_bytes - fixed) / 4) & ~static_cast<size_t>(255))) : 0;
+        const size_t need = a.near_tile >= std::max(256, 8 * Dp) ? 0 : hist_bytes + 1;
+        a.near_in_kernel = (base != nullptr && hist_bytes >= need && io.D <= kNearMaxD) ? 1 : 0;
+    }
     a.tiny_words = static_cast<int>((static_cast<size_t>(acc_bytes) * a.nb_cap * io.NB * (io.D + 1) / 4 / kSgWaves) & ~static_cast<size_t>(3));
     a.sync = io.sync; a.res = io.res; a.res_dev = io.res_dev; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
     a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof; a.scales_out = io.scales_out;

@@ -16,4 +16,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(200): m.step(tup(X), None, tup(Gs[i % 16]))
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 5
 m.set_profiling(2); m.step(tup(X), None, tup(Gs[0])); ph = dict(m.last_phase_times())
-print("rel %s D=%d %s: %.4f ms/step, replays %d bailouts %d of 221; last step phases: %s" % (os.environ["GBRL_HIP_NEARTIE_REL"], D, score, ms, ph.get("near_replays", 0), ph.get("near_bailouts", 0), {k: round(v, 4) for k, v in ph.items() if not k.startswith("near_")}))
+print("rel %s D=%d %s: %.4f ms/step, in-kernel %d, level-loop replays %d bailouts %d of 221; last step phases: %s" % (os.environ["GBRL_HIP_NEARTIE_REL"], D, score, ms, ph.get("near_in_kernel", 0), ph.get("near_replays", 0), ph.get("near_bailouts", 0), {k: round(v, 4) for k, v in ph.items() if not k.startswith("near_")}))

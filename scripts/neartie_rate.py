@@ -30,7 +30,7 @@ def run(env):
         for i in range(steps): m.step(tup(X), None, tup(Gs[i % 32]))
         torch.cuda.synchronize(); ms = min(ms, (time.perf_counter() - t0) * 1e3 / steps)
     m.set_profiling(2); m.step(tup(X), None, tup(Gs[0])); ph = dict(m.last_phase_times())
-    return ms, ph.get("near_replays", 0), ph.get("near_bailouts", 0)
+    return ms, ph.get("near_replays", 0), ph.get("near_bailouts", 0), ph.get("near_in_kernel", 0)
 for env in ({"GBRL_HIP_NO_NEARTIE_REPLAY": "1"}, {}, {"GBRL_HIP_NEARTIE_REL": "7.6e-6"}):
-    ms, rp, bo = run(env)
-    print("%-40s %dx%d D=%d depth %d %s %s: %.4f ms/step, levels replayed %d, trees handed to the level loop %d of %d" % (env or "default (2^-20)", N, F, D, depth, policy, score, ms, rp, bo, 5 * steps + 21))
+    ms, rp, bo, ik = run(env)
+    print("%-40s %dx%d D=%d depth %d %s %s: %.4f ms/step, levels replayed in the one-launch kernel %d, by the level loop %d, trees handed to the level loop %d of %d" % (env or "default (2^-20)", N, F, D, depth, policy, score, ms, ik, rp, bo, 5 * steps + 21))

@@ -8,7 +8,8 @@ the reference's structure even where the reference's own rounding decided.
   tests/test_oracle.py) and, where oracle/_ref is present, against those functions themselves -- bit for bit;
 * the near-tie specimen of the golden fixtures becomes exact, and is the explained near-tie of rounds 1-4 with the hook
   GBRL_HIP_NO_NEARTIE_REPLAY=1;
-* the one-launch growth kernel (which hands a tree with a near-tie to the level loop) and the level loop give the same bytes;
+* the one-launch growth kernel (which replays a near-tie at one node of a greedy level itself and hands every other flagged tree to the level
+  loop) and the level loop give the same bytes;
 * random cases against the reference build / the restatement: fewer structural differences with the replay than without, none unexplained.
 """
 import ctypes
@@ -128,7 +129,7 @@ def test_replay_matches_the_reference_where_the_exact_argmax_does_not(monkeypatc
     import neartie
     import oracle
     ref_mod = oracle.load_ref()
-    diffs_on = diffs_off = replays = 0
+    diffs_on = diffs_off = replays = in_kernel = 0
     for seed in range(31000, 31060):
         case = _sweep_case(seed)
         inputs = K.make_inputs(case)
@@ -142,6 +143,7 @@ def test_replay_matches_the_reference_where_the_exact_argmax_does_not(monkeypatc
             assert e_on[k].shape == e_loop[k].shape and e_on[k].tobytes() == e_loop[k].tobytes(), (case, k, "one-launch growth vs level loop")
         assert p_on.tobytes() == p_loop.tobytes(), case
         replays += ph.get("near_replays", 0)
+        in_kernel += ph.get("near_in_kernel", 0)
         m_on, m_off = neartie.first_mismatch(g, e_on, case["policy"]), neartie.first_mismatch(g, e_off, case["policy"])
         diffs_on += m_on is not None
         diffs_off += m_off is not None
@@ -150,6 +152,7 @@ def test_replay_matches_the_reference_where_the_exact_argmax_does_not(monkeypatc
         if m_on is not None:
             info = neartie.explain_first_mismatch(case, inputs[0], inputs[1], inputs[2], g, e_on)
             assert info["explained"], (case, info)
-    print("near-tie sweep: %d cases, differences without the replay %d, with it %d, levels replayed %d" % (60, diffs_off, diffs_on, replays))
+    print("near-tie sweep: %d cases, differences without the replay %d, with it %d, levels replayed by the level loop %d, inside the one-launch kernel %d" % (60, diffs_off, diffs_on, replays, in_kernel))
     assert diffs_on <= diffs_off
-    assert replays > 0, "no level of 60 cases was replayed: the detection never fired"
+    assert replays > 0, "no level of 60 cases was replayed by the level loop: the detection never fired"
+    assert in_kernel > 0, "the one-launch growth kernel never replayed a near-tie itself"
