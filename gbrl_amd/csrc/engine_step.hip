@@ -1409,7 +1409,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         io.seq = seq;
         io.scales_out = reinterpret_cast<kern::StepScales *>(c.pub_scales_dev);
         io.near_rel = near_on ? near_rel : 0.0f;
-        if (near_on) { io.near_scratch = d_sg_near_.ensure(kern::small_grow_near_bytes(small_G, N)); io.meanden = c.d_meanden; }
+        if (near_on) { io.near_scratch = d_sg_near_.ensure(kern::small_grow_near_bytes(small_G, N, MD)); io.meanden = c.d_meanden; }
         static const bool sg_prof = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_PROF"); return e && e[0] == '1'; }();   // measurement hook
         if (sg_prof) io.prof = reinterpret_cast<uint32_t *>(d_blk + o_status + 64);
         h_status[0] = 0;
@@ -1421,6 +1421,20 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         spin_until_published(h_status, seq, s, "small-step tree");
         const auto t_seen = std::chrono::steady_clock::now();
         hip_check(hipGetLastError(), "growth kernel");
+        if (h_status[3] == 2 && !io.replay) {
+            // a level of this tree has a near-tie: the kernel variant that replays a flagged node itself grows the tree once more (the
+            // default variant only detects: the replay code inside it slows every step, small_grow.hip)
+            io.replay = true;
+            seq = ++level_seq_;
+            if (seq == 0) seq = ++level_seq_;
+            io.seq = seq;
+            h_status[0] = 0;
+            phase_begin();
+            if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
+            phase_end("small_grow");
+            spin_until_published(h_status, seq, s, "small-step tree (near-tie replay)");
+            hip_check(hipGetLastError(), "growth kernel");
+        }
         near_in_kernel_ += h_status[4];
         if (h_status[3] == 2) {
             // a level of this tree has a near-tie: the level loop grows it, with the candidates in the window re-scored in the reference's order

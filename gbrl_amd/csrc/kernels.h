@@ -381,6 +381,7 @@ struct SmallGrowIO {
     StepScales *scales_out = nullptr;   // pinned, device-mapped: the step's scales for the host (what publish_pair hands over in the level loop)
     void *near_scratch = nullptr;   // device, small_grow_near_bytes(G, N): the kernel replays a near-tie at one node of a greedy level itself
     const float *meanden = nullptr; // L2: the step's standardisation (mean | std + 1e-8f) for that replay; nullptr: raw gradients (Cosine)
+    bool replay = false;        // the kernel variant that replays a flagged node itself (launched for a tree the default variant gave up: status word 3 = 2)
     float near_rel = 0.0f;      // > 0: near-tie detection -- the kernel gives the tree up (status word 3 = 2) at the first level whose runner-up
                                 // is within near_rel of the winner; the level loop then grows it with the replay (neartie.hip)
 };
@@ -388,7 +389,7 @@ bool small_grow_supported(int N, int D, int NB, int MD, int n_slots, int n_cand)
 int small_grow_blocks(int n_slots);
 size_t small_grow_bests_bytes(int MD, int G, bool oblivious);
 size_t small_grow_res_stride(int MD);
-size_t small_grow_near_bytes(int G, int N);
+size_t small_grow_near_bytes(int G, int N, int MD);
 bool small_grow(const SmallGrowIO &io, hipStream_t s);   // false: nothing was launched
 
 // ---- leaf values (A11) ----

@@ -291,7 +291,157 @@ __device__ float sg_tiny_zero_gain(const uint16_t *rc16, int N, int k, int n, co
     return __shfl(gain, 0, kWave);
 }
 
+// The in-kernel near-tie replay of ONE node of a greedy level (section "RL-sized steps" of DESIGN 3a): after the level's second scoring pass has
+// collected this block's candidates inside the window (s_clist).  Returns 0: win[kf] holds the
+// reference's choice; 1: a grid barrier gave up; 2: too many candidates -- the level loop takes the tree.
 template <typename ACC>
+__device__ __forceinline__ int sg_replay_node(const SmallGrowArgs &a, int level, bool obl, int n_act, unsigned &epoch, ACC *hist, const uint16_t *rc16, const int *tn,
+                                                        SgBest *win, int *wcat, float *wthr, const SgCand *s_clist, const int *s_kf_p, const int *s_ccount_p,
+                                                        const int *s_cover_p, int *s_near_p, int *s_abort_p) {
+    const int N = a.N, D = a.D, B = a.B, G = a.G;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, blk = blockIdx.x;
+        const int kf = *s_kf_p;
+        const int my_n = *s_cover_p ? 0xffff : min(*s_ccount_p, kSgCandCap);
+        if (tid < kSgCandCap && tid < (my_n & 0x7fff) && my_n != 0xffff) {
+            const SgCand cnd = s_clist[tid];
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&a.nt.list[static_cast<size_t>(blk) * kSgCandCap + tid]);
+            __hip_atomic_store(dst, (static_cast<unsigned long long>(static_cast<uint32_t>(cnd.ref)) << 32) | __float_as_uint(cnd.gain), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, (static_cast<unsigned long long>(cnd.nr) << 32) | cnd.slotbin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(&a.nt.count[blk], static_cast<uint32_t>(my_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, s_abort_p)) return 1;
+        // the idle histogram region: [replay core scratch | 1024 prefix words | merged list | final list | flags]
+        uint32_t *scr = reinterpret_cast<uint32_t *>(hist);
+        uint32_t *pre = scr + near_core_words(D, a.near_tile);
+        SgCand *mlist = reinterpret_cast<SgCand *>(pre + 64);
+        SgCand *fin = mlist + kSgMergeCap;
+        int *st = reinterpret_cast<int *>(fin + kNearCands);     // [0] merged count (-1: too many), [1] classes
+        if (wave == 0) {
+            int total = 0;
+            bool over = false;
+            for (int b0 = 0; b0 < G; b0 += kWave) {
+                const int b = b0 + lane;
+                const uint32_t cnt = b < G ? __hip_atomic_load(&a.nt.count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                over = over || __any(cnt == 0xffffu);
+                int incl = static_cast<int>(cnt == 0xffffu ? 0u : cnt);
+                for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o, kWave); if (lane >= o) incl += up; }
+                const int mine_n = static_cast<int>(cnt == 0xffffu ? 0u : cnt), off = total + incl - mine_n;
+                for (int e = 0; e < mine_n; ++e) {
+                    if (off + e >= kSgMergeCap) { over = true; break; }
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&a.nt.list[static_cast<size_t>(b) * kSgCandCap + e]);
+                    const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mlist[off + e] = SgCand{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
+                }
+                total += __shfl(incl, kWave - 1, kWave);
+                over = __any(over);
+            }
+            if (total > kSgMergeCap) over = true;
+            __builtin_amdgcn_wave_barrier();
+            // classes = distinct gains, each by its lowest reference index, best first (what k_near_list does in the level loop)
+            int n_cls = 0;
+            if (!over) {
+                SgCand me{-INFINITY, 0x7fffffff, 0u, 0u};
+                bool uniq = false;
+                if (lane < total) {
+                    me = mlist[lane];
+                    uniq = true;
+                    for (int j = 0; j < total; ++j) { const SgCand o = mlist[j]; if (o.gain == me.gain && o.ref < me.ref) uniq = false; }
+                }
+                int pos = 0;
+                for (int j = 0; j < total; ++j) {
+                    const SgCand o = mlist[j];
+                    bool ou = true;
+                    for (int q = 0; q < total; ++q) { const SgCand o2 = mlist[q]; if (o2.gain == o.gain && o2.ref < o.ref) ou = false; }
+                    if (ou && o.gain > me.gain) ++pos;
+                }
+                if (uniq && pos < kNearCands) fin[pos] = me;
+                n_cls = min(kNearCands, static_cast<int>(__popcll(__ballot(uniq))));
+            }
+            if (lane == 0) { st[0] = over ? -1 : total; st[1] = n_cls; }
+        }
+        __syncthreads();
+        if (st[0] <= 0) return 2;      // too many candidates (or none): the level loop takes the tree
+        const int n_cls = st[1];
+        // greedy: the node's classes and its parent score; oblivious: every class on every node of the level (fitter.cpp:426-435 sums them)
+        const int n_items = obl ? n_act * n_cls : n_cls + (level > 0 ? 1 : 0);
+        const NearGrads ng{a.grads, a.meanden, D};
+        for (int item = blk; item < n_items; item += G) {
+            const bool is_parent = !obl && item == n_cls;
+            const int inode = obl ? item / n_cls : kf, icls = obl ? item - inode * n_cls : item;
+            const SgCand cnd = is_parent ? SgCand{0.0f, 0, 0u, 0u} : fin[icls];
+            const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
+            const int ccat = is_parent ? 0 : a.slots[cslot].is_cat;
+            const bool fm = a.codes_fm != nullptr && cslot < a.n_fm;
+            const uint16_t *cs = fm ? a.codes_fm + static_cast<size_t>(cslot) * N : a.codes + (static_cast<size_t>(cslot >> 4) * N) * kCodeGroup + (cslot & (kCodeGroup - 1));
+            const int cstride = fm ? 1 : kCodeGroup;
+            // the node's rows in ascending order, bit 31 = goes right: thread t owns the rows [t * per, (t + 1) * per)
+            int32_t *ent = a.nt.ent + static_cast<size_t>(blk) * N;
+            const int per = (N + kSgThreads - 1) / kSgThreads, r_lo = min(N, tid * per), r_hi = min(N, r_lo + per);
+            int cnt = 0, cntr = 0;      // this thread's rows of the node, and those of them that go right
+            for (int r = r_lo; r < r_hi; ++r) {
+                if (rc16[2 * r] != static_cast<uint16_t>(inode)) continue;
+                ++cnt;
+                if (!is_parent) { const int code = cs[static_cast<size_t>(r) * cstride]; cntr += (ccat ? (code == cbin) : (code > cbin)) ? 1 : 0; }
+            }
+            int incl = cnt, inclr = cntr;
+            for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o, kWave), upr = __shfl_up(inclr, o, kWave); if (lane >= o) { incl += up; inclr += upr; } }
+            __syncthreads();
+            if (lane == kWave - 1) { pre[wave] = static_cast<uint32_t>(incl); pre[kSgWaves + wave] = static_cast<uint32_t>(inclr); }
+            __syncthreads();
+            int base = incl - cnt, n_node = 0, n_right = 0;
+            for (int w = 0; w < kSgWaves; ++w) { if (w < wave) base += static_cast<int>(pre[w]); n_node += static_cast<int>(pre[w]); n_right += static_cast<int>(pre[kSgWaves + w]); }
+            for (int r = r_lo; r < r_hi; ++r) {
+                if (rc16[2 * r] != static_cast<uint16_t>(inode)) continue;
+                bool right = false;
+                if (!is_parent) { const int code = cs[static_cast<size_t>(r) * cstride]; right = ccat ? (code == cbin) : (code > cbin); }
+                ent[base++] = r | static_cast<int32_t>(right ? 0x80000000u : 0u);
+            }
+            __threadfence_block();
+            __syncthreads();
+            const float res = near_replay_core(ent, n_node, n_right, ng, a.cosine != 0, is_parent, scr, a.near_tile);
+            if (tid == 0) __hip_atomic_store(&a.nt.rep[is_parent ? kNearCands : (obl ? inode * kNearCands + icls : icls)], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+        if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, s_abort_p)) return 1;
+        // the reference's comparison of the replayed candidates (fitter.cpp:332-357): highest gain, first index among equals
+        if (wave == 0) {
+            SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
+            const float par = (!obl && level > 0) ? __hip_atomic_load(&a.nt.rep[kNearCands], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            if (obl && lane < n_cls) {      // (sum over the level's nodes in node order, float32) * w  (fitter.cpp:426-435)
+                const SgCand cnd = fin[lane];
+                const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
+                const FeatureSlot csl = a.slots[cslot];
+                const float wgt = a.cand_w[csl.cand_base + (csl.is_cat ? cbin - 1 : cbin)];
+                float sc = 0.0f;
+                for (int nd = 0; nd < n_act; ++nd) sc += __hip_atomic_load(&a.nt.rep[nd * kNearCands + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m = SgBest{sc * wgt, cnd.ref, cnd.slotbin, 0u};
+            } else if (lane < n_cls) {
+                const SgCand cnd = fin[lane];
+                const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
+                const FeatureSlot csl = a.slots[cslot];
+                const float wgt = a.cand_w[csl.cand_base + (csl.is_cat ? cbin - 1 : cbin)];
+                const float sc = __hip_atomic_load(&a.nt.rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m = SgBest{fmaf(sc, wgt, -par), cnd.ref, cnd.slotbin, cnd.nr};
+            }
+            m = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, m));
+            if (lane == 0) {
+                const int wslot = m.ref == 0x7fffffff ? 0 : static_cast<int>(m.slotbin >> 16);
+                const int is_cat = a.slots[wslot].is_cat;
+                const int tslot = wslot < a.n_thr_slots ? wslot : 0;
+                const float tv = a.n_thr_slots > 0 ? a.thr[static_cast<size_t>(tslot) * B + min(static_cast<int>(m.slotbin & 0xffffu), B - 1)] : 0.0f;
+                win[kf] = m;
+                wcat[kf] = m.ref == 0x7fffffff ? 0 : is_cat;
+                wthr[kf] = (m.ref == 0x7fffffff || is_cat) ? (is_cat ? INFINITY : 0.0f) : tv;
+                *s_near_p = 0;
+            }
+        }
+    return 0;
+}
+
+// REPLAY: the variant that replays a flagged node itself (sg_replay_node).  The default variant only detects and gives a flagged tree up
+// (status 2); the host then launches this one for that tree -- with the replay inlined, the register allocation of the hot loops spills twice
+// as much (every step lost 10 %), and as a called function it needs a 1.3 KB stack per lane (the launch alone took 0.15 ms longer).
+template <typename ACC, bool REPLAY>
 __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a) {
     extern __shared__ __align__(16) unsigned char sg_lds[];
     const SgLayout &L = a.L;
@@ -360,13 +510,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         // (pass 1 only when the selection flags a near-tie at ONE node of a greedy level: the node's candidates are scored once more, those
         //  inside the window collected, re-scored in the reference's float32 order by the blocks, and the winner replaced -- below)
         bool leave = false;
-        for (int pass = 0; pass < 2 && !leave; ++pass) {
-        const bool redo = pass == 1;
+        for (int pass = 0; pass < (REPLAY ? 2 : 1) && !leave; ++pass) {
+        const bool redo = REPLAY && pass == 1;
         if (redo) { if (tid == 0) { s_ccount = 0; s_cover = 0; } }
         else if (obl) { if (tid == 0) { s_bbest = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; s_bbest2 = -INFINITY; } }
         else for (int k = tid; k < n_act; k += kSgThreads) { nbest[k] = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; nbest2[k] = -INFINITY; npar[k] = 0.0f; }
         __syncthreads();
-        const int k_begin = redo ? s_kf : 0, k_end = redo ? s_kf + 1 : n_act;
+        const int k_begin = (redo && !obl) ? s_kf : 0, k_end = (redo && !obl) ? s_kf + 1 : n_act;    // (an oblivious level is scored again on every node)
         for (int fs = blk; fs < a.n_slots; fs += G) {
             const FeatureSlot sl = a.slots[fs];
             const int NBe = sl.n_cand + 1;                       // classes of this slot
@@ -497,7 +647,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                             mine = SgBest{fmaf(out, sw[k], -par_sub), sref[k],
                                           (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), static_cast<uint32_t>(n_r)};
                         }
-                        if (redo) {
+                        if (REPLAY && redo) {
                             // collect the candidates inside the window; of a run of neighbours with the same gain (thresholds between the same
                             // two rows of the node) only the lowest reference index -- the last lane of the run
                             const float below = __shfl_down(mine.v, 1, kWave);
@@ -542,7 +692,26 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 __syncthreads();
                 SG_MARK(6);
             }
-            if (obl) {   // the slot's best candidate: (sum over nodes) * w, lowest reference index among maxima (fitter.cpp:435-444)
+            if (REPLAY && redo && obl) {
+                // collect the slot's candidates inside the window; of neighbours with the same score only the lowest reference index
+                for (int k0c = 0; k0c < sl.n_cand; k0c += kSgThreads) {
+                    const int k = k0c + tid;
+                    const float sc = k < sl.n_cand ? ssum[k] * sw[k] : -INFINITY;
+                    const bool keep = k < sl.n_cand && sc >= s_lo && (k == 0 || ssum[k - 1] * sw[k - 1] != sc);
+                    const unsigned long long mk = __ballot(keep);
+                    if (mk) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_ccount, __popcll(mk));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (keep) {
+                            const int at = base + __popcll(mk & ((1ull << lane) - 1ull));
+                            if (at < kSgCandCap) s_clist[at] = SgCand{sc, sref[k], (static_cast<uint32_t>(fs) << 16) | static_cast<uint32_t>(sl.is_cat ? k + 1 : k), 0u};
+                            else s_cover = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+            } else if (obl) {   // the slot's best candidate: (sum over nodes) * w, lowest reference index among maxima (fitter.cpp:435-444)
                 SgBest mine{-INFINITY, 0x7fffffff, 0u, 0u};
                 float sec = -INFINITY;
                 for (int k = tid; k < sl.n_cand; k += kSgThreads) {
@@ -566,128 +735,10 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
             }
         }
         __syncthreads();
-        if (redo) {
-            // ---- in-kernel near-tie replay of node s_kf (neartie.hip states the sequence; tests/test_gpu_neartie.py compares both paths) ----
-            const int kf = s_kf;
-            const int my_n = s_cover ? 0xffff : min(s_ccount, kSgCandCap);
-            if (tid < kSgCandCap && tid < (my_n & 0x7fff) && my_n != 0xffff) {
-                const SgCand cnd = s_clist[tid];
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(&a.nt.list[static_cast<size_t>(blk) * kSgCandCap + tid]);
-                __hip_atomic_store(dst, (static_cast<unsigned long long>(static_cast<uint32_t>(cnd.ref)) << 32) | __float_as_uint(cnd.gain), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, (static_cast<unsigned long long>(cnd.nr) << 32) | cnd.slotbin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (tid == 0) __hip_atomic_store(&a.nt.count[blk], static_cast<uint32_t>(my_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; leave = true; break; }
-            // the idle histogram region: [replay core scratch | 1024 prefix words | merged list | final list | flags]
-            uint32_t *scr = reinterpret_cast<uint32_t *>(hist);
-            uint32_t *pre = scr + near_core_words(D, a.near_tile);
-            SgCand *mlist = reinterpret_cast<SgCand *>(pre + 64);
-            SgCand *fin = mlist + kSgMergeCap;
-            int *st = reinterpret_cast<int *>(fin + kNearCands);     // [0] merged count (-1: too many), [1] classes
-            if (wave == 0) {
-                int total = 0;
-                bool over = false;
-                for (int b0 = 0; b0 < G; b0 += kWave) {
-                    const int b = b0 + lane;
-                    const uint32_t cnt = b < G ? __hip_atomic_load(&a.nt.count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                    over = over || __any(cnt == 0xffffu);
-                    int incl = static_cast<int>(cnt == 0xffffu ? 0u : cnt);
-                    for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o, kWave); if (lane >= o) incl += up; }
-                    const int mine_n = static_cast<int>(cnt == 0xffffu ? 0u : cnt), off = total + incl - mine_n;
-                    for (int e = 0; e < mine_n; ++e) {
-                        if (off + e >= kSgMergeCap) { over = true; break; }
-                        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&a.nt.list[static_cast<size_t>(b) * kSgCandCap + e]);
-                        const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        mlist[off + e] = SgCand{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
-                    }
-                    total += __shfl(incl, kWave - 1, kWave);
-                    over = __any(over);
-                }
-                if (total > kSgMergeCap) over = true;
-                __builtin_amdgcn_wave_barrier();
-                // classes = distinct gains, each by its lowest reference index, best first (what k_near_list does in the level loop)
-                int n_cls = 0;
-                if (!over) {
-                    SgCand me{-INFINITY, 0x7fffffff, 0u, 0u};
-                    bool uniq = false;
-                    if (lane < total) {
-                        me = mlist[lane];
-                        uniq = true;
-                        for (int j = 0; j < total; ++j) { const SgCand o = mlist[j]; if (o.gain == me.gain && o.ref < me.ref) uniq = false; }
-                    }
-                    int pos = 0;
-                    for (int j = 0; j < total; ++j) {
-                        const SgCand o = mlist[j];
-                        bool ou = true;
-                        for (int q = 0; q < total; ++q) { const SgCand o2 = mlist[q]; if (o2.gain == o.gain && o2.ref < o.ref) ou = false; }
-                        if (ou && o.gain > me.gain) ++pos;
-                    }
-                    if (uniq && pos < kNearCands) fin[pos] = me;
-                    n_cls = min(kNearCands, static_cast<int>(__popcll(__ballot(uniq))));
-                }
-                if (lane == 0) { st[0] = over ? -1 : total; st[1] = n_cls; }
-            }
-            __syncthreads();
-            if (st[0] <= 0) { near_exit = true; leave = true; break; }      // too many candidates (or none): the level loop takes the tree
-            const int n_cls = st[1];
-            const int n_items = n_cls + (level > 0 ? 1 : 0);
-            const NearGrads ng{a.grads, a.meanden, D};
-            for (int item = blk; item < n_items; item += G) {
-                const bool is_parent = item == n_cls;
-                const SgCand cnd = is_parent ? SgCand{0.0f, 0, 0u, 0u} : fin[item];
-                const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
-                const int ccat = is_parent ? 0 : a.slots[cslot].is_cat;
-                const bool fm = a.codes_fm != nullptr && cslot < a.n_fm;
-                const uint16_t *cs = fm ? a.codes_fm + static_cast<size_t>(cslot) * N : a.codes + (static_cast<size_t>(cslot >> 4) * N) * kCodeGroup + (cslot & (kCodeGroup - 1));
-                const int cstride = fm ? 1 : kCodeGroup;
-                // the node's rows in ascending order, bit 31 = goes right: thread t owns the rows [t * per, (t + 1) * per)
-                int32_t *ent = a.nt.ent + static_cast<size_t>(blk) * N;
-                const int per = (N + kSgThreads - 1) / kSgThreads, r_lo = min(N, tid * per), r_hi = min(N, r_lo + per);
-                int cnt = 0;
-                for (int r = r_lo; r < r_hi; ++r) cnt += rc16[2 * r] == static_cast<uint16_t>(kf) ? 1 : 0;
-                int incl = cnt;
-                for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o, kWave); if (lane >= o) incl += up; }
-                if (lane == kWave - 1) pre[wave] = static_cast<uint32_t>(incl);
-                __syncthreads();
-                int base = incl - cnt;
-                for (int w = 0; w < wave; ++w) base += static_cast<int>(pre[w]);
-                for (int r = r_lo; r < r_hi; ++r) {
-                    if (rc16[2 * r] != static_cast<uint16_t>(kf)) continue;
-                    bool right = false;
-                    if (!is_parent) { const int code = cs[static_cast<size_t>(r) * cstride]; right = ccat ? (code == cbin) : (code > cbin); }
-                    ent[base++] = r | static_cast<int32_t>(right ? 0x80000000u : 0u);
-                }
-                __threadfence_block();
-                __syncthreads();
-                const float res = near_replay_core(ent, tn[kf], is_parent ? 0 : static_cast<int>(cnd.nr), ng, a.cosine != 0, is_parent, scr, a.near_tile);
-                if (tid == 0) __hip_atomic_store(&a.nt.rep[is_parent ? kNearCands : item], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-            }
-            if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; leave = true; break; }
-            // the reference's comparison of the replayed candidates (fitter.cpp:332-357): highest gain, first index among equals
-            if (wave == 0) {
-                SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
-                const float par = level > 0 ? __hip_atomic_load(&a.nt.rep[kNearCands], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-                if (lane < n_cls) {
-                    const SgCand cnd = fin[lane];
-                    const int cslot = static_cast<int>(cnd.slotbin >> 16), cbin = static_cast<int>(cnd.slotbin & 0xffffu);
-                    const FeatureSlot csl = a.slots[cslot];
-                    const float wgt = a.cand_w[csl.cand_base + (csl.is_cat ? cbin - 1 : cbin)];
-                    const float sc = __hip_atomic_load(&a.nt.rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    m = SgBest{fmaf(sc, wgt, -par), cnd.ref, cnd.slotbin, cnd.nr};
-                }
-                m = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, m));
-                if (lane == 0) {
-                    const int wslot = m.ref == 0x7fffffff ? 0 : static_cast<int>(m.slotbin >> 16);
-                    const int is_cat = a.slots[wslot].is_cat;
-                    const int tslot = wslot < a.n_thr_slots ? wslot : 0;
-                    const float tv = a.n_thr_slots > 0 ? a.thr[static_cast<size_t>(tslot) * B + min(static_cast<int>(m.slotbin & 0xffffu), B - 1)] : 0.0f;
-                    win[kf] = m;
-                    wcat[kf] = m.ref == 0x7fffffff ? 0 : is_cat;
-                    wthr[kf] = (m.ref == 0x7fffffff || is_cat) ? (is_cat ? INFINITY : 0.0f) : tv;
-                    s_near = 0;
-                }
-            }
+        if constexpr (REPLAY) if (redo) {
+            const int rr = sg_replay_node<ACC>(a, level, obl, n_act, epoch, hist, rc16, tn, win, wcat, wthr, s_clist, &s_kf, &s_ccount, &s_cover, &s_near, &s_abort);
+            if (rr == 1) { ok = false; leave = true; break; }
+            if (rr == 2) { near_exit = true; leave = true; break; }
             ++n_replayed;
             __syncthreads();
             break;
@@ -766,7 +817,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         __syncthreads();
         SG_MARK(9);
         if (s_near == 0) break;                                        // (the usual case: no second pass)
-        if (s_near != 1 || obl || !a.near_in_kernel) { near_exit = true; leave = true; break; }   // more than one node, or no room: the level loop takes the tree
+        if (!REPLAY || s_near != 1 || !a.near_in_kernel) { near_exit = true; leave = true; break; }   // more than one node, or no room: the level loop takes the tree
         }   // passes
         if (leave) break;
         // ---- children: node ids in the host's order (for k in splitting: left, right), next level's table.  The child sizes of a greedy
@@ -962,8 +1013,9 @@ size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {   // the bests, t
     const int NC = 1 << std::max(0, MD - 1);
     return (sizeof(SgBest) + sizeof(float)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
 }
-size_t small_grow_near_bytes(int G, int N) {   // SgNearScratch: counts | candidate lists | replayed scores | ordered row lists
-    return 256 * ((sizeof(uint32_t) * G + 255) / 256) + sizeof(SgCand) * static_cast<size_t>(G) * kSgCandCap + 256 + sizeof(int32_t) * static_cast<size_t>(G) * N;
+static size_t small_grow_rep_bytes(int MD) { return 256 * ((sizeof(float) * ((static_cast<size_t>(1) << std::max(0, MD - 1)) * kNearCands + kNearCands + 1) + 255) / 256); }
+size_t small_grow_near_bytes(int G, int N, int MD) {   // SgNearScratch: counts | candidate lists | replayed scores | ordered row lists
+    return 256 * ((sizeof(uint32_t) * G + 255) / 256) + sizeof(SgCand) * static_cast<size_t>(G) * kSgCandCap + small_grow_rep_bytes(MD) + sizeof(int32_t) * static_cast<size_t>(G) * N;
 }
 size_t small_grow_res_stride(int MD) { return static_cast<size_t>(1 << std::max(0, MD - 1)) * 44 + 64; }
 
@@ -1041,7 +1093,7 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.meanden = io.meanden;
     {
         char *base = static_cast<char *>(io.near_scratch);
-        const size_t o_list = 256 * ((sizeof(uint32_t) * io.G + 255) / 256), o_rep = o_list + sizeof(SgCand) * static_cast<size_t>(io.G) * kSgCandCap, o_ent = o_rep + 256;
+        const size_t o_list = 256 * ((sizeof(uint32_t) * io.G + 255) / 256), o_rep = o_list + sizeof(SgCand) * static_cast<size_t>(io.G) * kSgCandCap, o_ent = o_rep + small_grow_rep_bytes(io.MD);
         a.nt.count = reinterpret_cast<uint32_t *>(base);
         a.nt.list = reinterpret_cast<SgCand *>(base + o_list);
         a.nt.rep = reinterpret_cast<float *>(base + o_rep);
@@ -1056,14 +1108,15 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.tiny_words = static_cast<int>((static_cast<size_t>(acc_bytes) * a.nb_cap * io.NB * (io.D + 1) / 4 / kSgWaves) & ~static_cast<size_t>(3));
     a.sync = io.sync; a.res = io.res; a.res_dev = io.res_dev; a.res_stride = static_cast<int>(small_grow_res_stride(io.MD)); a.max_front = a.NC;
     a.acc = io.acc; a.status = io.status; a.seq = io.seq; a.prof = io.prof; a.scales_out = io.scales_out;
-    static PerDeviceOnce attr32, attr64;
-    if (acc_bytes == 4) {
-        if (attr32.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_grow<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) { (void)hipGetLastError(); attr32.done = 0; return false; }
-        hipLaunchKernelGGL(k_small_grow<int32_t>, dim3(io.G), dim3(kSgThreads), a.L.total_bytes, s, a);
-    } else {
-        if (attr64.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_grow<long long>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) { (void)hipGetLastError(); attr64.done = 0; return false; }
-        hipLaunchKernelGGL(k_small_grow<long long>, dim3(io.G), dim3(kSgThreads), a.L.total_bytes, s, a);
-    }
+    static PerDeviceOnce attr[4];
+    const int which = (acc_bytes == 4 ? 0 : 1) + (io.replay ? 2 : 0);
+    const void *fn = which == 0 ? reinterpret_cast<const void *>(k_small_grow<int32_t, false>) : which == 1 ? reinterpret_cast<const void *>(k_small_grow<long long, false>)
+                   : which == 2 ? reinterpret_cast<const void *>(k_small_grow<int32_t, true>) : reinterpret_cast<const void *>(k_small_grow<long long, true>);
+    if (attr[which].first() && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) { (void)hipGetLastError(); attr[which].done = 0; return false; }
+    if (which == 0) hipLaunchKernelGGL((k_small_grow<int32_t, false>), dim3(io.G), dim3(kSgThreads), a.L.total_bytes, s, a);
+    else if (which == 1) hipLaunchKernelGGL((k_small_grow<long long, false>), dim3(io.G), dim3(kSgThreads), a.L.total_bytes, s, a);
+    else if (which == 2) hipLaunchKernelGGL((k_small_grow<int32_t, true>), dim3(io.G), dim3(kSgThreads), a.L.total_bytes, s, a);
+    else hipLaunchKernelGGL((k_small_grow<long long, true>), dim3(io.G), dim3(kSgThreads), a.L.total_bytes, s, a);
     return hipGetLastError() == hipSuccess;
 }
 

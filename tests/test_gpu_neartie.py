@@ -156,3 +156,41 @@ def test_replay_matches_the_reference_where_the_exact_argmax_does_not(monkeypatc
     assert diffs_on <= diffs_off
     assert replays > 0, "no level of 60 cases was replayed by the level loop: the detection never fired"
     assert in_kernel > 0, "the one-launch growth kernel never replayed a near-tie itself"
+
+
+@pytest.mark.parametrize("policy,score,D,depth", [("oblivious", "L2", 8, 7), ("greedy", "L2", 1, 4), ("greedy", "Cosine", 4, 5)])
+def test_one_launch_kernel_replays_what_the_level_loop_replays(policy, score, D, depth, monkeypatch):
+    """A boosting-like loop on 4096-row minibatches with structured gradients (where near-ties are frequent: one tree in 30-50): the
+    one-launch kernel -- which replays a flagged level itself, greedy and oblivious -- must grow the bytes the level loop grows, and must
+    have met flagged levels (otherwise this test shows nothing)."""
+    import gbrl_amd
+    rng = np.random.default_rng(5)
+    N, F, mini, trees = 1 << 15, 24, 4096, 120
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    W = rng.standard_normal((6, D)).astype(np.float32)
+    out = {}
+    for name, env in (("kernel", {}), ("loop", {"GBRL_HIP_NO_SMALL_GROW": "1"})):
+        for k in HOOKS:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        case = dict(name="ik", seed=1, N=mini, F=F, Fc=0, D=D, depth=depth, n_bins=256, score=score, gen="Quantile", policy=policy, trees=1, min_data_in_leaf=0)
+        m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+        m.set_feature_weights(np.ones(F, np.float32))
+        for o in K.optimizers(case):
+            m.set_optimizer(**o)
+        m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+        m.set_profiling(2)
+        g_rng = np.random.default_rng(9)
+        for i in range(trees):
+            o = (i * mini) % (N - mini + 1)
+            xs = np.ascontiguousarray(X[o:o + mini])
+            g = (np.tanh(xs[:, :6] @ W) + 0.5 * g_rng.standard_normal((mini, D))).astype(np.float32)
+            m.step(xs, None, np.ascontiguousarray(g))
+        out[name] = ({k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}, dict(m.last_phase_times()))
+    (ek, pk), (el, pl) = out["kernel"], out["loop"]
+    for k in ek:
+        assert ek[k].shape == el[k].shape and ek[k].tobytes() == el[k].tobytes(), (policy, score, k)
+    print("in-kernel replays %d, trees handed to the level loop %d; level loop alone replayed %d levels" % (pk.get("near_in_kernel", 0), pk.get("near_bailouts", 0), pl.get("near_replays", 0)))
+    assert pl.get("near_replays", 0) > 0, "no level of this loop was flagged: choose other inputs"
+    assert pk.get("near_in_kernel", 0) > 0, "the one-launch kernel never replayed a level itself"
