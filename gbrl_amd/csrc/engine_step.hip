@@ -1425,6 +1425,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             // a level of this tree has a near-tie: the kernel variant that replays a flagged node itself grows the tree once more (the
             // default variant only detects: the replay code inside it slows every step, small_grow.hip)
             io.replay = true;
+            io.resume = h_status[5] == 1;     // (the default variant left its state: only the flagged level's second pass and what follows run again)
             seq = ++level_seq_;
             if (seq == 0) seq = ++level_seq_;
             io.seq = seq;

@@ -381,6 +381,7 @@ struct SmallGrowIO {
     StepScales *scales_out = nullptr;   // pinned, device-mapped: the step's scales for the host (what publish_pair hands over in the level loop)
     void *near_scratch = nullptr;   // device, small_grow_near_bytes(G, N): the kernel replays a near-tie at one node of a greedy level itself
     const float *meanden = nullptr; // L2: the step's standardisation (mean | std + 1e-8f) for that replay; nullptr: raw gradients (Cosine)
+    bool resume = false;        // with replay: continue from the checkpoint the default variant left (status word 5 = 1) instead of growing from the root
     bool replay = false;        // the kernel variant that replays a flagged node itself (launched for a tree the default variant gave up: status word 3 = 2)
     float near_rel = 0.0f;      // > 0: near-tie detection -- the kernel gives the tree up (status word 3 = 2) at the first level whose runner-up
                                 // is within near_rel of the winner; the level loop then grows it with the replay (neartie.hip)

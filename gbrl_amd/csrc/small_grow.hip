@@ -174,6 +174,9 @@ struct SmallGrowArgs {
     SgNearScratch nt;           // in-kernel replay
     int near_in_kernel;         // the idle histogram region holds the replay's scratch (else a flagged tree goes to the level loop)
     int near_tile;              // floats of that scratch the replay stages a batch of rows in
+    uint32_t *ckpt;             // device: the tree state the default variant leaves when it gives a flagged tree up -- [16] header, then the fixed part of its LDS
+    int ckpt_words;             // 32-bit words of that fixed part (SgLayout::ttot / 4)
+    int resume;                 // REPLAY variant: continue from the checkpoint (the flagged level's second pass) instead of growing from the root
     const float *meanden;       // L2: the step's standardisation (mean | std + 1e-8f), nullptr for Cosine
     int tiny_words;             // 32-bit words of the histogram region every wave may use as scratch (sg_tiny_zero_gain)
     unsigned *sync;             // [0] groups arrived, [1] finished blocks, [2] abort, [32 + 32 g] arrivals of group g (kSmallGrowSyncBytes)
@@ -493,12 +496,27 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     for (int i = 0; i < 16; ++i) pacc[i] = 0;
 #define SG_MARK(i) do { if (a.prof && blk == 0 && tid == 0) { const long long n_ = wall_clock64(); pacc[i] += static_cast<unsigned>(n_ - pt); pt = n_; } } while (0)
 
-    for (int r = tid; r < N; r += kSgThreads) rc[r] = 0;
-    for (int i = tid; i < a.NIDS; i += kSgThreads) leafflag[i] = 0;
-    if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; s_near = 0; s_kf = 0; s_ccount = 0; s_cover = 0; s_lo = 0.0f; }
+    int cur = 0, level = 0, loaded_slot = -1;
+    bool resumed = false;
+    if (REPLAY && a.resume) {
+        // continue the tree the default variant gave up at a flagged level: every block takes over its tables, row words and that level's
+        // winners (the state is the same in all blocks; block 0 of the other kernel wrote it), and enters the level's second pass
+        uint32_t *lw = reinterpret_cast<uint32_t *>(sg_lds);
+        for (int i = tid; i < a.ckpt_words; i += kSgThreads) lw[i] = a.ckpt[16 + i];
+        if (tid == 0) {
+            s_abort = 0; s_stop = 0; s_ccount = 0; s_cover = 0;
+            s_nact = static_cast<int>(a.ckpt[0]); s_nextid = static_cast<int>(a.ckpt[1]); s_kf = static_cast<int>(a.ckpt[4]); s_lo = __uint_as_float(a.ckpt[5]); s_near = 1;
+        }
+        level = static_cast<int>(a.ckpt[2]);
+        cur = static_cast<int>(a.ckpt[3]);
+        resumed = true;
+    } else {
+        for (int r = tid; r < N; r += kSgThreads) rc[r] = 0;
+        for (int i = tid; i < a.NIDS; i += kSgThreads) leafflag[i] = 0;
+        if (tid == 0) { tn_b[0] = N; tid_b[0] = 0; s_abort = 0; s_nact = 1; s_nextid = 1; s_stop = 0; s_near = 0; s_kf = 0; s_ccount = 0; s_cover = 0; s_lo = 0.0f; }
+    }
     __syncthreads();
 
-    int cur = 0, level = 0, loaded_slot = -1;
     bool ok = true, near_exit = false;
     unsigned n_replayed = 0;      // levels whose near-tie this launch replayed itself
     for (; level < MD; ++level) {
@@ -510,7 +528,8 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         // (pass 1 only when the selection flags a near-tie at ONE node of a greedy level: the node's candidates are scored once more, those
         //  inside the window collected, re-scored in the reference's float32 order by the blocks, and the winner replaced -- below)
         bool leave = false;
-        for (int pass = 0; pass < (REPLAY ? 2 : 1) && !leave; ++pass) {
+        for (int pass = (REPLAY && resumed) ? 1 : 0; pass < (REPLAY ? 2 : 1) && !leave; ++pass) {
+        resumed = false;
         const bool redo = REPLAY && pass == 1;
         if (redo) { if (tid == 0) { s_ccount = 0; s_cover = 0; } }
         else if (obl) { if (tid == 0) { s_bbest = SgBest{-INFINITY, 0x7fffffff, 0u, 0u}; s_bbest2 = -INFINITY; } }
@@ -817,6 +836,15 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         __syncthreads();
         SG_MARK(9);
         if (s_near == 0) break;                                        // (the usual case: no second pass)
+        if (!REPLAY && s_near == 1 && a.near_in_kernel && a.ckpt != nullptr && blk == 0) {
+            // leave the tree's state for the variant that replays (it enters this level's second pass): header, then the fixed part of LDS
+            const uint32_t *lw = reinterpret_cast<const uint32_t *>(sg_lds);
+            for (int i = tid; i < a.ckpt_words; i += kSgThreads) a.ckpt[16 + i] = lw[i];
+            if (tid == 0) {
+                a.ckpt[0] = static_cast<uint32_t>(s_nact); a.ckpt[1] = static_cast<uint32_t>(s_nextid); a.ckpt[2] = static_cast<uint32_t>(level); a.ckpt[3] = static_cast<uint32_t>(cur);
+                a.ckpt[4] = static_cast<uint32_t>(s_kf); a.ckpt[5] = __float_as_uint(s_lo);
+            }
+        }
         if (!REPLAY || s_near != 1 || !a.near_in_kernel) { near_exit = true; leave = true; break; }   // more than one node, or no room: the level loop takes the tree
         }   // passes
         if (leave) break;
@@ -988,7 +1016,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
     __syncthreads();
     if (tid == 0) {
         if (blk == 0) {
-            a.status[1] = static_cast<uint32_t>(level); a.status[2] = static_cast<uint32_t>(s_nextid); a.status[4] = n_replayed;
+            a.status[1] = static_cast<uint32_t>(level); a.status[2] = static_cast<uint32_t>(s_nextid); a.status[4] = n_replayed; a.status[5] = (!REPLAY && near_exit && s_near == 1 && a.near_in_kernel && a.ckpt != nullptr) ? 1u : 0u;
             if (a.scales_out) *a.scales_out = *a.scales;
         }
         __threadfence_system();
@@ -1014,8 +1042,8 @@ size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {   // the bests, t
     return (sizeof(SgBest) + sizeof(float)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
 }
 static size_t small_grow_rep_bytes(int MD) { return 256 * ((sizeof(float) * ((static_cast<size_t>(1) << std::max(0, MD - 1)) * kNearCands + kNearCands + 1) + 255) / 256); }
-size_t small_grow_near_bytes(int G, int N, int MD) {   // SgNearScratch: counts | candidate lists | replayed scores | ordered row lists
-    return 256 * ((sizeof(uint32_t) * G + 255) / 256) + sizeof(SgCand) * static_cast<size_t>(G) * kSgCandCap + small_grow_rep_bytes(MD) + sizeof(int32_t) * static_cast<size_t>(G) * N;
+size_t small_grow_near_bytes(int G, int N, int MD) {   // (+ 192 KiB: the checkpoint -- at most the kernel's whole LDS)   // SgNearScratch: counts | candidate lists | replayed scores | ordered row lists
+    return 256 * ((sizeof(uint32_t) * G + 255) / 256) + sizeof(SgCand) * static_cast<size_t>(G) * kSgCandCap + small_grow_rep_bytes(MD) + sizeof(int32_t) * static_cast<size_t>(G) * N + 192 * 1024;
 }
 size_t small_grow_res_stride(int MD) { return static_cast<size_t>(1 << std::max(0, MD - 1)) * 44 + 64; }
 
@@ -1098,6 +1126,9 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
         a.nt.list = reinterpret_cast<SgCand *>(base + o_list);
         a.nt.rep = reinterpret_cast<float *>(base + o_rep);
         a.nt.ent = reinterpret_cast<int32_t *>(base + o_ent);
+        a.ckpt = base ? reinterpret_cast<uint32_t *>(base + o_ent + sizeof(int32_t) * static_cast<size_t>(io.G) * io.N) : nullptr;
+        a.ckpt_words = a.L.ttot / 4;
+        a.resume = (io.replay && io.resume) ? 1 : 0;
         const size_t hist_bytes = static_cast<size_t>(acc_bytes) * a.nb_cap * io.NB * (io.D + 1);
         const size_t fixed = sizeof(uint32_t) * (static_cast<size_t>(near_core_words(io.D, 0)) + 64) + sizeof(SgCand) * (kSgMergeCap + kNearCands) + 64;
         const int Dp = (io.D + 3) & ~3;
