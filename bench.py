@@ -319,6 +319,13 @@ def leg_cfg1(torch, np, gbrl_amd, dev, trees=30, N=4096, F=16, depth=4, B=256):
         if not split and rep > 0 and (best is None or loop < best):
             best = loop
         final = torch.from_dlpack(m.predict(tup(Xd), None, 0, 0)).cpu().numpy().reshape(N, 1)
+    # near-tie replay counters of the last model (cumulative since it was created; an extra, untimed step reads them)
+    m.set_profiling(2)
+    m.step(tup(Xd), None, tup(g))
+    ph = dict(m.last_phase_times())
+    out["near_tie_replay"] = {"levels_replayed_inside_the_growth_kernel": int(ph.get("near_in_kernel", 0)), "levels_replayed_by_the_level_loop": int(ph.get("near_replays", 0)),
+                              "trees_handed_to_the_level_loop": int(ph.get("near_bailouts", 0)), "trees": trees + 1,
+                              "what": "nodes whose runner-up is within 2^-20 of the exact best gain are re-scored in the reference's float32 sequence (DESIGN 3a); GBRL_HIP_NO_NEARTIE_REPLAY=1 switches it off"}
     out["product"] = {"ms_per_iteration": best / trees * 1e3, "trees_per_s": trees / best,
                       "ms_per_step": best_split[2] / trees * 1e3, "ms_per_predict_and_gradient": best_split[1] / trees * 1e3,
                       "ms_per_iteration_with_a_synchronisation_between_the_halves": best_split[0] / trees * 1e3,

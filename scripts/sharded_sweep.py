@@ -1,6 +1,7 @@
 """Randomised ROW-SHARDED sweep on one GPU: `world` processes (gloo group, reductions staged through the host, like
 tests/test_gpu_sharded_world2.py) grow random cases on uneven row shards; every rank must produce the tree -- and its shard of the
-predictions -- that ONE process grows from all the rows, bit for bit.
+predictions -- that ONE process grows from all the rows, bit for bit.  (Row-sharded runs do not replay near-ties, DESIGN section 3a: the
+one-process side runs with GBRL_HIP_NO_NEARTIE_REPLAY=1, i.e. both sides take the exact arg-max.)
     python scripts/sharded_sweep.py [n_cases] [first_seed] [world]      (world 1: the sharded path with the native RCCL exchange)"""
 import json, os, socket, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -82,6 +83,7 @@ def main():
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
         single = {}
         for c in cases:      # the single-process reference trees, grown here while the workers run
+            os.environ["GBRL_HIP_NO_NEARTIE_REPLAY"] = "1"      # (read per call; the sharded side never replays)
             try: single[c["name"]] = grow(c, 0, c["N"])
             except RuntimeError as ex: single[c["name"]] = str(ex)
         logs = [p.communicate(timeout=3000)[0].decode(errors="replace") for p in procs]
