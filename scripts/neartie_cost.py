@@ -1,3 +1,5 @@
+"""What a replayed level costs on an RL-sized step: the window forced wide (GBRL_HIP_NEARTIE_REL, default 1e-3) so that most trees are flagged:
+    python3 scripts/neartie_cost.py [window] [outputs] [score]      (4096 x 16, greedy depth 4, fresh gradients per step)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 os.environ["GBRL_HIP_NEARTIE_REL"] = sys.argv[1] if len(sys.argv) > 1 else "1e-3"

@@ -7,7 +7,7 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly
 read.  Calibrated here on kernels of this code base whose byte counts are known exactly (k_transpose_keys reads N*F*4 B and
 writes N*F*4 B; k_bin_cols reads N*F*4 B, writes N*F*2 B): FETCH_SIZE shows 0.500x of the read bytes for both (4 B/lane
 coalesced loads), WRITE_SIZE shows 1.000x of the written bytes.  Hence traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes)."""
-import glob, json, re, sqlite3, subprocess, sys, time
+import glob, json, os, re, sqlite3, subprocess, sys, time
 
 fetch_dir, write_dir, out_txt, out_json = sys.argv[1:5]
 EXTRA = sys.argv[5] if len(sys.argv) > 5 else ""
