@@ -431,7 +431,7 @@ int gbrl_hip_replay_scores(const float *grads, const uint8_t *in_node, const uin
     if (!grads || !in_node || !goes_right || !out_scores || n_rows < 1 || output_dim < 1) return GBRL_HIP_E_INVALID;
     return guarded([&] {
         if (!gbrl::kern::near_tie_selftest(grads, in_node, goes_right, n_rows, output_dim, meanden, cosine != 0, min_data_in_leaf, out_scores))
-            throw gbrl::Unsupported("near-tie replay: shape not supported (n_rows <= 65536, output_dim <= 2048) or no HIP device");
+            throw gbrl::Unsupported("near-tie replay: shape not supported (n_rows <= 65536, output_dim <= 1024) or no HIP device");
     });
 }
 

@@ -1852,7 +1852,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 io.rel = near_rel; io.n_act = n_act;
                 int32_t *lists = static_cast<int32_t *>(d_near_list_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * (kern::kNearCands + 1)));
                 io.list = lists; io.list_n = lists + static_cast<size_t>(max_front) * kern::kNearCands;
-                io.ent = static_cast<int32_t *>(d_near_ent_.ensure(sizeof(int32_t) * static_cast<size_t>(kern::kNearCands + 1) * N));
+                io.ent = static_cast<int32_t *>(d_near_ent_.ensure(sizeof(int32_t) * std::max(static_cast<size_t>(kern::kNearCands + 1) * N, static_cast<size_t>(n_cand))));
                 io.rep = static_cast<float *>(d_near_rep_.ensure(sizeof(float) * static_cast<size_t>(max_front) * (kern::kNearCands + 1)));
                 io.part_v = d_am_v; io.part_i = d_am_i; io.n_parts = oblivious ? am_parts : own_slots;
                 kern::near_tie_replay(io, s);

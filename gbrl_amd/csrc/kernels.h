@@ -277,7 +277,7 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
 // sequence, and the arg-max input of resolve_splits (part_v / part_i) is rewritten with the reference's comparison of them.
 constexpr int kNearCands = 16;         // distinct gains replayed per node (the closest ones)
 constexpr int kNearMaxRows = 65536;    // batches up to this many rows are replayed (a bit per row in LDS)
-constexpr int kNearMaxD = 2048;
+constexpr int kNearMaxD = 1024;      // (the replay block keeps two mean vectors, a tile and two row bitmaps in 64 KB of LDS)
 struct NearTieIO {
     const int32_t *rows;        // the level's row list
     const int32_t *seg_start;   // [n_act] first position of every active node's segment
@@ -302,7 +302,7 @@ struct NearTieIO {
     int n_act;
     int32_t *list;              // scratch [n_act][kNearCands]
     int32_t *list_n;            // scratch [n_act]
-    int32_t *ent;               // scratch [(kNearCands + 1) * N]: ordered row lists
+    int32_t *ent;               // scratch [max((kNearCands + 1) * N, n_cand)]: ordered row lists (the candidate list of an oblivious level keeps its level scores there first)
     float *rep;                 // scratch [n_act][kNearCands + 1]: replayed scores, [kNearCands] = the parent's
     float *part_v;              // arg-max stage-1 arrays of the level: rewritten for the replayed nodes
     int32_t *part_i;

@@ -65,10 +65,16 @@ __global__ __launch_bounds__(kNearThreads) void k_near_list(NearTieIO a) {
     float prev = INFINITY;
     int prev_n = 0x7fffffff;
     int count = 0;
+    // oblivious: every candidate's level score once (n_act loads each), kept in the row-list scratch, which nothing uses yet
+    float *lvl = reinterpret_cast<float *>(a.ent);
+    if (a.oblivious) {
+        for (int j = threadIdx.x; j < a.n_cand; j += kNearThreads) lvl[j] = near_level_score(a, j);
+        __syncthreads();
+    }
     for (; count < kNearCands; ++count) {
         float bv = -INFINITY; int bi = 0x7fffffff, bj = -1, bn = 0x7fffffff;
         for (int j = threadIdx.x; j < a.n_cand; j += kNearThreads) {
-            const float g = a.oblivious ? near_level_score(a, j) : near_gain(a, node, j);
+            const float g = a.oblivious ? lvl[j] : near_gain(a, node, j);
             const int n = a.cand_nr ? a.cand_nr[static_cast<size_t>(node) * a.n_cand + j] : 0;
             if (!(g >= lo) || !(g < prev || (g == prev && n > prev_n))) continue;
             const int r = a.cand_ref[j];

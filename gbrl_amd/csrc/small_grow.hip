@@ -350,15 +350,11 @@ __device__ __forceinline__ int sg_replay_node(const SmallGrowArgs &a, int level,
                     uniq = true;
                     for (int j = 0; j < total; ++j) { const SgCand o = mlist[j]; if (o.gain == me.gain && o.ref < me.ref) uniq = false; }
                 }
+                const unsigned long long um = __ballot(uniq);      // (at most 64 merged candidates: one per lane)
                 int pos = 0;
-                for (int j = 0; j < total; ++j) {
-                    const SgCand o = mlist[j];
-                    bool ou = true;
-                    for (int q = 0; q < total; ++q) { const SgCand o2 = mlist[q]; if (o2.gain == o.gain && o2.ref < o.ref) ou = false; }
-                    if (ou && o.gain > me.gain) ++pos;
-                }
+                for (unsigned long long rest = um; rest; rest &= rest - 1) { const int j = __ffsll(static_cast<long long>(rest)) - 1; if (mlist[j].gain > me.gain) ++pos; }
                 if (uniq && pos < kNearCands) fin[pos] = me;
-                n_cls = min(kNearCands, static_cast<int>(__popcll(__ballot(uniq))));
+                n_cls = min(kNearCands, static_cast<int>(__popcll(um)));
             }
             if (lane == 0) { st[0] = over ? -1 : total; st[1] = n_cls; }
         }
