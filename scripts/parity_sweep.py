@@ -46,6 +46,10 @@ for i in range(n_cases):
         case["feature_weights"] = [float(v) for v in rng.choice([0.0, 0.25, 0.5, 1.0, 1.0, 2.0], nin)]
         if max(case["feature_weights"]) == 0.0: case["feature_weights"][0] = 1.0
         case["bias"] = [float(v) for v in rng.standard_normal(case["D"]).astype(np.float32)]
+    only = os.environ.get("PARITY_ONLY")      # debugging: run ONE case of the sequence (the others only consume their random draws, as exact cases do)
+    if only is not None and int(only) != i:
+        if case["trees"] > 1: a_ = int(rng.integers(0, case["trees"] - 1)); int(rng.integers(a_ + 1, case["trees"] + 1))
+        continue
     X, Xc, G, y = K.make_inputs(case)
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
     try:
