@@ -236,6 +236,8 @@ def ref_score_probe():
         lib.ref_split_score.restype = lib.ref_parent_score.restype = C.c_float
         lib.ref_split_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         lib.ref_parent_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.ref_split_score_cat.restype = C.c_float
+        lib.ref_split_score_cat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]
         _PROBE = lib
     return _PROBE
 
@@ -250,3 +252,13 @@ def ref_scores(obs, grads, rows, feature, value, min_data, cosine):
     s = lib.ref_split_score(obs.ctypes.data, grads.ctypes.data, rows.ctypes.data, n, F, D, int(feature), float(value), int(min_data), 1 if cosine else 0)
     p = lib.ref_parent_score(grads.ctypes.data, rows.ctypes.data, n, D, 1 if cosine else 0) if n else 0.0
     return np.float32(s), np.float32(p)
+
+
+def ref_split_score_cat(cat_obs, grads, rows, feature, value, min_data, cosine):
+    """TreeNode::splitScoreCosineCategorical / splitScoreL2Categorical of the reference build: candidate cat_obs[:, feature] == value."""
+    lib = ref_score_probe()
+    cat_obs = np.ascontiguousarray(cat_obs, "S128")
+    grads = np.ascontiguousarray(grads, np.float32)
+    rows = np.ascontiguousarray(rows, np.int32)
+    return np.float32(lib.ref_split_score_cat(cat_obs.ctypes.data, grads.ctypes.data, rows.ctypes.data, len(rows), cat_obs.shape[1], grads.shape[1], int(feature),
+                                              bytes(value).ljust(128, b"\0"), int(min_data), 1 if cosine else 0))

@@ -20,8 +20,8 @@
 //   predict   predict_cpu / predict_over_trees / predict_over_leaves / SGDOptimizer::step
 //                                                      gbrl/src/cpp/predictor.cpp:122-265, optimizer.cpp:110-118
 // The algorithm is the reference's brute-force one on purpose (per-candidate scan of the node's rows,
-// float32 sums in row order), so that results agree with the reference to the last bit wherever the
-// compiler contracts the same expressions; it is also what bench.py times as the "port" CPU baseline.
+// float32 sums in row order); the split and parent scores are evaluated by replay_sequence.cpp, the reference's operation sequence
+// spelled out (explicit fmaf, no contraction), so that their bits do not depend on this file's compiler; it is also what bench.py times as the "port" CPU baseline.
 //
 // Deliberately NOT restated: control variates, Adam / Linear scheduler, fit(), SHAP, export.
 
@@ -36,6 +36,12 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+// the reference's float32 operation sequence, spelled out (replay_sequence.cpp, built without contraction; pinned bit for bit to the
+// reference's own functions by tests/test_oracle.py)
+extern "C" float oracle_seq_split(const float *g, const int *ridx, int nr, const int *lidx, int nl, int D, int cosine);
+extern "C" float oracle_replay_parent_cosine(const float *g, const int *rows, int n, int D);
+extern "C" float oracle_replay_parent_l2(const float *g, const int *rows, int n, int D);
 
 namespace {
 
@@ -163,45 +169,13 @@ void divide_by_vec(float *mat, const float *vec, int n_samples, int n_cols) {
     for (long i = 0; i < n_el; ++i) mat[i] /= (vec[i % n_cols] + 1e-8f);
 }
 
-// math_ops.h:476-485
-inline float squared_norm(const float *v, int n) {
-    float s = 0.0f;
-    for (int i = 0; i < n; ++i) s += (v[i] * v[i]);
-    return s;
-}
-
-// math_ops.h:432-449
-inline float mat_vec_dot_sum(const int *idx, const float *g, const float *vec, int n, int n_cols) {
-    float s = 0.0f;
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n_cols; ++c) s += g[idx[r] * n_cols + c] * vec[c];
-    return s;
-}
-
-// split_candidate_generator.cpp:293-320 (parent score, greedy/L2)
+// split_candidate_generator.cpp:293-320 (parent score, greedy/L2) and :262-290 + math_ops.h:504-524 (greedy/Cosine): replay_sequence.cpp
 float parent_l2(const std::vector<int> &rows, const float *g, int n_cols) {
-    std::vector<float> mean(n_cols, 0.0f);
-    const int n = static_cast<int>(rows.size());
-    const float nf = static_cast<float>(n), recip = 1.0f / nf;
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n_cols; ++c) mean[c] += g[rows[r] * n_cols + c];
-    for (int c = 0; c < n_cols; ++c) mean[c] *= recip;
-    return squared_norm(mean.data(), n_cols) * nf;
+    return oracle_replay_parent_l2(g, rows.data(), static_cast<int>(rows.size()), n_cols);
 }
-
-// split_candidate_generator.cpp:262-290 + math_ops.h:504-524 (parent score, greedy/Cosine)
 float parent_cosine(const std::vector<int> &rows, const float *g, int n_cols) {
-    std::vector<float> mean(n_cols, 0.0f);
-    const int n = static_cast<int>(rows.size());
-    const float nf = static_cast<float>(n), recip = 1.0f / nf;
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n_cols; ++c) mean[c] += g[rows[r] * n_cols + c];
-    for (int c = 0; c < n_cols; ++c) mean[c] *= recip;
-    if (n == 0) return 0.0f;
-    const float dot = mat_vec_dot_sum(rows.data(), g, mean.data(), n, n_cols);
-    const float denom = squared_norm(mean.data(), n_cols) * nf;
-    if (denom == 0.0f) return 0.0f;
-    return static_cast<float>(dot / sqrt(denom));  // reference calls double sqrt here
+    if (rows.empty()) return 0.0f;
+    return oracle_replay_parent_cosine(g, rows.data(), static_cast<int>(rows.size()), n_cols);
 }
 
 inline bool goes_right(const oracle_model *m, const float *obs, const char *cat, int row,
@@ -224,41 +198,15 @@ float split_score(const oracle_model *m, const Node &node, const float *obs, con
         }
     }
     const int n = static_cast<int>(node.rows.size());
-    std::vector<float> lsum(D, 0.0f), rsum(D, 0.0f);
-    std::vector<int> lidx, ridx;
-    const bool cosine = (m->score == ORACLE_COSINE);
-    if (cosine) { lidx.resize(n); ridx.resize(n); }
+    std::vector<int> lidx(n), ridx(n);
     int nl = 0, nr = 0;
     for (int k = 0; k < n; ++k) {
         const int row = node.rows[k];
-        const float *g = bg + static_cast<size_t>(row) * D;
-        if (goes_right(m, obs, cat, row, cand)) {
-            for (int d = 0; d < D; ++d) rsum[d] += g[d];
-            if (cosine) ridx[nr] = row;
-            ++nr;
-        } else {
-            for (int d = 0; d < D; ++d) lsum[d] += g[d];
-            if (cosine) lidx[nl] = row;
-            ++nl;
-        }
+        if (goes_right(m, obs, cat, row, cand)) ridx[nr++] = row; else lidx[nl++] = row;
     }
     if (nl < m->min_data_in_leaf || nr < m->min_data_in_leaf) return -INFINITY;
-    const float nlf = static_cast<float>(nl), nrf = static_cast<float>(nr);
-    const float lrec = nl > 0 ? 1.0f / nlf : 0.0f, rrec = nr > 0 ? 1.0f / nrf : 0.0f;
-    for (int d = 0; d < D; ++d) { lsum[d] *= lrec; rsum[d] *= rrec; }
-    if (!cosine) {  // node.cpp:360-373
-        const float ln = squared_norm(lsum.data(), D), rn = squared_norm(rsum.data(), D);
-        return nlf * ln + nrf * rn;
-    }
-    // math_ops.h:538-575 (called with right as "true", left as "false")
-    float tnum = 0.0f, fnum = 0.0f;
-    if (nr > 0) tnum = mat_vec_dot_sum(ridx.data(), bg, rsum.data(), nr, D);
-    if (nl > 0) fnum = mat_vec_dot_sum(lidx.data(), bg, lsum.data(), nl, D);
-    const float tden = squared_norm(rsum.data(), D) * nrf;
-    const float fden = squared_norm(lsum.data(), D) * nlf;
-    const float num = tnum + fnum, den = tden + fden;
-    if (den == 0.0f) return 0.0f;
-    return num / sqrtf(den);
+    // node.cpp:187-251 / 321-376 + math_ops.h:432-575 as the reference's release build evaluates them (replay_sequence.cpp)
+    return oracle_seq_split(bg, ridx.data(), nr, lidx.data(), nl, D, m->score == ORACLE_COSINE ? 1 : 0);
 }
 
 // node.cpp:64-149

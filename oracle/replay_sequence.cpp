@@ -87,3 +87,30 @@ extern "C" float oracle_replay_parent_l2(const float *g, const int *rows, int n,
     for (int d = 0; d < D; ++d) m[d] *= rec;
     return sqnorm(m.data(), D) * nf;
 }
+
+// ---- the same sequence on explicit side lists (rows in node order): what oracle.cpp's split_score / parent scores call, so that the
+// restatement's bits do not depend on how oracle.cpp's own compiler contracts "a * b + c * d" (the two sides are NOT interchangeable:
+// mirror-image candidates -- "== a" against "== b" on a two-token column -- tie exactly, and the last bit of the asymmetric expression decides)
+extern "C" float oracle_seq_split(const float *g, const int *ridx, int nr, const int *lidx, int nl, int D, int cosine) {
+    std::vector<float> lm(D, 0.f), rm(D, 0.f);
+    // (node.cpp:196-222 / 336-352: ONE pass over the node's rows adds each to its side; per side that is the side's rows in node order)
+    for (int k = 0; k < nr; ++k) for (int d = 0; d < D; ++d) rm[d] += g[(size_t)ridx[k] * D + d];
+    for (int k = 0; k < nl; ++k) for (int d = 0; d < D; ++d) lm[d] += g[(size_t)lidx[k] * D + d];
+    float nlf = nl, nrf = nr;
+    float lrec = nl > 0 ? 1.0f / nlf : 0.0f, rrec = nr > 0 ? 1.0f / nrf : 0.0f;
+    for (int d = 0; d < D; ++d) { lm[d] *= lrec; rm[d] *= rrec; }
+    if (!cosine) {
+        float ln = sqnorm(lm.data(), D), rn = sqnorm(rm.data(), D);
+        const float rp = nrf * rn;
+        return fmaf(nlf, ln, rp);
+    }
+    float tnum = 0.f, fnum = 0.f;
+    if (nr > 0) tnum = dot_rows(ridx, nr, g, rm.data(), D);
+    if (nl > 0) fnum = dot_rows(lidx, nl, g, lm.data(), D);
+    float tn = sqnorm(rm.data(), D), fn = sqnorm(lm.data(), D);
+    float fden = fn * nlf;
+    float den = fmaf(tn, nrf, fden);
+    float num = tnum + fnum;
+    if (den == 0.0f) return 0.0f;
+    return num / sqrtf(den);
+}

@@ -1,5 +1,5 @@
 """Randomised product-vs-oracle sweep on a GPU box (not part of the test suite; prints a summary).
-    python scripts/parity_sweep.py [n_cases] [first_seed] [wide|cat|dev|weights|ref|refweights]   (ref*: against the REAL reference build, oracle/_ref)
+    python scripts/parity_sweep.py [n_cases] [first_seed] [wide|cat|dev|weights|ref|refweights|refcat]   (ref*: against the REAL reference build, oracle/_ref)
     python scripts/parity_sweep.py [n_cases] [first_seed] [wide]      (wide: many outputs / bins / features, the less common kernels)
 Every case: random shape / policy / score / generator / bins / depth / min_data_in_leaf / categorical columns; the product must
 match the oracle restatement bit for bit in structure (or the first mismatch must be an explained near-tie) and within 1e-5
@@ -18,7 +18,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 dev = len(sys.argv) > 3 and sys.argv[3] == "dev"     # torch device tensors in (4-tuples), DLPack capsules out
-cat = len(sys.argv) > 3 and sys.argv[3] == "cat"     # categorical-heavy: many columns / tokens, few bins (mean-gradient ranking fallback)
+cat = len(sys.argv) > 3 and sys.argv[3] in ("cat", "refcat")     # categorical-heavy: many columns / tokens, few bins (mean-gradient ranking fallback)
 rng = np.random.default_rng(seed0)
 exact = near = bad = 0
 t0 = time.time()
@@ -71,7 +71,7 @@ for i in range(n_cases):
         continue
     # "refweights": the REAL reference build (oracle/_ref travels to the GPU box) instead of the restatement -- pins the restatement's
     # handling of weights on mixed numeric / categorical inputs (Q6) where no committed fixture does
-    ref = (oracle.load_ref().GBRL if len(sys.argv) > 3 and sys.argv[3] in ("refweights", "ref") else oracle.OracleGBRL)(**K.ctor_kwargs(case))
+    ref = (oracle.load_ref().GBRL if len(sys.argv) > 3 and sys.argv[3] in ("refweights", "ref", "refcat") else oracle.OracleGBRL)(**K.ctor_kwargs(case))
     pref = np.asarray(K.drive(ref, case, X, Xc, G, y))
     e, r = m.get_ensemble_data(), ref.get_ensemble_data()
     scale = float(np.abs(G).mean())

@@ -143,3 +143,44 @@ def test_replay_sequence_is_the_reference_functions_bit_for_bit(cosine):
         a = oracle.ref_scores(obs, g, rows, f, v, md, cosine)
         b = oracle.replay_scores(obs, g, rows, f, v, md, cosine)
         assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes(), (rep, a, b, g.shape, len(rows))
+
+
+@pytest.mark.parametrize("cosine", [True, False])
+def test_categorical_scores_follow_the_same_sequence(cosine):
+    """TreeNode::splitScoreCosineCategorical / splitScoreL2Categorical (node.cpp:253-319, 378-434) are separate functions of the reference: the
+    compiler could have contracted their expressions differently.  It did not: same bits as the restated sequence on the equivalent 0/1 column."""
+    if oracle.ref_score_probe() is None:
+        pytest.skip("oracle/_ref/ref_score_probe.so not built (needs /root/reference)")
+    rng = np.random.default_rng(3)
+    for rep in range(1500):
+        D, N = int(rng.integers(1, 41)), int(rng.integers(1, 500))
+        sc = np.exp(rng.standard_normal() * 3)
+        g = (rng.standard_normal((N, D)) * sc + (0.3 * sc if rep % 3 else 0)).astype(np.float32)
+        tok = rng.integers(0, 3, N)
+        cat = np.zeros((N, 1), "S128")
+        cat[:, 0] = np.array([b"a", b"b", b"c"])[tok]
+        rows = np.flatnonzero(rng.integers(0, 4, N) > 0).astype(np.int32)
+        a = oracle.ref_split_score_cat(cat, g, rows, 0, b"a", 0, cosine)
+        b = oracle.replay_scores((tok == 0).astype(np.float32).reshape(N, 1), g, rows, 0, 0.5, 0, cosine)[0]
+        assert a.tobytes() == b.tobytes(), (rep, a, b)
+
+
+@pytest.mark.parametrize("seed", [9894, 23064, 23089])
+def test_restatement_takes_the_references_side_of_a_mirror_tie(seed):
+    """Two-token categorical columns make mirror-image candidates ("== a" against "== b"): their scores tie exactly in exact arithmetic and the
+    reference's asymmetric float32 expression decides (fma(norm_r, n_r, norm_l * n_l)).  The restatement evaluates that expression as the
+    reference's build does (replay_sequence.cpp) -- before round 5 its own compiler's contraction decided, and these seeds came out the other way."""
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(seed)
+    case = dict(name="mirror", seed=seed, N=2500, F=0, Fc=2, D=int(rng.choice([1, 2])), depth=4, n_bins=4, score="Cosine", gen="Quantile", policy="greedy",
+                trees=1, min_data_in_leaf=5, n_tokens=3)
+    X, Xc, G, y = K.make_inputs(case)
+    a = ref.GBRL(**K.ctor_kwargs(case))
+    K.drive(a, case, X, Xc, G, y)
+    b = oracle.OracleGBRL(**K.ctor_kwargs(case))
+    K.drive(b, case, X, Xc, G, y)
+    ea, eb = a.get_ensemble_data(), b.get_ensemble_data()
+    for k in STRUCTURE_KEYS + VALUE_KEYS:
+        assert np.array_equal(np.asarray(ea[k]), eb[k]), k
