@@ -1172,7 +1172,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const float near_rel = [] { const char *e = std::getenv("GBRL_HIP_NEARTIE_REL"); return e ? static_cast<float>(std::atof(e)) : 9.5367431640625e-07f; }();   // 2^-20; measurement hook
     const bool near_on = !no_near && !has_coll_ && n_global == N && n_cand > 0 && kern::near_tie_supported(N, D);
     float *d_am_s = (near_on && !use_small) ? static_cast<float *>(d_am_s_.ensure(sizeof(float) * am_cap * 2)) : nullptr;
-    int32_t *d_am_n = d_am_s ? reinterpret_cast<int32_t *>(d_am_s + am_cap) : nullptr;
+    int32_t *d_am_n = (d_am_s && N > 8192) ? reinterpret_cast<int32_t *>(d_am_s + am_cap) : nullptr;    // child sizes tell classes apart in larger batches only (score_common.h near_class)
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
     int64_t *d_leafacc = static_cast<int64_t *>(d_leafacc_.ensure(sizeof(int64_t) * max_nodes * (D + 1)));
     {   // zero unless the last tree's publication handed these words back clean
@@ -1841,7 +1841,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (any) {
                 ++near_replays_;
                 phase_begin();
-                int32_t *d_cand_nr = oblivious ? nullptr : static_cast<int32_t *>(d_near_nr_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
+                int32_t *d_cand_nr = (oblivious || N <= 8192) ? nullptr : static_cast<int32_t *>(d_near_nr_.ensure(sizeof(int32_t) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
                 if (!oblivious)   // every candidate's exact score and child sizes (the greedy selection kept the per-slot bests only)
                     kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                            d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot, nullptr, d_am_i, s, 0, !drop_derived, nullptr, nullptr, d_cand_nr);

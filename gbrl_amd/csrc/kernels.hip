@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
             const int j = sl.cand_base + k;
             const float gain = fmaf(out, cand_w[j], -par_sub);
             const Best cb{gain, cand_ref[j]};
-            const int cls = near_class(n_r, n_tot);
+            const int cls = part_n ? near_class(n_r, n_tot) : 0;     // (part_n == nullptr: batches of <= 8192 rows, classes by the gain alone)
             second = second_merge(mine.v, mine_nr, second, gain, cls, -INFINITY);
             if (better_takes_second(mine, cb)) { mine = cb; mine_nr = cls; }
         } else {
@@ -1126,7 +1126,8 @@ __global__ __launch_bounds__(256, 5) void k_score(int64_t *__restrict__ hist, co
             }
             part_v[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.v;
             part_i[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = b.i;
-            if (part_s) { part_s[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = s2; part_n[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = nr; }
+            if (part_s) part_s[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = s2;
+            if (part_n) part_n[static_cast<size_t>(node) * gridDim.x + blockIdx.x] = nr;
         }
     }
 }

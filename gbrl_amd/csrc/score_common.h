@@ -51,8 +51,9 @@ __device__ __forceinline__ float second_merge(float v1, int nr1, float s1, float
 }
 // The class of a candidate that sends n_right of its node's n_node rows right.  Every row on one side -- either side -- is ONE class (the
 // reference scores both the same, operation for operation).  Nodes of up to 1024 rows tell classes apart by the gain alone: mirror-image
-// partitions of a few rows tie exactly all the time there (one tree in five flagged at 64 rows, none in 500 at 1024 on random data), and
-// re-scoring them would cost more than the tree.
+// partitions of a few rows tie exactly all the time there (one tree in five flagged at 64 rows, none in 500 at 1024 on random data).  The
+// callers apply it to batches of more than 8192 rows only: in the one-launch kernel of the smaller ones carrying the child size through the
+// selection costs 3.5 % of every step (profiles/r05_neartie_cost.txt), and both growth paths must flag the same nodes.
 constexpr int kNearClassRows = 1024;
 __device__ __forceinline__ int near_class(long long n_right, long long n_node) { return (n_node <= kNearClassRows || n_right == n_node) ? 0 : static_cast<int>(n_right); }
 __device__ __forceinline__ bool better_takes_second(Best a, Best b) { return b.v > a.v || (b.v == a.v && b.v > -INFINITY && b.i < a.i); }

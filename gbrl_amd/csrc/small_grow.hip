@@ -345,21 +345,14 @@ __device__ __forceinline__ int sg_replay_node(const SmallGrowArgs &a, int level,
             if (!over) {
                 SgCand me{-INFINITY, 0x7fffffff, 0u, 0u};
                 bool uniq = false;
-                const int n_kf = obl ? 0 : tn[kf];
-                int my_cls = 0;
-                if (lane < total) {
+                if (lane < total) {      // (batches of <= 8192 rows: classes by the gain alone, score_common.h near_class)
                     me = mlist[lane];
-                    my_cls = obl ? 0 : near_class(me.nr, n_kf);
                     uniq = true;
-                    for (int j = 0; j < total; ++j) { const SgCand o = mlist[j]; if (o.gain == me.gain && (obl ? 0 : near_class(o.nr, n_kf)) == my_cls && o.ref < me.ref) uniq = false; }
+                    for (int j = 0; j < total; ++j) { const SgCand o = mlist[j]; if (o.gain == me.gain && o.ref < me.ref) uniq = false; }
                 }
                 const unsigned long long um = __ballot(uniq);      // (at most 64 merged candidates: one per lane)
-                int pos = 0;       // classes in front of this one: higher gain, or the same gain and a lower class (k_near_list's order)
-                for (unsigned long long rest = um; rest; rest &= rest - 1) {
-                    const int j = __ffsll(static_cast<long long>(rest)) - 1;
-                    const SgCand o = mlist[j];
-                    if (o.gain > me.gain || (o.gain == me.gain && (obl ? 0 : near_class(o.nr, n_kf)) < my_cls)) ++pos;
-                }
+                int pos = 0;
+                for (unsigned long long rest = um; rest; rest &= rest - 1) { const int j = __ffsll(static_cast<long long>(rest)) - 1; if (mlist[j].gain > me.gain) ++pos; }
                 if (uniq && pos < kNearCands) fin[pos] = me;
                 n_cls = min(kNearCands, static_cast<int>(__popcll(um)));
             }
@@ -673,8 +666,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                             // collect the candidates inside the window; of a run of neighbours with the same gain (thresholds between the same
                             // two rows of the node) only the lowest reference index -- the last lane of the run
                             const float below = __shfl_down(mine.v, 1, kWave);
-                            const int cls = near_class(static_cast<long long>(mine.pad), n_tot), below_cls = __shfl_down(cls, 1, kWave);
-                            const bool keep = have && mine.v >= s_lo && (lane == kWave - 1 || below != mine.v || below_cls != cls);
+                            const bool keep = have && mine.v >= s_lo && (lane == kWave - 1 || below != mine.v);
                             const unsigned long long mk = __ballot(keep);
                             if (mk) {
                                 int base = 0;
@@ -689,11 +681,8 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                             continue;
                         }
                         const float own = mine.v;
-                        const int own_cls = near_class(static_cast<long long>(mine.pad), n_tot);
                         mine = sg_wave_best(sg_better(SgBest{-INFINITY, 0x7fffffff, 0u, 0u}, mine));
-                        float sec = detect ? sg_wave_second(own, -INFINITY, mine.v) : -INFINITY;
-                        // (a candidate of ANOTHER class with the best's gain is a runner-up at distance 0: score_common.h near_class)
-                        if (detect && __any(have && own == mine.v && own_cls != near_class(static_cast<long long>(mine.pad), n_tot))) sec = mine.v;
+                        const float sec = detect ? sg_wave_second(own, -INFINITY, mine.v) : -INFINITY;
                         if (lane == 0) { ibest[it] = mine; ibest2[it] = sec; if (t == 0) npar[k_abs] = par_sub; }
                     }
                 }
@@ -710,8 +699,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                     for (int kb = tid; kb < nbk; kb += kSgThreads) {
                         SgBest b = nbest[k0 + kb];
                         float b2 = nbest2[k0 + kb];
-                        const int nn = tn[k0 + kb];
-                        for (int t = 0; t < T; ++t) { const SgBest o = ibest[kb * T + t]; b2 = second_merge(b.v, near_class(b.pad, nn), b2, o.v, near_class(o.pad, nn), ibest2[kb * T + t]); b = sg_better(b, o); }
+                        for (int t = 0; t < T; ++t) { b2 = second_distinct(b.v, b2, ibest[kb * T + t].v, ibest2[kb * T + t]); b = sg_better(b, ibest[kb * T + t]); }
                         nbest[k0 + kb] = b;
                         nbest2[k0 + kb] = b2;
                     }
@@ -796,17 +784,13 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (q0 + u * kWave < G) {
-                    if (detect) m2 = obl ? second_distinct(m.v, m2, b4[u].v, s4[u]) : second_merge(m.v, near_class(m.pad, tn[k]), m2, b4[u].v, near_class(b4[u].pad, tn[k]), s4[u]);
+                    if (detect) m2 = second_distinct(m.v, m2, b4[u].v, s4[u]);
                     m = sg_better(m, b4[u]);
                 }
             }
             const float own = m.v;
-            const int own_cls = obl ? 0 : near_class(m.pad, tn[k]);
             m = sg_wave_best(m);
-            if (detect) {
-                m2 = sg_wave_second(own, m2, m.v);
-                if (!obl && __any(own == m.v && own > -INFINITY && own_cls != near_class(m.pad, tn[k]))) m2 = m.v;
-            }
+            if (detect) m2 = sg_wave_second(own, m2, m.v);
             const float par = (detect && !obl) ? npar[k] : 0.0f;       // (every block derives the same parent score from the node's totals)
             int tiny_k = 0;
             if (lane == 0 && detect && m.v != -INFINITY) {
