@@ -158,14 +158,15 @@ def test_replay_matches_the_reference_where_the_exact_argmax_does_not(monkeypatc
     assert in_kernel > 0, "the one-launch growth kernel never replayed a near-tie itself"
 
 
-@pytest.mark.parametrize("policy,score,D,depth", [("oblivious", "L2", 8, 7), ("greedy", "L2", 1, 4), ("greedy", "Cosine", 4, 5)])
-def test_one_launch_kernel_replays_what_the_level_loop_replays(policy, score, D, depth, monkeypatch):
+@pytest.mark.parametrize("policy,score,D,depth,mini", [("oblivious", "L2", 8, 7, 4096), ("greedy", "L2", 1, 4, 4096), ("greedy", "Cosine", 4, 5, 4096),
+                                                        ("greedy", "L2", 2, 5, 8192), ("oblivious", "Cosine", 3, 6, 6000)])   # (4097+ rows: the int64 histogram variant)
+def test_one_launch_kernel_replays_what_the_level_loop_replays(policy, score, D, depth, mini, monkeypatch):
     """A boosting-like loop on 4096-row minibatches with structured gradients (where near-ties are frequent: one tree in 30-50): the
     one-launch kernel -- which replays a flagged level itself, greedy and oblivious -- must grow the bytes the level loop grows, and must
     have met flagged levels (otherwise this test shows nothing)."""
     import gbrl_amd
     rng = np.random.default_rng(5)
-    N, F, mini, trees = 1 << 15, 24, 4096, 120
+    N, F, trees = 1 << 15, 24, 120
     X = rng.standard_normal((N, F)).astype(np.float32)
     W = rng.standard_normal((6, D)).astype(np.float32)
     out = {}
