@@ -45,7 +45,7 @@ constexpr unsigned kLeafBit = 0x8000u;     // rownode: the row has reached a lea
 
 // One candidate in the arg-max: gain / score, reference candidate index (ties: the lower wins), feature slot << 16 | bin (numeric: threshold
 // index; categorical: class), and -- greedy growth -- `pad` = the rows the candidate sends RIGHT in its node (known where the candidate is
-// scored; travels with the winner so that nobody has to count the children's rows).
+// scored; travels with the winner so that nobody has to count the children's rows; at most 8192, bit 31 carries the near-tie flag between blocks).
 struct alignas(16) SgBest { float v; int32_t ref; uint32_t slotbin; uint32_t pad; };
 
 __device__ __forceinline__ SgBest sg_better(SgBest a, SgBest b) {
@@ -169,7 +169,6 @@ struct SmallGrowArgs {
     int G, NC, nb_cap, Tmax, NIDS;
     uint32_t magicW;            // floor(2^32 / (D + 1)) + 1
     SgBest *bests;              // greedy [MD][NC][G], oblivious [MD][G]
-    float *seconds;             // same shape: the best gain strictly below the block's best -- near-tie detection
     float near_rel;             // 0: no detection
     SgNearScratch nt;           // in-kernel replay
     int near_in_kernel;         // the idle histogram region holds the replay's scratch (else a flagged tree goes to the level loop)
@@ -209,8 +208,6 @@ __device__ __forceinline__ SgBest sg_load_best(const SgBest *p) {
     const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return SgBest{__uint_as_float(static_cast<uint32_t>(lo)), static_cast<int32_t>(static_cast<uint32_t>(lo >> 32)), static_cast<uint32_t>(hi), static_cast<uint32_t>(hi >> 32)};
 }
-__device__ __forceinline__ void sg_store_second(float *p, float sec) { __hip_atomic_store(p, sec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float sg_load_second(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Arrivals are counted per GROUP of 16 blocks (counters 128 bytes apart) and the last block of a group arrives at the top counter: 256
 // atomics on ONE word took ~7 us per barrier (a device-scope atomic unit retires ~30 same-address operations per microsecond).
 constexpr int kSgGroup = 16;
@@ -761,11 +758,19 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         // ---- publish this block's bests, ONE grid barrier, reduce to the winners -------------------------------------------------
         SG_MARK(7);
         SgBest *lv = a.bests + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
-        float *lv2 = a.seconds + static_cast<size_t>(level) * (obl ? 1 : NC) * G;
-        if (obl) { if (tid == 0) { sg_store_best(&lv[blk], s_bbest); if (detect) sg_store_second(&lv2[blk], s_bbest2); } }
-        else for (int k = tid; k < n_act; k += kSgThreads) {
-            sg_store_best(&lv[static_cast<size_t>(k) * G + blk], nbest[k]);
-            if (detect) sg_store_second(&lv2[static_cast<size_t>(k) * G + blk], nbest2[k]);
+        // Near-tie detection travels in the record: bit 31 of `pad` = "this block's own runner-up is inside the window of its best".  The level's
+        // runner-up is either another block's best (all of them are read below anyway) or the runner-up of a block whose best IS the level's
+        // best -- and for those the block's own test is the level's test (same best, same parent score).
+        if (obl) {
+            if (tid == 0) {
+                SgBest r = s_bbest;
+                if (detect && s_bbest2 != -INFINITY && r.v - s_bbest2 <= a.near_rel * fabsf(r.v)) r.pad |= 0x80000000u;
+                sg_store_best(&lv[blk], r);
+            }
+        } else for (int k = tid; k < n_act; k += kSgThreads) {
+            SgBest r = nbest[k];
+            if (detect && nbest2[k] != -INFINITY && r.v - nbest2[k] <= a.near_rel * fmaxf(fabsf(r.v + npar[k]), fabsf(npar[k]))) r.pad |= 0x80000000u;
+            sg_store_best(&lv[static_cast<size_t>(k) * G + blk], r);
         }
         if (!sg_grid_barrier(a.sync, static_cast<unsigned>(G), epoch, &s_abort)) { ok = false; leave = true; break; }
         SG_MARK(8);
@@ -773,24 +778,24 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
         for (int k = wave; k < n_win; k += kSgWaves) {
             SgBest m{-INFINITY, 0x7fffffff, 0u, 0u};
             float m2 = -INFINITY;
+            bool mf = false;        // a record with this lane's best value carries the flag
             for (int q0 = lane; q0 < G; q0 += kWave * 4) {          // (G <= 256 blocks: one round of four loads in flight)
                 SgBest b4[4];
-                float s4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) b4[u] = sg_load_best(lv + static_cast<size_t>(k) * G + min(q0 + u * kWave, G - 1));
-                if (detect) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) s4[u] = sg_load_second(lv2 + static_cast<size_t>(k) * G + min(q0 + u * kWave, G - 1));
-                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (q0 + u * kWave < G) {
-                    if (detect) m2 = second_distinct(m.v, m2, b4[u].v, s4[u]);
+                    const bool f = (b4[u].pad & 0x80000000u) != 0;
+                    if (b4[u].v > m.v) mf = f; else if (b4[u].v == m.v) mf = mf || f;
+                    m2 = second_distinct(m.v, m2, b4[u].v, -INFINITY);
                     m = sg_better(m, b4[u]);
                 }
             }
             const float own = m.v;
             m = sg_wave_best(m);
-            if (detect) m2 = sg_wave_second(own, m2, m.v);
+            m.pad &= 0x7fffffffu;
+            bool flagged = false;
+            if (detect) { m2 = sg_wave_second(own, m2, m.v); flagged = __any(mf && own == m.v) != 0; }
             const float par = (detect && !obl) ? npar[k] : 0.0f;       // (every block derives the same parent score from the node's totals)
             int tiny_k = 0;
             if (lane == 0 && detect && m.v != -INFINITY) {
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(kSgThreads) void k_small_grow(const SmallGrowArgs a
                 // too).  Every block evaluates it on the same records, so all of them leave together.
                 const float mag = obl ? fabsf(m.v) : fmaxf(fabsf(m.v + par), fabsf(par));
                 const float win_w = a.near_rel * mag;
-                bool near = m2 != -INFINITY && m.v - m2 <= win_w;
+                bool near = flagged || (m2 != -INFINITY && m.v - m2 <= win_w);
                 int tiny = 0;
                 if (!obl && level > 0 && fabsf(m.v) <= win_w) {
                     const int nr = static_cast<int>(m.pad), nn = tn[k];
@@ -1033,9 +1038,9 @@ int align16(int x) { return (x + 15) & ~15; }
 
 // ---------------------------------------------------------------------------------------------------- host side
 
-size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {   // the bests, then the (second, parent) pairs of the near-tie detection
+size_t small_grow_bests_bytes(int MD, int G, bool oblivious) {
     const int NC = 1 << std::max(0, MD - 1);
-    return (sizeof(SgBest) + sizeof(float)) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
+    return sizeof(SgBest) * static_cast<size_t>(MD) * (oblivious ? 1 : NC) * G;
 }
 static size_t small_grow_rep_bytes(int MD) { return 256 * ((sizeof(float) * ((static_cast<size_t>(1) << std::max(0, MD - 1)) * kNearCands + kNearCands + 1) + 255) / 256); }
 size_t small_grow_near_bytes(int G, int N, int MD) {   // (+ 192 KiB: the checkpoint -- at most the kernel's whole LDS)   // SgNearScratch: counts | candidate lists | replayed scores | ordered row lists
@@ -1112,7 +1117,6 @@ bool small_grow(const SmallGrowIO &io, hipStream_t s) {
     a.G = io.G; a.NC = 1 << std::max(0, io.MD - 1); a.NIDS = 2 << io.MD;
     a.magicW = static_cast<uint32_t>((1ull << 32) / static_cast<unsigned>(io.D + 1)) + 1u;
     a.bests = static_cast<SgBest *>(io.bests);
-    a.seconds = reinterpret_cast<float *>(static_cast<SgBest *>(io.bests) + static_cast<size_t>(io.MD) * (io.oblivious ? 1 : a.NC) * io.G);
     a.near_rel = io.near_rel;
     a.meanden = io.meanden;
     {
