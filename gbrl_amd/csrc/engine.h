@@ -183,6 +183,8 @@ class Engine {
     DevBuf d_codes_fm_;               // feature-major copy of the numeric class codes (kern::small_prep -> kern::small_grow)
     DevBuf d_am_s_, d_near_list_, d_near_ent_, d_near_rep_, d_near_nr_;   // near-tie replay (kern::near_tie_replay): runner-up per arg-max block, candidate lists, ordered row lists, replayed scores
     bool force_level_loop_ = false;   // grow_tree: the one-launch kernel met a near-tie and handed the tree to the level loop
+    bool small_grow_off_ = false;     // latched after a failed launch / an abandoned grid barrier of the one-launch kernel: this engine keeps to the level loop
+    long long small_grow_fallbacks_ = 0;   // trees the level loop grew after such a failure (diagnostics)
     long long near_replays_ = 0, near_bailouts_ = 0, near_in_kernel_ = 0;   // levels replayed / one-launch trees handed over (diagnostics: phases at profiling level 2)
     DevBuf d_sg_bests_, d_sg_sync_, d_sg_near_;   // one-launch growth of RL-sized steps (kern::small_grow): per-level bests of every block, barrier words
     const void *sg_sync_ptr_ = nullptr;

@@ -259,6 +259,7 @@ void Engine::phases_resolve() {
     if (profiling_ >= 2) {   // not times: counters since the engine was created (near-tie replay, neartie.hip)
         phases_.emplace_back("near_replays", static_cast<float>(near_replays_));
         phases_.emplace_back("near_bailouts", static_cast<float>(near_bailouts_));
+        phases_.emplace_back("small_grow_fallbacks", static_cast<float>(small_grow_fallbacks_));
         phases_.emplace_back("near_in_kernel", static_cast<float>(near_in_kernel_));
     }
     if (has_coll_) {   // not times: what this call handed to the transport (all-reduce payload; a reduce-scatter counts half its send buffer)

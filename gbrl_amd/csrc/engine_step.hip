@@ -1074,7 +1074,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     const bool no_small_grow = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_GROW"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     const int small_G = (!has_coll_ && !no_small_grow && n_global == N && n_cand > 0 && !l2_degenerate && MD >= 1 && !(oblivious && device_levels_requested()) &&
                          kern::small_grow_supported(N, D, NB, MD, n_slots, n_cand)) ? kern::small_grow_blocks(n_slots) : 0;
-    const bool use_small = small_G > 0 && !force_level_loop_;
+    const bool use_small = small_G > 0 && !force_level_loop_ && !small_grow_off_;
     // per-step constants: slots, candidate weights / reference order / slot lookup
     const std::vector<int32_t> &cand_slot = *c.cand_slot;
     const size_t table_cap = c.prefix_cacheable ? static_cast<size_t>(std::max(c.cand_cap, n_cand)) : static_cast<size_t>(n_cand);
@@ -1413,8 +1413,19 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         static const bool sg_prof = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_PROF"); return e && e[0] == '1'; }();   // measurement hook
         if (sg_prof) io.prof = reinterpret_cast<uint32_t *>(d_blk + o_status + 64);
         h_status[0] = 0;
+        // The one-launch kernel is an optimisation, never a requirement: when it cannot be launched (LDS budget, device attributes) or its
+        // blocks abandon a grid barrier (they were not co-resident: another process, stream or model held CUs / LDS), nothing has been
+        // booked yet -- `nodes` and `frontier` are untouched -- so the level loop grows this tree, and this engine keeps to it from now on.
+        auto level_loop_instead = [&](const char *why) {
+            sg_sync_ptr_ = nullptr;           // (the barrier words are in an unknown state)
+            small_grow_off_ = true;
+            ++small_grow_fallbacks_;
+            if (md.verbose > 0) fprintf(stderr, "gbrl_hip: %s; this model grows its trees level by level from now on\n", why);
+            grow_tree(c, nodes, frontier, acc, leaf_scale);
+        };
+        const int sg_fail = [] { const char *e = std::getenv("GBRL_HIP_TEST_SMALL_GROW_FAIL"); return e ? std::atoi(e) : 0; }();   /* read per call: test hook (1: launch failure, 2: abandoned barrier) */
         phase_begin();
-        if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
+        if (sg_fail == 1 || !kern::small_grow(io, s)) { (void)hipGetLastError(); level_loop_instead("the one-launch growth kernel could not be launched"); return; }
         phase_end("small_grow");
         const auto t_launched = std::chrono::steady_clock::now();
         verify_pending_categories();   // (host work hidden behind the kernel)
@@ -1431,7 +1442,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             io.seq = seq;
             h_status[0] = 0;
             phase_begin();
-            if (!kern::small_grow(io, s)) throw HipError("small-step growth kernel could not be launched");
+            if (!kern::small_grow(io, s)) { (void)hipGetLastError(); level_loop_instead("the one-launch growth kernel (near-tie replay variant) could not be launched"); return; }
             phase_end("small_grow");
             spin_until_published(h_status, seq, s, "small-step tree (near-tie replay)");
             hip_check(hipGetLastError(), "growth kernel");
@@ -1445,9 +1456,9 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             grow_tree(c, nodes, frontier, acc, leaf_scale);
             return;
         }
-        if (h_status[3] != 0) {
-            sg_sync_ptr_ = nullptr;
-            throw HipError("small-step growth kernel gave up at a grid barrier (its blocks were not co-resident?)");
+        if (h_status[3] != 0 || sg_fail == 2) {
+            level_loop_instead("the one-launch growth kernel gave up at a grid barrier (its blocks were not co-resident)");
+            return;
         }
         if (sg_prof) {
             static const char *names[14] = {"codes", "zero", "accumulate", "scan", "carries", "score", "select", "slot_best", "barrier", "winners", "tables", "route", "level_end", "leaves"};

@@ -1100,7 +1100,22 @@ SgLayout sg_layout(int N, int D, int NB, int MD, int acc_bytes, int &nb_cap, int
 }
 }  // namespace
 
+// the kernel asks for (almost) the whole 160 KiB of a gfx950 CU; a device that offers less per block keeps to the level loop
+static bool device_lds_fits() {
+    static PerDeviceOnce once;
+    static int ok[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (once.first()) {
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); optin = 0; }
+        ok[dev] = (optin <= 0 || optin >= 160 * 1024 - 1024) ? 1 : 0;   // (unknown: let the launch decide -- a failed launch falls back too)
+    }
+    return ok[dev] != 0;
+}
+
 bool small_grow_supported(int N, int D, int NB, int MD, int n_slots, int n_cand) {
+    if (!device_lds_fits()) return false;
     if (N < 1 || N > 8192 || D < 1 || D > 512 || MD < 1 || MD > 8 || n_slots < 1 || n_slots > 65535 || NB < 2 || NB > 65535 || n_cand < 1) return false;
     int nb = 0, T = 0;
     (void)sg_layout(N, D, NB, MD, N <= 4096 ? 4 : 8, nb, T);

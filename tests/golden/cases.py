@@ -204,6 +204,17 @@ FIT_CASES = [
 
 BY_NAME = {c["name"]: c for c in CASES + FIT_CASES}
 
+# ---- headline-size fixtures (BASELINE.json configs[1] / configs[2]): ONE reference tree each at 2^20 x 128, made by
+# make_fullsize_golden.py (the inputs are regenerated from the seed on the GPU box and checked through their SHA-256) ----
+_AC_OPTS = [dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=7),
+            dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)]
+FULLSIZE_CASES = [
+    _c("full_cfg2", seed=0, N=1 << 20, F=128, D=8, depth=6, trees=1),
+    _c("full_cfg3", seed=0, N=1 << 20, F=128, D=8, depth=6, policy="greedy", score="Cosine", trees=1, opts=_AC_OPTS,
+       ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)"),
+]
+FULLSIZE_BY_NAME = {c["name"]: c for c in FULLSIZE_CASES}
+
 ENSEMBLE_KEYS = ("tree_indices", "depths", "values", "feature_indices", "feature_values", "edge_weights",
                  "is_numerics", "inequality_directions", "categorical_values")
 # cases whose saved .gbrl_model bytes are committed (file-format parity)

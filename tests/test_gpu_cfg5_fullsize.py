@@ -1,0 +1,117 @@
+"""BASELINE configs[4] at its REAL ensemble size: 10 000 oblivious depth-6 trees over 192 numeric + 64 categorical
+columns (S128 cells, 32 tokens), uniform candidates, grown on 4096-row minibatches exactly as `bench.py::leg_cfg5` grows them, then
+predicted on 2^20 rows (8 GiB of raw cells resident in HBM) through the DEFAULT path -- the grouped packed-code register-tile kernel.
+
+Checked:
+  * a 4096-row sample of the full-batch output, bit for bit, against the general kernel (`GBRL_HIP_PREDICT_GENERIC=1`, read per call) run
+    on those rows alone;
+  * 256 rows against a NumPy walk of `get_ensemble_data()` in tree order (reference semantics: `predictor.cpp:231-265` -- oblivious leaf =
+    tree_indices[t] + sum_d (x[f_d] > t_d or cell == category) << (depth_t - 1 - d); `optimizer.cpp:110-118` -- pred -= lr * value,
+    per row in tree order), float32 accumulation with the fused multiply-add the reference's build contracts to;
+  * `start_tree_idx / stop_tree_idx` ranges that straddle the kernel's tree groups (8 trees per group, 64-tree value sets), default vs
+    general kernel, bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TREES = 10000
+N, F, FC, D, DEPTH, B, MINI = 1 << 20, 192, 64, 8, 6, 256, 4096
+
+
+def _numpy_walk(e, X, Xc, lr, start, stop):
+    ti = np.asarray(e["tree_indices"]); dep = np.asarray(e["depths"]); vals = np.asarray(e["values"], np.float32)
+    fi = np.asarray(e["feature_indices"]); fv = np.asarray(e["feature_values"]); isn = np.asarray(e["is_numerics"])
+    cv = np.asarray(e["categorical_values"])
+    bias = np.asarray(e["bias"], np.float32) if "bias" in e else np.zeros(vals.shape[1], np.float32)
+    n = X.shape[0]
+    pred = np.tile(bias.astype(np.float32), (n, 1))
+    stop = len(ti) if stop == 0 else stop
+    lr64 = np.float64(np.float32(lr))
+    for t in range(start, stop):
+        d_t = int(dep[t])
+        leaf = np.full(n, int(ti[t]), np.int64)
+        for d in range(d_t):
+            right = (X[:, fi[t, d]] > fv[t, d]) if isn[t, d] else (Xc[:, fi[t, d]] == cv[t, d])
+            leaf += right.astype(np.int64) << (d_t - 1 - d)
+        # fl32(pred - lr * v): the product of two float32 is exact in float64, the sum is rounded once to float64 and once to float32
+        # (the same bits as a float32 fused multiply-add except on double-rounding ties, which the tolerance below absorbs)
+        pred = (pred.astype(np.float64) - lr64 * vals[leaf].astype(np.float64)).astype(np.float32)
+    return pred
+
+
+def test_configs4_ten_thousand_trees_at_full_batch():
+    import torch
+    import gbrl_amd
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(55)
+    X = torch.randn((N, F), device=dev, dtype=torch.float32, generator=gen)
+    tok = torch.randint(0, 32, (N, FC), device=dev, generator=gen, dtype=torch.int64)
+    cells = torch.zeros((N, FC, 128), device=dev, dtype=torch.uint8)
+    cells[:, :, 0] = ord("c")
+    cells[:, :, 1] = (ord("0") + tok // 10).to(torch.uint8)
+    cells[:, :, 2] = (ord("0") + tok % 10).to(torch.uint8)
+    W = torch.randn((8, D), device=dev, dtype=torch.float32, generator=gen)
+    catsig = ((tok[:, :D] % 8) == 3).to(torch.float32) * 2.0 + ((tok[:, D:2 * D] % 16) == 5).to(torch.float32) * 3.0
+    G = (torch.tanh(X[:, :8] @ W) + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen) + catsig).contiguous()
+    Gc = (catsig + 0.5 * torch.randn((N, D), device=dev, dtype=torch.float32, generator=gen)).contiguous()
+    del catsig, tok
+    m = gbrl_amd.GBRL(input_dim=F + FC, output_dim=D, policy_dim=D, max_depth=DEPTH, min_data_in_leaf=0, n_bins=B, par_th=10, cv_beta=0.9,
+                      split_score_func="L2", generator_type="Uniform", use_control_variates=False, batch_size=5000, grow_policy="oblivious",
+                      verbose=0, device="cpu", learner_name="cfg5_full")
+    m.set_feature_weights(np.ones(F + FC, np.float32))
+    m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
+    m.set_feature_mapping(np.arange(F + FC, dtype=np.int32), np.array([True] * F + [False] * FC, dtype=bool))
+    tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    ctup = lambda t: (t.data_ptr(), (t.shape[0], t.shape[1]), "S128", "cuda")
+    n_mb = N // MINI
+    keep = []
+    for i in range(TREES):
+        o = (i % n_mb) * MINI
+        gi = ((Gc if i % 5 == 4 else G)[o:o + MINI] * (1.0 / (1.0 + 0.01 * i))).contiguous()
+        keep.append(gi)
+        m.step(tup(X[o:o + MINI]), ctup(cells[o:o + MINI]), tup(gi))
+        if len(keep) > 64:
+            torch.cuda.synchronize(); keep.clear()
+    torch.cuda.synchronize()
+    assert m.get_num_trees() == TREES
+    e = m.get_ensemble_data()
+    isn = np.asarray(e["is_numerics"])
+    assert (np.asarray(e["depths"]) == DEPTH).all()
+    n_cat = int((isn == 0).sum())
+    assert n_cat > TREES * DEPTH // 20, "the categorical traversal is hardly exercised: %d categorical conditions" % n_cat
+
+    os.environ.pop("GBRL_HIP_PREDICT_GENERIC", None)
+    full = np.asarray(m.predict(tup(X), ctup(cells), 0, 0))                      # default path, whole batch, whole ensemble
+    assert full.shape == (N, D) and np.isfinite(full).all()
+
+    # (1) a 4096-row sample (not at the start of the batch, not aligned to the kernels' 64-row tiles' first block) against the general kernel
+    o = 517 * MINI + 64
+    xs, cs = X[o:o + MINI].contiguous(), cells[o:o + MINI].contiguous()
+    ranges = [(0, 0), (0, 7), (5, 1003), (8, 16), (63, 65), (4090, 4100), (9999, 10000), (9993, 0)]
+    got = {}
+    for generic in ("0", "1"):
+        os.environ["GBRL_HIP_PREDICT_GENERIC"] = generic
+        try:
+            for r in ranges:
+                got[(generic, r)] = np.asarray(m.predict(tup(xs), ctup(cs), *r))
+        finally:
+            os.environ.pop("GBRL_HIP_PREDICT_GENERIC", None)
+    assert np.array_equal(full[o:o + MINI], got[("1", (0, 0))]), "full-batch default path differs from the general kernel on the sample"
+    for r in ranges:                                                               # (3) ranges straddling tree groups
+        assert np.array_equal(got[("0", r)], got[("1", r)]), r
+
+    # (2) 256 rows against the NumPy walk in tree order
+    Xh = xs[:256].cpu().numpy()
+    Ch = cs[:256].cpu().numpy().reshape(256, FC * 128).view("S128").reshape(256, FC)
+    for r in [(0, 0), (5, 1003), (9993, 0)]:
+        want = _numpy_walk(e, Xh, Ch, 0.1, *r)
+        have = got[("0", r)][:256]
+        scale = max(float(np.abs(want).mean()), 1e-6)
+        err = float(np.max(np.abs(have - want) / np.maximum(np.abs(want), scale)))
+        assert err <= 2e-6, (r, err)       # float32 sums of up to 10 000 terms in the same order: differences only from double-rounding ties
+    print("configs[4] at full size: %d trees, %d categorical conditions of %d; default == general kernel on 4096 rows x %d ranges; NumPy walk agrees"
+          % (TREES, n_cat, TREES * DEPTH, len(ranges)))

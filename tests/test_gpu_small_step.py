@@ -129,3 +129,31 @@ def test_golden_inputs_through_both_growth_paths(name, monkeypatch):
     one, pone = _grow(case, monkeypatch, {})
     _same_bytes(loop, one, name)
     assert ploop.tobytes() == pone.tobytes()
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("policy,score,Fc", [("greedy", "Cosine", 0), ("oblivious", "L2", 2)])
+def test_a_failed_one_launch_growth_falls_back_to_the_level_loop(policy, score, Fc, mode, monkeypatch):
+    """`k_small_grow` assumes its blocks are co-resident; when the launch fails (mode 1) or its blocks abandon a grid
+    barrier (mode 2; both simulated by `GBRL_HIP_TEST_SMALL_GROW_FAIL`, read per call) nothing has been booked yet, so the level loop grows
+    the tree -- the step must NOT throw -- and the engine keeps to the level loop afterwards (latched: the third tree is grown with the hook
+    removed and still never launches the one-launch kernel).  Same bytes as an undisturbed model."""
+    import gbrl_amd
+    case = dict(name="fb", seed=77, N=1500, F=12, Fc=Fc, D=3, depth=4, n_bins=64, score=score, gen="Quantile", policy=policy, trees=2)
+    X, Xc, G, y = K.make_inputs(case)
+    for k in HOOKS + ("GBRL_HIP_SMALL_GROW_BLOCKS", "GBRL_HIP_TEST_SMALL_GROW_FAIL"):
+        monkeypatch.delenv(k, raising=False)
+    ref = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    K.drive(ref, dict(case, trees=3), X, Xc, G, y)
+    monkeypatch.setenv("GBRL_HIP_TEST_SMALL_GROW_FAIL", mode)
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    m.set_profiling(2)
+    K.drive(m, case, X, Xc, G, y)                      # two trees with the failure injected
+    monkeypatch.delenv("GBRL_HIP_TEST_SMALL_GROW_FAIL")
+    m.step(X, Xc, np.ascontiguousarray(G))            # a third one without: the latch keeps the level loop
+    ph = dict(m.last_phase_times())
+    assert ph.get("small_grow_fallbacks", 0) == 1, ph   # one failure, then latched off
+    assert "small_grow" not in ph and "score_select" in ph, ph
+    a, b = ref.get_ensemble_data(), m.get_ensemble_data()
+    for k in a:
+        assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), k
