@@ -89,9 +89,9 @@ def test_configs4_ten_thousand_trees_at_full_batch():
     assert full.shape == (N, D) and np.isfinite(full).all()
 
     # (1) a 4096-row sample (not at the start of the batch, not aligned to the kernels' 64-row tiles' first block) against the general kernel
-    o = 517 * MINI + 64
+    o = 117 * MINI + 64
     xs, cs = X[o:o + MINI].contiguous(), cells[o:o + MINI].contiguous()
-    ranges = [(0, 0), (0, 7), (5, 1003), (8, 16), (63, 65), (4090, 4100), (9999, 10000), (9993, 0)]
+    ranges = [(0, 0), (0, 7), (5, 1003), (5, 3003), (8, 16), (63, 65), (4090, 4100), (9999, 10000), (9993, 0)]
     got = {}
     for generic in ("0", "1"):
         os.environ["GBRL_HIP_PREDICT_GENERIC"] = generic
@@ -101,17 +101,32 @@ def test_configs4_ten_thousand_trees_at_full_batch():
         finally:
             os.environ.pop("GBRL_HIP_PREDICT_GENERIC", None)
     assert np.array_equal(full[o:o + MINI], got[("1", (0, 0))]), "full-batch default path differs from the general kernel on the sample"
-    for r in ranges:                                                               # (3) ranges straddling tree groups
-        assert np.array_equal(got[("0", r)], got[("1", r)]), r
-
-    # (2) 256 rows against the NumPy walk in tree order
+    # (2) + (3): 256 rows against the NumPy walk in tree order, whole ensemble and ranges that straddle the kernels' tree groups; both kernels
     Xh = xs[:256].cpu().numpy()
     Ch = cs[:256].cpu().numpy().reshape(256, FC * 128).view("S128").reshape(256, FC)
-    for r in [(0, 0), (5, 1003), (9993, 0)]:
+    report = []
+    for r in ranges:
         want = _numpy_walk(e, Xh, Ch, 0.1, *r)
-        have = got[("0", r)][:256]
         scale = max(float(np.abs(want).mean()), 1e-6)
-        err = float(np.max(np.abs(have - want) / np.maximum(np.abs(want), scale)))
-        assert err <= 2e-6, (r, err)       # float32 sums of up to 10 000 terms in the same order: differences only from double-rounding ties
-    print("configs[4] at full size: %d trees, %d categorical conditions of %d; default == general kernel on 4096 rows x %d ranges; NumPy walk agrees"
+        errs = {}
+        for generic in ("0", "1"):
+            have = got[(generic, r)][:256]
+            errs[generic] = float(np.max(np.abs(have - want) / np.maximum(np.abs(want), scale)))
+        same = bool(np.array_equal(got[("0", r)], got[("1", r)]))
+        report.append((r, same, errs["0"], errs["1"], bool(np.array_equal(got[("0", r)][:256], want))))
+    print("range, default == general bitwise, rel err default vs walk, rel err general vs walk, default == walk bitwise")
+    for rec in report:
+        print("  ", rec)
+    for r, same, e0, e1, exact in report:
+        trees = (r[1] if r[1] else TREES) - r[0]
+        if 128 <= trees <= 2048:
+            # the one documented window in which a 4096-row batch does NOT run the per-row chain: 128 .. 2048 trees on at most 16 384 rows are
+            # spread over blocks and the per-range partial sums added in tree order (kern::predict; the reference's CPU path does the same
+            # for small batches, predictor.cpp:144-184): another association of the same float32 terms, inside north_star's 1e-5
+            assert e0 <= 1e-5 and e1 <= 1e-5, (r, e0, e1)
+        else:
+            # everywhere else -- the whole ensemble, unaligned starts, single trees, ranges across the 8-tree groups and 64-tree value sets --
+            # both kernels reproduce the walk (pred = fma(-lr, value, pred) per row in tree order, optimizer.cpp:110-118) BIT FOR BIT
+            assert same and exact and e0 == 0.0 and e1 == 0.0, (r, same, e0, e1, exact)
+    print("configs[4] at full size: %d trees, %d categorical conditions of %d; full batch == general kernel on a 4096-row sample; NumPy walk agrees on %d ranges"
           % (TREES, n_cat, TREES * DEPTH, len(ranges)))
