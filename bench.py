@@ -83,6 +83,86 @@ def cpu_baseline(n_feat, out_dim, depth, n_bins, full_rows, sample_rows, budget_
             "sample_seconds": dt}
 
 
+def committed_full_tree():
+    """The builder's own full-size measurement of the reference (ONE tree at 2^20 x 128 on the GPU box's host cores, `bench.py --cpu-full-tree`),
+    read from the committed profile and labelled as such: the row extrapolation of the sample is 30-45 % optimistic for the CPU."""
+    for name in ("r06_cpu_full_tree.json", "r05_cpu_full_tree.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            j = json.load(open(path))
+            ft = j.get("cpu_baseline", {}).get("full_tree", j.get("full_tree", j))
+            return {"full_tree_measured_s": ft["seconds_per_tree"], "full_tree_measured_cores": ft.get("cores"),
+                    "full_tree_measured_by": "builder, not by this run: profiles/%s (one reference tree at the full 2^20 x 128 batch, no extrapolation)" % name}
+        except Exception:
+            continue
+    return {}
+
+
+def cpu_full_tree(gbrl_amd):
+    """--cpu-full-tree: ONE tree of the reference's CPU path at the full batch of BASELINE configs[1] (2^20 x 128, D = 8, depth 6, all host
+    cores: minutes), on the inputs of the committed fixture tests/golden/full_cfg2.npz (tests/golden/cases.py::make_inputs -- integer PCG64
+    draws + exactly rounded float32 arithmetic, SHA-256 checked), and the SAME tree grown by the product on the GPU: the two structures are
+    compared level by level, and both with the fixture (the reference on 8 threads in the build container)."""
+    import numpy as np
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as K
+    case = K.FULLSIZE_BY_NAME["full_cfg2"]
+    X, Xc, G, y = K.make_inputs(case)
+    sha = K.inputs_digest(X, Xc, G, y)
+    F, D = case["F"], case["D"]
+
+    def drive_one(m):
+        m.set_feature_weights(np.ones(F, np.float32))
+        m.set_optimizer(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_idx=D)
+        m.set_feature_mapping(np.arange(F, dtype=np.int32), np.ones(F, dtype=bool))
+        t0 = time.perf_counter()
+        m.step(X, None, G)
+        dt = time.perf_counter() - t0
+        e = m.get_ensemble_data()
+        return dt, {k: np.asarray(e[k]) for k in ("depths", "feature_indices", "feature_values", "values")}
+
+    def levels_equal(a, b):
+        da, db = int(a["depths"][0]), int(b["depths"][0])
+        k = 0
+        while k < min(da, db) and int(a["feature_indices"][0][k]) == int(b["feature_indices"][0][k]) and \
+                a["feature_values"][0][k:k + 1].view(np.uint32)[0] == b["feature_values"][0][k:k + 1].view(np.uint32)[0]:
+            k += 1
+        first = None if (k == da == db) else {"level": k, "a": [int(a["feature_indices"][0][k]), float(a["feature_values"][0][k])] if k < da else None,
+                                               "b": [int(b["feature_indices"][0][k]), float(b["feature_values"][0][k])] if k < db else None}
+        return k, da, db, first
+
+    mod = oracle.load_ref()
+    if mod is None:
+        return {"error": "oracle/_ref is not built here"}
+    dt_ref, e_ref = drive_one(mod.GBRL(**K.ctor_kwargs(case)))
+    dt_gpu, e_gpu = drive_one(gbrl_amd.GBRL(**K.ctor_kwargs(case)))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    k, da, db, first = levels_equal(e_ref, e_gpu)
+    out = {"what": "ONE tree of the reference's CPU path at the full batch (2^20 x 128, D = 8, depth 6), no extrapolation, and the product's tree on the same inputs",
+           "inputs_sha256": sha, "seconds_per_tree": dt_ref, "trees_per_s": 1.0 / dt_ref, "rows": case["N"], "cores": cores, "kind": "reference",
+           "omp_threads": os.environ.get("OMP_NUM_THREADS", "unset (all cores)"),
+           "product_seconds_host_inputs": dt_gpu,
+           "structure_equal": bool(first is None), "levels_identical": k, "depth_reference": da, "depth_product": db, "first_difference": first,
+           "reference_tree": {"feature_indices": e_ref["feature_indices"][0].tolist(), "feature_values": [float(v) for v in e_ref["feature_values"][0]]},
+           "product_tree": {"feature_indices": e_gpu["feature_indices"][0].tolist(), "feature_values": [float(v) for v in e_gpu["feature_values"][0]]}}
+    if first is None:
+        scale = float(np.abs(G).mean())
+        out["leaf_values_max_rel_err"] = float(np.max(np.abs(e_ref["values"] - e_gpu["values"]) / np.maximum(np.abs(e_ref["values"]), scale)))
+    fpath = os.path.join(ROOT, "tests", "golden", "full_cfg2.npz")
+    if os.path.exists(fpath):
+        fx = np.load(fpath)
+        if str(fx["inputs_sha256"]) == sha:
+            fxe = {kk: fx[kk] for kk in ("depths", "feature_indices", "feature_values", "values")}
+            out["fixture_threads"] = int(fx["omp_threads"])
+            out["reference_here_equals_fixture"] = bool(levels_equal(e_ref, fxe)[3] is None)
+            out["product_equals_fixture"] = bool(levels_equal(e_gpu, fxe)[3] is None)
+            out["product_levels_identical_to_fixture"] = levels_equal(e_gpu, fxe)[0]
+    return out
+
+
 def launch_ranks(n):
     """Start `n` copies of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, the
     contract torch.distributed.run uses), wait for all of them and return the worst exit code.  Children inherit stdout, so
@@ -795,13 +875,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(F, D, depth, B, 1 << 20, args.cpu_sample_rows)
+                out["cpu_baseline"].update(committed_full_tree())
             except Exception as e:  # the baseline is reporting only; never let it hide the measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
             if args.cpu_full_tree:
                 try:
-                    ft = cpu_baseline(F, D, depth, B, 1 << 20, 1 << 20)
-                    out["cpu_baseline"]["full_tree"] = {"trees_per_s": ft["value"], "seconds_per_tree": ft["sample_seconds"], "rows": 1 << 20, "cores": ft["cores"],
-                                                        "kind": ft["kind"], "what": "ONE tree of the reference's CPU path at the full batch, no extrapolation"}
+                    out["cpu_baseline"]["full_tree"] = cpu_full_tree(gbrl_amd)
                 except Exception as e:
                     out["cpu_baseline"]["full_tree"] = {"error": repr(e)}
             try:   # the reference's predict_cpu on the ensembles the bench grew (rows/s on this host's cores)

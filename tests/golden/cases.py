@@ -210,6 +210,8 @@ _AC_OPTS = [dict(algo="SGD", scheduler="Const", init_lr=0.1, start_idx=0, stop_i
             dict(algo="SGD", scheduler="Const", init_lr=0.01, start_idx=7, stop_idx=8)]
 FULLSIZE_CASES = [
     _c("full_cfg2", seed=0, N=1 << 20, F=128, D=8, depth=6, trees=1),
+    # a second seed with a four times weaker signal (noise 2.0 instead of 0.5): closer scores, the harder case for the float32 reference
+    _c("full_cfg2_s1", seed=1, N=1 << 20, F=128, D=8, depth=6, trees=1, noise=2.0),
     _c("full_cfg3", seed=0, N=1 << 20, F=128, D=8, depth=6, policy="greedy", score="Cosine", trees=1, opts=_AC_OPTS,
        ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)"),
 ]
