@@ -321,7 +321,8 @@ def leg_collective(torch, np, gbrl_amd, workload, X, G, F, D, depth, B, steps, p
 
 def leg_predict_deep(torch, np, gbrl_amd, dev, X, D, B, depth=8, trees=1000, mini=4096):
     """predict() over 1000 oblivious trees of max_depth 8 on the bench's 2^20 x 128 rows (the reference has no depth limit,
-    predictor.cpp:231-265; the register-tile kernels stop at depth 6, so this leg runs the LDS-tile kernel).  The trees are grown on
+    predictor.cpp:231-265; since round 5 the register-tile kernels take depth 7-8 too -- `VariantDeep`, one record buffer and two value sets per group
+    of 8 trees -- and this leg exercises them).  The trees are grown on
     4096-row minibatches of the same matrix (the one-launch growth: a second per 1000 trees)."""
     N, F = X.shape
     m = make_model(gbrl_amd, np, "cfg2", F, 0, D, depth, B, "bench_deep")
@@ -828,11 +829,13 @@ def main():
         achieved = alg / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
         traffic = None
         traffic_src = None
+        traffic_levels = None
         tpath = os.path.join(ROOT, "profiles", "hist_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from the committed rocprofv3 PMC passes (scripts/pmc_summary.py)
             try:
                 tj = json.load(open(tpath))
                 traffic = tj["bytes_per_launch"]
+                traffic_levels = tj.get("levels")
                 traffic_src = "profiles/hist_traffic.json = the builder's rocprofv3 PMC passes (%s; %s, taken %s)" % (tj.get("method", "2*FETCH_SIZE + WRITE_SIZE"), tj.get("commit", "?"), tj.get("taken", "?"))
             except Exception:
                 traffic = None
@@ -862,6 +865,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_hist_build (split-score histogram build), %d launches per tree" % depth,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_levels": traffic_levels,   # per tree level: HBM-side bytes, FETCH_SIZE factor, duration under --pmc (profiles/r06_hist_levels_traffic.txt)
                          "traffic_measured_by": ("builder, not by this run: committed PMC summary profiles/hist_traffic.json" if traffic is not None else None),
                          "algorithmic_bytes_per_launch": alg / depth,
                          "avg_launch_us": build_ms * 1e3 / depth, "launches_per_tree": depth,

@@ -14,6 +14,7 @@
 
 #include "../../include/gbrl_hip.h"
 #include "engine.h"
+#include "hooks.h"
 #include "explain.h"
 #include "rccl_dyn.h"
 
@@ -30,6 +31,7 @@ thread_local std::string g_err;
 
 template <typename Fn>
 int guarded(Fn &&fn) {
+    gbrl::hooks::begin_call();   // environment hooks are read at most once per API call (hooks.h)
     try {
         fn();
         return GBRL_HIP_OK;
@@ -348,6 +350,14 @@ int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int 
     return guarded([&] {
         if (!m) throw gbrl::InvalidArgument("null model");
         m->engine.set_rccl(id128, world_size, rank);
+    });
+}
+
+int gbrl_hip_set_rccl_flags(gbrl_hip_model *m, const void *id128, int world_size, int rank, unsigned flags) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        if (flags & ~static_cast<unsigned>(GBRL_HIP_RCCL_KEEP_WORLD1)) throw gbrl::InvalidArgument("unknown RCCL flags");
+        m->engine.set_rccl(id128, world_size, rank, (flags & GBRL_HIP_RCCL_KEEP_WORLD1) != 0);
     });
 }
 

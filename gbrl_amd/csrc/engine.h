@@ -102,7 +102,7 @@ class Engine {
     void set_collective(const gbrl_hip_collective *hooks);
     // Native exchange: an RCCL communicator of this engine's own, collectives enqueued on its stream (no host sync).
     // id128 = gbrl_hip_rccl_unique_id() of rank 0, distributed by the caller.  Collective call (all ranks).
-    void set_rccl(const void *id128, int world_size, int rank);
+    void set_rccl(const void *id128, int world_size, int rank, bool keep_world1 = false);
     int device_ordinal();                 // latches the device like the first step()/predict() would
     void set_stream(hipStream_t s);       // nullptr: back to the engine's own blocking stream
     void set_profiling(int level) { profiling_ = level; }   // 0 off, 1 histogram build only (one launch in seven, every level in turn), 2 every phase
@@ -255,6 +255,7 @@ class Engine {
     void verify_pending_categories();
     std::vector<std::pair<int, const char *>> cat_pending_;   // (item, published cell) pairs whose bytes are still to be compared this step
     bool cat_clash_ = false;
+    long long cat_clash_redos_ = 0;   // steps grown a second time on the host scan after a 64-bit hash clash (diagnostics)
     std::vector<detail::CatItem> cat_items_;            // every distinct (feature, cell) met so far
     std::vector<uint64_t> cat_tab_key_;                 // (raw hash, feature) -> head of the chain through CatItem::next: open-addressed
     std::vector<int32_t> cat_tab_id_;                   //   table (keys | item ids, -1 = empty), at most half full

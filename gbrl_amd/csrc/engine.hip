@@ -2,6 +2,7 @@
 // row-sharded mode (native RCCL or caller hooks) and the per-phase timing events.  The step / fit orchestration is in
 // engine_step.hip, model mirroring and predict in engine_predict.hip (see engine.h).
 #include "engine.h"
+#include "hooks.h"
 
 #include <numeric>
 #include <random>
@@ -119,7 +120,7 @@ void Engine::set_stream(hipStream_t s) {
 void Engine::set_collective(const gbrl_hip_collective *hooks) {
     // world_size 1 normally means "no exchange"; GBRL_HIP_FORCE_COLLECTIVE=1 keeps the hooks installed anyway so that the
     // sharded code path (hook calls, stream hand-over, no sibling subtraction, counting quantiles) can be tested on ONE GPU
-    const char *force = std::getenv("GBRL_HIP_FORCE_COLLECTIVE");
+    const char *force = gbrl::hooks::raw(gbrl::hooks::FORCE_COLLECTIVE);
     if (rccl_comm_ && rccl_api().ok) { (void)rccl_api().CommDestroy(rccl_comm_); rccl_comm_ = nullptr; }
     if (hooks == nullptr || (hooks->world_size <= 1 && !(force && force[0] == '1'))) {
         has_coll_ = false;
@@ -131,7 +132,7 @@ void Engine::set_collective(const gbrl_hip_collective *hooks) {
     has_coll_ = true;
 }
 
-void Engine::set_rccl(const void *id128, int world_size, int rank) {
+void Engine::set_rccl(const void *id128, int world_size, int rank, bool keep_world1) {
     const RcclApi &api = rccl_api();
     if (!api.ok) throw Unsupported("RCCL is not available in this process");
     if (world_size < 1 || rank < 0 || rank >= world_size || id128 == nullptr) throw InvalidArgument("invalid RCCL communicator arguments");
@@ -146,8 +147,9 @@ void Engine::set_rccl(const void *id128, int world_size, int rank) {
     coll_ = gbrl_hip_collective{};
     coll_.world_size = world_size;
     coll_.rank = rank;
-    const char *force = std::getenv("GBRL_HIP_FORCE_COLLECTIVE");
-    has_coll_ = world_size > 1 || (force && force[0] == '1');
+    // world size 1 normally means "no exchange"; the caller's flag (GBRL_HIP_RCCL_KEEP_WORLD1, bench.py's `collective` leg) or the diagnostic
+    // hook keeps the row-sharded code path anyway
+    has_coll_ = world_size > 1 || keep_world1 || hooks::on(hooks::FORCE_COLLECTIVE);
 }
 
 // One exchange point: in-place all-reduce of a device buffer.  With an RCCL communicator the call is enqueued on the engine's
@@ -260,6 +262,7 @@ void Engine::phases_resolve() {
         phases_.emplace_back("near_replays", static_cast<float>(near_replays_));
         phases_.emplace_back("near_bailouts", static_cast<float>(near_bailouts_));
         phases_.emplace_back("small_grow_fallbacks", static_cast<float>(small_grow_fallbacks_));
+        phases_.emplace_back("cat_clash_redos", static_cast<float>(cat_clash_redos_));
         phases_.emplace_back("near_in_kernel", static_cast<float>(near_in_kernel_));
     }
     if (has_coll_) {   // not times: what this call handed to the transport (all-reduce payload; a reduce-scatter counts half its send buffer)

@@ -1,5 +1,6 @@
 // engine_explain.hip -- Linear TreeSHAP of the ensemble on the device (see shap.hip; host evaluation: explain.cpp).
 #include "engine.h"
+#include "hooks.h"
 #include "explain.h"
 
 #include <cstdlib>
@@ -28,7 +29,7 @@ bool Engine::shap_on_device(int tree_idx, const float *obs, const char *cat, int
                             const float *offset, float *out) {
     const gbrl_hip_metadata &md = model.meta;
     const int D = md.output_dim, depth = md.max_depth, n_num = md.n_num_features, n_cat = md.n_cat_features;
-    if (const char *e = std::getenv("GBRL_HIP_SHAP_HOST")) { if (e[0] == '1') return false; }   // test hook: host evaluation
+    if (const char *e = hooks::raw(hooks::SHAP_HOST)) { if (e[0] == '1') return false; }   // test hook: host evaluation
     if (kern::shap_block_threads(depth, D) == 0) return false;
     try { ensure_device(); } catch (const NoDeviceError &) { return false; }   // inspection also works on a machine without a GPU
     if (md.n_trees == 0 || n <= 0) return true;

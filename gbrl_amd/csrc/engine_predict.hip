@@ -1,6 +1,7 @@
 // engine_predict.hip -- the device mirror of the ensemble (append-only structure-of-arrays + the packed records the fast predict
 // kernels read) and GBRL::predict (see engine.h).
 #include "engine.h"
+#include "hooks.h"
 
 #include <functional>
 #include "cat_hash.h"
@@ -453,7 +454,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     // odd number of features, unaligned rows).  The code book follows the model; the rows are packed inside kern::predict.
     pm.pc_cond = nullptr; pm.pc_rows = nullptr;
     {
-        const char *no_pc = std::getenv("GBRL_HIP_PREDICT_NO_PC"), *no_reg = std::getenv("GBRL_HIP_PREDICT_NO_REG"), *mr = std::getenv("GBRL_HIP_PREDICT_REG_MIN_ROWS");
+        const char *no_pc = hooks::raw(hooks::PREDICT_NO_PC), *no_reg = hooks::raw(hooks::PREDICT_NO_REG), *mr = hooks::raw(hooks::PREDICT_REG_MIN_ROWS);
         const int min_rows = mr ? std::atoi(mr) : 32768;
         const bool fp32_takes_it = n_cat == 0 && n_num <= 128 && (n_num & 3) == 0 && (reinterpret_cast<uintptr_t>(dobs) & 15) == 0 && !(no_reg && no_reg[0] == '1');
         if (!(no_pc && no_pc[0] == '1') && !in_fit_ && pm.values_sw != nullptr && model.oblivious() && n >= min_rows && !fp32_takes_it &&
@@ -467,10 +468,10 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
             pm.pc_rows = static_cast<uint32_t *>(d_pc_rows_.ensure(static_cast<size_t>(n) * pc_row_words_ * sizeof(uint32_t)));
         }
     }
-    if (const char *e = std::getenv("GBRL_HIP_PREDICT_OBL1")) {      // test / measurement hook: the first-generation oblivious kernel
+    if (const char *e = hooks::raw(hooks::PREDICT_OBL1)) {      // test / measurement hook: the first-generation oblivious kernel
         if (e[0] == '1') pm.obl2_maxd = 0;
     }
-    if (const char *e = std::getenv("GBRL_HIP_PREDICT_GENERIC")) {   // test hook: the general kernels only
+    if (const char *e = hooks::raw(hooks::PREDICT_GENERIC)) {   // test hook: the general kernels only
         if (e[0] == '1') { pm.grd_ok = 0; pm.obl_ok = 0; }
     }
     pm.coef_ok = D <= 64 ? 1 : 0;
@@ -488,7 +489,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     // (not inside fit(): its gradients follow the reference's per-row tree-order chain at every batch size)
     pm.par_th = md.par_th;
     // (nor for a model whose file cleared parallel_predict: the reference then runs the chain for every batch, predictor.cpp:144)
-    const char *nosplit = std::getenv("GBRL_HIP_PREDICT_NOSPLIT");   // measurement hook: no partial sums over tree ranges
+    const char *nosplit = hooks::raw(hooks::PREDICT_NOSPLIT);   // measurement hook: no partial sums over tree ranges
     if (!in_fit_ && model.parallel_predict && n <= 64 * 256 && stop - start_tree >= 128 && !(nosplit && nosplit[0] == '1')) {
         pm.partial_floats = std::min<size_t>(static_cast<size_t>(64) * n * D, size_t(16) << 20);
         pm.partial = static_cast<float *>(d_pred_partial_.ensure(pm.partial_floats * sizeof(float)));
@@ -501,7 +502,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     {
         const int trees = stop - start_tree;
         bool want = (n <= kChainMaxRows && trees >= kChainMinTrees) || (n <= 1024 && trees >= 128);
-        if (const char *e = std::getenv("GBRL_HIP_PREDICT_CHAIN")) want = e[0] == '1' ? (n <= 64 * 256 && trees >= 1) : false;
+        if (const char *e = hooks::raw(hooks::PREDICT_CHAIN)) want = e[0] == '1' ? (n <= 64 * 256 && trees >= 1) : false;
         if (want) {
             const size_t ints = kern::predict_chain_slot_ints(n, trees);
             if (ints <= (size_t(1) << 27)) {

@@ -10,6 +10,7 @@
 // The reference grows greedy trees depth-first; the split chosen for a node depends only on that node's rows, so growing
 // level by level and emitting the leaves in depth-first (left first) order afterwards gives the identical tree.
 #include "engine.h"
+#include "hooks.h"
 
 #include <numeric>
 #include <random>
@@ -281,7 +282,7 @@ md.iteration += 1;  // fitter.cpp:114
 // GBRL_HIP_DEVICE_LEVELS=1 (opt-in device-planned level loop), latched at the first use: the cached root row list and the choice of
 // the loop must see the same value for the whole process.
 static bool device_levels_requested() {
-    static const bool v = [] { const char *e = std::getenv("GBRL_HIP_DEVICE_LEVELS"); return e && e[0] == '1'; }();
+    const bool v = [] { const char *e = hooks::raw(hooks::DEVICE_LEVELS); return e && e[0] == '1'; }();
     return v;
 }
 // Host side of the copy-free hand-overs: poll a sequence word in coherent pinned memory; every 16384 polls ask the stream for errors
@@ -290,7 +291,7 @@ static bool device_levels_requested() {
 // Before giving up the stream is synchronised: kernels still in flight would otherwise keep storing into the pinned result blocks and
 // pools that the next call reuses; a stream that does drain turns the timeout into an ordinary completion.
 static void spin_until_published(volatile uint32_t *flag, uint32_t seq, hipStream_t s, const char *what) {
-    static const double kSpinSeconds = [] { const char *e = std::getenv("GBRL_HIP_SPIN_SECONDS"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    const double kSpinSeconds = [] { const char *e = hooks::raw(hooks::SPIN_SECONDS); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
     int idle = 0;
     std::chrono::steady_clock::time_point t0;
     bool timed = false;
@@ -541,7 +542,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
         if (h_hdr[0] != 0 && log2_cap < full_log2) { log2_cap = full_log2; continue; }   // a table (or the list) overflowed: once more at full size
         break;
     }
-    static const bool cat_prof = [] { const char *e = std::getenv("GBRL_HIP_CAT_PROF"); return e && e[0] == '1'; }();   // measurement hook
+    const bool cat_prof = [] { const char *e = hooks::raw(hooks::CAT_PROF); return e && e[0] == '1'; }();   // measurement hook
     std::chrono::steady_clock::time_point cp[6];
     if (cat_prof) cp[0] = std::chrono::steady_clock::now();
     int n_distinct = h_hdr[2];
@@ -718,7 +719,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
     // The replay leans on libstdc++ internals.  Production processes check it against the real container on their FIRST categorical
     // steps (eight of them: the early ones have the fewest rehashes) and then trust it; GBRL_HIP_CAT_CHECK=1 (the test suite) checks
     // every step, =0 never.  A disagreement is an error, not a silent reordering of the candidates.
-    static const int check_mode = [] { const char *e = std::getenv("GBRL_HIP_CAT_CHECK"); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2; }();
+    const int check_mode = [] { const char *e = hooks::raw(hooks::CAT_CHECK); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2; }();
     static std::atomic<int> checks_left{8};
     const bool check_replay = check_mode == 1 || (check_mode == 2 && !order.empty() && checks_left.load(std::memory_order_relaxed) > 0 &&
                                                    checks_left.fetch_sub(1, std::memory_order_relaxed) > 0);
@@ -818,6 +819,7 @@ bool Engine::device_categorical_candidates(const char *dcells, const char *hcell
 void Engine::verify_pending_categories() {
     bool clash = false;
     for (const auto &pq : cat_pending_) clash = clash || std::memcmp(cat_items_[pq.first].name, pq.second, kCat) != 0;
+    if (!cat_pending_.empty() && hooks::on(hooks::TEST_CAT_CLASH)) clash = true;   // test hook: pretend a remembered cell's bytes differ
     cat_pending_.clear();
     if (clash) cat_clash_ = true;
 }
@@ -920,7 +922,7 @@ void Engine::numeric_thresholds(const float *dobs, int N, int F, int B, long lon
                 // RL-sized batch: the column fits in LDS -- sort it and read the ranks (one launch)
                 int64_t *d_cum = upload_cum(cum);
                 // (the sort kernel also writes the class codes of its feature: no separate binning launch)
-                const bool no_fuse = [] { const char *e = std::getenv("GBRL_HIP_SORT_NO_CODES"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
+                const bool no_fuse = [] { const char *e = hooks::raw(hooks::SORT_NO_CODES); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
                 uint16_t *cdst = no_fuse ? nullptr : d_codes_out;
                 kern::sort_quantiles(d_kt, N, F, d_cum, B, d_thrkeys, d_thr, s, cdst);
                 if (cdst && codes_written) *codes_written = true;
@@ -1071,7 +1073,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // RL-sized steps on one GPU grow the whole tree in ONE launch (kern::small_grow, small_grow.hip): no level buffers, no partials,
     // no row lists.  GBRL_HIP_NO_SMALL_GROW=1 (tests / measurement): the level loop below for every shape.
     const bool l2_degenerate = !c.cosine && n_global < 2;
-    const bool no_small_grow = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_GROW"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool no_small_grow = [] { const char *e = hooks::raw(hooks::NO_SMALL_GROW); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     const int small_G = (!has_coll_ && !no_small_grow && n_global == N && n_cand > 0 && !l2_degenerate && MD >= 1 && !(oblivious && device_levels_requested()) &&
                          kern::small_grow_supported(N, D, NB, MD, n_slots, n_cand)) ? kern::small_grow_blocks(n_slots) : 0;
     const bool use_small = small_G > 0 && !force_level_loop_ && !small_grow_off_;
@@ -1168,8 +1170,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // Near-tie replay (neartie.hip; one GPU, batches of <= 65 536 rows): the selection also tracks the best DISTINCT runner-up; a node whose
     // runner-up is within `near_rel` of the winner (or whose winning gain is that close to zero) has the candidates in the window re-scored
     // in the reference's float32 sequence.  GBRL_HIP_NO_NEARTIE_REPLAY=1: the exact arg-max decides everywhere (rounds 1-4).
-    const bool no_near = [] { const char *e = std::getenv("GBRL_HIP_NO_NEARTIE_REPLAY"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
-    const float near_rel = [] { const char *e = std::getenv("GBRL_HIP_NEARTIE_REL"); return e ? static_cast<float>(std::atof(e)) : 9.5367431640625e-07f; }();   // 2^-20; measurement hook
+    const bool no_near = [] { const char *e = hooks::raw(hooks::NO_NEARTIE_REPLAY); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const float near_rel = [] { const char *e = hooks::raw(hooks::NEARTIE_REL); return e ? static_cast<float>(std::atof(e)) : 9.5367431640625e-07f; }();   // 2^-20; measurement hook
     const bool near_on = !no_near && !has_coll_ && n_global == N && n_cand > 0 && kern::near_tie_supported(N, D);
     float *d_am_s = (near_on && !use_small) ? static_cast<float *>(d_am_s_.ensure(sizeof(float) * am_cap * 2)) : nullptr;
     int32_t *d_am_n = (d_am_s && N > 8192) ? reinterpret_cast<int32_t *>(d_am_s + am_cap) : nullptr;    // child sizes tell classes apart in larger batches only (score_common.h near_class)
@@ -1200,7 +1202,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         hip_check(hipMemsetAsync(d_pub_done, 0, 256, s), "memset publication counter");
         pub_done_ptr_ = d_pub_done;
     }
-    const bool event_results = [] { const char *e = std::getenv("GBRL_HIP_EVENT_RESULTS"); return e && e[0] == '1'; }();   // measurement hook
+    const bool event_results = [] { const char *e = hooks::raw(hooks::EVENT_RESULTS); return e && e[0] == '1'; }();   // measurement hook
     int32_t *d_best_idx = reinterpret_cast<int32_t *>(d_res);
     float *d_best_score = reinterpret_cast<float *>(d_res + 4 * static_cast<size_t>(max_front));
     int64_t *d_counts4 = reinterpret_cast<int64_t *>(d_res + 8 * static_cast<size_t>(max_front));
@@ -1212,7 +1214,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     bool iota_root = false;
     if (!use_small) {
         // the device-planned loop partitions INTO d_rows[depth parity]: it must never be handed the cached list (same latched flag as below)
-        const char *e2 = std::getenv("GBRL_HIP_NO_IOTA_CACHE");   // measurement hook
+        const char *e2 = hooks::raw(hooks::NO_IOTA_CACHE);   // measurement hook
         if (!(oblivious && device_levels_requested()) && !(e2 && e2[0] == '1')) {
             int32_t *d_iota = static_cast<int32_t *>(d_rows_iota_.ensure(sizeof(int32_t) * N));
             if (d_iota != iota_ptr_ || iota_n_ < N) {
@@ -1410,7 +1412,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         io.scales_out = reinterpret_cast<kern::StepScales *>(c.pub_scales_dev);
         io.near_rel = near_on ? near_rel : 0.0f;
         if (near_on) { io.near_scratch = d_sg_near_.ensure(kern::small_grow_near_bytes(small_G, N, MD)); io.meanden = c.d_meanden; }
-        static const bool sg_prof = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_PROF"); return e && e[0] == '1'; }();   // measurement hook
+        const bool sg_prof = [] { const char *e = hooks::raw(hooks::SMALL_GROW_PROF); return e && e[0] == '1'; }();   // measurement hook
         if (sg_prof) io.prof = reinterpret_cast<uint32_t *>(d_blk + o_status + 64);
         h_status[0] = 0;
         // The one-launch kernel is an optimisation, never a requirement: when it cannot be launched (LDS budget, device attributes) or its
@@ -1423,7 +1425,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (md.verbose > 0) fprintf(stderr, "gbrl_hip: %s; this model grows its trees level by level from now on\n", why);
             grow_tree(c, nodes, frontier, acc, leaf_scale);
         };
-        const int sg_fail = [] { const char *e = std::getenv("GBRL_HIP_TEST_SMALL_GROW_FAIL"); return e ? std::atoi(e) : 0; }();   /* read per call: test hook (1: launch failure, 2: abandoned barrier) */
+        const int sg_fail = [] { const char *e = hooks::raw(hooks::TEST_SMALL_GROW_FAIL); return e ? std::atoi(e) : 0; }();   /* read per call: test hook (1: launch failure, 2: abandoned barrier) */
         phase_begin();
         if (sg_fail == 1 || !kern::small_grow(io, s)) { (void)hipGetLastError(); level_loop_instead("the one-launch growth kernel could not be launched"); return; }
         phase_end("small_grow");
@@ -1660,7 +1662,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // RL-sized levels on one GPU: every accumulated node is ONE chunk (empty nodes included) and k_hist_build stores the node's
         // int64 histogram itself -- no partials, no hist_reduce launch (kern::HistDirect).  A block then walks up to `direct_cap` rows
         // alone: the cap keeps that below ~10 us of LDS atomics ((D + 1) per row and feature).
-        const bool no_direct = [] { const char *e = std::getenv("GBRL_HIP_NO_DIRECT_HIST"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
+        const bool no_direct = [] { const char *e = hooks::raw(hooks::NO_DIRECT_HIST); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
         const int direct_cap = std::min(8192, std::max(1024, 9216 / (D + 1)));
         bool hist_direct = !has_coll_ && !no_direct && kern::hist_direct_supported(FG) && !compute_ids.empty() && compute_ids.size() <= static_cast<size_t>(hist_max_chunks);
         for (int id : compute_ids) hist_direct = hist_direct && nodes[id].n_local <= direct_cap;
@@ -1721,7 +1723,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // root of a numeric-only tree on one GPU whose candidates came from the radix selection: the class counts are known from the
         // selection's ranks, so the histogram build skips the count atomic (8 instead of 9 per (row, feature) at D = 8) and hist_reduce
         // writes the counts (GBRL_HIP_ROOT_COUNTS=0: accumulate them like every other level; =2: do both and compare, the tests)
-        const int root_mode = [] { const char *e = std::getenv("GBRL_HIP_ROOT_COUNTS"); return e ? std::atoi(e) : 1; }();   /* read per call: the tests flip it; 2 = verify */
+        const int root_mode = [] { const char *e = hooks::raw(hooks::ROOT_COUNTS); return e ? std::atoi(e) : 1; }();   /* read per call: the tests flip it; 2 = verify */
         const bool root_countless = depth == 0 && c.root_le != nullptr && root_mode != 0 && !hist_direct && !has_coll_ && n_global == N && NB == B + 1 &&
                                     kern::hist_countless_supported(D, FG, N);
         bool hist_written = false;
@@ -1771,7 +1773,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // (row-sharded: this rank scores its own feature slots only; candidates of the other ranks stay at -inf)
         if (has_coll_ && oblivious) kern::fill_f32(d_scores, static_cast<size_t>(n_act) * n_cand, -INFINITY, s);
         // last level on one GPU: the derived siblings are scored but not written back (nothing subtracts from them any more)
-        static const bool skip_hook = [] { const char *e = std::getenv("GBRL_HIP_KEEP_LAST_DERIVED"); return e && e[0] == '1'; }();   // measurement hook
+        const bool skip_hook = [] { const char *e = hooks::raw(hooks::KEEP_LAST_DERIVED); return e && e[0] == '1'; }();   // measurement hook
         const bool drop_derived = !has_coll_ && !skip_hook && depth > 0 && depth == MD - 1;
         if (own_slots > 0)
             kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
@@ -1838,7 +1840,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             const int64_t *near_h = reinterpret_cast<const int64_t *>(h_res + 8 * static_cast<size_t>(max_front)) + 2 * static_cast<size_t>(max_front);
             bool any = false;
             for (int k = 0; k < (oblivious ? 1 : n_act); ++k) any = any || near_h[k] != 0;
-            static const bool near_debug = [] { const char *e = std::getenv("GBRL_HIP_NEARTIE_DEBUG"); return e && e[0] == '1'; }();   // measurement hook
+            const bool near_debug = [] { const char *e = hooks::raw(hooks::NEARTIE_DEBUG); return e && e[0] == '1'; }();   // measurement hook
             if (any && near_debug) {
                 const float *bs = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
                 for (int k = 0; k < (oblivious ? 1 : n_act); ++k)
@@ -1969,10 +1971,10 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     ev_names_.clear();
     exch_bytes_ = 0;
     exch_calls_ = 0;
-    if (const char *e = std::getenv("GBRL_HIP_FORCE_BISECTION")) force_bisection_ = e[0] == '1';   // test hook
-    if (const char *e = std::getenv("GBRL_HIP_HOST_CATEGORICAL")) force_host_categorical_ = e[0] == '1';   // test hook: host scan of every cell
-    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_RADIX")) force_radix_ = e[0] == '1';   // test hook: radix multi-select also for small batches
-    if (const char *e = std::getenv("GBRL_HIP_QUANTILE_SAMPLE")) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
+    if (const char *e = hooks::raw(hooks::FORCE_BISECTION)) force_bisection_ = e[0] == '1';   // test hook
+    if (const char *e = hooks::raw(hooks::HOST_CATEGORICAL)) force_host_categorical_ = e[0] == '1';   // test hook: host scan of every cell
+    if (const char *e = hooks::raw(hooks::QUANTILE_RADIX)) force_radix_ = e[0] == '1';   // test hook: radix multi-select also for small batches
+    if (const char *e = hooks::raw(hooks::QUANTILE_SAMPLE)) force_sample_select_ = e[0] == '1';   // test hook: the sample/splitter selection on one GPU
     hipStream_t s = stream_;
     const int N = n, F = n_num, Fc = n_cat, D = md.output_dim, B = md.n_bins, MD = md.max_depth;
     const bool cosine = md.split_score_func == GBRL_HIP_SCORE_COSINE;
@@ -2044,9 +2046,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
     // RL-sized steps on one GPU: statistics, quantisation, split candidates and class codes in ONE launch (kern::small_prep, below, where the
     // candidate buffers exist); GBRL_HIP_NO_SMALL_PREP=1 (tests / measurement): the separate launches
-    const bool no_small_prep = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_PREP"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
-    const bool no_small_stats = [] { const char *e = std::getenv("GBRL_HIP_NO_SMALL_STATS"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
-    const bool no_sort_codes = [] { const char *e = std::getenv("GBRL_HIP_SORT_NO_CODES"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool no_small_prep = [] { const char *e = hooks::raw(hooks::NO_SMALL_PREP); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool no_small_stats = [] { const char *e = hooks::raw(hooks::NO_SMALL_STATS); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool no_sort_codes = [] { const char *e = hooks::raw(hooks::SORT_NO_CODES); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     const bool uniform_gen = md.generator_type == GBRL_HIP_GEN_UNIFORM;
     const bool prep_candidate = !has_coll_ && n_global == N && F > 0 && fixed_thr_.empty() && !candidates_only_ && !no_small_prep && !no_sort_codes &&
                                 !force_bisection_ && !force_sample_select_ && !force_radix_ && N <= (uniform_gen ? 8192 : kern::sort_quantiles_max_rows());
@@ -2329,9 +2331,18 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     grow_tree(gc, nodes, frontier, acc, leaf_scale);
     verify_pending_categories();
     if (cat_clash_) {
+        // Two different cells of one feature share a 64-bit hash (2^-64 per pair of cells).  The tree just grown used the wrong
+        // dictionary id for one of them, but nothing has been booked yet (append_tree below is what changes the model): forget the remembered
+        // cells, switch THIS model to the host scan of every cell -- it compares bytes, so the pair cannot clash again -- and grow the tree
+        // once more from the same inputs.  (Before round 6 the step threw, and every later step that held both cells threw again.)
         cat_clash_ = false;
         cat_items_.clear(); cat_tab_key_.clear(); cat_tab_id_.clear(); std::fill(cat_seen_.begin(), cat_seen_.end(), 0u);
-        throw HipError("two different categories of one feature share a 64-bit hash: step refused (GBRL_HIP_HOST_CATEGORICAL=1 scans the cells on the host)");
+        if (force_host_categorical_) throw HipError("two different categories of one feature share a 64-bit hash on the host scan (internal error)");
+        if (has_coll_) throw HipError("two different categories of one feature share a 64-bit hash: step refused (row-sharded run: set GBRL_HIP_HOST_CATEGORICAL=1 on every rank)");
+        force_host_categorical_ = true;
+        ++cat_clash_redos_;
+        step(obs, obs_dev, cat, cat_dev, grads, grads_dev, n, n_num, n_cat);
+        return;
     }
     append_tree(model, nodes, frontier, acc, leaf_scale, cat_cands);
     (void)world;

@@ -7,6 +7,7 @@
 // (deterministic, and bit-identical for 1/2/4/8 row shards).  Scores are evaluated in fp64 from those exact sums and
 // rounded to fp32 once, then compared the way the reference compares them (fitter.cpp:332-341, 435-444).
 #include "kernels.h"
+#include "hooks.h"
 #include "kernels_common.h"
 #include "score_common.h"
 #include "small_prep.h"
@@ -1662,7 +1663,7 @@ template <int DT, int U>
 static void launch_hist(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
                         int n_chunks, int n_groups, int FG, int shift, int NB, int32_t *partials, size_t lds, hipStream_t s,
                         hipEvent_t ev_start, hipEvent_t ev_stop, const HistDirect &direct = HistDirect{}, bool count_rows = true) {
-    static const bool pipe = []() { const char *e = std::getenv("GBRL_HIP_HIST_PIPE"); return !(e && e[0] == '0'); }();   // measurement hook
+    const bool pipe = [] { const char *e = hooks::raw(hooks::HIST_PIPE); return !(e && e[0] == '0'); }();   // measurement hook
     if constexpr (DT != 0) {
         if (pipe && !count_rows) { launch_hist_p<DT, U, true, false>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct); return; }
         if (pipe) { launch_hist_p<DT, U, true>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, direct); return; }
@@ -1737,8 +1738,8 @@ static bool launch_hist_wide(int P, int H, const uint16_t *codes, int n_rows, co
 bool hist_direct_supported(int FG) { return FG != 8 && FG != 4; }
 // the count-less variant exists for the compile-time-D kernels with the software pipeline (what hist_build takes for FG == 16, D <= 16)
 bool hist_countless_supported(int D, int FG, int n_rows) {
-    static const bool generic_only = [] { const char *e = std::getenv("GBRL_HIP_HIST_GENERIC"); return e && e[0] == '1'; }();
-    static const bool pipe = []() { const char *e = std::getenv("GBRL_HIP_HIST_PIPE"); return !(e && e[0] == '0'); }();
+    const bool generic_only = [] { const char *e = hooks::raw(hooks::HIST_GENERIC); return e && e[0] == '1'; }();
+    const bool pipe = [] { const char *e = hooks::raw(hooks::HIST_PIPE); return !(e && e[0] == '0'); }();
     return !generic_only && pipe && FG == 16 && D >= 1 && D <= 16 && n_rows <= (1 << 26);
 }
 bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, const int32_t *rows, const Chunk *chunks,
@@ -1748,7 +1749,7 @@ bool hist_build(const uint16_t *codes, int n_rows, const int32_t *qg, int D, con
     int shift = 0;
     while ((1 << shift) < FG) ++shift;
     const size_t lds = hist_lds_bytes(NB, D, FG);
-    static const bool generic_only = [] { const char *e = std::getenv("GBRL_HIP_HIST_GENERIC"); return e && e[0] == '1'; }();   // test hook
+    const bool generic_only = [] { const char *e = hooks::raw(hooks::HIST_GENERIC); return e && e[0] == '1'; }();   // test hook
     // the compile-time-D kernels address codes and gradients with 32-bit byte offsets from block-uniform bases (64 bytes per row at D = 16)
     if (generic_only || n_rows > (1 << 26)) {
         launch_hist<0, 4>(codes, n_rows, qg, D, rows, chunks, n_chunks, n_groups, FG, shift, NB, partials, lds, s, ev_start, ev_stop, dir);

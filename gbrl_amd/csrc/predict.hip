@@ -1,6 +1,7 @@
 // predict.hip -- gfx950 kernels behind GBRL::predict (A13): the general kernels (any ensemble the file format can hold) and the
 // fast paths for oblivious and greedy ensembles, plus the dispatcher kern::predict.
 #include "kernels.h"
+#include "hooks.h"
 #include "kernels_common.h"
 
 #include <algorithm>
@@ -729,7 +730,7 @@ void predict(const PredictModel &pm_in, const float *obs, int F, const int32_t *
     if (pm.oblivious && pm.obl_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 64 && stop_tree > start_tree) {
         if (pm.tree_chunk == 0 && pm.obl2_maxd != 0 && predict_reg(pm, obs, F, Fc, n, start_tree, stop_tree, out, s)) return;
         if (pm.tree_chunk == 0 && pm.obl2_maxd != 0 && predict_pc(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) return;
-        if (const char *e = std::getenv("GBRL_HIP_PREDICT_REG_ONLY"))   // test hook: a shape the tests expect the register-tile kernel to take
+        if (const char *e = hooks::raw(hooks::PREDICT_REG_ONLY))   // test hook: a shape the tests expect the register-tile kernel to take
             if (e[0] == '1') throw std::runtime_error("GBRL_HIP_PREDICT_REG_ONLY=1: the register-tile kernel does not take this shape");
         if (predict_obl2(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; }
         if (pm.D <= 4) { if (launch_predict_obl_d<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }

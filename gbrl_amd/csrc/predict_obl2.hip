@@ -16,6 +16,7 @@
 //     consumed) with ONE barrier per group (or single-buffered with two, when that buys a fourth wave per SIMD).
 //   * categorical conditions compare 16-bit dictionary ids packed behind the row's numeric features in the same LDS tile.
 #include "kernels.h"
+#include "hooks.h"
 #include "kernels_common.h"
 
 #include <algorithm>
@@ -587,9 +588,9 @@ static bool obl2_plan(int F, int Fc, bool cat, int maxd, int DMAX, bool greedy, 
         return tt >= 4 ? tt : 0;
     };
     int rg_env = 0, tt_env = 0, nb_env = 0;
-    if (const char *e = std::getenv("GBRL_HIP_PREDICT_RG")) rg_env = std::atoi(e);
-    if (const char *e = std::getenv("GBRL_HIP_PREDICT_TT")) tt_env = std::atoi(e);
-    if (const char *e = std::getenv("GBRL_HIP_PREDICT_NB")) nb_env = std::atoi(e);
+    if (const char *e = hooks::raw(hooks::PREDICT_RG)) rg_env = std::atoi(e);
+    if (const char *e = hooks::raw(hooks::PREDICT_TT)) tt_env = std::atoi(e);
+    if (const char *e = hooks::raw(hooks::PREDICT_NB)) nb_env = std::atoi(e);
     int best_rg = 0, best_tt = 0, best_nb = greedy ? 1 : 2;   // greedy descents read the group's node records from LDS: two barriers per
                                                                 // group either way, so one value buffer (and larger groups) is the better trade
     if (rg_env >= 1 && rg_env <= rg_max) {
@@ -636,12 +637,12 @@ static bool launch_obl2(const PredictModel &pm, const float *obs, int F, const i
     const int n_tiles = (n + R - 1) / R;
     if constexpr (!CAT) {
         // small ensemble over a large batch: persistent blocks that prefetch their next row tile (the HBM-bound regime)
-        const bool no_persist = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_PERSIST"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
+        const bool no_persist = [] { const char *e = hooks::raw(hooks::PREDICT_NO_PERSIST); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
         // (with <= 16 trees of <= 2 KiB of values each, two 8-tree value buffers hold the whole ensemble: staged once per block)
         int resident_vals = 0;
         {
             const size_t vtb = (static_cast<size_t>(1) << MAXD) * (DMAX * sizeof(float) + (GREEDY ? 16 : 0));
-            const bool no_res = [] { const char *e = std::getenv("GBRL_HIP_PREDICT_NO_RESIDENT"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
+            const bool no_res = [] { const char *e = hooks::raw(hooks::PREDICT_NO_RESIDENT); return e && e[0] == '1'; }();   /* read per call: the tests flip it */   // test / measurement hook
             // (a 256-thread block stages kObl2MaxVec float4 per thread = 16 KiB per group: an 8-tree group must fit that, i.e. <= 2 KiB
             // of values per tree -- depth 7-8 trees with 4 outputs, 4 KiB each, keep the regular plan)
             if (!no_res && !GREEDY && pl.RG == 1 && trees <= 16 && DMAX <= 8 && 8 * vtb <= static_cast<size_t>(kObl2MaxVec) * 256 * 16) {

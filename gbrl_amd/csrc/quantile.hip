@@ -14,6 +14,7 @@
 // Everything is exact; the sample only balances the classes.  If a list would overflow its budget the engine falls back
 // to the 32-pass bisection of kernels.hip (same results, slower).
 #include "kernels.h"
+#include "hooks.h"
 #include "kernels_common.h"
 #include "small_prep.h"
 
@@ -697,7 +698,7 @@ __global__ void k_scatter_cat_codes_grouped(const uint16_t *__restrict__ cat_cod
 
 void transpose_keys(const float *obs, int n, int F, uint32_t *kt, hipStream_t s) {
     dim3 grid((n + 63) / 64, (F + 63) / 64);
-    static const bool plain = [] { const char *e = std::getenv("GBRL_HIP_TRANSPOSE_PLAIN"); return e && e[0] == '1'; }();   // measurement hook
+    const bool plain = [] { const char *e = hooks::raw(hooks::TRANSPOSE_PLAIN); return e && e[0] == '1'; }();   // measurement hook
     if ((F & 3) == 0 && (n & 3) == 0 && !plain && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && (reinterpret_cast<uintptr_t>(kt) & 15) == 0)
         hipLaunchKernelGGL(k_transpose_keys_v4, grid, dim3(256), 0, s, obs, n, F, kt);
     else
@@ -794,7 +795,7 @@ void bin_cols(const uint32_t *kt, int n, int F, const uint32_t *thr_keys, int B,
     const long long tiles = (static_cast<long long>(n) + 255) / 256;
     int tpb = static_cast<int>(std::min<long long>(kBinTiles, std::max<long long>(1, tiles * groups / 1024)));
     dim3 grid(static_cast<unsigned>((tiles + tpb - 1) / tpb), groups);
-    const bool plain = [] { const char *e = std::getenv("GBRL_HIP_BIN_PLAIN"); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
+    const bool plain = [] { const char *e = hooks::raw(hooks::BIN_PLAIN); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     if (!plain && (levels == 8 || levels == 9)) {
         const size_t lds_fast = static_cast<size_t>(kGroup) * (1u << levels) * sizeof(uint32_t) + 256 * kGroup * sizeof(uint16_t);
         static PerDeviceOnce attr_fast;

@@ -15,6 +15,7 @@
 // Slot lookup is O(1): slot1 = map1[top 12 bits]; every slot keeps a 128-bit set of the next digits that still lead to a
 // target and the id of its first child; child slot = first child + popcount(set bits below the digit).
 #include "kernels.h"
+#include "hooks.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -564,7 +565,7 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
         return 0;
     };
     int rc = 0;
-    static const bool plain_loads = [] { const char *e = std::getenv("GBRL_HIP_RADIX_PLAIN_LOADS"); return e && e[0] == '1'; }();   // measurement hook
+    const bool plain_loads = [] { const char *e = hooks::raw(hooks::RADIX_PLAIN_LOADS); return e && e[0] == '1'; }();   // measurement hook
     if (pass1_chunks > 0) {   // the first digit was counted by transpose_keys_count
         if ((rc = finish_pass(1, pass1_chunks)) != 0) return rc;
     } else {
@@ -583,7 +584,7 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
 // (to be handed to radix_select as pass1_chunks), or 0 when the shape does not fit (the caller then transposes with
 // transpose_keys and radix_select counts the first digit itself).
 int transpose_keys_count(const float *obs, int n, int F, uint32_t *kt, uint32_t *partial, hipStream_t s) {
-    const char *env_off = std::getenv("GBRL_HIP_TRANSPOSE_COUNT");   // measurement / test hook, read per call
+    const char *env_off = hooks::raw(hooks::TRANSPOSE_COUNT);   // measurement / test hook, read per call
     const bool off = env_off && env_off[0] == '0';
     const int chunks = (n + kTcChunk - 1) / kTcChunk;
     if (off || n < (1 << 16) || (n & 3) || (F & 3) || chunks > kTcMaxChunks || (reinterpret_cast<uintptr_t>(obs) & 15) ||

@@ -27,6 +27,7 @@
 // Reference: fit_greedy_tree (fitter.cpp:263-375), fit_oblivious_tree (:377-484), splitScoreL2 / Cosine (node.cpp:187-251, 321-376),
 // splitNode (node.cpp:64-149), calc_leaf_value (fitter.cpp:545-582).
 #include "kernels.h"
+#include "hooks.h"
 #include "kernels_common.h"
 #include "score_common.h"
 #include "neartie_core.h"
@@ -1051,7 +1052,7 @@ size_t small_grow_res_stride(int MD) { return static_cast<size_t>(1 << std::max(
 int small_grow_blocks(int n_slots) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
-    const int cap = [] { const char *e = std::getenv("GBRL_HIP_SMALL_GROW_BLOCKS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 1 << 30; }();   /* read per call: the tests flip it */   // test / measurement hook
+    const int cap = [] { const char *e = hooks::raw(hooks::SMALL_GROW_BLOCKS); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 1 << 30; }();   /* read per call: the tests flip it */   // test / measurement hook
     return std::max(1, std::min(std::min(n_slots, cus), cap));
 }
 

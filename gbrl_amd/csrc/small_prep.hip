@@ -12,6 +12,7 @@
 // GBRL_HIP_NO_SMALL_PREP=1 is the separate launches).
 // Reference: Fitter::step_cpu (fitter.cpp:57-90), quantileSplitCandidates / uniformSplitCandidates (split_candidate_generator.cpp:59-115, 216-249).
 #include "kernels.h"
+#include "hooks.h"
 #include "kernels_common.h"
 #include "small_prep.h"
 
@@ -91,7 +92,7 @@ bool small_prep(const float *obs, int N, int F, int B, bool uniform, const int64
     a.grads = grads; a.D = D; a.centred = centred ? 1 : 0; a.chunk_rows = chunk_rows; a.stat = stat; a.meanden = meanden; a.sc = sc; a.qg = qg;
     {   // measurement hook: GBRL_HIP_SMALL_PREP_PROF=1 prints feature 0's stage times of the previous launch
         static uint32_t *h_prof = nullptr;
-        static const bool on = [] { const char *e = std::getenv("GBRL_HIP_SMALL_PREP_PROF"); return e && e[0] == '1'; }();
+        const bool on = [] { const char *e = hooks::raw(hooks::SMALL_PREP_PROF); return e && e[0] == '1'; }();
         if (on) {
             if (!h_prof) { (void)hipHostMalloc(reinterpret_cast<void **>(&h_prof), 64, hipHostMallocCoherent | hipHostMallocMapped); for (int i = 0; i < 16; ++i) h_prof[i] = 0; }
             else fprintf(stderr, "[small_prep feature 0, us] load %.2f sort %.2f thresholds %.2f codes %.2f\n", h_prof[0] / 100.0, h_prof[1] / 100.0, h_prof[2] / 100.0, h_prof[3] / 100.0);

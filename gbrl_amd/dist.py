@@ -80,15 +80,34 @@ class TorchCollective:
     def allreduce_min_f32(self, arr): return self._cbs[3](None, arr.ctypes.data, arr.size)
 
 
+_LIB = None
+
+
+def _lib():
+    """The library handle with the argument types of the exchange entry points (include/gbrl_hip.h), opened once."""
+    global _LIB
+    if _LIB is None:
+        from . import LIB_PATH
+        lib = C.CDLL(LIB_PATH)
+        lib.gbrl_hip_rccl_available.restype = C.c_int
+        lib.gbrl_hip_rccl_unique_id.argtypes = [C.c_void_p]
+        lib.gbrl_hip_rccl_unique_id.restype = C.c_int
+        lib.gbrl_hip_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.gbrl_hip_set_rccl.restype = C.c_int
+        lib.gbrl_hip_set_rccl_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint]
+        lib.gbrl_hip_set_rccl_flags.restype = C.c_int
+        lib.gbrl_hip_set_collective.argtypes = [C.c_void_p, C.c_void_p]
+        lib.gbrl_hip_set_collective.restype = C.c_int
+        lib.gbrl_hip_last_error.restype = C.c_char_p
+        _LIB = lib
+    return _LIB
+
+
 def install_torch_collective(model, device, group=None) -> TorchCollective:
     """Attach torch.distributed hooks to a gbrl_amd.GBRL model.  Keep the returned object alive."""
-    from . import LIB_PATH
     coll = TorchCollective(device, group)
-    lib = C.CDLL(LIB_PATH)
-    lib.gbrl_hip_set_collective.argtypes = [C.c_void_p, C.POINTER(_Coll)]
-    lib.gbrl_hip_set_collective.restype = C.c_int
-    lib.gbrl_hip_last_error.restype = C.c_char_p
-    rc = lib.gbrl_hip_set_collective(C.c_void_p(model._handle()), C.byref(coll.struct))
+    lib = _lib()
+    rc = lib.gbrl_hip_set_collective(C.c_void_p(model._handle()), C.cast(C.byref(coll.struct), C.c_void_p))
     if rc != 0:
         raise RuntimeError(lib.gbrl_hip_last_error().decode())
     return coll   # the caller must keep this object alive for as long as the model may call the hooks
@@ -101,15 +120,7 @@ def install_rccl(model, device, group=None) -> None:
     communicator is created, so a rank that cannot take part makes EVERY rank raise instead of leaving the others waiting."""
     import torch
     import torch.distributed as dist
-    from . import LIB_PATH
-    lib = C.CDLL(LIB_PATH)
-    lib.gbrl_hip_rccl_available.restype = C.c_int
-    lib.gbrl_hip_rccl_unique_id.argtypes = [C.c_void_p]
-    lib.gbrl_hip_rccl_unique_id.restype = C.c_int
-    lib.gbrl_hip_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    lib.gbrl_hip_set_rccl.restype = C.c_int
-    lib.gbrl_hip_set_collective.argtypes = [C.c_void_p, C.c_void_p]
-    lib.gbrl_hip_last_error.restype = C.c_char_p
+    lib = _lib()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     on_dev = str(dist.get_backend(group)).lower() == "nccl"
     where = device if on_dev else "cpu"
@@ -137,29 +148,13 @@ def install_rccl(model, device, group=None) -> None:
 def install_rccl_single(model) -> None:
     """A world-size-1 RCCL communicator of the model's own, without torch.distributed: the row-sharded code path (statistics / selection
     count / histogram reduce-scatter / winner / leaf-sum exchanges, all enqueued on the model's stream) on ONE GPU.  `bench.py` uses it to
-    report what that path costs before any byte crosses xGMI.  The engine drops a world-size-1 communicator unless
-    GBRL_HIP_FORCE_COLLECTIVE=1 is set while this call runs (it is set and restored here)."""
-    import os
-    from . import LIB_PATH
-    lib = C.CDLL(LIB_PATH)
-    lib.gbrl_hip_rccl_available.restype = C.c_int
-    lib.gbrl_hip_rccl_unique_id.argtypes = [C.c_void_p]
-    lib.gbrl_hip_rccl_unique_id.restype = C.c_int
-    lib.gbrl_hip_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    lib.gbrl_hip_set_rccl.restype = C.c_int
-    lib.gbrl_hip_last_error.restype = C.c_char_p
+    report what that path costs before any byte crosses xGMI.  The engine drops a world-size-1 communicator unless the caller asks to keep
+    it: `gbrl_hip_set_rccl_flags(..., GBRL_HIP_RCCL_KEEP_WORLD1)` (a call argument -- no process-global state is touched)."""
+    lib = _lib()
     if lib.gbrl_hip_rccl_available() != 1:
         raise RuntimeError("RCCL is not available: " + (lib.gbrl_hip_last_error() or b"").decode())
     buf = (C.c_char * 128)()
     if lib.gbrl_hip_rccl_unique_id(buf) != 0:
         raise RuntimeError("ncclGetUniqueId failed: " + (lib.gbrl_hip_last_error() or b"").decode())
-    old = os.environ.get("GBRL_HIP_FORCE_COLLECTIVE")
-    os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = "1"
-    try:
-        if lib.gbrl_hip_set_rccl(C.c_void_p(model._handle()), buf, 1, 0) != 0:
-            raise RuntimeError("gbrl_hip_set_rccl failed: " + (lib.gbrl_hip_last_error() or b"").decode())
-    finally:
-        if old is None:
-            os.environ.pop("GBRL_HIP_FORCE_COLLECTIVE", None)
-        else:
-            os.environ["GBRL_HIP_FORCE_COLLECTIVE"] = old
+    if lib.gbrl_hip_set_rccl_flags(C.c_void_p(model._handle()), buf, 1, 0, 1) != 0:   # 1 = GBRL_HIP_RCCL_KEEP_WORLD1
+        raise RuntimeError("gbrl_hip_set_rccl_flags failed: " + (lib.gbrl_hip_last_error() or b"").decode())

@@ -175,6 +175,11 @@ int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks)
 int gbrl_hip_rccl_available(void);   /* 1 when an RCCL library could be bound in this process */
 int gbrl_hip_rccl_unique_id(void *id128);
 int gbrl_hip_set_rccl(gbrl_hip_model *m, const void *id128, int world_size, int rank);
+/* The same with flags.  GBRL_HIP_RCCL_KEEP_WORLD1: keep the row-sharded code path (every exchange enqueued on the stream) at world size 1,
+ * which gbrl_hip_set_rccl drops as "nothing to exchange" -- what bench.py's `collective` leg measures (the fixed cost of that path before a
+ * byte crosses xGMI).  No reference counterpart (the reference has no collective). */
+#define GBRL_HIP_RCCL_KEEP_WORLD1 1u
+int gbrl_hip_set_rccl_flags(gbrl_hip_model *m, const void *id128, int world_size, int rank, unsigned flags);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* ---- inspection, served from the host copy of the ensemble ---------------------- */

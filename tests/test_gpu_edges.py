@@ -613,3 +613,32 @@ def test_categorical_steps_with_changing_cardinality_and_weights(policy):
     assert_structure_equal(e, o, what="categorical cardinality jump: ")
     assert_values_close(e, o, float(np.abs(G).mean()), TOL)
     assert int((np.asarray(e["is_numerics"]) == 0).sum()) > 0, "no categorical condition was chosen: the test would not see a wrong candidate order"
+
+
+def test_a_categorical_hash_clash_regrows_the_step_on_the_host_scan(monkeypatch):
+    """a cell met before is recognised by (feature, 64-bit hash) and its bytes are compared while the tree grows.  When that
+    comparison fails (simulated: `GBRL_HIP_TEST_CAT_CLASH=1`, read per call) the step used to throw -- and every later step holding both
+    cells threw again.  Now nothing has been booked at that point, so the tree is grown once more with the host scan of every cell (which
+    compares bytes) and the model keeps to that scan: same ensemble as an undisturbed model, no exception."""
+    import gbrl_amd
+    case = _case("clash", seed=91, N=1200, F=5, Fc=3, D=2, depth=4, n_bins=32, policy="greedy", gen="Quantile", trees=4, n_tokens=6)
+    X, Xc, G, y = K.make_inputs(case)
+    monkeypatch.delenv("GBRL_HIP_TEST_CAT_CLASH", raising=False)
+    monkeypatch.delenv("GBRL_HIP_HOST_CATEGORICAL", raising=False)
+    ref = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    pref = np.asarray(K.drive(ref, case, X, Xc, G, y))
+    m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+    m.set_profiling(2)
+    one = dict(case, trees=1)
+    K.drive(m, one, X, Xc, G, y)                         # first step: every cell is new, nothing pending
+    monkeypatch.setenv("GBRL_HIP_TEST_CAT_CLASH", "1")
+    m.step(X, Xc, np.ascontiguousarray(G))               # second step: the remembered cells "clash" -> regrown on the host scan
+    monkeypatch.delenv("GBRL_HIP_TEST_CAT_CLASH")
+    m.step(X, Xc, np.ascontiguousarray(G))
+    m.step(X, Xc, np.ascontiguousarray(G))
+    assert dict(m.last_phase_times()).get("cat_clash_redos", 0) == 1
+    pred = np.asarray(m.predict(X, Xc, 0, 0))
+    a, b = ref.get_ensemble_data(), m.get_ensemble_data()
+    for k in a:
+        assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), k
+    assert pref.tobytes() == pred.tobytes()
