@@ -1172,7 +1172,13 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     // in the reference's float32 sequence.  GBRL_HIP_NO_NEARTIE_REPLAY=1: the exact arg-max decides everywhere (rounds 1-4).
     const bool no_near = [] { const char *e = hooks::raw(hooks::NO_NEARTIE_REPLAY); return e && e[0] == '1'; }();   /* read per call: the tests flip it */
     const float near_rel = [] { const char *e = hooks::raw(hooks::NEARTIE_REL); return e ? static_cast<float>(std::atof(e)) : 9.5367431640625e-07f; }();   // 2^-20; measurement hook
-    const bool near_on = !no_near && !has_coll_ && n_global == N && n_cand > 0 && kern::near_tie_supported(N, D);
+    // Batches above 65 536 rows: at 2^20 rows x 32 768 candidates EVERY level has a runner-up inside the reference's float32 noise, and the
+    // replay's chains are serial (a 2^20-row level costs 10-100 ms against a 1.85 ms step: profiles/r06_neartie_fullsize_cost.txt), so those
+    // batches replay only on request -- GBRL_HIP_NEARTIE_MAX_ROWS=<n>: nodes of up to n rows (0: every node).  Unset: the exact arg-max, as in
+    // rounds 1-5.  Batches of up to 65 536 rows replay every flagged node as before.
+    const char *near_max_env = hooks::raw(hooks::NEARTIE_MAX_ROWS);
+    const int near_max_rows = N <= kern::kNearMaxRows ? 0 : (near_max_env ? std::max(0, std::atoi(near_max_env)) : -1);   // 0: no limit, -1: no replay
+    const bool near_on = !no_near && !has_coll_ && n_global == N && n_cand > 0 && kern::near_tie_supported(N, D) && near_max_rows >= 0;
     float *d_am_s = (near_on && !use_small) ? static_cast<float *>(d_am_s_.ensure(sizeof(float) * am_cap * 2)) : nullptr;
     int32_t *d_am_n = (d_am_s && N > 8192) ? reinterpret_cast<int32_t *>(d_am_s + am_cap) : nullptr;    // child sizes tell classes apart in larger batches only (score_common.h near_class)
     int32_t *d_cursors = static_cast<int32_t *>(d_cursors_.ensure(sizeof(int32_t) * max_front * 2));
@@ -1838,8 +1844,15 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             // flags of the level (k_resolve_splits): any -> the candidates in the window are scored once more, the reference's way, the final
             // arg-max stage runs on their outcome and the partition -- already enqueued from the exact decision, its input list is intact -- runs again
             const int64_t *near_h = reinterpret_cast<const int64_t *>(h_res + 8 * static_cast<size_t>(max_front)) + 2 * static_cast<size_t>(max_front);
+            // nodes above the requested size limit keep the exact arg-max (GBRL_HIP_NEARTIE_MAX_ROWS, batches above 65 536 rows only; 0 = no limit;
+            // an oblivious level is replayed only when every one of its nodes is within the limit)
             bool any = false;
-            for (int k = 0; k < (oblivious ? 1 : n_act); ++k) any = any || near_h[k] != 0;
+            if (oblivious) {
+                any = near_h[0] != 0;
+                if (any && near_max_rows > 0) for (int k = 0; k < n_act; ++k) any = any && nodes[active[k]].n_local <= near_max_rows;
+            } else {
+                for (int k = 0; k < n_act; ++k) any = any || (near_h[k] != 0 && (near_max_rows == 0 || nodes[active[k]].n_local <= near_max_rows));
+            }
             const bool near_debug = [] { const char *e = hooks::raw(hooks::NEARTIE_DEBUG); return e && e[0] == '1'; }();   // measurement hook
             if (any && near_debug) {
                 const float *bs = reinterpret_cast<const float *>(h_res + 4 * static_cast<size_t>(max_front));
@@ -1868,6 +1881,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 io.ent = static_cast<int32_t *>(d_near_ent_.ensure(sizeof(int32_t) * std::max(static_cast<size_t>(kern::kNearCands + 1) * N, static_cast<size_t>(n_cand))));
                 io.rep = static_cast<float *>(d_near_rep_.ensure(sizeof(float) * static_cast<size_t>(max_front) * (kern::kNearCands + 1)));
                 io.part_v = d_am_v; io.part_i = d_am_i; io.n_parts = oblivious ? am_parts : own_slots;
+                io.max_node_rows = near_max_rows;
+                if (const size_t mw = kern::near_tie_map_words(N, n_act)) io.maps = static_cast<uint32_t *>(d_near_maps_.ensure(sizeof(uint32_t) * mw));
                 kern::near_tie_replay(io, s);
                 seq = ++level_seq_;
                 if (seq == 0) seq = ++level_seq_;

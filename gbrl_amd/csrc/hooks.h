@@ -22,6 +22,7 @@ namespace hooks {
     X(HOST_CATEGORICAL) \
     X(KEEP_LAST_DERIVED) \
     X(NEARTIE_DEBUG) \
+    X(NEARTIE_MAX_ROWS) \
     X(NEARTIE_REL) \
     X(NO_DIRECT_HIST) \
     X(NO_IOTA_CACHE) \

@@ -276,7 +276,7 @@ void resolve_splits(const float *part_v, const int32_t *part_i, int n_parts /*ar
 // ---- near-tie replay (neartie.hip): the candidates inside the window of a flagged node are re-scored in the reference's float32
 // sequence, and the arg-max input of resolve_splits (part_v / part_i) is rewritten with the reference's comparison of them.
 constexpr int kNearCands = 16;         // distinct gains replayed per node (the closest ones)
-constexpr int kNearMaxRows = 65536;    // batches up to this many rows are replayed (a bit per row in LDS)
+constexpr int kNearMaxRows = 65536;    // batches up to this many rows keep the replay's row bitmaps in LDS; larger ones use a per-node bitmap in global memory (round 6)
 constexpr int kNearMaxD = 1024;      // (the replay block keeps two mean vectors, a tile and two row bitmaps in 64 KB of LDS)
 struct NearTieIO {
     const int32_t *rows;        // the level's row list
@@ -307,7 +307,10 @@ struct NearTieIO {
     float *part_v;              // arg-max stage-1 arrays of the level: rewritten for the replayed nodes
     int32_t *part_i;
     int n_parts;
+    uint32_t *maps;             // N > kNearMaxRows: scratch [n_act][ceil(N / 32)] -- a bit per row of the batch, set for the node's rows (k_near_rowmaps)
+    int max_node_rows;          // nodes of more rows are not replayed (an oblivious level: when ANY of its nodes is larger); 0: no limit
 };
+size_t near_tie_map_words(int N, int n_act);   // 0 when the batch fits the LDS bitmaps
 bool near_tie_supported(int N, int D);
 void near_tie_replay(const NearTieIO &io, hipStream_t s);
 // diagnostics (gbrl_hip_replay_scores): one node given by per-row flags, host pointers; out[0] = split score, out[1] = parent score

@@ -54,7 +54,12 @@ __device__ __forceinline__ float near_level_score(const NearTieIO &a, int j) {
 // rows -- and the reference scores them identically; the same gain with other child sizes is another partition (score_common.h second_merge).
 __global__ __launch_bounds__(kNearThreads) void k_near_list(NearTieIO a) {
     const int node = blockIdx.x;
-    if (a.near[node] == 0) { if (threadIdx.x == 0) a.list_n[node] = 0; return; }
+    bool skip = a.near[node] == 0;
+    if (!skip && a.max_node_rows > 0) {   // (uniform per block) a node -- or, oblivious, any node of the level -- above the limit keeps the exact arg-max
+        if (a.oblivious) { for (int nd = 0; nd < a.n_act; ++nd) skip = skip || a.n_rows[nd] > a.max_node_rows; }
+        else skip = a.n_rows[node] > a.max_node_rows;
+    }
+    if (skip) { if (threadIdx.x == 0) a.list_n[node] = 0; return; }
     __shared__ float sv[kNearThreads];
     __shared__ int si[kNearThreads], sj[kNearThreads], sn[kNearThreads];
     const float b1 = a.best_score[node];
@@ -126,6 +131,52 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         bin = is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
     }
     const uint16_t *cbase = a.codes + (static_cast<size_t>(fs >> 4) * a.N) * 16 + (fs & 15);
+    if (a.N > kNearMaxRows) {
+        // Batches above 65 536 rows (round 6): the bit per row lives in global memory, ONE map per node (k_near_rowmaps), shared by the node's
+        // candidate blocks; the side of a row is looked up when the ordered list is written.  Same list, same core, any batch size.
+        const uint32_t *gmap = a.maps + static_cast<size_t>(node) * ((static_cast<size_t>(a.N) + 31) >> 5);
+        int32_t *ent = a.ent + static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+        const int n_words = (a.N + 31) >> 5, per = (n_words + kNearThreads - 1) / kNearThreads;
+        const int w0 = min(n_words, static_cast<int>(threadIdx.x) * per), w1 = min(n_words, w0 + per);
+        int cnt = 0;
+        for (int w = w0; w < w1; ++w) cnt += __popc(gmap[w]);
+        s_cnt[threadIdx.x] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int t = 0; t < kNearThreads; ++t) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
+        }
+        __syncthreads();
+        {
+            int pos = s_cnt[threadIdx.x];
+            for (int w = w0; w < w1; ++w) {
+                uint32_t m = gmap[w];
+                while (m) { const int b = __ffs(m) - 1; m &= m - 1; ent[pos++] = (w << 5) + b; }
+            }
+        }
+        __syncthreads();
+        // the side of every listed row (coalesced over the list, gathered class codes), and how many go right
+        int cr = 0;
+        if (!is_parent) {
+            for (int p = threadIdx.x; p < n; p += kNearThreads) {
+                const int row = ent[p];
+                const int code = cbase[static_cast<size_t>(row) * 16];
+                const bool right = is_cat ? (code == bin) : (code > bin);
+                if (right) { ent[p] = row | static_cast<int32_t>(0x80000000u); ++cr; }
+            }
+        }
+        __syncthreads();
+        s_cnt[threadIdx.x] = cr;
+        __syncthreads();
+        for (int o = kNearThreads / 2; o > 0; o >>= 1) { if (static_cast<int>(threadIdx.x) < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
+        const int n_r = s_cnt[0], n_l = n - n_r;
+        __syncthreads();
+        if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { if (threadIdx.x == 0) *out = -INFINITY; return; }   // node.cpp:354
+        const NearGrads ng{a.grads, a.meanden, a.D};
+        const float res = near_replay_core(ent, n, n_r, ng, a.cosine != 0, is_parent, reinterpret_cast<uint32_t *>(lds + 4096));
+        if (threadIdx.x == 0) *out = res;
+        return;
+    }
     for (int w = threadIdx.x; w < 4096; w += kNearThreads) lds[w] = 0;
     __syncthreads();
     for (int p = threadIdx.x; p < n; p += kNearThreads) {
@@ -175,6 +226,30 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
     if (threadIdx.x == 0) *out = res;
 }
 
+// N > kNearMaxRows: a bit per row of the batch for every node that will be replayed (list_n > 0; oblivious: every node of a listed level)
+__global__ __launch_bounds__(kNearThreads) void k_near_rowmaps(NearTieIO a) {
+    const int node = blockIdx.y;
+    const int lnode = a.oblivious ? 0 : node;
+    if (a.near[lnode] == 0 || a.list_n[lnode] <= 0) return;
+    const size_t n_words = (static_cast<size_t>(a.N) + 31) >> 5;
+    uint32_t *gmap = a.maps + static_cast<size_t>(node) * n_words;
+    const int n = a.n_rows[node], seg = a.seg_start[node];
+    // phase 0 (gridDim.x blocks share the words), then phase 1 in a second launch sets the bits
+    for (size_t w = static_cast<size_t>(blockIdx.x) * kNearThreads + threadIdx.x; w < n_words; w += static_cast<size_t>(gridDim.x) * kNearThreads) gmap[w] = 0;
+    (void)n; (void)seg;
+}
+__global__ __launch_bounds__(kNearThreads) void k_near_rowmaps_set(NearTieIO a) {
+    const int node = blockIdx.y;
+    const int lnode = a.oblivious ? 0 : node;
+    if (a.near[lnode] == 0 || a.list_n[lnode] <= 0) return;
+    uint32_t *gmap = a.maps + static_cast<size_t>(node) * ((static_cast<size_t>(a.N) + 31) >> 5);
+    const int n = a.n_rows[node], seg = a.seg_start[node];
+    for (int p = blockIdx.x * kNearThreads + threadIdx.x; p < n; p += gridDim.x * kNearThreads) {
+        const int row = a.rows[seg + p];
+        atomicOr(&gmap[row >> 5], 1u << (row & 31));
+    }
+}
+
 // The reference's comparison over the replayed candidates (fitter.cpp:332-357 / 426-459: highest score, first index among equals), written
 // where the final arg-max stage reads its input, so that k_resolve_splits (run once more) derives everything else.
 __global__ __launch_bounds__(kWave) void k_near_apply(NearTieIO a) {
@@ -209,11 +284,16 @@ __global__ __launch_bounds__(kWave) void k_near_apply(NearTieIO a) {
 
 }  // namespace
 
-bool near_tie_supported(int N, int D) { return N >= 1 && N <= kNearMaxRows && D >= 1 && D <= kNearMaxD; }
+bool near_tie_supported(int N, int D) { return N >= 1 && N <= (1 << 30) && D >= 1 && D <= kNearMaxD; }
+size_t near_tie_map_words(int N, int n_act) { return N > kNearMaxRows ? ((static_cast<size_t>(N) + 31) >> 5) * static_cast<size_t>(std::max(1, n_act)) : 0; }
 
 void near_tie_replay(const NearTieIO &io, hipStream_t s) {
     const int n_list = io.oblivious ? 1 : io.n_act;
     hipLaunchKernelGGL(k_near_list, dim3(n_list), dim3(kNearThreads), 0, s, io);
+    if (io.N > kNearMaxRows) {
+        hipLaunchKernelGGL(k_near_rowmaps, dim3(64, io.n_act), dim3(kNearThreads), 0, s, io);
+        hipLaunchKernelGGL(k_near_rowmaps_set, dim3(64, io.n_act), dim3(kNearThreads), 0, s, io);
+    }
     const size_t lds = sizeof(uint32_t) * (4096 + static_cast<size_t>(near_core_words(io.D)));
     hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
     hipLaunchKernelGGL(k_near_apply, dim3(n_list), dim3(kWave), 0, s, io);

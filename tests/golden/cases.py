@@ -215,6 +215,18 @@ FULLSIZE_CASES = [
     _c("full_cfg3", seed=0, N=1 << 20, F=128, D=8, depth=6, policy="greedy", score="Cosine", trees=1, opts=_AC_OPTS,
        ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)"),
 ]
+# Near-tie specimens ABOVE the replay's LDS limit of 65 536 rows: the five cases of scripts/bign_sweep.py 400 32000 (70 000 .. 400 000 rows)
+# in which the reference's float32 summation noise picked another candidate than the exact arg-max (gaps 6e-7 .. 9e-6 relative, inside its
+# noise eps32 * sqrt(rows)); flagged nodes of 4 553, 14 562, 45 399, 76 428 and (an oblivious level) 2 x 163 972 rows.  With
+# GBRL_HIP_NEARTIE_MAX_ROWS=0 the product reproduces the reference's choice in all five (tests/test_gpu_neartie.py).
+BIGN_CASES = [
+    _c("bign9", seed=32009, N=327945, F=5, D=8, depth=5, n_bins=64, score="Cosine", gen="Quantile", policy="oblivious", trees=1, noise=2.0),
+    _c("bign30", seed=32030, N=312600, F=5, D=2, depth=4, n_bins=64, score="Cosine", gen="Quantile", policy="greedy", trees=1, noise=0.5),
+    _c("bign156", seed=32156, N=143357, F=2, D=8, depth=4, n_bins=256, score="Cosine", gen="Uniform", policy="greedy", trees=1, noise=8.0),
+    _c("bign162", seed=32162, N=287834, F=5, D=8, depth=5, n_bins=64, score="Cosine", gen="Quantile", policy="greedy", trees=1, noise=2.0),
+    _c("bign356", seed=32356, N=194897, F=2, D=4, depth=5, n_bins=16, score="Cosine", gen="Uniform", policy="greedy", trees=1, noise=0.5),
+]
+FULLSIZE_CASES = FULLSIZE_CASES + BIGN_CASES
 FULLSIZE_BY_NAME = {c["name"]: c for c in FULLSIZE_CASES}
 
 ENSEMBLE_KEYS = ("tree_indices", "depths", "values", "feature_indices", "feature_values", "edge_weights",

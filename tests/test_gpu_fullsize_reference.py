@@ -5,9 +5,14 @@ oblivious / L2 / quantile) and tests/golden/full_cfg3.npz (configs[2]: greedy / 
 build), made by tests/golden/make_fullsize_golden.py (835 s / tree on 8 vCPU).  The 512 MiB of inputs are regenerated from the
 seed (integer PCG64 draws + exactly rounded float32 arithmetic only) and checked through their SHA-256 before anything is compared.
 
-Bar: bit-identical structure.  Where a level / node differs, the float64 scores of both candidates on the node's rows are printed next
-to the reference's own float32 summation noise (eps32 * sqrt(rows), node.cpp:336-352 sums sequentially in float32), and the COUNT of
-differing levels / nodes is asserted against the committed bound below.
+Bar: bit-identical structure.  Two modes:
+  * GBRL_HIP_NEARTIE_MAX_ROWS=0 -- every flagged node re-scored in the reference's float32 operation sequence (serial chains over up to 2^20
+    rows: 80-170 ms per tree): configs[1] 6 of 6 levels, configs[2] 63 of 63 internal nodes, both asserted exactly;
+  * default -- batches above 65 536 rows keep the exact float64 arg-max (1.9 ms per tree): configs[1] 6 of 6; configs[2] 22 of 63 -- the
+    reference's float32 noise (4e-5 relative at a 522 256-row node) prefers a neighbouring threshold whose true score is 5e-6 lower, and the
+    41 nodes below it sit on another partition.  Where a level / node differs, the float64 scores of both candidates on the node's rows are
+    printed next to the reference's own float32 summation noise (eps32 * sqrt(rows), node.cpp:336-352 sums sequentially in float32), and
+    the COUNT of differing levels / nodes is asserted against the committed bounds below.
 """
 import json
 import os
@@ -22,8 +27,9 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # committed bounds (measured on MI355X, round 6; see README "Parity at the headline size")
-MAX_DIFFERING_LEVELS_CFG2 = 0
-MAX_DIFFERING_NODES_CFG3 = 0
+MAX_DIFFERING_LEVELS_CFG2 = {"replay": 0, "default": 0}
+MAX_DIFFERING_NODES_CFG3 = {"replay": 0, "default": 41}
+MODES = {"replay": "0", "default": None}     # GBRL_HIP_NEARTIE_MAX_ROWS
 
 
 def _fixture(name):
@@ -37,8 +43,13 @@ def _fixture(name):
     return fx, case, X, G
 
 
-def _grow(case, X, G, monkeypatch, root_mode=None):
+def _grow(case, X, G, monkeypatch, root_mode=None, mode="default"):
     import gbrl_amd
+    monkeypatch.delenv("GBRL_HIP_NO_NEARTIE_REPLAY", raising=False)
+    if MODES[mode] is None:
+        monkeypatch.delenv("GBRL_HIP_NEARTIE_MAX_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("GBRL_HIP_NEARTIE_MAX_ROWS", MODES[mode])
     if root_mode is None:
         monkeypatch.delenv("GBRL_HIP_ROOT_COUNTS", raising=False)
     else:
@@ -52,15 +63,17 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def test_config2_tree_is_the_reference_tree_at_full_size(monkeypatch):
-    fx, case, X, G = _fixture("full_cfg2")
-    e = _grow(case, X, G, monkeypatch)
+@pytest.mark.parametrize("mode", ["replay", "default"])
+@pytest.mark.parametrize("fixture", ["full_cfg2", "full_cfg2_s1"])
+def test_config2_tree_is_the_reference_tree_at_full_size(fixture, mode, monkeypatch):
+    fx, case, X, G = _fixture(fixture)
+    e = _grow(case, X, G, monkeypatch, mode=mode)
     depth_ref, depth = int(fx["depths"][0]), int(e["depths"][0])
     fi_r, fv_r, fi, fv = fx["feature_indices"][0], fx["feature_values"][0], e["feature_indices"][0], e["feature_values"][0]
     same = [bool(l < depth and fi[l] == fi_r[l] and _bits(fv[l:l + 1])[0] == _bits(fv_r[l:l + 1])[0]) for l in range(depth_ref)]
     lead = next((l for l, s in enumerate(same) if not s), depth_ref)
-    print("config 2 at 2^20 x 128: %d of %d levels identical to the reference's tree (%d leading); reference %s / product %s"
-          % (sum(same), depth_ref, lead, list(zip(fi_r.tolist(), fv_r.tolist()))[:depth_ref], list(zip(fi.tolist(), fv.tolist()))[:depth]))
+    print("config 2 (%s, %s) at 2^20 x 128: %d of %d levels identical to the reference's tree (%d leading); reference %s / product %s"
+          % (fixture, mode, sum(same), depth_ref, lead, list(zip(fi_r.tolist(), fv_r.tolist()))[:depth_ref], list(zip(fi.tolist(), fv.tolist()))[:depth]))
     if lead < depth_ref:
         # the first differing level: float64 scores of both choices on the partition of the common prefix, against the reference's noise
         thr = fullsize.quantile_thresholds(X, case["n_bins"])
@@ -79,7 +92,7 @@ def test_config2_tree_is_the_reference_tree_at_full_size(monkeypatch):
         print("  level %d: reference (%d, bin %d) float64 score %.9g | product (%d, bin %d) %.9g | gap %.2e relative; reference float32 noise eps32*sqrt(N) = %.1e"
               % (lead, fi_r[lead], b_ref, s_ref, fi[lead], b_got, s_got, (s_got - s_ref) / abs(s_got), 2.0 ** -24 * np.sqrt(X.shape[0])))
     assert depth == depth_ref
-    assert depth_ref - sum(same) <= MAX_DIFFERING_LEVELS_CFG2, same
+    assert depth_ref - sum(same) <= MAX_DIFFERING_LEVELS_CFG2[mode], same
     if all(same):
         assert np.array_equal(e["tree_indices"], fx["tree_indices"]) and np.array_equal(e["inequality_directions"], fx["inequality_directions"])
         scale = float(np.abs(G).mean())
@@ -88,9 +101,10 @@ def test_config2_tree_is_the_reference_tree_at_full_size(monkeypatch):
         print("  leaf values: max relative error %.2e (bar 1e-5); edge weights max abs difference %.1e" % (err, werr))
         assert err <= 1e-5 and werr <= 1e-6
     # the cross-check mode of the root level (class counts from the selection's ranks AND accumulated, compared entry by entry inside the engine)
-    e2 = _grow(case, X, G, monkeypatch, root_mode="2")
-    for k in e:
-        assert np.asarray(e[k]).tobytes() == np.asarray(e2[k]).tobytes(), k
+    if mode == "default" and fixture == "full_cfg2":
+        e2 = _grow(case, X, G, monkeypatch, root_mode="2")
+        for k in e:
+            assert np.asarray(e[k]).tobytes() == np.asarray(e2[k]).tobytes(), k
 
 
 def _greedy_nodes(e):
@@ -108,16 +122,18 @@ def _greedy_nodes(e):
     return nodes
 
 
-def test_config3_tree_is_the_reference_tree_at_full_size(monkeypatch):
+@pytest.mark.parametrize("mode", ["replay", "default"])
+def test_config3_tree_is_the_reference_tree_at_full_size(mode, monkeypatch):
     fx, case, X, G = _fixture("full_cfg3")
-    e = _grow(case, X, G, monkeypatch)
+    e = _grow(case, X, G, monkeypatch, mode=mode)
     ref = {k: fx[k] for k in fx.files}
     n_ref, n_got = _greedy_nodes(ref), _greedy_nodes(e)
     same = sum(1 for p, s in n_ref.items() if n_got.get(p) == s)
-    print("config 3 at 2^20 x 128: %d of the reference's %d internal nodes identical (product grew %d); leaves %d / %d"
-          % (same, len(n_ref), len(n_got), len(ref["depths"]), len(e["depths"])))
+    print("config 3 (%s) at 2^20 x 128: %d of the reference's %d internal nodes identical (product grew %d); leaves %d / %d"
+          % (mode, same, len(n_ref), len(n_got), len(ref["depths"]), len(e["depths"])))
     differing = [(p, s, n_got.get(p)) for p, s in n_ref.items() if n_got.get(p) != s]
     top = sorted(differing, key=lambda t: len(t[0]))[:4]
+    first_gap = None
     if top:
         thr = fullsize.quantile_thresholds(X, case["n_bins"])
         for p, s, g in top:
@@ -133,9 +149,15 @@ def test_config3_tree_is_the_reference_tree_at_full_size(monkeypatch):
                 def score_of(f, vb):
                     return float(sc[feats.index(f), int(np.nonzero(_bits(thr[f]) == vb)[0][0])])
                 a, b = score_of(*s), score_of(*g)
+                if first_gap is None:
+                    first_gap = (a, b, len(idx))
                 line += "; float64 scores %.9g / %.9g, gap %.2e relative, reference float32 noise %.1e" % (a, b, (b - a) / abs(b), 2.0 ** -24 * np.sqrt(len(idx)))
             print(line)
-    assert len(n_ref) - same <= MAX_DIFFERING_NODES_CFG3
+    assert len(n_ref) - same <= MAX_DIFFERING_NODES_CFG3[mode]
+    if mode == "default" and first_gap is not None:
+        # the shallowest difference must be an explained near-tie: the product at (or above) the reference's true score, the gap inside its noise
+        a, b, n_rows = first_gap
+        assert b >= a and (b - a) / abs(b) <= 4 * 2.0 ** -24 * np.sqrt(n_rows) + 1e-12, first_gap
     if same == len(n_ref) == len(n_got):
         for k in ("depths", "feature_indices", "inequality_directions", "tree_indices"):
             assert np.array_equal(e[k], ref[k]), k
