@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         __syncthreads();
         if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { if (threadIdx.x == 0) *out = -INFINITY; return; }   // node.cpp:354
         const NearGrads ng{a.grads, a.meanden, a.D};
-        const float res = near_replay_core(ent, n, n_r, ng, a.cosine != 0, is_parent, reinterpret_cast<uint32_t *>(lds + 4096));
+        const float res = near_replay_core(ent, n, n_r, ng, a.cosine != 0, is_parent, reinterpret_cast<uint32_t *>(lds), kNearBigTile, kNearBigTileRows);
         if (threadIdx.x == 0) *out = res;
         return;
     }
@@ -294,7 +294,13 @@ void near_tie_replay(const NearTieIO &io, hipStream_t s) {
         hipLaunchKernelGGL(k_near_rowmaps, dim3(64, io.n_act), dim3(kNearThreads), 0, s, io);
         hipLaunchKernelGGL(k_near_rowmaps_set, dim3(64, io.n_act), dim3(kNearThreads), 0, s, io);
     }
-    const size_t lds = sizeof(uint32_t) * (4096 + static_cast<size_t>(near_core_words(io.D)));
+    const bool big = io.N > kNearMaxRows && near_core_words(io.D, kNearBigTile, kNearBigTileRows) * 4 <= 150 * 1024 && 4 * ((io.D + 3) & ~3) <= kNearBigTile;
+    const size_t lds = big ? sizeof(uint32_t) * static_cast<size_t>(near_core_words(io.D, kNearBigTile, kNearBigTileRows))
+                           : sizeof(uint32_t) * (4096 + static_cast<size_t>(near_core_words(io.D)));
+    if (big) {
+        static PerDeviceOnce attr;
+        if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_near_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); attr.done = 0; }
+    }
     hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
     hipLaunchKernelGGL(k_near_apply, dim3(n_list), dim3(kWave), 0, s, io);
 }
