@@ -21,3 +21,9 @@ run scripts/fit_sweep.py 100 13600
 run scripts/fit_sweep.py 40 7000
 run scripts/sharded_sweep.py 120
 TAILN=1 run scripts/chain_sweep.py
+run scripts/parity_sweep.py 300 23000 refcat
+run scripts/parity_sweep.py 200 24000 refweights
+run scripts/parity_sweep.py 500 20000
+echo "== batches above 65 536 rows against the reference build: default (exact arg-max) and with every near-tie replayed"
+run scripts/bign_sweep.py 200 35000
+GBRL_HIP_NEARTIE_MAX_ROWS=0 run scripts/bign_sweep.py 200 35000
