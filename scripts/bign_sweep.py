@@ -48,4 +48,4 @@ for i in range(n_cases):
         else:
             bad += 1
             print("MISMATCH", case, why, flush=True)
-print("big-N cases %d (70 000 .. 400 000 rows; GBRL_HIP_NEARTIE_MAX_ROWS=%s, GBRL_HIP_NO_NEARTIE_REPLAY=%s): exact %d, explained near-ties %d, unexplained %d  (%.1f s)" % (n_cases, os.environ.get("GBRL_HIP_NEARTIE_MAX_ROWS", "default 65536"), os.environ.get("GBRL_HIP_NO_NEARTIE_REPLAY", "0"), exact, near, bad, time.time() - t0))
+print("big-N cases %d (70 000 .. 400 000 rows; GBRL_HIP_NEARTIE_MAX_ROWS=%s, GBRL_HIP_NO_NEARTIE_REPLAY=%s): exact %d, explained near-ties %d, unexplained %d  (%.1f s)" % (n_cases, os.environ.get("GBRL_HIP_NEARTIE_MAX_ROWS", "unset (exact arg-max above 65 536 rows)"), os.environ.get("GBRL_HIP_NO_NEARTIE_REPLAY", "0"), exact, near, bad, time.time() - t0))
