@@ -445,6 +445,13 @@ int gbrl_hip_replay_scores(const float *grads, const uint8_t *in_node, const uin
     });
 }
 
+int gbrl_hip_seq_sums(const float *x, const uint32_t *lens, const float *starts, int n_chains, float *out, uint32_t *n_slow_blocks) {
+    if (!lens || !out || n_chains < 0) return GBRL_HIP_E_INVALID;
+    return guarded([&] {
+        if (!gbrl::kern::seq_sums_selftest(x, lens, starts, n_chains, out, n_slow_blocks)) throw gbrl::HipError("sequential-sum kernels failed (no HIP device?)");
+    });
+}
+
 int gbrl_hip_set_profiling(gbrl_hip_model *m, int enabled) {
     if (!m) return GBRL_HIP_E_INVALID;
     m->engine.set_profiling(enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled));

@@ -316,6 +316,13 @@ void near_tie_replay(const NearTieIO &io, hipStream_t s);
 // diagnostics (gbrl_hip_replay_scores): one node given by per-row flags, host pointers; out[0] = split score, out[1] = parent score
 bool near_tie_selftest(const float *grads, const uint8_t *in_node, const uint8_t *goes_right, int n_rows, int D, const float *meanden, bool cosine, int min_data, float *out);
 
+// seqsum.hip: sequential float32 sums of many arrays ("chains"), evaluated in parallel and bit for bit (block summaries that depend on the
+// running sum's parity only; the serial loop where a power of two is crossed)
+struct SeqChain { const float *x; uint32_t len; uint32_t blk0; float start; };   // blk0: first of the chain's ceil(len / 256) blocks in the flat block arrays (ascending over the chains)
+size_t seq_sums_scratch_bytes(uint32_t n_blocks);
+void seq_sums(const SeqChain *d_chains, int n_chains, uint32_t n_blocks, void *d_scratch, float *d_out, uint32_t *d_n_slow /*nullable*/, hipStream_t s);
+bool seq_sums_selftest(const float *x, const uint32_t *lens, const float *starts /*nullable*/, int n_chains, float *out, uint32_t *n_slow_out /*nullable*/);
+
 // rows going right per node for the chosen splits (row-sharded runs: local child sizes without a local histogram)
 void localize_splits(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, hipStream_t s);
 void localize_publish(NodeSplit *splits, const int32_t *n_local, const int64_t *right_local, int n_nodes, void *d_src, void *h_dst_mapped, size_t bytes,

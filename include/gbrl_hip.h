@@ -224,6 +224,12 @@ int gbrl_hip_set_profiling(gbrl_hip_model *m, int level);
 int gbrl_hip_replay_scores(const float *grads, const uint8_t *in_node, const uint8_t *goes_right, int n_rows, int output_dim,
                            const float *meanden, int cosine, int min_data_in_leaf, float *out_scores);
 
+/* Diagnostics for the tests: sequential float32 sums -- s = start; for every element in order: s = (float)(s + x) -- of `n_chains` arrays stored
+ * back to back in `x` (`lens[i]` elements each), evaluated by the parallel block-summary kernels of seqsum.hip; the results must equal the plain
+ * loop bit for bit.  Host pointers; starts nullable (zeros); n_slow_blocks nullable: how many 256-element blocks took the serial fallback.
+ * No reference counterpart (the reference IS the plain loop: node.cpp:336-352). */
+int gbrl_hip_seq_sums(const float *x, const uint32_t *lens, const float *starts, int n_chains, float *out, uint32_t *n_slow_blocks);
+
 /* ---- device / stream contract (new; the reference pins everything to device 0 and the null stream, cuda_types.cu:32-106) -- */
 /* The device the model computes on: the ordinal given at creation, or -- for -1 -- the calling thread's current device at the
  * first call that needs it (it is latched by this call too).  -1 when no HIP device is usable.  A caller that hands out
