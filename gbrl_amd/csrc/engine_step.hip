@@ -1883,6 +1883,20 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                 io.part_v = d_am_v; io.part_i = d_am_i; io.n_parts = oblivious ? am_parts : own_slots;
                 io.max_node_rows = near_max_rows;
                 if (const size_t mw = kern::near_tie_map_words(N, n_act)) io.maps = static_cast<uint32_t *>(d_near_maps_.ensure(sizeof(uint32_t) * mw));
+                if (kern::near_tie_fast_supported(N, D) && !hooks::on(hooks::NEARTIE_SERIAL)) {
+                    // big batch, D a multiple of 4: the float32 chains are evaluated by seqsum.hip on the whole GPU (GBRL_HIP_NEARTIE_SERIAL=1: the
+                    // one-lane-per-chain core of neartie_core.h, same bits -- the tests compare the two)
+                    const size_t rows17 = static_cast<size_t>(kern::kNearCands + 1) * N, blocks17 = static_cast<size_t>(n_act) * (kern::kNearCands + 1);
+                    io.fast = 1;
+                    io.pos = static_cast<int32_t *>(d_near_pos_.ensure(sizeof(int32_t) * rows17));
+                    io.nr = static_cast<int32_t *>(d_near_nrb_.ensure(sizeof(int32_t) * blocks17));
+                    io.vals = static_cast<float *>(d_near_vals_.ensure(sizeof(float) * rows17 * D));
+                    io.means = static_cast<float *>(d_near_means_.ensure(sizeof(float) * blocks17 * 2 * D));
+                    io.sums = static_cast<float *>(d_near_sums_.ensure(sizeof(float) * blocks17 * 2 * D));
+                    io.seq_blocks = kern::near_tie_fast_blocks(N, D, n_act);
+                    io.chains_bytes = kern::near_tie_fast_chain_bytes(N, D, n_act);
+                    io.chains = d_near_chains_.ensure(io.chains_bytes);
+                }
                 kern::near_tie_replay(io, s);
                 seq = ++level_seq_;
                 if (seq == 0) seq = ++level_seq_;

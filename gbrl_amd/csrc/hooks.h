@@ -24,6 +24,7 @@ namespace hooks {
     X(NEARTIE_DEBUG) \
     X(NEARTIE_MAX_ROWS) \
     X(NEARTIE_REL) \
+    X(NEARTIE_SERIAL) \
     X(NO_DIRECT_HIST) \
     X(NO_IOTA_CACHE) \
     X(NO_NEARTIE_REPLAY) \

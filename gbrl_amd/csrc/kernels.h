@@ -307,10 +307,23 @@ struct NearTieIO {
     float *part_v;              // arg-max stage-1 arrays of the level: rewritten for the replayed nodes
     int32_t *part_i;
     int n_parts;
+    // N > kNearMaxRows and D % 4 == 0 (round 6): the chains are evaluated by seqsum.hip on the whole GPU instead of one lane per chain
+    int fast;                   // 1: k_near_replay only orders the rows; the fill / chain / finish kernels do the rest
+    int32_t *pos;               // scratch [(kNearCands + 1) * N]: a listed row's place among the rows of its side
+    int32_t *nr;                // scratch [n_act][kNearCands + 1]: rows going right (-1: block not replayed)
+    float *vals;                // scratch [(kNearCands + 1) * N * D]: the chains' elements (column-major per side, then the dot chains' products)
+    float *means;               // scratch [n_act][kNearCands + 1][2][D]
+    float *sums;                // scratch [n_act][kNearCands + 1][2][D]: chain results (pass 1: per column; pass 2: [side][0])
+    void *chains;               // scratch: SeqChain table [n_act * (kNearCands + 1) * 2 * D] + seq_sums scratch behind it
+    size_t chains_bytes;
+    uint32_t seq_blocks;        // upper bound of the chains' 256-element blocks
     uint32_t *maps;             // N > kNearMaxRows: scratch [n_act][ceil(N / 32)] -- a bit per row of the batch, set for the node's rows (k_near_rowmaps)
     int max_node_rows;          // nodes of more rows are not replayed (an oblivious level: when ANY of its nodes is larger); 0: no limit
 };
 size_t near_tie_map_words(int N, int n_act);   // 0 when the batch fits the LDS bitmaps
+bool near_tie_fast_supported(int N, int D);     // big batch, D a multiple of 4: chains through seqsum.hip
+uint32_t near_tie_fast_blocks(int N, int D, int n_act);
+size_t near_tie_fast_chain_bytes(int N, int D, int n_act);
 bool near_tie_supported(int N, int D);
 void near_tie_replay(const NearTieIO &io, hipStream_t s);
 // diagnostics (gbrl_hip_replay_scores): one node given by per-row flags, host pointers; out[0] = split score, out[1] = parent score

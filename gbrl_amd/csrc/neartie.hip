@@ -171,6 +171,29 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         for (int o = kNearThreads / 2; o > 0; o >>= 1) { if (static_cast<int>(threadIdx.x) < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
         const int n_r = s_cnt[0], n_l = n - n_r;
         __syncthreads();
+        if (a.fast) {
+            // round 6: only the order is produced here -- every listed row's place among the rows of its side -- and the chains are evaluated on
+            // the whole GPU (k_near_fill1 / seq_sums / k_near_means / k_near_fill2 / seq_sums / k_near_finish)
+            if (threadIdx.x == 0) a.nr[static_cast<size_t>(node) * (kNearCands + 1) + i] = n_r;
+            int32_t *pos = a.pos + static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+            int base_r = 0;
+            for (int p0 = 0; p0 < n; p0 += kNearThreads) {
+                const int p = p0 + static_cast<int>(threadIdx.x);
+                const bool in = p < n;
+                const bool right = in && (static_cast<uint32_t>(ent[min(p, n - 1)]) >> 31) != 0;
+                const unsigned long long mr = __ballot(right);
+                const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+                __syncthreads();
+                if (lane == 0) s_cnt[wv] = __popcll(mr);
+                __syncthreads();
+                int wbase = 0, tot = 0;
+                for (int w = 0; w < kNearThreads / kWave; ++w) { const int c = s_cnt[w]; if (w < wv) wbase += c; tot += c; }
+                const int before_r = base_r + wbase + __popcll(mr & (lane == 0 ? 0ull : (~0ull >> (kWave - lane))));
+                if (in) pos[p] = right ? before_r : (p - before_r);
+                base_r += tot;
+            }
+            return;
+        }
         if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { if (threadIdx.x == 0) *out = -INFINITY; return; }   // node.cpp:354
         const NearGrads ng{a.grads, a.meanden, a.D};
         const float res = near_replay_core(ent, n, n_r, ng, a.cosine != 0, is_parent, reinterpret_cast<uint32_t *>(lds), kNearBigTile, kNearBigTileRows);
@@ -250,6 +273,155 @@ __global__ __launch_bounds__(kNearThreads) void k_near_rowmaps_set(NearTieIO a) 
     }
 }
 
+// ---- round 6: the chains of a big node on the whole GPU (seqsum.hip) ---------------------------------------------------------------------
+// (node, i) = block of the replay; its n rows own a region of n * D floats in a.vals: [right: D columns of n_r | left: D columns of n_l], and for
+// the dot chains afterwards [right: n_r rows of D products | left: n_l rows].  Chain index = ((node * 17 + i) * 2 + side) * D + c.
+__global__ __launch_bounds__(256) void k_near_nr_clear(NearTieIO a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < a.n_act * (kNearCands + 1)) a.nr[t] = -1;
+}
+// one block: the chain table of a pass (pass 1: one chain per (block, side, column); pass 2: per (block, side)), blocks numbered by a running prefix
+__global__ __launch_bounds__(1024) void k_near_chains(NearTieIO a, int pass) {
+    SeqChain *ch = static_cast<SeqChain *>(a.chains);
+    const int D = a.D, per = pass == 1 ? 2 * D : 2;
+    const int n_chains = a.n_act * (kNearCands + 1) * per;
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_chains; c0 += 1024) {
+        const int ci = c0 + static_cast<int>(threadIdx.x);
+        uint32_t len = 0; const float *x = a.vals;
+        if (ci < n_chains) {
+            const int blk = ci / per, r = ci - blk * per;
+            const int node = blk / (kNearCands + 1), i = blk - node * (kNearCands + 1);
+            const int n_r = a.nr[blk];
+            if (n_r >= 0) {
+                const int n = a.n_rows[node], n_l = n - n_r;
+                const float *base = a.vals + (static_cast<size_t>(a.seg_start[node]) * (kNearCands + 1) + static_cast<size_t>(i) * n) * D;
+                if (pass == 1) { const int side = r / D, c = r - side * D; len = side ? n_l : n_r; x = base + (side ? static_cast<size_t>(D) * n_r : 0) + static_cast<size_t>(c) * len; }
+                else { const int side = r; len = static_cast<uint32_t>(side ? n_l : n_r) * D; x = base + (side ? static_cast<size_t>(D) * n_r : 0); }
+            }
+        }
+        const uint32_t nb = (len + 255u) / 256u;
+        s_part[threadIdx.x] = nb;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) { const uint32_t v = threadIdx.x >= static_cast<unsigned>(o) ? s_part[threadIdx.x - o] : 0u; __syncthreads(); s_part[threadIdx.x] += v; __syncthreads(); }
+        const uint32_t incl = s_part[threadIdx.x], base = s_base;
+        if (ci < n_chains) { ch[ci].x = x; ch[ci].len = len; ch[ci].blk0 = base + incl - nb; ch[ci].start = 0.0f; }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = base + incl;
+        __syncthreads();
+    }
+}
+// pass 1 elements: grid (tiles, kNearCands + 1, n_act); a thread takes float4 pieces of listed rows
+__global__ __launch_bounds__(256) void k_near_fill1(NearTieIO a) {
+#pragma clang fp contract(off)
+    const int node = blockIdx.z, i = blockIdx.y;
+    const int n_r = a.nr[static_cast<size_t>(node) * (kNearCands + 1) + i];
+    if (n_r < 0) return;
+    const int n = a.n_rows[node], D = a.D, Q = D >> 2, n_l = n - n_r;
+    const size_t off = static_cast<size_t>(a.seg_start[node]) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+    const int32_t *ent = a.ent + off, *pos = a.pos + off;
+    float *base = a.vals + off * D;
+    typedef float near_f4 __attribute__((ext_vector_type(4)));
+    for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < static_cast<long long>(n) * Q; u += static_cast<long long>(gridDim.x) * 256) {
+        const int p = static_cast<int>(u / Q), q4 = static_cast<int>(u - static_cast<long long>(p) * Q) * 4;
+        const int32_t e = ent[p];
+        const int row = e & 0x7fffffff, k = pos[p];
+        const bool right = (static_cast<uint32_t>(e) >> 31) != 0;
+        const near_f4 v = *reinterpret_cast<const near_f4 *>(a.grads + static_cast<size_t>(row) * D + q4);
+        const float g4[4] = {v.x, v.y, v.z, v.w};
+        float *col = base + (right ? 0 : static_cast<size_t>(D) * n_r);
+        const int len = right ? n_r : n_l;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cc = q4 + t;
+            col[static_cast<size_t>(cc) * len + k] = a.meanden == nullptr ? g4[t] : (g4[t] - a.meanden[cc]) / a.meanden[D + cc];   // near_grad's operations
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_near_means(NearTieIO a) {
+#pragma clang fp contract(off)
+    const int D = a.D, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.n_act * (kNearCands + 1) * 2 * D) return;
+    const int blk = t / (2 * D), r = t - blk * 2 * D, side = r / D;
+    const int n_r = a.nr[blk];
+    if (n_r < 0) return;
+    const int node = blk / (kNearCands + 1);
+    const int n_l = a.n_rows[node] - n_r;
+    const float rec = side ? (n_l > 0 ? 1.0f / static_cast<float>(n_l) : 0.0f) : (n_r > 0 ? 1.0f / static_cast<float>(n_r) : 0.0f);
+    a.means[t] = a.sums[t] * rec;
+}
+// pass 2 elements (Cosine): the rounded products g * mean_side[col] in (row, column) order
+__global__ __launch_bounds__(256) void k_near_fill2(NearTieIO a) {
+#pragma clang fp contract(off)
+    const int node = blockIdx.z, i = blockIdx.y;
+    const int blk = node * (kNearCands + 1) + i;
+    const int n_r = a.nr[blk];
+    if (n_r < 0) return;
+    const int n = a.n_rows[node], D = a.D, Q = D >> 2;
+    const size_t off = static_cast<size_t>(a.seg_start[node]) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+    const int32_t *ent = a.ent + off, *pos = a.pos + off;
+    float *base = a.vals + off * D;
+    const float *mean = a.means + static_cast<size_t>(blk) * 2 * D;
+    typedef float near_f4 __attribute__((ext_vector_type(4)));
+    for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < static_cast<long long>(n) * Q; u += static_cast<long long>(gridDim.x) * 256) {
+        const int p = static_cast<int>(u / Q), q4 = static_cast<int>(u - static_cast<long long>(p) * Q) * 4;
+        const int32_t e = ent[p];
+        const int row = e & 0x7fffffff, k = pos[p];
+        const bool right = (static_cast<uint32_t>(e) >> 31) != 0;
+        const near_f4 v = *reinterpret_cast<const near_f4 *>(a.grads + static_cast<size_t>(row) * D + q4);
+        const float g4[4] = {v.x, v.y, v.z, v.w};
+        const float *m = mean + (right ? 0 : D);
+        near_f4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cc = q4 + t;
+            const float g = a.meanden == nullptr ? g4[t] : (g4[t] - a.meanden[cc]) / a.meanden[D + cc];
+            const float pr = g * m[cc];
+            if (t == 0) o.x = pr; else if (t == 1) o.y = pr; else if (t == 2) o.z = pr; else o.w = pr;
+        }
+        *reinterpret_cast<near_f4 *>(base + (right ? 0 : static_cast<size_t>(D) * n_r) + static_cast<size_t>(k) * D + q4) = o;
+    }
+}
+// the scores from the means and the dot sums: the tail of near_replay_core, operation for operation
+__global__ __launch_bounds__(64) void k_near_finish(NearTieIO a) {
+#pragma clang fp contract(off)
+    const int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= a.n_act * (kNearCands + 1)) return;
+    const int n_r = a.nr[blk];
+    if (n_r < 0) return;
+    const int node = blk / (kNearCands + 1), i = blk - node * (kNearCands + 1), D = a.D;
+    const bool is_parent = i == kNearCands, cosine = a.cosine != 0;
+    const int n_l = a.n_rows[node] - n_r;
+    float *out = a.rep + blk;
+    if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { *out = -INFINITY; return; }   // node.cpp:354
+    const float *mean = a.means + static_cast<size_t>(blk) * 2 * D;
+    const float nrf = static_cast<float>(n_r), nlf = static_cast<float>(n_l);
+    const float num_r = cosine ? a.sums[static_cast<size_t>(blk) * 2 + 0] : 0.0f, num_l = cosine ? a.sums[static_cast<size_t>(blk) * 2 + 1] : 0.0f;   // (pass 2's chains: [block][side])
+    float res;
+    if (is_parent) {
+        if (cosine) {
+            const float den = near_sqnorm(mean + D, D) * nlf;
+            res = (n_l == 0 || den == 0.0f) ? 0.0f : static_cast<float>(static_cast<double>(num_l) / sqrt(static_cast<double>(den)));
+        } else {
+            res = near_sqnorm(mean + D, D) * nlf;
+        }
+    } else if (cosine) {
+        const float tn = near_sqnorm(mean, D), fn = near_sqnorm(mean + D, D);
+        const float fden = fn * nlf;
+        const float den = fmaf(tn, nrf, fden);
+        const float num = num_r + num_l;
+        res = den == 0.0f ? 0.0f : num / sqrtf(den);
+    } else {
+        const float ln = near_sqnorm(mean + D, D), rn = near_sqnorm(mean, D);
+        const float rp = nrf * rn;
+        res = fmaf(nlf, ln, rp);
+    }
+    *out = res;
+}
+
 // The reference's comparison over the replayed candidates (fitter.cpp:332-357 / 426-459: highest score, first index among equals), written
 // where the final arg-max stage reads its input, so that k_resolve_splits (run once more) derives everything else.
 __global__ __launch_bounds__(kWave) void k_near_apply(NearTieIO a) {
@@ -285,6 +457,16 @@ __global__ __launch_bounds__(kWave) void k_near_apply(NearTieIO a) {
 }  // namespace
 
 bool near_tie_supported(int N, int D) { return N >= 1 && N <= (1 << 30) && D >= 1 && D <= kNearMaxD; }
+bool near_tie_fast_supported(int N, int D) { return N > kNearMaxRows && D >= 4 && (D & 3) == 0; }
+// every listed row contributes D elements to at most one chain per pass, so the chains of a level hold at most 17 N D elements: that many
+// 256-element blocks plus one partial block per chain
+uint32_t near_tie_fast_blocks(int N, int D, int n_act) {
+    const unsigned long long el = static_cast<unsigned long long>(kNearCands + 1) * static_cast<unsigned long long>(N) * D;
+    return static_cast<uint32_t>(el / 256 + static_cast<unsigned long long>(n_act) * (kNearCands + 1) * 2 * D + 1);
+}
+size_t near_tie_fast_chain_bytes(int N, int D, int n_act) {
+    return 256 * ((sizeof(SeqChain) * static_cast<size_t>(n_act) * (kNearCands + 1) * 2 * D + 255) / 256) + seq_sums_scratch_bytes(near_tie_fast_blocks(N, D, n_act));
+}
 size_t near_tie_map_words(int N, int n_act) { return N > kNearMaxRows ? ((static_cast<size_t>(N) + 31) >> 5) * static_cast<size_t>(std::max(1, n_act)) : 0; }
 
 void near_tie_replay(const NearTieIO &io, hipStream_t s) {
@@ -301,7 +483,25 @@ void near_tie_replay(const NearTieIO &io, hipStream_t s) {
         static PerDeviceOnce attr;
         if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_near_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); attr.done = 0; }
     }
+    if (io.fast) hipLaunchKernelGGL(k_near_nr_clear, dim3((io.n_act * (kNearCands + 1) + 255) / 256), dim3(256), 0, s, io);
     hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
+    if (io.fast) {
+        const int n_blk = io.n_act * (kNearCands + 1), D = io.D;
+        SeqChain *chains = static_cast<SeqChain *>(io.chains);
+        const size_t table = 256 * ((sizeof(SeqChain) * static_cast<size_t>(n_blk) * 2 * D + 255) / 256);
+        void *seq_scratch = static_cast<char *>(io.chains) + table;
+        const unsigned tiles = static_cast<unsigned>(std::min<long long>(1024, std::max<long long>(1, (static_cast<long long>(io.N) * (D / 4) + 256 * 16 - 1) / (256 * 16))));
+        hipLaunchKernelGGL(k_near_fill1, dim3(tiles, kNearCands + 1, io.n_act), dim3(256), 0, s, io);
+        hipLaunchKernelGGL(k_near_chains, dim3(1), dim3(1024), 0, s, io, 1);
+        seq_sums(chains, n_blk * 2 * D, io.seq_blocks, seq_scratch, io.sums, nullptr, s);
+        hipLaunchKernelGGL(k_near_means, dim3((n_blk * 2 * D + 255) / 256), dim3(256), 0, s, io);
+        if (io.cosine) {
+            hipLaunchKernelGGL(k_near_fill2, dim3(tiles, kNearCands + 1, io.n_act), dim3(256), 0, s, io);
+            hipLaunchKernelGGL(k_near_chains, dim3(1), dim3(1024), 0, s, io, 2);
+            seq_sums(chains, n_blk * 2, io.seq_blocks, seq_scratch, io.sums, nullptr, s);
+        }
+        hipLaunchKernelGGL(k_near_finish, dim3((n_blk + 63) / 64), dim3(64), 0, s, io);
+    }
     hipLaunchKernelGGL(k_near_apply, dim3(n_list), dim3(kWave), 0, s, io);
 }
 

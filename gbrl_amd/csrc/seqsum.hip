@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void k_seq_blocksum(const SeqChain *__restrict
     const int lane = threadIdx.x & 63;
     const int ci = seq_chain_of(chains, n_chains, b);
     const SeqChain c = chains[ci];
+    if (b - c.blk0 >= (c.len + kSeqBlock - 1) / kSeqBlock) return;   // (n_blocks may be an upper bound: nothing behind the last chain's blocks)
     float v[4];
     seq_load(c, b - c.blk0, lane, v);
     double s = ((static_cast<double>(v[0]) + static_cast<double>(v[1])) + static_cast<double>(v[2])) + static_cast<double>(v[3]);
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void k_seq_summary(const SeqChain *__restrict_
     const int lane = threadIdx.x & 63;
     const int ci = seq_chain_of(chains, n_chains, b);
     const SeqChain c = chains[ci];
+    if (b - c.blk0 >= (c.len + kSeqBlock - 1) / kSeqBlock) return;
     const float start = static_cast<float>(static_cast<double>(c.start) + blk[b]);   // the running sum this block will (very nearly) start from
     const uint32_t sb = __float_as_uint(start);
     const int sex = static_cast<int>((sb >> 23) & 0xffu);

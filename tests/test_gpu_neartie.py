@@ -234,6 +234,12 @@ def test_near_ties_above_65536_rows_follow_the_reference_on_request(name, monkey
 
     e_all = grow(0)
     assert same(e_all), "with every node replayed the tree must be the reference's"
+    # the chains through seqsum.hip (default for these shapes when D % 4 == 0) and through the one-lane-per-chain core: the same bytes
+    monkeypatch.setenv("GBRL_HIP_NEARTIE_SERIAL", "1")
+    e_serial = grow(0)
+    monkeypatch.delenv("GBRL_HIP_NEARTIE_SERIAL")
+    for k in e_all:
+        assert np.asarray(e_all[k]).tobytes() == np.asarray(e_serial[k]).tobytes(), k
     scale = float(np.abs(G).mean())
     assert float(np.max(np.abs(e_all["values"] - ref["values"]) / np.maximum(np.abs(ref["values"]), scale))) <= 1e-5
     e_def = grow(None)
