@@ -158,11 +158,18 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         // the side of every listed row (coalesced over the list, gathered class codes), and how many go right
         int cr = 0;
         if (!is_parent) {
-            for (int p = threadIdx.x; p < n; p += kNearThreads) {
-                const int row = ent[p];
-                const int code = cbase[static_cast<size_t>(row) * 16];
-                const bool right = is_cat ? (code == bin) : (code > bin);
-                if (right) { ent[p] = row | static_cast<int32_t>(0x80000000u); ++cr; }
+            for (int p0 = threadIdx.x; p0 < n; p0 += kNearThreads * 8) {     // eight list entries per thread in flight (two dependent round trips each)
+                int row[8], code[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) row[u] = ent[min(p0 + u * kNearThreads, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * 16];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + u * kNearThreads;
+                    const bool right = is_cat ? (code[u] == bin) : (code[u] > bin);
+                    if (p < n && right) { ent[p] = row[u] | static_cast<int32_t>(0x80000000u); ++cr; }
+                }
             }
         }
         __syncthreads();
@@ -177,20 +184,35 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
             if (threadIdx.x == 0) a.nr[static_cast<size_t>(node) * (kNearCands + 1) + i] = n_r;
             int32_t *pos = a.pos + static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
             int base_r = 0;
-            for (int p0 = 0; p0 < n; p0 += kNearThreads) {
-                const int p = p0 + static_cast<int>(threadIdx.x);
-                const bool in = p < n;
-                const bool right = in && (static_cast<uint32_t>(ent[min(p, n - 1)]) >> 31) != 0;
-                const unsigned long long mr = __ballot(right);
-                const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+            const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+            constexpr int NW = kNearThreads / kWave;
+            for (int p0 = 0; p0 < n; p0 += kNearThreads * 4) {      // 1024 entries per pair of barriers, four loads per thread in flight
+                unsigned long long mr[4];
+                bool rt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u * kNearThreads + static_cast<int>(threadIdx.x);
+                    rt[u] = p < n && (static_cast<uint32_t>(ent[min(p, n - 1)]) >> 31) != 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mr[u] = __ballot(rt[u]);
                 __syncthreads();
-                if (lane == 0) s_cnt[wv] = __popcll(mr);
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s_cnt[u * NW + wv] = __popcll(mr[u]);
+                }
                 __syncthreads();
-                int wbase = 0, tot = 0;
-                for (int w = 0; w < kNearThreads / kWave; ++w) { const int c = s_cnt[w]; if (w < wv) wbase += c; tot += c; }
-                const int before_r = base_r + wbase + __popcll(mr & (lane == 0 ? 0ull : (~0ull >> (kWave - lane))));
-                if (in) pos[p] = right ? before_r : (p - before_r);
-                base_r += tot;
+                int run = base_r;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int wbase = 0, tot = 0;
+                    for (int w = 0; w < NW; ++w) { const int c = s_cnt[u * NW + w]; if (w < wv) wbase += c; tot += c; }
+                    const int p = p0 + u * kNearThreads + static_cast<int>(threadIdx.x);
+                    const int before_r = run + wbase + __popcll(mr[u] & (lane == 0 ? 0ull : (~0ull >> (kWave - lane))));
+                    if (p < n) pos[p] = rt[u] ? before_r : (p - before_r);
+                    run += tot;
+                }
+                base_r = run;
             }
             return;
         }

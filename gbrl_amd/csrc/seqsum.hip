@@ -226,9 +226,15 @@ __global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ 
                 ++slow;
                 float v[4];
                 seq_load(c, b0 + j, lane, v);
-                for (int l = 0; l < kWave; ++l) {
+                // sixteen elements (four lanes' worth) are read into scalars before their adds: the broadcasts do not depend on the chain
+                for (int l = 0; l < kWave; l += 4) {
+                    float x[16];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) s = s + __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v[u])), l)));
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) x[q * 4 + u] = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v[u])), l + q)));
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) s = s + x[q];
                 }
             }
         }
