@@ -145,6 +145,9 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         if (threadIdx.x == 0) {
             int run = 0;
             for (int t = 0; t < kNearThreads; ++t) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
+#ifdef GBRL_NEAR_DEBUG
+            if (run != n) printf("[near debug] node %d cand %d: bitmap holds %d rows, the node %d (seg %d, N %d)\n", node, i, run, n, seg, a.N);
+#endif
         }
         __syncthreads();
         {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
             for (int p0 = threadIdx.x; p0 < n; p0 += kNearThreads * 8) {     // eight list entries per thread in flight (two dependent round trips each)
                 int row[8], code[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) row[u] = ent[min(p0 + u * kNearThreads, n - 1)];
+                for (int u = 0; u < 8; ++u) row[u] = ent[min(p0 + u * kNearThreads, n - 1)] & 0x7fffffff;   // (the clamped lanes may see ent[n - 1] AFTER its owner has set the side bit: without the mask their class-code gather goes to a wild address)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * 16];
 #pragma unroll
