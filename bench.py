@@ -506,6 +506,89 @@ def leg_cfg3(torch, np, gbrl_amd, dev, X, G, D, depth, B, steps=6, warmup=2):
                         "kernel_ms": m.last_phase_times().get("predict", 0.0), "roofline": predict_roofline(N, F, D, T, depth, dtp)}}
 
 
+def leg_fullsize_parity(torch, np, gbrl_amd, dev):
+    """north_star's acceptance sentence, measured live: the product's tree at 2^20 x 128 against the tree the REFERENCE's own CPU path grew on
+    the same inputs (committed fixtures tests/golden/full_cfg2.npz / full_cfg3.npz, written in the build container by oracle/_ref: 835 s and
+    1230 s per tree on 8 vCPU; the 512 MiB of inputs are regenerated from the seed -- tests/golden/cases.py, exactly rounded arithmetic -- and
+    checked through their SHA-256).  Two modes: the default (exact float64 arg-max above 65 536 rows) and GBRL_HIP_NEARTIE_MAX_ROWS=0 (every
+    near-tie re-scored in the reference's float32 sequence), each with its step time (device-resident inputs)."""
+    import json as _json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as K
+    out = {}
+    tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    saved = os.environ.get("GBRL_HIP_NEARTIE_MAX_ROWS")
+    try:
+        for name in ("full_cfg2", "full_cfg3"):
+            path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+            if not os.path.exists(path):
+                out[name] = {"error": "fixture missing"}
+                continue
+            fx = np.load(path)
+            case = _json.loads(str(fx["case_json"]))
+            Xh, _, Gh, _ = K.make_inputs(case)
+            if K.inputs_digest(Xh, None, Gh, None) != str(fx["inputs_sha256"]):
+                out[name] = {"error": "regenerated inputs differ from the fixture's"}
+                continue
+            X, G = torch.from_numpy(Xh).to(dev), torch.from_numpy(Gh).to(dev)
+            rec = {"workload": "BASELINE configs[%d] at 2^20 x 128, depth 6, D = 8; reference tree from %d OpenMP threads (%.0f s)" % (1 if name == "full_cfg2" else 2, int(fx["omp_threads"]), float(fx["wall_s"]))}
+            for mode, env in (("default", None), ("near_tie_replay_everywhere", "0")):
+                if env is None:
+                    os.environ.pop("GBRL_HIP_NEARTIE_MAX_ROWS", None)
+                else:
+                    os.environ["GBRL_HIP_NEARTIE_MAX_ROWS"] = env
+                ms = []
+                for rep in range(2):     # (first: allocations)
+                    m = gbrl_amd.GBRL(**K.ctor_kwargs(case, device="cuda"))
+                    m.set_feature_weights(np.ones(case["F"], np.float32))
+                    for o in K.optimizers(case):
+                        m.set_optimizer(**o)
+                    m.set_feature_mapping(np.arange(case["F"], dtype=np.int32), np.ones(case["F"], dtype=bool))
+                    if rep:
+                        m.step(tup(X), None, tup(G)); torch.cuda.synchronize()      # warm
+                    t0 = time.perf_counter()
+                    m.step(tup(X), None, tup(G))
+                    torch.cuda.synchronize()
+                    ms.append((time.perf_counter() - t0) * 1e3)
+                    if not rep:
+                        e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items()}
+                if case["policy"] == "oblivious":
+                    d_ref, d_got = int(fx["depths"][0]), int(e["depths"][0])
+                    same = sum(1 for l in range(d_ref) if l < d_got and e["feature_indices"][0][l] == fx["feature_indices"][0][l]
+                               and bits(e["feature_values"][0][l:l + 1])[0] == bits(fx["feature_values"][0][l:l + 1])[0])
+                    r = {"levels_identical": same, "levels": d_ref}
+                    identical = same == d_ref == d_got
+                else:
+                    def nodes(a):
+                        fi, fv, dr, dp = np.asarray(a["feature_indices"]), bits(np.asarray(a["feature_values"])).reshape(np.asarray(a["feature_values"]).shape), np.asarray(a["inequality_directions"]), np.asarray(a["depths"])
+                        tab = {}
+                        for leaf in range(len(dp)):
+                            pre = ()
+                            for k in range(int(dp[leaf])):
+                                sp = (int(fi[leaf, k]), int(fv[leaf, k])); tab.setdefault(pre, sp); pre = pre + ((sp[0], sp[1], int(dr[leaf, k])),)
+                        return tab
+                    nr, ng = nodes({k: fx[k] for k in fx.files}), nodes(e)
+                    same = sum(1 for pth, sp in nr.items() if ng.get(pth) == sp)
+                    r = {"internal_nodes_identical": same, "internal_nodes": len(nr)}
+                    identical = same == len(nr) == len(ng)
+                if identical:
+                    scale = float(np.abs(Gh).mean())
+                    r["leaf_values_max_rel_err"] = float(np.max(np.abs(e["values"] - fx["values"]) / np.maximum(np.abs(fx["values"]), scale)))
+                r["structure_identical"] = bool(identical)
+                r["ms_per_step"] = ms[-1]
+                rec[mode] = r
+            out[name] = rec
+            del X, G
+            torch.cuda.empty_cache()
+    finally:
+        if saved is None:
+            os.environ.pop("GBRL_HIP_NEARTIE_MAX_ROWS", None)
+        else:
+            os.environ["GBRL_HIP_NEARTIE_MAX_ROWS"] = saved
+    return out
+
+
 def leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, trees, N=1 << 20, F=192, Fc=64, mini=4096):
     """BASELINE configs[4]: 192 numeric + 64 categorical columns (32 ASCII tokens, S128 cells), uniform candidates, an ensemble of
     `trees` oblivious depth-6 trees grown on 4096-row minibatches, predict on 2^20 rows.  The categorical input of predict is the
@@ -812,6 +895,10 @@ def main():
             extra["cfg1"] = leg_cfg1(torch, np, gbrl_amd, dev)
         except Exception as e:
             extra["cfg1"] = {"error": repr(e)}
+        try:
+            extra["full_size_parity"] = leg_fullsize_parity(torch, np, gbrl_amd, dev)
+        except Exception as e:
+            extra["full_size_parity"] = {"error": repr(e)}
 
     if rank == 0:
         steps = args.steps
@@ -858,6 +945,7 @@ def main():
                         "row_trees_per_s": world * N * n_trees / dtp, "roofline": predict_roofline(N, F, D, n_trees, depth, dtp)},
             "predict_large_ensemble": large,
             "cfg3": extra.get("cfg3"), "predict_cfg5": extra.get("predict_cfg5"), "predict_depth8": extra.get("predict_depth8"), "cfg1": extra.get("cfg1"),
+            "full_size_parity": extra.get("full_size_parity"),
             "phases_ms_per_step": {k: v / diag_steps for k, v in sorted(diag_acc.items())},
             "collective": (extra.get("collective") if coll is None else
                            {"calls_per_step": coll.calls / float(args.warmup + steps + diag_steps), "bytes_per_step": coll.bytes / float(args.warmup + steps + diag_steps)}),

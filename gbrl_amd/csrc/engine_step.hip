@@ -1888,7 +1888,7 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                     if ((oblivious || near_h[k] != 0) && (near_max_rows == 0 || nodes[active[k]].n_local <= near_max_rows)) near_largest = std::max(near_largest, nodes[active[k]].n_local);
                 // (below ~10^5 rows per node the one-lane-per-chain core is the faster one: the parallel evaluation summarises 17 N D elements
                 // per pass whatever the nodes' sizes -- profiles/r06_neartie_fullsize_cost.txt)
-                if (kern::near_tie_fast_supported(N, D) && !hooks::on(hooks::NEARTIE_SERIAL) && near_largest > (cosine ? 32768 : 98304)) {   // (the dot chains of Cosine are D times longer: the parallel evaluation pays off earlier)
+                if (kern::near_tie_fast_supported(N, D) && (reinterpret_cast<uintptr_t>(dgrads) & 15) == 0 /* float4 pieces of the gradient rows */ && !hooks::on(hooks::NEARTIE_SERIAL) && near_largest > (cosine ? 32768 : 98304)) {   // (the dot chains of Cosine are D times longer: the parallel evaluation pays off earlier)
                     // big batch, D a multiple of 4: the float32 chains are evaluated by seqsum.hip on the whole GPU (GBRL_HIP_NEARTIE_SERIAL=1: the
                     // one-lane-per-chain core of neartie_core.h, same bits -- the tests compare the two)
                     const size_t rows17 = static_cast<size_t>(kern::kNearCands + 1) * N, blocks17 = static_cast<size_t>(n_act) * (kern::kNearCands + 1);
