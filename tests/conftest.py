@@ -6,7 +6,7 @@ import sys
 # any OpenMP runtime starts.
 os.environ.setdefault("OMP_NUM_THREADS", "8")
 # Every categorical step of the test suite replays the reference's string-keyed candidate container beside the engine's
-# hash-replay of it and throws when the two iteration orders differ (engine_step.hip, device_categorical_candidates).
+# hash-replay of it and throws when the two iteration orders differ (engine_candidates.hip, device_categorical_candidates).
 os.environ.setdefault("GBRL_HIP_CAT_CHECK", "1")
 # The suite runs the PRODUCTION root mode (class counts of the root level from the radix selection's ranks, GBRL_HIP_ROOT_COUNTS unset = 1;
 # VERDICT r05 item 8).  The cross-check mode 2 (also accumulate them, compare entry by entry inside the engine, raise on a difference) is
