@@ -29,37 +29,38 @@ namespace kern {
 namespace {
 
 constexpr int kSeqBlock = 256;            // elements per summary (one wave, four per lane)
-constexpr long long kSeqBig = 1ll << 40;  // clamp of a summary's fields (anything beyond 2^25 already fails the binade check)
+constexpr int kSeqBig = 1 << 28;          // clamp of a summary's fields (anything beyond 2^25 already fails the binade check; two clamped values add without overflow)
 
-struct SeqSumm { long long d[2], lo[2], hi[2]; };   // per starting parity: total change, least and greatest partial sum (relative to the start, after >= 1 element)
+struct SeqSumm { int d[2], lo[2], hi[2]; };   // per starting parity: total change, least and greatest partial sum (relative to the start, after >= 1 element)
 
-__device__ __forceinline__ long long seq_clamp(long long v) { return v > kSeqBig ? kSeqBig : (v < -kSeqBig ? -kSeqBig : v); }
+__device__ __forceinline__ int seq_clamp(int v) { return max(-kSeqBig, min(kSeqBig, v)); }
 
-// one element under ulp exponent e (u = 2^(e - 23)): f = floor(x / u), h = 0 (fraction below a half) | 1 (above) | 2 (tie); false: not summarisable
-__device__ __forceinline__ bool seq_element(float x, int e, long long &f, int &h) {
+// one element under ulp exponent e (u = 2^(e - 23)): f = floor(x / u), h = 0 (fraction below a half) | 1 (above) | 2 (tie); false: not summarisable.
+// An element whose exponent reaches the running sum's (k <= 0) always takes the sum out of its binade (same sign: beyond 2^(e+1); opposite: below
+// 2^e or through zero), so it is not summarisable by definition -- which keeps every quantity inside 32 bits (|f| < 2^23).
+__device__ __forceinline__ bool seq_element(float x, int e, int &f, int &h) {
     const uint32_t b = __float_as_uint(x);
     const int ex = static_cast<int>((b >> 23) & 0xffu);
     if (ex == 0xff) return false;                               // inf / nan: the serial loop decides
-    const long long m = ex ? static_cast<long long>((b & 0x7fffffu) | 0x800000u) : static_cast<long long>(b & 0x7fffffu);
-    const long long sm = (b >> 31) ? -m : m;                    // x = sm * 2^(ee - 23)
+    const int m = ex ? static_cast<int>((b & 0x7fffffu) | 0x800000u) : static_cast<int>(b & 0x7fffffu);
+    const int sm = (b >> 31) ? -m : m;                          // x = sm * 2^(ee - 23)
     const int ee = ex ? ex - 127 : -126;
-    int k = e - ee;
-    if (k <= 0) {
-        if (k < -30) return false;                              // far larger than the running sum: leaves the binade anyway
-        f = sm << (-k); h = 0;
+    const int k = e - ee;
+    if (k <= 0) return false;
+    if (k >= 25) {                                              // |x| < u / 2: positive rounds away, negative floors to -1 and rounds back up
+        f = sm < 0 ? -1 : 0; h = sm < 0 ? 1 : 0;
         return true;
     }
-    if (k > 62) k = 62;                                         // (m < 2^24: every k >= 25 behaves alike)
     f = sm >> k;                                                // arithmetic shift = floor
-    const long long rem = sm - (f << k), half = 1ll << (k - 1);
+    const int rem = sm - (f << k), half = 1 << (k - 1);
     h = rem < half ? 0 : (rem > half ? 1 : 2);
     return true;
 }
-__device__ __forceinline__ SeqSumm seq_one(long long f, int h) {
+__device__ __forceinline__ SeqSumm seq_one(int f, int h) {
     SeqSumm s;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        long long t = f;
+        int t = f;
         if (h == 1) t += 1;
         else if (h == 2) t += (p + f) & 1;
         s.d[p] = t; s.lo[p] = t; s.hi[p] = t;
@@ -71,8 +72,8 @@ __device__ __forceinline__ SeqSumm seq_compose(const SeqSumm &a, const SeqSumm &
     SeqSumm r;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const long long d = a.d[p];
-        const int q = static_cast<int>((p + d) & 1);
+        const int d = a.d[p];
+        const int q = (p + d) & 1;
         r.d[p] = seq_clamp(d + b.d[q]);
         r.lo[p] = seq_clamp(min(a.lo[p], d + b.lo[q]));
         r.hi[p] = seq_clamp(max(a.hi[p], d + b.hi[q]));
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64) void k_seq_prefix(const SeqChain *__restrict__ 
 
 // summaries as six planes + the exponent they were formed under (-1000: not summarisable)
 __global__ __launch_bounds__(256) void k_seq_summary(const SeqChain *__restrict__ chains, int n_chains, uint32_t n_blocks, const double *__restrict__ blk,
-                                                     long long *__restrict__ planes /*[6][n_blocks]*/, int32_t *__restrict__ expo) {
+                                                     int32_t *__restrict__ planes /*[6][n_blocks]*/, int32_t *__restrict__ expo) {
     const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= n_blocks) return;
     const int lane = threadIdx.x & 63;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void k_seq_summary(const SeqChain *__restrict_
     bool ok = e != -1000;
     SeqSumm s{};
     if (ok) {
-        long long f; int h;
+        int f, h;
         ok = seq_element(v[0], e, f, h);
         if (ok) s = seq_one(seq_clamp(f), h);
 #pragma unroll
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_seq_summary(const SeqChain *__restrict_
     for (int o = 1; o < kWave; o <<= 1) {
         SeqSumm other;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { other.d[p] = seq_shfl_xor(s.d[p], o); other.lo[p] = seq_shfl_xor(s.lo[p], o); other.hi[p] = seq_shfl_xor(s.hi[p], o); }
+        for (int p = 0; p < 2; ++p) { other.d[p] = __shfl_xor(s.d[p], o, kWave); other.lo[p] = __shfl_xor(s.lo[p], o, kWave); other.hi[p] = __shfl_xor(s.hi[p], o, kWave); }
         s = (lane & o) ? seq_compose(other, s) : seq_compose(s, other);     // the lower lanes' elements come first
     }
     if (lane == 0) {
@@ -187,13 +188,8 @@ __global__ __launch_bounds__(256) void k_seq_summary(const SeqChain *__restrict_
     }
 }
 
-__device__ __forceinline__ long long seq_readlane64(long long v, int j) {
-    const int lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffll), j), hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), j);
-    return (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo);
-}
-
 // one wave per chain; every lane carries the same running sum (the control flow is wave-uniform)
-__global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ chains, int n_chains, uint32_t n_blocks, const long long *__restrict__ planes,
+__global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ chains, int n_chains, uint32_t n_blocks, const int32_t *__restrict__ planes,
                                                    const int32_t *__restrict__ expo, float *__restrict__ out, uint32_t *__restrict__ n_slow /*nullable: blocks added one by one*/) {
     const int ci = blockIdx.x, lane = threadIdx.x;
     if (ci >= n_chains) return;
@@ -205,7 +201,7 @@ __global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ 
         const uint32_t b = c.blk0 + b0 + lane;
         const bool in = b0 + lane < nb;
         const int my_e = in ? expo[b] : -1000;
-        long long my[6];
+        int my[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) my[q] = in ? planes[q * static_cast<size_t>(n_blocks) + b] : 0;
         const int cnt = static_cast<int>(min(static_cast<uint32_t>(kWave), nb - b0));
@@ -215,11 +211,11 @@ __global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ 
             const int sex = static_cast<int>((sb >> 23) & 0xffu);
             bool fast = false;
             if (e != -1000 && sex - 127 == e) {
-                const long long m = static_cast<long long>((sb & 0x7fffffu) | 0x800000u);
-                const long long A0 = (sb >> 31) ? -m : m;
-                const int p = static_cast<int>(A0 & 1);
-                const long long d = seq_readlane64(p ? my[1] : my[0], j), lo = seq_readlane64(p ? my[3] : my[2], j), hi = seq_readlane64(p ? my[5] : my[4], j);
-                fast = A0 > 0 ? (A0 + lo >= (1ll << 23) && A0 + hi < (1ll << 24)) : (A0 + hi <= -(1ll << 23) && A0 + lo > -(1ll << 24));
+                const int m = static_cast<int>((sb & 0x7fffffu) | 0x800000u);
+                const int A0 = (sb >> 31) ? -m : m;
+                const int p = A0 & 1;
+                const int d = __builtin_amdgcn_readlane(p ? my[1] : my[0], j), lo = __builtin_amdgcn_readlane(p ? my[3] : my[2], j), hi = __builtin_amdgcn_readlane(p ? my[5] : my[4], j);
+                fast = A0 > 0 ? (A0 + lo >= (1 << 23) && A0 + hi < (1 << 24)) : (A0 + hi <= -(1 << 23) && A0 + lo > -(1 << 24));
                 if (fast) s = ldexpf(static_cast<float>(A0 + d), e - 23);     // exact: |A0 + d| < 2^24
             }
             if (!fast) {
@@ -244,14 +240,14 @@ __global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ 
 
 }  // namespace
 
-size_t seq_sums_scratch_bytes(uint32_t n_blocks) { return static_cast<size_t>(n_blocks) * (sizeof(double) + 6 * sizeof(long long) + sizeof(int32_t)) + 256; }
+size_t seq_sums_scratch_bytes(uint32_t n_blocks) { return static_cast<size_t>(n_blocks) * (sizeof(double) + 7 * sizeof(int32_t)) + 256; }
 
 void seq_sums(const SeqChain *d_chains, int n_chains, uint32_t n_blocks, void *d_scratch, float *d_out, uint32_t *d_n_slow, hipStream_t s) {
     if (n_chains <= 0) return;
     char *base = static_cast<char *>(d_scratch);
     double *blk = reinterpret_cast<double *>(base);
-    long long *planes = reinterpret_cast<long long *>(base + static_cast<size_t>(n_blocks) * sizeof(double));
-    int32_t *expo = reinterpret_cast<int32_t *>(base + static_cast<size_t>(n_blocks) * (sizeof(double) + 6 * sizeof(long long)));
+    int32_t *planes = reinterpret_cast<int32_t *>(base + static_cast<size_t>(n_blocks) * sizeof(double));
+    int32_t *expo = planes + 6 * static_cast<size_t>(n_blocks);
     const unsigned g = (n_blocks + 3) / 4;
     if (g) hipLaunchKernelGGL(k_seq_blocksum, dim3(g), dim3(256), 0, s, d_chains, n_chains, n_blocks, blk);
     hipLaunchKernelGGL(k_seq_prefix, dim3(n_chains), dim3(64), 0, s, d_chains, n_chains, blk);
