@@ -181,7 +181,7 @@ class Engine {
     const void *leafacc_clean_ptr_ = nullptr;   // leaf accumulators known to be zero (handed back clean by the last publication)
     size_t leafacc_clean_bytes_ = 0;
     DevBuf d_codes_fm_;               // feature-major copy of the numeric class codes (kern::small_prep -> kern::small_grow)
-    DevBuf d_am_s_, d_near_list_, d_near_ent_, d_near_rep_, d_near_nr_, d_near_maps_, d_near_pos_, d_near_nrb_, d_near_vals_, d_near_means_, d_near_sums_, d_near_chains_;   // near-tie replay (kern::near_tie_replay): runner-up per arg-max block, candidate lists, ordered row lists, replayed scores
+    DevBuf d_am_s_, d_near_list_, d_near_ent_, d_near_rep_, d_near_nr_, d_near_maps_, d_near_pos_, d_near_nrb_, d_near_vals_, d_near_means_, d_near_sums_, d_near_chains_, d_near_rowsort_, d_near_tiles_;   // near-tie replay (kern::near_tie_replay): runner-up per arg-max block, candidate lists, ordered row lists, replayed scores
     bool force_level_loop_ = false;   // grow_tree: the one-launch kernel met a near-tie and handed the tree to the level loop
     bool small_grow_off_ = false;     // latched after a failed launch / an abandoned grid barrier of the one-launch kernel: this engine keeps to the level loop
     long long small_grow_fallbacks_ = 0;   // trees the level loop grew after such a failure (diagnostics)

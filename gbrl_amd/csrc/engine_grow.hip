@@ -866,6 +866,8 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
                     io.vals = static_cast<float *>(d_near_vals_.ensure(sizeof(float) * rows17 * D));
                     io.means = static_cast<float *>(d_near_means_.ensure(sizeof(float) * blocks17 * 2 * D));
                     io.sums = static_cast<float *>(d_near_sums_.ensure(sizeof(float) * blocks17 * 2 * D));
+                    io.rowsort = static_cast<int32_t *>(d_near_rowsort_.ensure(sizeof(int32_t) * static_cast<size_t>(N)));
+                    io.tiles = static_cast<int32_t *>(d_near_tiles_.ensure(sizeof(int32_t) * kern::near_tie_fast_tiles(N, n_act)));
                     io.seq_blocks = kern::near_tie_fast_blocks(N, D, n_act);
                     io.chains_bytes = kern::near_tie_fast_chain_bytes(N, D, n_act);
                     io.chains = d_near_chains_.ensure(io.chains_bytes);

@@ -311,6 +311,8 @@ struct NearTieIO {
     int fast;                   // 1: k_near_replay only orders the rows; the fill / chain / finish kernels do the rest
     int32_t *pos;               // scratch [(kNearCands + 1) * N]: a listed row's place among the rows of its side
     int32_t *nr;                // scratch [n_act][kNearCands + 1]: rows going right (-1: block not replayed)
+    int32_t *rowsort;           // scratch [N]: every replayed node's rows in ascending order (one list per node, shared by its candidates)
+    int32_t *tiles;             // scratch [near_tie_fast_tiles]: per 2048-entry tile of a (node, candidate) list: rows going right, then their exclusive prefix
     float *vals;                // scratch [(kNearCands + 1) * N * D]: the chains' elements (column-major per side, then the dot chains' products)
     float *means;               // scratch [n_act][kNearCands + 1][2][D]
     float *sums;                // scratch [n_act][kNearCands + 1][2][D]: chain results (pass 1: per column; pass 2: [side][0])
@@ -324,6 +326,7 @@ size_t near_tie_map_words(int N, int n_act);   // 0 when the batch fits the LDS 
 bool near_tie_fast_supported(int N, int D);     // big batch, D a multiple of 4: chains through seqsum.hip
 uint32_t near_tie_fast_blocks(int N, int D, int n_act);
 size_t near_tie_fast_chain_bytes(int N, int D, int n_act);
+size_t near_tie_fast_tiles(int N, int n_act);
 bool near_tie_supported(int N, int D);
 void near_tie_replay(const NearTieIO &io, hipStream_t s);
 // diagnostics (gbrl_hip_replay_scores): one node given by per-row flags, host pointers; out[0] = split score, out[1] = parent score

@@ -181,44 +181,6 @@ __global__ __launch_bounds__(kNearThreads) void k_near_replay(NearTieIO a) {
         for (int o = kNearThreads / 2; o > 0; o >>= 1) { if (static_cast<int>(threadIdx.x) < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
         const int n_r = s_cnt[0], n_l = n - n_r;
         __syncthreads();
-        if (a.fast) {
-            // round 6: only the order is produced here -- every listed row's place among the rows of its side -- and the chains are evaluated on
-            // the whole GPU (k_near_fill1 / seq_sums / k_near_means / k_near_fill2 / seq_sums / k_near_finish)
-            if (threadIdx.x == 0) a.nr[static_cast<size_t>(node) * (kNearCands + 1) + i] = n_r;
-            int32_t *pos = a.pos + static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
-            int base_r = 0;
-            const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-            constexpr int NW = kNearThreads / kWave;
-            for (int p0 = 0; p0 < n; p0 += kNearThreads * 4) {      // 1024 entries per pair of barriers, four loads per thread in flight
-                unsigned long long mr[4];
-                bool rt[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + u * kNearThreads + static_cast<int>(threadIdx.x);
-                    rt[u] = p < n && (static_cast<uint32_t>(ent[min(p, n - 1)]) >> 31) != 0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) mr[u] = __ballot(rt[u]);
-                __syncthreads();
-                if (lane == 0) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) s_cnt[u * NW + wv] = __popcll(mr[u]);
-                }
-                __syncthreads();
-                int run = base_r;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int wbase = 0, tot = 0;
-                    for (int w = 0; w < NW; ++w) { const int c = s_cnt[u * NW + w]; if (w < wv) wbase += c; tot += c; }
-                    const int p = p0 + u * kNearThreads + static_cast<int>(threadIdx.x);
-                    const int before_r = run + wbase + __popcll(mr[u] & (lane == 0 ? 0ull : (~0ull >> (kWave - lane))));
-                    if (p < n) pos[p] = rt[u] ? before_r : (p - before_r);
-                    run += tot;
-                }
-                base_r = run;
-            }
-            return;
-        }
         if (!is_parent && (n_l < a.min_data || n_r < a.min_data)) { if (threadIdx.x == 0) *out = -INFINITY; return; }   // node.cpp:354
         const NearGrads ng{a.grads, a.meanden, a.D};
         const float res = near_replay_core(ent, n, n_r, ng, a.cosine != 0, is_parent, reinterpret_cast<uint32_t *>(lds), kNearBigTile, kNearBigTileRows);
@@ -298,13 +260,133 @@ __global__ __launch_bounds__(kNearThreads) void k_near_rowmaps_set(NearTieIO a) 
     }
 }
 
+// ---- round 6: the ORDER of a big node's rows on the whole GPU (the one-lane core's ordering stage redid the bitmap scan in each of a node's 17
+// candidate blocks and ranked the places with a pair of barriers per 1024 entries: 1.5 ms per level) ------------------------------------------
+constexpr int kNearTileEnt = 2048;
+__device__ __forceinline__ bool near_block_active(const NearTieIO &a, int node, int i) {
+    const int lnode = a.oblivious ? 0 : node;
+    if (a.near[lnode] == 0 || a.list_n[lnode] <= 0) return false;
+    return i == kNearCands ? !(a.oblivious || a.is_root[node]) : i < a.list_n[lnode];
+}
+__device__ __forceinline__ size_t near_tile0(const NearTieIO &a, int node, int i) {    // first tile of block (node, i) in a.tiles; the blocks' tile ranges do not overlap
+    return (static_cast<size_t>(a.seg_start[node]) * (kNearCands + 1) + static_cast<size_t>(i) * a.n_rows[node]) / kNearTileEnt + static_cast<size_t>(node) * (kNearCands + 1) + i;
+}
+// one block per node: the node's bitmap -> its rows in ascending order (once, for all its candidates)
+__global__ __launch_bounds__(1024) void k_near_rows(NearTieIO a) {
+    const int node = blockIdx.x;
+    const int lnode = a.oblivious ? 0 : node;
+    if (a.near[lnode] == 0 || a.list_n[lnode] <= 0) return;
+    __shared__ int s_c[1024];
+    const uint32_t *gmap = a.maps + static_cast<size_t>(node) * ((static_cast<size_t>(a.N) + 31) >> 5);
+    const int n_words = (a.N + 31) >> 5, per = (n_words + 1023) / 1024;
+    const int w0 = min(n_words, static_cast<int>(threadIdx.x) * per), w1 = min(n_words, w0 + per);
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) cnt += __popc(gmap[w]);
+    s_c[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const int v = static_cast<int>(threadIdx.x) >= o ? s_c[threadIdx.x - o] : 0; __syncthreads(); s_c[threadIdx.x] += v; __syncthreads(); }
+    int pos = s_c[threadIdx.x] - cnt;
+    int32_t *out = a.rowsort + a.seg_start[node];
+    for (int w = w0; w < w1; ++w) {
+        uint32_t m = gmap[w];
+        while (m) { const int b = __ffs(m) - 1; m &= m - 1; out[pos++] = (w << 5) + b; }
+    }
+}
+// grid (tiles, kNearCands + 1, n_act): the side of every listed row, its rank among the tile's right rows (parked in a.pos), the tile's count
+__global__ __launch_bounds__(256) void k_near_sides(NearTieIO a) {
+    const int node = blockIdx.z, i = blockIdx.y;
+    if (!near_block_active(a, node, i)) return;
+    const bool is_parent = i == kNearCands;
+    const int n = a.n_rows[node], seg = a.seg_start[node];
+    int fs = 0, bin = -1, is_cat = 0;
+    if (!is_parent) {
+        const int j = a.list[static_cast<size_t>(a.oblivious ? 0 : node) * kNearCands + i];
+        fs = a.cand_slot[j];
+        const FeatureSlot sl = a.slots[fs];
+        is_cat = sl.is_cat;
+        bin = is_cat ? (j - sl.cand_base + 1) : (j - sl.cand_base);
+    }
+    const uint16_t *cbase = a.codes + (static_cast<size_t>(fs >> 4) * a.N) * 16 + (fs & 15);
+    const size_t off = static_cast<size_t>(seg) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+    int32_t *ent = a.ent + off, *pos = a.pos + off;
+    const int32_t *rows = a.rowsort + seg;
+    const size_t t0 = near_tile0(a, node, i);
+    __shared__ int s_c[8 * 4];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    for (int t = blockIdx.x; t * kNearTileEnt < n; t += gridDim.x) {
+        int row[8], code[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row[u] = rows[min(t * kNearTileEnt + u * 256 + static_cast<int>(threadIdx.x), n - 1)];
+        if (!is_parent) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) code[u] = cbase[static_cast<size_t>(row[u]) * 16];
+        }
+        unsigned long long mr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = t * kNearTileEnt + u * 256 + static_cast<int>(threadIdx.x);
+            const bool right = !is_parent && p < n && (is_cat ? (code[u] == bin) : (code[u] > bin));
+            mr[u] = __ballot(right);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s_c[u * 4 + wv] = __popcll(mr[u]);
+        }
+        __syncthreads();
+        int run = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int wbase = 0, tot = 0;
+            for (int w = 0; w < 4; ++w) { const int c = s_c[u * 4 + w]; if (w < wv) wbase += c; tot += c; }
+            const int p = t * kNearTileEnt + u * 256 + static_cast<int>(threadIdx.x);
+            const bool right = (mr[u] >> lane) & 1ull;
+            if (p < n) {
+                ent[p] = row[u] | (right ? static_cast<int32_t>(0x80000000u) : 0);
+                pos[p] = run + wbase + __popcll(mr[u] & (lane == 0 ? 0ull : (~0ull >> (kWave - lane))));      // right rows of the tile in front of p
+            }
+            run += tot;
+        }
+        if (threadIdx.x == 0) a.tiles[t0 + t] = run;
+    }
+}
+// grid (kNearCands + 1, n_act), one wave: exclusive prefix over the block's tiles; the total is the block's number of right rows
+__global__ __launch_bounds__(64) void k_near_tilescan(NearTieIO a) {
+    const int node = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+    int32_t *nr = a.nr + static_cast<size_t>(node) * (kNearCands + 1) + i;
+    if (!near_block_active(a, node, i)) { if (lane == 0) *nr = -1; return; }
+    const int n = a.n_rows[node], n_tiles = (n + kNearTileEnt - 1) / kNearTileEnt;
+    int32_t *tl = a.tiles + near_tile0(a, node, i);
+    int carry = 0;
+    for (int b0 = 0; b0 < n_tiles; b0 += kWave) {
+        const int b = b0 + lane;
+        const int c = b < n_tiles ? tl[b] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(inc, o, kWave); if (lane >= o) inc += up; }
+        if (b < n_tiles) tl[b] = carry + inc - c;
+        carry += __shfl(inc, kWave - 1, kWave);
+    }
+    if (lane == 0) *nr = carry;
+}
+// grid (tiles, kNearCands + 1, n_act): a listed row's place among the rows of its side
+__global__ __launch_bounds__(256) void k_near_places(NearTieIO a) {
+    const int node = blockIdx.z, i = blockIdx.y;
+    if (!near_block_active(a, node, i)) return;
+    const int n = a.n_rows[node];
+    const size_t off = static_cast<size_t>(a.seg_start[node]) * (kNearCands + 1) + static_cast<size_t>(i) * n;
+    const int32_t *ent = a.ent + off;
+    int32_t *pos = a.pos + off;
+    const int32_t *tl = a.tiles + near_tile0(a, node, i);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const int before_r = tl[p / kNearTileEnt] + pos[p];
+        pos[p] = (static_cast<uint32_t>(ent[p]) >> 31) ? before_r : p - before_r;
+    }
+}
+
 // ---- round 6: the chains of a big node on the whole GPU (seqsum.hip) ---------------------------------------------------------------------
 // (node, i) = block of the replay; its n rows own a region of n * D floats in a.vals: [right: D columns of n_r | left: D columns of n_l], and for
 // the dot chains afterwards [right: n_r rows of D products | left: n_l rows].  Chain index = ((node * 17 + i) * 2 + side) * D + c.
-__global__ __launch_bounds__(256) void k_near_nr_clear(NearTieIO a) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < a.n_act * (kNearCands + 1)) a.nr[t] = -1;
-}
 // one block: the chain table of a pass (pass 1: one chain per (block, side, column); pass 2: per (block, side)), blocks numbered by a running prefix
 __global__ __launch_bounds__(1024) void k_near_chains(NearTieIO a, int pass) {
     SeqChain *ch = static_cast<SeqChain *>(a.chains);
@@ -492,6 +574,7 @@ uint32_t near_tie_fast_blocks(int N, int D, int n_act) {
 size_t near_tie_fast_chain_bytes(int N, int D, int n_act) {
     return 256 * ((sizeof(SeqChain) * static_cast<size_t>(n_act) * (kNearCands + 1) * 2 * D + 255) / 256) + seq_sums_scratch_bytes(near_tie_fast_blocks(N, D, n_act));
 }
+size_t near_tie_fast_tiles(int N, int n_act) { return static_cast<size_t>(kNearCands + 1) * N / kNearTileEnt + static_cast<size_t>(n_act) * (kNearCands + 1) * 2 + 4; }
 size_t near_tie_map_words(int N, int n_act) { return N > kNearMaxRows ? ((static_cast<size_t>(N) + 31) >> 5) * static_cast<size_t>(std::max(1, n_act)) : 0; }
 
 void near_tie_replay(const NearTieIO &io, hipStream_t s) {
@@ -508,10 +591,16 @@ void near_tie_replay(const NearTieIO &io, hipStream_t s) {
         static PerDeviceOnce attr;
         if (attr.first() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_near_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); attr.done = 0; }
     }
-    if (io.fast) hipLaunchKernelGGL(k_near_nr_clear, dim3((io.n_act * (kNearCands + 1) + 255) / 256), dim3(256), 0, s, io);
-    hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
+    if (!io.fast) hipLaunchKernelGGL(k_near_replay, dim3(kNearCands + 1, io.n_act), dim3(kNearThreads), lds, s, io);
     if (io.fast) {
         const int n_blk = io.n_act * (kNearCands + 1), D = io.D;
+        {   // the order: rows once per node, then sides / places of every (node, candidate) list with the whole GPU
+            const unsigned tl = static_cast<unsigned>(std::min(512, std::max(1, (io.N + kNearTileEnt - 1) / kNearTileEnt)));
+            hipLaunchKernelGGL(k_near_rows, dim3(io.n_act), dim3(1024), 0, s, io);
+            hipLaunchKernelGGL(k_near_sides, dim3(tl, kNearCands + 1, io.n_act), dim3(256), 0, s, io);
+            hipLaunchKernelGGL(k_near_tilescan, dim3(kNearCands + 1, io.n_act), dim3(64), 0, s, io);
+            hipLaunchKernelGGL(k_near_places, dim3(tl, kNearCands + 1, io.n_act), dim3(256), 0, s, io);
+        }
         SeqChain *chains = static_cast<SeqChain *>(io.chains);
         const size_t table = 256 * ((sizeof(SeqChain) * static_cast<size_t>(n_blk) * 2 * D + 255) / 256);
         void *seq_scratch = static_cast<char *>(io.chains) + table;
