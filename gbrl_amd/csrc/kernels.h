@@ -308,7 +308,8 @@ struct NearTieIO {
     int32_t *part_i;
     int n_parts;
     // N > kNearMaxRows and D % 4 == 0 (round 6): the chains are evaluated by seqsum.hip on the whole GPU instead of one lane per chain
-    int fast;                   // 1: k_near_replay only orders the rows; the fill / chain / finish kernels do the rest
+    int lvl_ready;              // oblivious: the level scores of all candidates already sit in `ent` (k_near_level_scores ran: big levels)
+    int fast;                   // 1: the order, the chains and the scores are produced by the whole GPU (k_near_rows .. k_near_finish)
     int32_t *pos;               // scratch [(kNearCands + 1) * N]: a listed row's place among the rows of its side
     int32_t *nr;                // scratch [n_act][kNearCands + 1]: rows going right (-1: block not replayed)
     int32_t *rowsort;           // scratch [N]: every replayed node's rows in ascending order (one list per node, shared by its candidates)

@@ -188,7 +188,24 @@ __global__ __launch_bounds__(256) void k_seq_summary(const SeqChain *__restrict_
     }
 }
 
-// one wave per chain; every lane carries the same running sum (the control flow is wave-uniform)
+// Does the running sum s (normal, exponent e) stay inside its binade through a run summarised by (d, lo, hi)[parity]?  If so apply it.
+__device__ __forceinline__ bool seq_apply(float &s, int e, int d0, int d1, int lo0, int lo1, int hi0, int hi1) {
+    const uint32_t sb = __float_as_uint(s);
+    if (static_cast<int>((sb >> 23) & 0xffu) - 127 != e) return false;
+    const int m = static_cast<int>((sb & 0x7fffffu) | 0x800000u);
+    const int A0 = (sb >> 31) ? -m : m;
+    const bool odd = (A0 & 1) != 0;
+    const int d = odd ? d1 : d0, lo = odd ? lo1 : lo0, hi = odd ? hi1 : hi0;
+    const bool ok = A0 > 0 ? (A0 + lo >= (1 << 23) && A0 + hi < (1 << 24)) : (A0 + hi <= -(1 << 23) && A0 + lo > -(1 << 24));
+    if (ok) s = ldexpf(static_cast<float>(A0 + d), e - 23);     // exact: |A0 + d| < 2^24
+    return ok;
+}
+
+// one wave per chain; every lane carries the same running sum (the control flow is wave-uniform).  Two levels: the summaries of 16 consecutive
+// blocks formed under ONE exponent are composed (they are the same kind of function) and tried first -- a chain that drifts away from zero (a
+// dot chain, a column with a mean) crosses a power of two a few dozen times in 2^20 elements and takes 4096 elements per step in between; a
+// group that fails is walked block by block, a block that fails element by element.
+constexpr int kSeqGroup = 16;
 __global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ chains, int n_chains, uint32_t n_blocks, const int32_t *__restrict__ planes,
                                                    const int32_t *__restrict__ expo, float *__restrict__ out, uint32_t *__restrict__ n_slow /*nullable: blocks added one by one*/) {
     const int ci = blockIdx.x, lane = threadIdx.x;
@@ -200,38 +217,56 @@ __global__ __launch_bounds__(64) void k_seq_stitch(const SeqChain *__restrict__ 
     for (uint32_t b0 = 0; b0 < nb; b0 += kWave) {
         const uint32_t b = c.blk0 + b0 + lane;
         const bool in = b0 + lane < nb;
-        const int my_e = in ? expo[b] : -1000;
-        int my[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) my[q] = in ? planes[q * static_cast<size_t>(n_blocks) + b] : 0;
         const int cnt = static_cast<int>(min(static_cast<uint32_t>(kWave), nb - b0));
-        for (int j = 0; j < cnt; ++j) {
-            const int e = __builtin_amdgcn_readlane(my_e, j);
-            const uint32_t sb = __float_as_uint(s);
-            const int sex = static_cast<int>((sb >> 23) & 0xffu);
-            bool fast = false;
-            if (e != -1000 && sex - 127 == e) {
-                const int m = static_cast<int>((sb & 0x7fffffu) | 0x800000u);
-                const int A0 = (sb >> 31) ? -m : m;
-                const int p = A0 & 1;
-                const int d = __builtin_amdgcn_readlane(p ? my[1] : my[0], j), lo = __builtin_amdgcn_readlane(p ? my[3] : my[2], j), hi = __builtin_amdgcn_readlane(p ? my[5] : my[4], j);
-                fast = A0 > 0 ? (A0 + lo >= (1 << 23) && A0 + hi < (1 << 24)) : (A0 + hi <= -(1 << 23) && A0 + lo > -(1 << 24));
-                if (fast) s = ldexpf(static_cast<float>(A0 + d), e - 23);     // exact: |A0 + d| < 2^24
-            }
-            if (!fast) {
-                ++slow;
-                float v[4];
-                seq_load(c, b0 + j, lane, v);
-                // sixteen elements (four lanes' worth) are read into scalars before their adds: the broadcasts do not depend on the chain
-                for (int l = 0; l < kWave; l += 4) {
-                    float x[16];
+        int my_e = in ? expo[b] : -1000;
+        SeqSumm mine;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+        for (int p = 0; p < 2; ++p) {
+            mine.d[p] = in ? planes[(0 + p) * static_cast<size_t>(n_blocks) + b] : 0;
+            mine.lo[p] = in ? planes[(2 + p) * static_cast<size_t>(n_blocks) + b] : kSeqBig;       // (beyond the chain's end: the identity)
+            mine.hi[p] = in ? planes[(4 + p) * static_cast<size_t>(n_blocks) + b] : -kSeqBig;
+        }
+        if (!in) my_e = __builtin_amdgcn_readlane(my_e, cnt - 1);       // the padding takes the last block's exponent: it must not break a group
+        // the groups' summaries: an ordered composition inside every 16-lane segment; valid when the 16 exponents agree
+        SeqSumm grp = mine;
+        int g_ok = my_e != -1000 ? 1 : 0;
+        for (int o = 1; o < kSeqGroup; o <<= 1) {
+            SeqSumm other;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) x[q * 4 + u] = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v[u])), l + q)));
+            for (int p = 0; p < 2; ++p) { other.d[p] = __shfl_xor(grp.d[p], o, kWave); other.lo[p] = __shfl_xor(grp.lo[p], o, kWave); other.hi[p] = __shfl_xor(grp.hi[p], o, kWave); }
+            const int oe = __shfl_xor(my_e, o, kWave), ook = __shfl_xor(g_ok, o, kWave);
+            g_ok = g_ok & ook & (oe == my_e ? 1 : 0);
+            grp = (lane & o) ? seq_compose(other, grp) : seq_compose(grp, other);
+        }
+        for (int g0 = 0; g0 < cnt; g0 += kSeqGroup) {
+            const int ge = __builtin_amdgcn_readlane(my_e, g0);
+            if (__builtin_amdgcn_readlane(g_ok, g0) &&
+                seq_apply(s, ge, __builtin_amdgcn_readlane(grp.d[0], g0), __builtin_amdgcn_readlane(grp.d[1], g0), __builtin_amdgcn_readlane(grp.lo[0], g0),
+                          __builtin_amdgcn_readlane(grp.lo[1], g0), __builtin_amdgcn_readlane(grp.hi[0], g0), __builtin_amdgcn_readlane(grp.hi[1], g0)))
+                continue;
+            const int g1 = min(cnt, g0 + kSeqGroup);
+            float v[4], vn[4];
+            seq_load(c, b0 + g0, lane, v);           // the elements of the block being tried, and of the next one, travel while the summaries are tried
+            for (int j = g0; j < g1; ++j) {
+                if (j + 1 < g1) seq_load(c, b0 + j + 1, lane, vn);
+                const int e = __builtin_amdgcn_readlane(my_e, j);
+                const bool fast = e != -1000 && seq_apply(s, e, __builtin_amdgcn_readlane(mine.d[0], j), __builtin_amdgcn_readlane(mine.d[1], j), __builtin_amdgcn_readlane(mine.lo[0], j),
+                                                          __builtin_amdgcn_readlane(mine.lo[1], j), __builtin_amdgcn_readlane(mine.hi[0], j), __builtin_amdgcn_readlane(mine.hi[1], j));
+                if (!fast) {
+                    ++slow;
+                    // sixteen elements (four lanes' worth) are read into scalars before their adds: the broadcasts do not depend on the chain
+                    for (int l = 0; l < kWave; l += 4) {
+                        float x[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) s = s + x[q];
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) x[q * 4 + u] = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v[u])), l + q)));
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) s = s + x[q];
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = vn[u];
             }
         }
     }
