@@ -278,21 +278,29 @@ __device__ __forceinline__ bool near_block_active(const NearTieIO &a, int node, 
 __device__ __forceinline__ size_t near_tile0(const NearTieIO &a, int node, int i) {    // first tile of block (node, i) in a.tiles; the blocks' tile ranges do not overlap
     return (static_cast<size_t>(a.seg_start[node]) * (kNearCands + 1) + static_cast<size_t>(i) * a.n_rows[node]) / kNearTileEnt + static_cast<size_t>(node) * (kNearCands + 1) + i;
 }
-// one block per node: the node's bitmap -> its rows in ascending order (once, for all its candidates)
-__global__ __launch_bounds__(1024) void k_near_rows(NearTieIO a) {
-    const int node = blockIdx.x;
+// grid (kNearRowRanges, n_act), two launches: the node's bitmap -> its rows in ascending order (once, for all its candidates).  Pass 0 counts the
+// set bits of every range of words into a.tiles (free until k_near_sides), pass 1 emits behind the ranges in front (one block per node took
+// 0.6 ms for a 2^20-row root).
+constexpr int kNearRowRanges = 64;
+__global__ __launch_bounds__(256) void k_near_rows(NearTieIO a, int pass) {
+    const int node = blockIdx.y, r = blockIdx.x;
     const int lnode = a.oblivious ? 0 : node;
     if (a.near[lnode] == 0 || a.list_n[lnode] <= 0) return;
-    __shared__ int s_c[1024];
+    __shared__ int s_c[256];
     const uint32_t *gmap = a.maps + static_cast<size_t>(node) * ((static_cast<size_t>(a.N) + 31) >> 5);
-    const int n_words = (a.N + 31) >> 5, per = (n_words + 1023) / 1024;
-    const int w0 = min(n_words, static_cast<int>(threadIdx.x) * per), w1 = min(n_words, w0 + per);
+    const int n_words = (a.N + 31) >> 5, per_r = (n_words + kNearRowRanges - 1) / kNearRowRanges;
+    const int r0 = min(n_words, r * per_r), r1 = min(n_words, r0 + per_r);
+    const int per = (r1 - r0 + 255) / 256;
+    const int w0 = min(r1, r0 + static_cast<int>(threadIdx.x) * per), w1 = min(r1, w0 + per);
     int cnt = 0;
     for (int w = w0; w < w1; ++w) cnt += __popc(gmap[w]);
     s_c[threadIdx.x] = cnt;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) { const int v = static_cast<int>(threadIdx.x) >= o ? s_c[threadIdx.x - o] : 0; __syncthreads(); s_c[threadIdx.x] += v; __syncthreads(); }
+    for (int o = 1; o < 256; o <<= 1) { const int v = static_cast<int>(threadIdx.x) >= o ? s_c[threadIdx.x - o] : 0; __syncthreads(); s_c[threadIdx.x] += v; __syncthreads(); }
+    int32_t *cnts = a.tiles + static_cast<size_t>(node) * kNearRowRanges;
+    if (pass == 0) { if (threadIdx.x == 255) cnts[r] = s_c[255]; return; }
     int pos = s_c[threadIdx.x] - cnt;
+    for (int q = 0; q < r; ++q) pos += cnts[q];
     int32_t *out = a.rowsort + a.seg_start[node];
     for (int w = w0; w < w1; ++w) {
         uint32_t m = gmap[w];
@@ -581,7 +589,7 @@ uint32_t near_tie_fast_blocks(int N, int D, int n_act) {
 size_t near_tie_fast_chain_bytes(int N, int D, int n_act) {
     return 256 * ((sizeof(SeqChain) * static_cast<size_t>(n_act) * (kNearCands + 1) * 2 * D + 255) / 256) + seq_sums_scratch_bytes(near_tie_fast_blocks(N, D, n_act));
 }
-size_t near_tie_fast_tiles(int N, int n_act) { return static_cast<size_t>(kNearCands + 1) * N / kNearTileEnt + static_cast<size_t>(n_act) * (kNearCands + 1) * 2 + 4; }
+size_t near_tie_fast_tiles(int N, int n_act) { return std::max(static_cast<size_t>(kNearCands + 1) * N / kNearTileEnt + static_cast<size_t>(n_act) * (kNearCands + 1) * 2 + 4, static_cast<size_t>(n_act) * kNearRowRanges); }
 size_t near_tie_map_words(int N, int n_act) { return N > kNearMaxRows ? ((static_cast<size_t>(N) + 31) >> 5) * static_cast<size_t>(std::max(1, n_act)) : 0; }
 
 void near_tie_replay(const NearTieIO &io, hipStream_t s) {
@@ -608,7 +616,8 @@ void near_tie_replay(const NearTieIO &io, hipStream_t s) {
         const int n_blk = io.n_act * (kNearCands + 1), D = io.D;
         {   // the order: rows once per node, then sides / places of every (node, candidate) list with the whole GPU
             const unsigned tl = static_cast<unsigned>(std::min(512, std::max(1, (io.N + kNearTileEnt - 1) / kNearTileEnt)));
-            hipLaunchKernelGGL(k_near_rows, dim3(io.n_act), dim3(1024), 0, s, io);
+            hipLaunchKernelGGL(k_near_rows, dim3(kNearRowRanges, io.n_act), dim3(256), 0, s, io, 0);
+            hipLaunchKernelGGL(k_near_rows, dim3(kNearRowRanges, io.n_act), dim3(256), 0, s, io, 1);
             hipLaunchKernelGGL(k_near_sides, dim3(tl, kNearCands + 1, io.n_act), dim3(256), 0, s, io);
             hipLaunchKernelGGL(k_near_tilescan, dim3(kNearCands + 1, io.n_act), dim3(64), 0, s, io);
             hipLaunchKernelGGL(k_near_places, dim3(tl, kNearCands + 1, io.n_act), dim3(256), 0, s, io);
