@@ -7,7 +7,7 @@ seed (integer PCG64 draws + exactly rounded float32 arithmetic only) and checked
 
 Bar: bit-identical structure.  Two modes:
   * GBRL_HIP_NEARTIE_MAX_ROWS=0 -- every flagged node re-scored in the reference's float32 operation sequence (serial chains over up to 2^20
-    rows; evaluated in parallel by seqsum.hip: 15-23 ms per tree): configs[1] 6 of 6 levels, configs[2] 63 of 63 internal nodes, both asserted exactly;
+    rows; evaluated in parallel by seqsum.hip: 14-22 ms per tree): configs[1] 6 of 6 levels, configs[2] 63 of 63 internal nodes, both asserted exactly;
   * default -- batches above 65 536 rows keep the exact float64 arg-max (1.9 ms per tree): configs[1] 6 of 6; configs[2] 22 of 63 -- the
     reference's float32 noise (4e-5 relative at a 522 256-row node) prefers a neighbouring threshold whose true score is 5e-6 lower, and the
     41 nodes below it sit on another partition.  Where a level / node differs, the float64 scores of both candidates on the node's rows are
