@@ -95,3 +95,29 @@ def test_two_ranks_grow_the_trees_of_one_process_on_the_same_rows(tmp_path):
     assert len(ea["tree_indices"]) == 3
     for k in ea.files:
         assert np.array_equal(ea[k], eb[k]), k
+
+
+@pytest.mark.gpu
+def test_the_bench_line_keeps_its_contract():
+    """One JSON line with the driver's keys, the `roofline` object of the dominant kernel and the `cpu_baseline` object (kind "reference" or
+    "port", cores, sample), at a reduced shape so that the test takes seconds (the numbers are not the headline's)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--rows", "131072", "--features", "32",
+                          "--no-extra-legs", "--large-ensemble", "0", "--cpu-sample-rows", "4096"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE json line on stdout"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 3 * (131072 / float(1 << 20)) / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
