@@ -248,3 +248,37 @@ def test_near_ties_above_65536_rows_follow_the_reference_on_request(name, monkey
     assert why and why["explained"] and why["product_is_true_max"], why
     small_node = {"bign30": True, "bign162": True, "bign356": True, "bign9": False, "bign156": False}[name]   # deciding node <= 65 536 rows?
     assert same(grow(65536)) == small_node
+
+
+@pytest.mark.parametrize("policy,score,D,Fc", [("greedy", "Cosine", 4, 1), ("oblivious", "L2", 8, 1), ("greedy", "L2", 12, 0), ("oblivious", "Cosine", 4, 1), ("greedy", "Cosine", 6, 0)])
+def test_big_batch_replay_parallel_chains_equal_the_one_lane_core(policy, score, D, Fc, monkeypatch):
+    """Batches above 65 536 rows with every near-tie replayed, through seqsum.hip's parallel chains and through the one-lane core
+    (GBRL_HIP_NEARTIE_SERIAL=1): the same bytes.  The inputs are built to BE near-ties: a step signal on column 0, column 1 a copy of column 0
+    with 1e-4 of noise (its thresholds cut the rows a few places away from column 0's), and -- Fc = 1 -- a categorical column that says on which
+    side of a nearby value column 0 lies (the side test of a category is `code == class`).  Widths that are and are not multiples of 4 (D = 6:
+    the parallel evaluation declines and both runs take the core).  The replay counter must say that levels were replayed."""
+    import gbrl_amd
+    rng = np.random.default_rng(200 + D)
+    N, F = 150000 + 1000 * D, 4
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    X[:, 1] = (X[:, 0] + 1e-4 * rng.standard_normal(N)).astype(np.float32)
+    step = np.where(X[:, 0] > 0.1, 1.0, -1.0)
+    G = (step[:, None] * rng.uniform(0.5, 1.5, D)[None, :] + 2.0 * rng.standard_normal((N, D)) + 0.2).astype(np.float32)
+    Xc = None
+    if Fc:
+        Xc = np.where(X[:, 0] > 0.1003, K.TOKENS[1], K.TOKENS[0]).reshape(N, 1).astype("S128")
+    case = dict(name="bigrep", seed=0, N=N, F=F, Fc=Fc, D=D, depth=3, n_bins=256, score=score, gen="Quantile", policy=policy, trees=1)
+    out = []
+    for serial in ("0", "1"):
+        monkeypatch.delenv("GBRL_HIP_NO_NEARTIE_REPLAY", raising=False)
+        monkeypatch.setenv("GBRL_HIP_NEARTIE_MAX_ROWS", "0")
+        monkeypatch.setenv("GBRL_HIP_NEARTIE_SERIAL", serial)
+        m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
+        m.set_profiling(2)
+        K.drive(m, case, X, Xc, G, None)
+        m.step(X, Xc, np.ascontiguousarray(G))
+        out.append(({k: np.asarray(v) for k, v in m.get_ensemble_data().items()}, dict(m.last_phase_times()).get("near_replays", 0)))
+    (a, ra), (b, rb) = out
+    assert ra == rb and ra >= 1, (ra, rb)
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), k
