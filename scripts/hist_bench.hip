@@ -4,7 +4,9 @@
 //   2 non-temporal class-code loads;  3 16-bit gradient records (the harness then reads the int32 array as int16 pairs: timing only);
 //   4 PAIR layout of the class codes (round 4): the 32-byte records of groups 2p and 2p+1 of a row share one 64-byte sector
 //     ([pair][row][2][16] instead of [group][row][16]) -- timing only: the same buffer read at other addresses, modulo the class count
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gbrl_amd/csrc [-DVARIANT=n] scripts/hist_bench.hip -o scripts/bin/hist_bench
+//   5 ROW-MAJOR layout (round 6): [row][128] uint16 -- a gathered row's eight 32-byte records are the two 128-byte lines of that row, shared by the
+//     eight group blocks of a chunk through their XCD's L2, instead of one line per group with three other rows' records in it -- timing only
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gbrl_amd/csrc [-DVARIANT=n] scripts/hist_bench.hip gbrl_amd/csrc/hooks.cpp -o scripts/bin/hist_bench
 #include "../gbrl_amd/csrc/kernels.hip"
 #ifndef VARIANT
 #define VARIANT 0
@@ -31,6 +33,12 @@ struct ExpPairLayout : HistLoads {
         const uint32_t g = static_cast<uint32_t>((cgroup - g_codes_base) / (static_cast<size_t>(g_rows_total) * 32u));   // block-uniform
         const char *pair = g_codes_base + static_cast<size_t>(g >> 1) * g_rows_total * 64u + (g & 1u) * 32u;
         return *reinterpret_cast<const uint16_t *>(pair + (row * 64u + coff));
+    }
+};
+struct ExpRowMajor : HistLoads {
+    static __device__ __forceinline__ int code(const char *cgroup, uint32_t row, uint32_t coff) {
+        const uint32_t g = static_cast<uint32_t>((cgroup - g_codes_base) / (static_cast<size_t>(g_rows_total) * 32u));   // block-uniform
+        return *reinterpret_cast<const uint16_t *>(g_codes_base + (static_cast<size_t>(row) * 256u + g * 32u + coff));
     }
 };
 template <class Ld>
@@ -92,8 +100,10 @@ int main(int argc, char **argv) {
         launch_variant<ExpNtCodes>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
 #elif VARIANT == 3
         launch_variant<ExpQ16>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
-#else
+#elif VARIANT == 4
         launch_variant<ExpPairLayout>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
+#else
+        launch_variant<ExpRowMajor>(dc, N, dq, D, dr, dk, (int)chunks.size(), n_groups, NB, dp);
 #endif
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
