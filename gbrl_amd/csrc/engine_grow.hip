@@ -129,6 +129,15 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
     int64_t *d_hist_coll = has_coll_ ? static_cast<int64_t *>(d_hist_local_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_P) * coll_Fs * feat_elems)) : nullptr;
     int64_t *d_hist_recv = has_coll_ ? static_cast<int64_t *>(d_hist_recv_.ensure(sizeof(int64_t) * max_front * static_cast<size_t>(coll_Fs) * feat_elems)) : nullptr;
     int64_t *d_gather = has_coll_ ? static_cast<int64_t *>(d_gather_.ensure(sizeof(int64_t) * static_cast<size_t>(coll_P) * 3 * max_front)) : nullptr;
+    // Small levels are all-reduced WHOLE instead (round 6): every rank then holds the global sums of all features, scores all candidates
+    // and resolves the winner itself -- no winner exchange, no score fill, one exchange per level instead of two.  The all-reduce moves
+    // twice the reduce-scatter's bytes, so it pays while that difference costs less than the winner's small all-reduce and its three
+    // launches: up to ~10 MB of level payload on xGMI (8 ranks: (P-1)/P x 10 MB at ~200 GB/s bus bandwidth ~ 45 us against a ~25 us
+    // all-reduce + ~20 us of launches; unmeasured beyond one GPU -- GBRL_HIP_HIST_ALLREDUCE_MAX_KB tunes it, 0 = always reduce-scatter).
+    // The levels taken this way are a PREFIX of the tree: a reduce-scattered level leaves only this rank's feature slice in the level
+    // buffer, and the next level's sibling subtraction reads that buffer.
+    const size_t ar_max_bytes = [] { const char *e = hooks::raw(hooks::HIST_ALLREDUCE_MAX_KB); return static_cast<size_t>(e ? std::max(0L, std::atol(e)) : 10240L) * 1024; }();
+    bool ar_prefix = has_coll_;      // false from the first reduce-scattered level on
     float *d_scores = static_cast<float *>(d_scores_.ensure(use_small ? 256 : sizeof(float) * static_cast<size_t>(max_front) * std::max(1, n_cand)));
     float *d_parent = static_cast<float *>(d_parent_.ensure(sizeof(float) * max_front));
     const int am_parts = kern::argmax_parts(std::max(1, n_cand));
@@ -700,6 +709,9 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         const int root_mode = [] { const char *e = hooks::raw(hooks::ROOT_COUNTS); return e ? std::atoi(e) : 1; }();   /* read per call: the tests flip it; 2 = verify */
         const bool root_countless = depth == 0 && c.root_le != nullptr && root_mode != 0 && !hist_direct && !has_coll_ && n_global == N && NB == B + 1 &&
                                     kern::hist_countless_supported(D, FG, N);
+        const bool ar_level = ar_prefix && sizeof(int64_t) * compute_ids.size() * hist_node_elems <= ar_max_bytes;
+        ar_prefix = ar_level;
+        const int lvl_slots = ar_level ? n_slots : own_slots, lvl_lo = (has_coll_ && !ar_level) ? coll_lo : 0;   // the feature slots this rank scores at this level
         bool hist_written = false;
         if (!h_chunks.empty()) {
             const auto ev = kernel_events("hist_build", /*key=*/true);   // the dispatch's own timestamps: no bubble in the stream
@@ -713,6 +725,15 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
             if (!compute_ids.empty() && !hist_written)
                 kern::hist_reduce(d_partials, d_chunk_begin, d_slotmap, static_cast<int>(compute_ids.size()), n_groups, FG, NB, D, Fp, d_hist, s,
                                   static_cast<int>(h_chunks.size() / compute_ids.size()), 0, root_countless ? c.root_le : nullptr, F, B, N);
+        } else if (!compute_ids.empty() && ar_level) {
+            // whole-level all-reduce: plain [node][feature][class][D+1] layout (scatter with ONE owner), global sums to the level slots
+            const int nc = static_cast<int>(compute_ids.size());
+            bool in_place = true;      // the computed nodes fill the first level slots in order (the root; a level whose first nc nodes are the smaller children)
+            for (int k = 0; k < nc; ++k) in_place = in_place && slot_map[k] == k;
+            int64_t *buf = in_place ? d_hist : d_hist_coll;
+            kern::hist_reduce(d_partials, d_chunk_begin, nullptr, nc, n_groups, FG, NB, D, Fp, buf, s, static_cast<int>(h_chunks.size() / nc), Fp);
+            exchange(Red::SumI64, buf, static_cast<size_t>(nc) * hist_node_elems);
+            if (!in_place) kern::hist_place(buf, d_hist, d_slotmap, nc, hist_node_elems, s);
         } else if (!compute_ids.empty()) {
             // local sums of the computed nodes in the feature-scattered send layout -> ONE reduce-scatter -> this rank's feature
             // slice of the global sums goes to the nodes' level slots (the other features of d_hist are never read on this rank)
@@ -745,14 +766,14 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         // -- scores, selection, and the child sizes of the selected split(s): all on the device, ONE read-back
         phase_begin();
         // (row-sharded: this rank scores its own feature slots only; candidates of the other ranks stay at -inf)
-        if (has_coll_ && oblivious) kern::fill_f32(d_scores, static_cast<size_t>(n_act) * n_cand, -INFINITY, s);
+        if (has_coll_ && !ar_level && oblivious) kern::fill_f32(d_scores, static_cast<size_t>(n_act) * n_cand, -INFINITY, s);
         // last level on one GPU: the derived siblings are scored but not written back (nothing subtracts from them any more)
         const bool skip_hook = [] { const char *e = hooks::raw(hooks::KEEP_LAST_DERIVED); return e && e[0] == '1'; }();   // measurement hook
         const bool drop_derived = !has_coll_ && !skip_hook && depth > 0 && depth == MD - 1;
-        if (own_slots > 0)
-            kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, own_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
+        if (lvl_slots > 0)
+            kern::score_candidates(d_hist, d_hist_prev, depth > 0 ? d_sub_par : nullptr, d_sub_sib, n_act, Fp, NB, D, d_slots, lvl_slots, d_thr, B, n_cand, md.min_data_in_leaf, cosine ? 1 : 0,
                                    d_scales, d_path_len, d_path_slot, d_path_val, d_path_bin, d_scores, d_parent, d_cand_w, d_cand_ref, d_isroot,
-                                   oblivious ? nullptr : d_am_v, d_am_i, s, has_coll_ ? coll_lo : 0, !drop_derived, oblivious ? nullptr : d_am_s, oblivious ? nullptr : d_am_n);
+                                   oblivious ? nullptr : d_am_v, d_am_i, s, lvl_lo, !drop_derived, oblivious ? nullptr : d_am_s, oblivious ? nullptr : d_am_n);
         // oblivious: the scores are summed over the level's nodes first (stage 1 below); greedy: k_score has already reduced every
         // feature of every node to its best gain, so only the final reduction inside k_resolve_splits is left
         if (oblivious)
@@ -767,21 +788,25 @@ void Engine::grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nod
         }
         const bool near_level = d_am_s != nullptr && publish_in_resolve;
         const kern::NearDetect near_detect{d_am_s, oblivious ? nullptr : d_am_n, near_rel, d_parent, d_isroot, cosine ? 1 : 0, N};
-        kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : own_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
+        kern::resolve_splits(d_am_v, d_am_i, oblivious ? am_parts : lvl_slots, d_best_idx, d_best_score, oblivious, n_act, d_ref_to_internal, d_cand_slot, d_slots, d_hist, nullptr, Fp, NB, D, d_resolved,
                              d_counts4, max_front, d_seg_starts, d_cursors, c.d_thrkeys, B, s, publish_in_resolve ? h_res_dev : nullptr, d_flag, seq, d_pub_done,
                              drop_derived ? d_hist_prev : nullptr, drop_derived ? d_sub_par : nullptr, drop_derived ? d_sub_sib : nullptr, near_level ? &near_detect : nullptr);
         if (has_coll_) {
-            // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
-            const int n_win = oblivious ? 1 : n_act;
-            const size_t gwords = static_cast<size_t>(coll_P) * (n_win + 2 * n_act);
-            kern::winner_pack(d_best_idx, d_best_score, d_counts4, max_front, n_win, n_act, coll_.rank, d_gather, s, coll_P);
-            exchange(Red::SumI64, d_gather, gwords);
-            kern::winner_adopt(d_gather, coll_P, n_win, n_act, oblivious, d_ref_to_internal, d_cand_slot, d_slots, d_seg_starts, c.d_thrkeys, B, d_best_idx, d_best_score,
-                               d_counts4, max_front, d_resolved, d_cursors, s);
+            if (!ar_level) {
+                // the level's winner over all ranks: every rank holds the best of ITS features and the child sizes it induces
+                const int n_win = oblivious ? 1 : n_act;
+                const size_t gwords = static_cast<size_t>(coll_P) * (n_win + 2 * n_act);
+                kern::winner_pack(d_best_idx, d_best_score, d_counts4, max_front, n_win, n_act, coll_.rank, d_gather, s, coll_P);
+                exchange(Red::SumI64, d_gather, gwords);
+                kern::winner_adopt(d_gather, coll_P, n_win, n_act, oblivious, d_ref_to_internal, d_cand_slot, d_slots, d_seg_starts, c.d_thrkeys, B, d_best_idx, d_best_score,
+                                   d_counts4, max_front, d_resolved, d_cursors, s);
+            }
+            // (whole-level all-reduce: k_resolve_splits has resolved the global winner on every rank and cleared the third counts array)
             int64_t *d_right_local = d_counts4 + 2 * static_cast<size_t>(max_front);   // (cleared by winner_adopt)
             if (!count_chunks.empty())
                 kern::count_right(d_rows[cur], d_codes, c.d_kt, N, d_count_chunks, static_cast<int>(count_chunks.size()), d_resolved, d_right_local, s);
-            // global left sizes -> this rank's, and the completed result block to the host: one launch
+            // global left sizes -> this rank's, and the completed result block to the host: one launch.  (Round 6: the counting kernel's last
+            // block doing this instead cost 8 us per level MORE -- its 256 blocks queue on one completion counter, ~30 ns per returning atomic.)
             if (event_results) kern::localize_splits(d_resolved, d_n_locals, d_right_local, n_act, s);
             else kern::localize_publish(d_resolved, d_n_locals, d_right_local, n_act, d_res, h_res_dev, res_bytes, d_flag, seq, s);
         }

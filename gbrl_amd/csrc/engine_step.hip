@@ -171,17 +171,9 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     const bool oblivious = model.oblivious();
     const int world = has_coll_ ? coll_.world_size : 1;
 
-    // global row count (rows are sharded over ranks)
+    // global row count (rows are sharded over ranks): it travels with the first gradient-statistics message below (round 6: no exchange and no
+    // idle device for it); until then n_global holds this rank's count and nothing reads it
     long long n_global = N;
-    if (has_coll_) {
-        int64_t *tmp = static_cast<int64_t *>(d_ntotal_.ensure(sizeof(int64_t)));
-        int64_t hv = N;
-        hip_check(hipMemcpyAsync(tmp, &hv, sizeof(hv), hipMemcpyHostToDevice, s), "H2D n");
-        exchange(Red::SumI64, tmp, 1);
-        hip_check(hipMemcpyAsync(&hv, tmp, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H n");
-        hip_check(hipStreamSynchronize(s), "sync");
-        n_global = hv;
-    }
 
     // ---- inputs on the device -------------------------------------------------------------------------------------
     phase_begin();
@@ -230,7 +222,8 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
     // the fixed-point scale is derived from.  Leaf sums: int64 fixed point with n_global * max|g| * 2^lbits < 2^62.
     // It depends on the GLOBAL row count only (clamped to [4096, 65536]), so the scale -- and with it every integer sum -- is
     // the same for any sharding of the same rows.
-    const int chunk_rows = static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n_global + 31) / 32))));
+    auto chunk_rows_of = [](long long n) { return static_cast<int>(std::min<long long>(65536, std::max<long long>(4096, 2 * ((n + 31) / 32)))); };
+    int chunk_rows = chunk_rows_of(n_global);      // (row-sharded: set again once the global count is known)
     kern::StepScales *d_scales = static_cast<kern::StepScales *>(d_scales_.ensure(sizeof(kern::StepScales)));
     bool stats_fused = false;
     int32_t *d_qg = static_cast<int32_t *>(d_qg_.ensure(sizeof(int32_t) * n_el));
@@ -249,12 +242,22 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
         // so one GPU and N GPUs execute the same instructions on the same global sums.
         double *d_stat2 = d_stat + 2 * D;
         // one message per statistics round: the sums and every rank's maxima (gathered through the sum, kern::stats_pack)
-        double *d_smsg = has_coll_ ? static_cast<double *>(d_maxbits_.ensure(sizeof(double) * static_cast<size_t>(D) * (world + 1))) : nullptr;
-        auto exchange_stats = [&](double *st) {
+        // (+ one word: this rank's row count in the first round -- integers below 2^53 add exactly in float64)
+        const size_t smsg_words = static_cast<size_t>(D) * (world + 1) + 1;
+        double *d_smsg = has_coll_ ? static_cast<double *>(d_maxbits_.ensure(sizeof(double) * smsg_words)) : nullptr;
+        auto exchange_stats = [&](double *st, bool with_row_count) {
             if (!has_coll_) return;
-            kern::stats_pack(st, D, world, coll_.rank, d_smsg, s);
-            exchange(Red::SumF64, d_smsg, static_cast<size_t>(D) * (world + 1));
+            kern::stats_pack(st, D, world, coll_.rank, d_smsg, s, with_row_count ? static_cast<double>(N) : 0.0);
+            exchange(Red::SumF64, d_smsg, smsg_words);
             kern::stats_unpack(d_smsg, D, world, st, s);
+            if (with_row_count) {
+                // the host needs the global count from here on (chunk length -> fixed-point scale, target ranks of the selection, leaf scale)
+                double hv = 0.0;
+                hip_check(hipMemcpyAsync(&hv, d_smsg + smsg_words - 1, sizeof(hv), hipMemcpyDeviceToHost, s), "D2H n");
+                hip_check(hipStreamSynchronize(s), "sync");
+                n_global = static_cast<long long>(hv);
+                chunk_rows = chunk_rows_of(n_global);
+            }
         };
         // RL-sized batch on one GPU: statistics and quantisation in ONE launch with the same reduction tree (kern::small_stats)
         if (!has_coll_ && !no_small_stats && n_global == N && kern::small_stats(dgrads, N, D, !cosine, chunk_rows, d_stat, d_meanden, d_scales, d_qg, s)) {
@@ -262,11 +265,11 @@ void Engine::step(const float *obs, bool obs_dev, const char *cat, bool cat_dev,
             if (!cosine) { d_mean = d_meanden; d_den = d_meanden + D; }
         } else {
         kern::column_sums(dgrads, N, D, nullptr, d_part, nblk, d_stat, s);
-        exchange_stats(d_stat);
+        exchange_stats(d_stat, true);
         if (!cosine) {
             kern::stats_mean(d_stat, n_global, D, d_meanden, s);
             kern::column_sums(dgrads, N, D, d_meanden, d_part, nblk, d_stat2, s);
-            exchange_stats(d_stat2);
+            exchange_stats(d_stat2, false);
             kern::stats_finish(d_stat, d_stat2, n_global, D, chunk_rows, d_meanden, d_scales, s);
             d_mean = d_meanden;
             d_den = d_meanden + D;

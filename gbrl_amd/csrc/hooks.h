@@ -17,6 +17,7 @@ namespace hooks {
     X(EVENT_RESULTS) \
     X(FORCE_BISECTION) \
     X(FORCE_COLLECTIVE) \
+    X(HIST_ALLREDUCE_MAX_KB) \
     X(HIST_GENERIC) \
     X(HIST_PIPE) \
     X(HOST_CATEGORICAL) \

@@ -100,7 +100,8 @@ void sub_arrays(const float *a, const float *b, float *out, size_t n, hipStream_
 void gather_rows(const float *src, const int32_t *perm, float *dst, int n, int width, hipStream_t s);
 void f64_to_f32(const double *in, float *out, int n, hipStream_t s);
 // row-sharded statistics: [D sums | P x D maxima, one row per rank] summed over ranks = sums + gathered maxima (kernels.hip)
-void stats_pack(const double *st, int D, int P, int rank, double *msg, hipStream_t s);
+// (+ one trailing word, `extra`, summed like the rest: this rank's row count in the first round)
+void stats_pack(const double *st, int D, int P, int rank, double *msg, hipStream_t s, double extra = 0.0);
 void stats_unpack(const double *msg, int D, int P, double *st, hipStream_t s);
 void negate_f32(float *p, int n, hipStream_t s);
 void f32_to_f64(const float *in, double *out, int n, hipStream_t s);

@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                 pub_counts[(2 * pass + 1) * static_cast<size_t>(max_front) + node] = right;
             }
             if (pass == 0) n_left = static_cast<int>(tot - right);
-            if (pass == 0 && node == src_node && !hist_global) {
+            if (pass == 0 && !hist_global) {
                 // near-tie flag (one GPU: counts4's third array is free there): the runner-up -- the best DISTINCT gain -- is within the window of
                 // the winner, relative to the scores' magnitude, or (greedy) the winning gain is that close to zero, where "split" and "leaf"
                 // part (fitter.cpp:357).  The host then has the candidates in the window re-scored in the reference's float32 order (neartie.hip).
@@ -1294,8 +1294,8 @@ __global__ __launch_bounds__(64) void k_resolve_splits(const float *__restrict__
                 // parent score operation for operation (node.cpp:321-376 against split_candidate_generator.cpp:293-320) and its gain is exactly
                 // 0 as well.  (Cosine divides by sqrtf in one and by a double sqrt in the other: there the last bit decides, and is replayed.)
                 long long near = 0;
-                if (part_s && best_v != -INFINITY) {
-                    float mag;
+                if (part_s && best_v != -INFINITY && node == src_node) {   // (an oblivious level carries ONE flag; the other nodes' words are cleared:
+                    float mag;                                               //  row-sharded levels count this rank's right-going rows into them next)
                     if (oblivious) mag = fabsf(best_v);
                     else { const float par = is_root[node] ? 0.0f : parent[node]; mag = fmaxf(fabsf(best_v + par), fabsf(par)); }
                     const float win = near_window_rel(near_rel, oblivious ? near_rows : tot) * mag;
@@ -1547,8 +1547,9 @@ __global__ void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ 
 // Row-sharded statistics in ONE sum all-reduce: msg = [D column sums | P rows of D maxima, one per rank].  A rank writes its maxima
 // into its own row and zeros into the others, so the SUM over ranks is a gather (x + 0 = x exactly; maxima are >= 0), and the maximum
 // over the P rows is taken locally afterwards.  Replaces a sum all-reduce + a max all-reduce (and two conversion launches).
-__global__ void k_stats_pack(const double *__restrict__ st /*[2D] sums | maxima*/, int D, int P, int rank, double *__restrict__ msg /*[D + P D]*/) {
+__global__ void k_stats_pack(const double *__restrict__ st /*[2D] sums | maxima*/, int D, int P, int rank, double *__restrict__ msg /*[D + P D + 1]*/, double extra) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) msg[D + P * D] = extra;     // one more summed word (the rank's row count in the first round)
     if (i < D) msg[i] = st[i];
     if (i < P * D) msg[D + i] = (i / D == rank) ? st[D + i % D] : 0.0;
 }
@@ -1560,8 +1561,8 @@ __global__ void k_stats_unpack(const double *__restrict__ msg, int D, int P, dou
     for (int r = 0; r < P; ++r) m = fmax(m, msg[D + r * D + d]);
     st[D + d] = m;
 }
-void stats_pack(const double *st, int D, int P, int rank, double *msg, hipStream_t s) {
-    hipLaunchKernelGGL(k_stats_pack, dim3((std::max(1, P) * D + D + 255) / 256), dim3(256), 0, s, st, D, P, rank, msg);
+void stats_pack(const double *st, int D, int P, int rank, double *msg, hipStream_t s, double extra) {
+    hipLaunchKernelGGL(k_stats_pack, dim3((std::max(1, P) * D + D + 255) / 256), dim3(256), 0, s, st, D, P, rank, msg, extra);
 }
 void stats_unpack(const double *msg, int D, int P, double *st, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_unpack, dim3((D + 255) / 256), dim3(256), 0, s, msg, D, P, st);

@@ -23,6 +23,10 @@ def make_cases(n_cases, seed0):
         if c["N"] < c["n_bins"] + 1: c["n_bins"] = 32
         if c["n_bins"] >= 300: c["D"] = min(c["D"], 11)
         if c["F"] + c["Fc"] == 0: c["F"] = 2
+        # how the level histograms travel (GBRL_HIP_HIST_ALLREDUCE_MAX_KB, the same on every rank): whole-level all-reduce everywhere
+        # (fixture-sized levels are all below the default 10 MB), feature reduce-scatter + winner exchange everywhere, or a switch inside the tree
+        node_kb = (c["F"] + c["Fc"]) * (c["n_bins"] + 1) * (c["D"] + 1) * 8 / 1024.0
+        c["hist_kb"] = [None, "0", str(int(2.5 * node_kb) + 1)][i % 3]
         out.append(c)
     return out
 
@@ -59,6 +63,8 @@ def worker(rank, world, port, cases_json, outdir):
         install = lambda m: install_torch_collective(m, dev)
     for case in json.load(open(cases_json)):
         cuts = cuts_of(case["N"], world)
+        os.environ.pop("GBRL_HIP_HIST_ALLREDUCE_MAX_KB", None)
+        if case.get("hist_kb") is not None: os.environ["GBRL_HIP_HIST_ALLREDUCE_MAX_KB"] = case["hist_kb"]      # (read at every call)
         try:
             e, pred = grow(case, cuts[rank], cuts[rank + 1], install)
             np.savez(os.path.join(outdir, "%s_r%d.npz" % (case["name"], rank)), pred=pred, **e)

@@ -56,13 +56,20 @@ def _run_world(name, world, tmp_path, extra_env=None):
                                         ("cfg1_rmse_loop", 2), ("obl_l2_q_dups", 3), ("grd_l2_q_mdl", 2),
                                         ("obl_l2_q_cat", 2), ("grd_cos_u_cat", 3), ("grd_l2_q_catonly", 2), ("obl_cos_q_cat_rmse", 2),
                                         ("grd_l2_q_catrank", 2), ("grd_l2_q_catrank", 3), ("obl_cos_u_catrank", 3)])
-def test_sharded_ranks_grow_the_single_process_tree(name, world, tmp_path):
+@pytest.mark.parametrize("hist", ["allreduce", "reduce_scatter", "switch"])
+def test_sharded_ranks_grow_the_single_process_tree(name, world, hist, tmp_path):
+    """`hist`: how the level histograms travel (GBRL_HIP_HIST_ALLREDUCE_MAX_KB) -- whole-level all-reduce and every rank
+    resolves the winner itself (the default below 10 MB of level payload: every level of these fixtures), feature reduce-scatter + winner
+    exchange (0: what large levels take), or the first levels one way and the rest the other (limit = 2.5 node histograms)."""
     import gbrl_amd
     case, g, (X, Xc, G, y) = load_golden(name)
+    if hist == "switch" and (case["depth"] < 4 or world == 3): pytest.skip("the switch needs levels on both sides of the limit (and runs at world size 2)")
     m = gbrl_amd.GBRL(**K.ctor_kwargs(case))
     pred = np.asarray(K.drive(m, case, X, Xc, G, y))
     e = {k: np.asarray(v) for k, v in m.get_ensemble_data().items() if k in K.ENSEMBLE_KEYS}
-    ranks = _run_world(name, world, tmp_path)
+    node_kb = (case["F"] + case.get("Fc", 0)) * (case["n_bins"] + 1) * (case["D"] + 1) * 8 / 1024.0
+    env = {"allreduce": {}, "reduce_scatter": {"GBRL_HIP_HIST_ALLREDUCE_MAX_KB": "0"}, "switch": {"GBRL_HIP_HIST_ALLREDUCE_MAX_KB": str(int(2.5 * node_kb) + 1)}}[hist]
+    ranks = _run_world(name, world, tmp_path, env)
     for r, d in enumerate(ranks):
         for k in K.ENSEMBLE_KEYS:
             assert np.array_equal(e[k], d[k]), (name, world, r, k)
