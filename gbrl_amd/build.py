@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libgbrl_hip.so")
 EXT = os.path.join(HERE, "gbrl_cpp" + sysconfig.get_config_var("EXT_SUFFIX"))
 ARCH = os.environ.get("PYTORCH_ROCM_ARCH", "gfx950").split(";")[0]
 
-LIB_SRCS = ["kernels.hip", "small_grow.hip", "small_prep.hip", "neartie.hip", "seqsum.hip", "predict.hip", "predict_obl2.hip", "predict_reg.hip", "predict_chain.hip", "categorical.hip", "quantile.hip", "radix_select.hip", "engine.hip", "engine_step.hip", "engine_candidates.hip", "engine_grow.hip", "engine_predict.hip", "engine_explain.hip", "shap.hip", "c_api.cpp", "model.cpp", "rccl_dyn.cpp", "explain.cpp", "hooks.cpp"]
+LIB_SRCS = ["kernels.hip", "small_grow.hip", "small_prep.hip", "neartie.hip", "seqsum.hip", "predict.hip", "predict_obl2.hip", "predict_grd_stream.hip", "predict_reg.hip", "predict_chain.hip", "categorical.hip", "quantile.hip", "radix_select.hip", "engine.hip", "engine_step.hip", "engine_candidates.hip", "engine_grow.hip", "engine_predict.hip", "engine_explain.hip", "shap.hip", "c_api.cpp", "model.cpp", "rccl_dyn.cpp", "explain.cpp", "hooks.cpp"]
 LIB_DEPS = LIB_SRCS + ["kernels.h", "kernels_common.h", "score_common.h", "neartie_core.h", "small_prep.h", "predict_reg_asm.h", "engine.h", "model.h", "explain.h", "cat_hash.h", "rccl_dyn.h", "hooks.h", "engine_step_detail.h", os.path.join("..", "..", "include", "gbrl_hip.h")]
 EXT_SRCS = ["binding.cpp"]
 

@@ -36,6 +36,7 @@ namespace hooks {
     X(PREDICT_GENERIC) \
     X(PREDICT_NB) \
     X(PREDICT_NOSPLIT) \
+    X(PREDICT_NO_GRD_STREAM) \
     X(PREDICT_NO_PC) \
     X(PREDICT_NO_PERSIST) \
     X(PREDICT_NO_REG) \

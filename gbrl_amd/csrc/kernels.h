@@ -482,6 +482,9 @@ bool predict_chain(const PredictModel &pm, const float *obs, int F, const int32_
                    float *out, hipStream_t s);
 bool predict_obl2(const PredictModel &pm, const float *obs, int F, const int32_t *cat_codes, int Fc, int n, int start_tree, int stop_tree,
                   float *out, hipStream_t s);   // false: shape not covered, nothing was launched
+// Small greedy ensembles over large batches (predict_grd_stream.hip, round 6): the whole ensemble in LDS, one barrier-free pipeline per
+// wave with the next row tile held in registers.  Same mirror and the same bits as predict_obl2's greedy mode; false: not covered.
+bool predict_grd_stream(const PredictModel &pm, const float *obs, int F, int Fc, int n, int start_tree, int stop_tree, float *out, hipStream_t s);
 // Third-generation oblivious path for large batches (predict_reg.hip): the row tile lives in a bank of VGPRs, every level is a
 // VGPR-relative compare, the only LDS traffic is the leaf-value gather.  Same mirrors as predict_obl2; false: not covered.
 bool predict_reg(const PredictModel &pm, const float *obs, int F, int Fc, int n, int start_tree, int stop_tree, float *out, hipStream_t s);

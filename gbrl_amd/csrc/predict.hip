@@ -746,6 +746,7 @@ void predict(const PredictModel &pm_in, const float *obs, int F, const int32_t *
     // fast path: greedy ensembles whose trees were rebuilt as binary trees (descent instead of the leaf-by-leaf walk)
     if (!pm.oblivious && pm.grd_ok && pm.coef_ok && pm.coef_cover == all_out && (F > 0 || Fc > 0) && pm.D <= 64 && stop_tree > start_tree &&
         pm.grd_max_leaves <= 256) {
+        if (pm.obl2_maxd != 0 && predict_grd_stream(pm, obs, F, Fc, n, start_tree, stop_tree, out, s)) return;
         if (predict_obl2(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; }
         if (pm.D <= 4) { if (launch_predict_grd<4>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }
         else if (pm.D <= 8) { if (launch_predict_grd<8>(pm, obs, F, cat_codes, Fc, n, start_tree, stop_tree, out, s)) { if (pm.tree_chunk > 0) combine(); return; } }

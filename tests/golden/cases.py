@@ -214,6 +214,9 @@ FULLSIZE_CASES = [
     _c("full_cfg2_s1", seed=1, N=1 << 20, F=128, D=8, depth=6, trees=1, noise=2.0),
     _c("full_cfg3", seed=0, N=1 << 20, F=128, D=8, depth=6, policy="greedy", score="Cosine", trees=1, opts=_AC_OPTS,
        ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)"),
+    # configs[2] once more: another seed, the weaker signal
+    _c("full_cfg3_s1", seed=1, N=1 << 20, F=128, D=8, depth=6, policy="greedy", score="Cosine", trees=1, opts=_AC_OPTS, noise=2.0,
+       ref_patch="types.h:49 INITAL_MAX_TREES 50000 -> 16384 (capacity only)"),
 ]
 # Near-tie specimens ABOVE the replay's LDS limit of 65 536 rows: the five cases of scripts/bign_sweep.py 400 32000 (70 000 .. 400 000 rows)
 # in which the reference's float32 summation noise picked another candidate than the exact arg-max (gaps 6e-7 .. 9e-6 relative, inside its
