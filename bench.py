@@ -503,7 +503,9 @@ def leg_cfg3(torch, np, gbrl_amd, dev, X, G, D, depth, B, steps=6, warmup=2):
             "rows": N, "n_features": F, "output_dim": D, "max_depth": depth, "steps": steps, "ms_per_step": dt * 1e3, "trees_per_s": 1.0 / dt,
             "leaves_per_tree": e_leaves / float(T), "phases_ms_per_step": {k: v for k, v in sorted(acc.items())},
             "predict": {"trees": T, "ms_per_call": dtp * 1e3, "rows_per_s": N / dtp, "row_trees_per_s": N * T / dtp,
-                        "kernel_ms": m.last_phase_times().get("predict", 0.0), "roofline": predict_roofline(N, F, D, T, depth, dtp)}}
+                        "kernel_ms": m.last_phase_times().get("predict", 0.0), "roofline": predict_roofline(N, F, D, T, depth, dtp),
+                        "kernel": "k_predict_grd_stream (round 6: the ensemble in LDS, one barrier-free row-tile pipeline per wave; HBM-bound -- the issue bounds "
+                                  "above describe the oblivious kernels)"}}
 
 
 def leg_fullsize_parity(torch, np, gbrl_amd, dev):

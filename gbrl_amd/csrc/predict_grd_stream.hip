@@ -24,13 +24,14 @@ namespace kern {
 
 namespace {
 
-constexpr int kGsWaves = 4;             // per block = per CU: one per SIMD
+// Waves per block (= per CU): four -- one per SIMD -- when the ensemble leaves room for four tiles, three for larger ensembles (11-20 trees at 128
+// features: 127-180 us against 151-195 for the cooperative kernel); with two the walk no longer overlaps enough (GBRL_HIP_PREDICT_GRD_STREAM_WAVES=2).
 constexpr size_t kGsLds = 160 * 1024;   // bytes of LDS a block may ask for
 
 template <int DMAX>
 struct GsCoef { float lr[DMAX]; };
 
-template <int MAXD, int DMAX, int NV>
+template <int MAXD, int DMAX, int NV, int kGsWaves>
 __global__ __launch_bounds__(64 * kGsWaves) void k_predict_grd_stream(const float *__restrict__ vsw, const float *__restrict__ bias, GsCoef<DMAX> coef, int D,
                                                                        const float *__restrict__ obs, int n, int start_tree, int trees,
                                                                        float *__restrict__ out, int n_tiles) {
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(64 * kGsWaves) void k_predict_grd_stream(const floa
     }
 }
 
-template <int MAXD, int DMAX, int NV>
-bool launch_gs(const PredictModel &pm, const float *obs, int n, int start_tree, int stop_tree, float *out, hipStream_t s) {
+template <int MAXD, int DMAX, int NV, int kGsWaves>
+bool launch_gs_w(const PredictModel &pm, const float *obs, int n, int start_tree, int stop_tree, float *out, hipStream_t s) {
     constexpr int LS = 1 << MAXD, REC = LS * DMAX * 4 + LS * 16, F = 4 * NV, XS = F + 1;
     const int trees = stop_tree - start_tree;
     const size_t lds = static_cast<size_t>(trees) * REC + static_cast<size_t>(kGsWaves) * 64 * XS * 4;
@@ -159,7 +160,7 @@ bool launch_gs(const PredictModel &pm, const float *obs, int n, int start_tree, 
     static uint64_t attr_done = 0;   // per device
     static int cus[64] = {0};
     if (dev < 64 && !((attr_done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_grd_stream<MAXD, DMAX, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGsLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_predict_grd_stream<MAXD, DMAX, NV, kGsWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGsLds));
         int c = 0;
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
         cus[dev] = c;
@@ -169,9 +170,18 @@ bool launch_gs(const PredictModel &pm, const float *obs, int n, int start_tree, 
     for (int j = 0; j < DMAX; ++j) coef.lr[j] = j < pm.D ? pm.coef[j] : 0.0f;
     const int n_tiles = (n + 63) / 64;
     const int blocks = std::min(dev < 64 ? cus[dev] : 256, (n_tiles + kGsWaves - 1) / kGsWaves);
-    hipLaunchKernelGGL((k_predict_grd_stream<MAXD, DMAX, NV>), dim3(blocks), dim3(64 * kGsWaves), lds, s, pm.values_sw, pm.bias, coef, pm.D, obs, n, start_tree, trees,
+    hipLaunchKernelGGL((k_predict_grd_stream<MAXD, DMAX, NV, kGsWaves>), dim3(blocks), dim3(64 * kGsWaves), lds, s, pm.values_sw, pm.bias, coef, pm.D, obs, n, start_tree, trees,
                        out, n_tiles);
     return true;
+}
+
+template <int MAXD, int DMAX, int NV>
+bool launch_gs(const PredictModel &pm, const float *obs, int n, int start_tree, int stop_tree, float *out, hipStream_t s) {
+    int min_waves = 3;      // (two waves: 264 against 215 us for the cooperative kernel at 24 trees -- scripts/greedy_predict_sweep.py)
+    if (const char *e = hooks::raw(hooks::PREDICT_GRD_STREAM_WAVES)) min_waves = std::max(1, std::atoi(e));      // measurement hook: 4 = only the four-wave shape
+    return launch_gs_w<MAXD, DMAX, NV, 4>(pm, obs, n, start_tree, stop_tree, out, s) ||
+           (min_waves <= 3 && launch_gs_w<MAXD, DMAX, NV, 3>(pm, obs, n, start_tree, stop_tree, out, s)) ||
+           (min_waves <= 2 && launch_gs_w<MAXD, DMAX, NV, 2>(pm, obs, n, start_tree, stop_tree, out, s));
 }
 
 template <int MAXD, int DMAX>

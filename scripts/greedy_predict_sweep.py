@@ -1,4 +1,5 @@
-"""cfg3's predict (greedy depth-6 trees, 2^20 x 128 rows, D = 8) under the launch-plan hooks of k_predict_obl2<GREEDY> (measurement):
+"""cfg3's predict (greedy depth-6 trees, 2^20 x 128 rows, D = 8): the streaming kernel against the block-cooperative one (measurement;
+SWEEP_PLANS=1: also the launch-plan hooks of k_predict_obl2<GREEDY>):
     python3 scripts/greedy_predict_sweep.py [trees]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,20 +15,20 @@ m = bench.make_model(gbrl_amd, np, "cfg3", F, 0, D, 6, 256, "sweep")
 for i in range(T):
     sl = slice(i * 4096, (i + 1) * 4096)
     m.step(tup(X[sl].contiguous()), None, tup(G[sl].contiguous()))
+HOOKS = ("GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT", "GBRL_HIP_PREDICT_NB", "GBRL_HIP_PREDICT_NO_PERSIST", "GBRL_HIP_PREDICT_NO_GRD_STREAM", "GBRL_HIP_PREDICT_GRD_STREAM_WAVES")
+ENVS = [{}, {"GBRL_HIP_PREDICT_NO_GRD_STREAM": "1"}]
+if os.environ.get("SWEEP_PLANS") == "1":      # the launch-plan hooks of the cooperative kernel
+    ENVS += [dict(e, GBRL_HIP_PREDICT_NO_GRD_STREAM="1") for e in ({"GBRL_HIP_PREDICT_TT": "4"}, {"GBRL_HIP_PREDICT_NO_PERSIST": "1"},
+             {"GBRL_HIP_PREDICT_RG": "1", "GBRL_HIP_PREDICT_NB": "2"}, {"GBRL_HIP_PREDICT_RG": "2"}, {"GBRL_HIP_PREDICT_RG": "2", "GBRL_HIP_PREDICT_TT": "4"})]
 base = None
-HOOKS = ("GBRL_HIP_PREDICT_RG", "GBRL_HIP_PREDICT_TT", "GBRL_HIP_PREDICT_NB", "GBRL_HIP_PREDICT_NO_PERSIST")
-for env in ({}, {"GBRL_HIP_PREDICT_TT": "4"}, {"GBRL_HIP_PREDICT_NO_PERSIST": "1"}, {"GBRL_HIP_PREDICT_TT": "4", "GBRL_HIP_PREDICT_NO_PERSIST": "1"},
-            {"GBRL_HIP_PREDICT_RG": "1", "GBRL_HIP_PREDICT_NB": "2"}, {"GBRL_HIP_PREDICT_RG": "2"}, {"GBRL_HIP_PREDICT_RG": "2", "GBRL_HIP_PREDICT_TT": "4"},
-            {"GBRL_HIP_PREDICT_RG": "1", "GBRL_HIP_PREDICT_TT": "4", "GBRL_HIP_PREDICT_NB": "2"}, {}):
+for env in ENVS:
     for h in HOOKS: os.environ.pop(h, None)
     os.environ.update(env)
     m.set_profiling(1)
     p = torch.from_dlpack(m.predict(tup(X), None, 0, 0)).clone()
     if base is None: base = p
     same = bool(torch.equal(p, base))
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(200):
+    for _ in range(100):      # back to back, like bench.py's time_predict (spaced calls run ~7 % slower: clocks)
         q = m.predict(tup(X), None, 0, 0); del q
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / 200
-    print("%-70s %.1f us per call, kernel %.1f us, bits %s" % (env or "default", dt * 1e6, m.last_phase_times().get("predict", 0.0) * 1e3, "same" if same else "DIFFERENT"), flush=True)
+    best = m.last_phase_times().get("predict", 1e9)
+    print("%3d trees  %-60s kernel %.1f us, bits %s" % (T, env or "default (k_predict_grd_stream where it fits)", best * 1e3, "same" if same else "DIFFERENT"), flush=True)
