@@ -1,14 +1,16 @@
 """The headline configuration against the REFERENCE ITSELF (north_star's acceptance sentence): the product's tree at
 batch = 2^20, n_feat = 128, depth = 6, D = 8 compared with the tree the reference's own CPU path (oracle/_ref, built from
 /root/reference by oracle/Makefile) grew on the same inputs in the build container -- tests/golden/full_cfg2.npz (BASELINE configs[1]:
-oblivious / L2 / quantile) and tests/golden/full_cfg3.npz (configs[2]: greedy / Cosine / policy + value optimisers; capacity-patched
-build), made by tests/golden/make_fullsize_golden.py (835 s / tree on 8 vCPU).  The 512 MiB of inputs are regenerated from the
+oblivious / L2 / quantile; full_cfg2_s1: a second seed with a four times weaker signal) and tests/golden/full_cfg3.npz (configs[2]: greedy /
+Cosine / policy + value optimisers; capacity-patched build; full_cfg3_s1: second seed, weaker signal), made by
+tests/golden/make_fullsize_golden.py (835 - 1230 s / tree on 8 vCPU).  The 512 MiB of inputs are regenerated from the
 seed (integer PCG64 draws + exactly rounded float32 arithmetic only) and checked through their SHA-256 before anything is compared.
 
 Bar: bit-identical structure.  Two modes:
   * GBRL_HIP_NEARTIE_MAX_ROWS=0 -- every flagged node re-scored in the reference's float32 operation sequence (serial chains over up to 2^20
-    rows; evaluated in parallel by seqsum.hip: 14-22 ms per tree): configs[1] 6 of 6 levels, configs[2] 63 of 63 internal nodes, both asserted exactly;
-  * default -- batches above 65 536 rows keep the exact float64 arg-max (1.9 ms per tree): configs[1] 6 of 6; configs[2] 22 of 63 -- the
+    rows; evaluated in parallel by seqsum.hip: 14-22 ms per tree): configs[1] 6 of 6 levels, configs[2] 63 of 63 internal nodes, on both seeds of
+    both, asserted exactly;
+  * default -- batches above 65 536 rows keep the exact float64 arg-max (1.9 ms per tree): configs[1] 6 of 6 (both seeds); configs[2] 22 of 63 (28 of 63 on the second seed) -- the
     reference's float32 noise (4e-5 relative at a 522 256-row node) prefers a neighbouring threshold whose true score is 5e-6 lower, and the
     41 nodes below it sit on another partition.  Where a level / node differs, the float64 scores of both candidates on the node's rows are
     printed next to the reference's own float32 summation noise (eps32 * sqrt(rows), node.cpp:336-352 sums sequentially in float32), and
@@ -28,7 +30,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 # committed bounds (measured on MI355X, round 6; see README "Parity at the headline size")
 MAX_DIFFERING_LEVELS_CFG2 = {"replay": 0, "default": 0}
-MAX_DIFFERING_NODES_CFG3 = {"replay": 0, "default": 41}
+MAX_DIFFERING_NODES_CFG3 = {"full_cfg3": {"replay": 0, "default": 41}, "full_cfg3_s1": {"replay": 0, "default": 35}}
 MODES = {"replay": "0", "default": None}     # GBRL_HIP_NEARTIE_MAX_ROWS
 
 
@@ -123,14 +125,15 @@ def _greedy_nodes(e):
 
 
 @pytest.mark.parametrize("mode", ["replay", "default"])
-def test_config3_tree_is_the_reference_tree_at_full_size(mode, monkeypatch):
-    fx, case, X, G = _fixture("full_cfg3")
+@pytest.mark.parametrize("fixture", ["full_cfg3", "full_cfg3_s1"])
+def test_config3_tree_is_the_reference_tree_at_full_size(fixture, mode, monkeypatch):
+    fx, case, X, G = _fixture(fixture)
     e = _grow(case, X, G, monkeypatch, mode=mode)
     ref = {k: fx[k] for k in fx.files}
     n_ref, n_got = _greedy_nodes(ref), _greedy_nodes(e)
     same = sum(1 for p, s in n_ref.items() if n_got.get(p) == s)
-    print("config 3 (%s) at 2^20 x 128: %d of the reference's %d internal nodes identical (product grew %d); leaves %d / %d"
-          % (mode, same, len(n_ref), len(n_got), len(ref["depths"]), len(e["depths"])))
+    print("config 3 (%s, %s) at 2^20 x 128: %d of the reference's %d internal nodes identical (product grew %d); leaves %d / %d"
+          % (fixture, mode, same, len(n_ref), len(n_got), len(ref["depths"]), len(e["depths"])))
     differing = [(p, s, n_got.get(p)) for p, s in n_ref.items() if n_got.get(p) != s]
     top = sorted(differing, key=lambda t: len(t[0]))[:4]
     first_gap = None
@@ -153,7 +156,7 @@ def test_config3_tree_is_the_reference_tree_at_full_size(mode, monkeypatch):
                     first_gap = (a, b, len(idx))
                 line += "; float64 scores %.9g / %.9g, gap %.2e relative, reference float32 noise %.1e" % (a, b, (b - a) / abs(b), 2.0 ** -24 * np.sqrt(len(idx)))
             print(line)
-    assert len(n_ref) - same <= MAX_DIFFERING_NODES_CFG3[mode]
+    assert len(n_ref) - same <= MAX_DIFFERING_NODES_CFG3[fixture][mode]
     if mode == "default" and first_gap is not None:
         # the shallowest difference must be an explained near-tie: the product at (or above) the reference's true score, the gap inside its noise
         a, b, n_rows = first_gap
