@@ -645,6 +645,32 @@ def leg_cfg5(torch, np, gbrl_amd, dev, D, depth, B, trees, N=1 << 20, F=192, Fc=
            "grown": "%d steps on %d-row minibatches in %.1f s (%.2f ms/step)" % (trees, mini, grow_s, grow_s * 1e3 / trees),
            "roofline": predict_roofline(N, F + Fc, D, T, depth, dtp)}
     out["categorical_fraction"] = n_cat_conditions / max(1, out["conditions"])
+    # The same batch with its cells encoded ONCE (SURVEY 8d allows it when stated; the product's extension encode_categorical /
+    # predict_encoded, include/gbrl_hip.h): what a serving loop pays per call when it keeps the int32 ids of its batch.  Same bits.
+    try:
+        t1 = time.perf_counter()
+        ids_cap, token = m.encode_categorical(co)
+        ids = torch.from_dlpack(ids_cap)
+        torch.cuda.synchronize()
+        enc_once = time.perf_counter() - t1
+        io = (ids.data_ptr(), tuple(ids.shape), "torch.int32", "cuda")
+        ref = torch.from_dlpack(m.predict(xo, co, 0, 0))
+        same = bool(torch.equal(ref, torch.from_dlpack(m.predict_encoded(xo, io, token, 0, 0))))
+        del ref
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            p = m.predict_encoded(xo, io, token, 0, 0)
+            del p
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t1) / 2
+        out["pre_encoded"] = {"ms_per_call": dte * 1e3, "rows_per_s": N / dte, "row_trees_per_s": N * T / dte, "encode_once_ms": enc_once * 1e3,
+                              "ids_bytes": int(ids.numel()) * 4, "bitwise_equal_to_the_raw_call": same,
+                              "what": "categorical cells of the batch encoded once into int32 dictionary ids (encode_categorical), every call predicts from the ids "
+                                      "(predict_encoded); an extension -- the reference and the numbers above take the raw cells in every call"}
+        del ids, ids_cap
+    except Exception as ex:      # (the leg's headline numbers above do not depend on the extension)
+        out["pre_encoded"] = {"error": str(ex)[:200]}
     del X, cells, G, Gc
     torch.cuda.empty_cache()
     return out

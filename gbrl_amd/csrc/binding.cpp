@@ -50,12 +50,12 @@ void capsule_destructor(PyObject *cap) {
     }
 }
 
-py::object make_dlpack(void *data, const std::vector<int64_t> &shape, bool on_device, int device_id) {
+py::object make_dlpack(void *data, const std::vector<int64_t> &shape, bool on_device, int device_id, bool int32 = false) {
     auto *mt = new DLManagedTensor_;
     mt->dl_tensor.data = data;
     mt->dl_tensor.device = {on_device ? kDLROCM_ : kDLCPU_, on_device ? device_id : 0};
     mt->dl_tensor.ndim = static_cast<int32_t>(shape.size());
-    mt->dl_tensor.dtype = {2 /*kDLFloat*/, 32, 1};
+    mt->dl_tensor.dtype = {static_cast<uint8_t>(int32 ? 0 /*kDLInt*/ : 2 /*kDLFloat*/), 32, 1};
     mt->dl_tensor.shape = new int64_t[shape.size()];
     std::copy(shape.begin(), shape.end(), mt->dl_tensor.shape);
     mt->dl_tensor.strides = nullptr;
@@ -78,7 +78,8 @@ struct Input {
 };
 
 // handle_input_info (binding.cpp:156-190): None | NumPy array | (data_ptr, shape, dtype, device)
-Input read_input(py::object &obj, const std::string &name, bool none_allowed, const std::string &fn, bool categorical) {
+// `categorical`: 0 = float32 values, 1 = 128-byte cells, 2 = int32 dictionary ids (encode_categorical / predict_encoded, an extension)
+Input read_input(py::object &obj, const std::string &name, bool none_allowed, const std::string &fn, int categorical) {
     Input in;
     if (obj.is_none()) {
         if (!none_allowed) fail("Cannot call " + fn + " without " + name + "!");
@@ -88,7 +89,7 @@ Input read_input(py::object &obj, const std::string &name, bool none_allowed, co
         py::array arr = py::array::ensure(obj, py::array::c_style | py::array::forcecast);
         if (!arr) fail("Could not convert object to a contiguous NumPy array");
         py::buffer_info info = arr.request();
-        const std::string want = categorical ? "128s" : py::format_descriptor<float>::format();
+        const std::string want = categorical == 1 ? "128s" : categorical == 2 ? py::format_descriptor<int32_t>::format() : py::format_descriptor<float>::format();
         if (info.format != want) {
             std::stringstream ss;
             ss << "Expected array of format '" << want << "', but got '" << info.format << "'";
@@ -106,7 +107,9 @@ Input read_input(py::object &obj, const std::string &name, bool none_allowed, co
         in.ptr = (raw == 0 || raw == static_cast<uintptr_t>(-1)) ? nullptr : reinterpret_cast<const void *>(raw);
         for (py::handle d : t[1].cast<py::tuple>()) in.shape.push_back(d.cast<size_t>());
         const std::string dtype = t[2].cast<std::string>();
-        if (categorical) {
+        if (categorical == 2) {
+            if (dtype != "torch.int32") fail("Expected dtype torch.int32, but got " + dtype);
+        } else if (categorical) {
             // extension over the reference (which takes categorical cells as NumPy S128 arrays only): a device-resident cell
             // matrix, [n, n_cat] cells of 128 bytes each (e.g. a torch.uint8 tensor [n, n_cat, 128]), announced as dtype "S128"
             if (dtype != "S128" && dtype != "|S128") fail("Unsupported data type: " + dtype);
@@ -170,7 +173,7 @@ class PyGBRL {
 };
 
 py::object predict_impl(PyGBRL &self, py::object &obs, py::object &cat, py::object start_obj, py::object stop_obj,
-                        bool return_torch) {
+                        bool return_torch, const uint64_t *ids_token = nullptr /* non-null: `cat` holds int32 dictionary ids (predict_encoded) */) {
     const gbrl_hip_metadata md = self.meta();
     const int start = start_obj.is_none() ? 0 : start_obj.cast<int>();
     const int stop = stop_obj.is_none() ? 0 : stop_obj.cast<int>();
@@ -186,7 +189,7 @@ py::object predict_impl(PyGBRL &self, py::object &obs, py::object &cat, py::obje
         fail(ss.str());
     }
     Input o = read_input(obs, "obs", true, "predict", false);
-    Input c = read_input(cat, "cat_obs", true, "predict", true);
+    Input c = read_input(cat, "cat_obs", true, "predict", ids_token ? 2 : 1);
     if (!o.ptr && !c.ptr) fail("Cannot call predict without observations!");
     int n = 0, n_num = 0, n_cat = 0;
     const int in_dim = md.input_dim;
@@ -237,6 +240,10 @@ py::object predict_impl(PyGBRL &self, py::object &obs, py::object &cat, py::obje
     int rc;
     {
         py::gil_scoped_release release;  // binding.cpp:934
+        if (ids_token)
+            rc = gbrl_hip_predict_encoded(self.h, static_cast<const float *>(o.ptr), o.on_device, static_cast<const int32_t *>(c.ptr), c.on_device, *ids_token,
+                                          n, n_num, n_cat, start, stop, out, dev_out);
+        else
         rc = gbrl_hip_predict(self.h, static_cast<const float *>(o.ptr), o.on_device, static_cast<const char *>(c.ptr),
                               c.on_device, n, n_num, n_cat, start, stop, out, dev_out);
     }
@@ -248,6 +255,39 @@ py::object predict_impl(PyGBRL &self, py::object &obs, py::object &cat, py::obje
     py::capsule owner(out, [](void *p) { delete[] static_cast<float *>(p); });
     std::vector<py::ssize_t> shp(shape.begin(), shape.end());
     return py::array_t<float>(shp, out, owner);
+}
+
+// Extension: (ids, token) = encode_categorical(categorical_obs): int32 dictionary ids [n, n_cat] of a batch of cells -- a DLPack capsule on the
+// model's device for a "cuda" model, a NumPy array otherwise -- for predict_encoded(obs, ids, token, ...).
+py::tuple encode_categorical_impl(PyGBRL &self, py::object &cat) {
+    Input c = read_input(cat, "cat_obs", false, "encode_categorical", 1);
+    if (!c.ptr) fail("Cannot call encode_categorical without cat_obs!");
+    const int n = static_cast<int>(c.shape[0]), n_cat = c.shape.size() > 1 ? static_cast<int>(c.shape[1]) : 1;
+    const bool dev_out = self.device == 1;
+    int32_t *ids = nullptr;
+    int dev_id = 0;
+    if (dev_out) {
+        dev_id = gbrl_hip_device_ordinal(self.h);
+        if (dev_id < 0) fail(gbrl_hip_last_error());
+        ids = static_cast<int32_t *>(gbrl_hip_device_alloc_on(dev_id, sizeof(int32_t) * static_cast<size_t>(n) * n_cat));
+        if (!ids) fail(gbrl_hip_last_error());
+    } else {
+        ids = new int32_t[static_cast<size_t>(n) * n_cat];
+    }
+    uint64_t token = 0;
+    int rc;
+    {
+        py::gil_scoped_release release;
+        rc = gbrl_hip_encode_categorical(self.h, static_cast<const char *>(c.ptr), c.on_device, n, n_cat, ids, dev_out, &token);
+    }
+    if (rc != GBRL_HIP_OK) {
+        if (dev_out) gbrl_hip_device_free(ids); else delete[] ids;
+        fail(gbrl_hip_last_error());
+    }
+    const std::vector<int64_t> shape = {n, n_cat};
+    if (dev_out) return py::make_tuple(make_dlpack(ids, shape, true, dev_id, /*int32=*/true), token);
+    py::capsule owner(ids, [](void *p) { delete[] static_cast<int32_t *>(p); });
+    return py::make_tuple(py::array_t<int32_t>(std::vector<py::ssize_t>{n, n_cat}, ids, owner), token);
 }
 
 void step_impl(PyGBRL &self, py::object &obs, py::object &cat, py::object &grads) {
@@ -428,8 +468,15 @@ PYBIND11_MODULE(gbrl_cpp, m) {
     }, py::return_value_policy::take_ownership);
     g.def("to_device", [](PyGBRL &self, const std::string &d) { self.device = parse_device(d); }, py::arg("device"));
     g.def("step", &step_impl, py::arg("obs"), py::arg("categorical_obs"), py::arg("grads"));
-    g.def("predict", &predict_impl, py::arg("obs"), py::arg("categorical_obs"), py::arg("start_tree_idx") = 0,
-          py::arg("stop_tree_idx") = 0, py::arg("return_torch") = false);
+    g.def("predict", [](PyGBRL &self, py::object &obs, py::object &cat, py::object start, py::object stop, bool return_torch) {
+        return predict_impl(self, obs, cat, start, stop, return_torch);
+    }, py::arg("obs"), py::arg("categorical_obs"), py::arg("start_tree_idx") = 0, py::arg("stop_tree_idx") = 0, py::arg("return_torch") = false);
+    // extension (no counterpart in the reference): categorical cells encoded once, predicted many times (include/gbrl_hip.h)
+    g.def("encode_categorical", &encode_categorical_impl, py::arg("categorical_obs"));
+    g.def("predict_encoded", [](PyGBRL &self, py::object &obs, py::object &ids, uint64_t token, py::object start, py::object stop, bool return_torch) {
+        return predict_impl(self, obs, ids, start, stop, return_torch, &token);
+    }, py::arg("obs"), py::arg("categorical_ids"), py::arg("dictionary_token"), py::arg("start_tree_idx") = 0, py::arg("stop_tree_idx") = 0,
+          py::arg("return_torch") = false);
     g.def("fit", &fit_impl, py::arg("obs"), py::arg("categorical_obs"), py::arg("targets"), py::arg("iterations"),
           py::arg("shuffle") = true, py::arg("loss_type") = "MultiRMSE");
     g.def("set_bias", [](PyGBRL &self, py::object &bias) {

@@ -328,6 +328,24 @@ int gbrl_hip_predict(gbrl_hip_model *m, const float *obs, int obs_on_device, con
     });
 }
 
+int gbrl_hip_encode_categorical(gbrl_hip_model *m, const char *cat_obs, int cat_on_device, int n_samples, int n_cat_features, int32_t *ids_out,
+                                int ids_on_device, uint64_t *dictionary_token) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.encode_categorical(cat_obs, cat_on_device != 0, n_samples, n_cat_features, ids_out, ids_on_device != 0, dictionary_token);
+    });
+}
+
+int gbrl_hip_predict_encoded(gbrl_hip_model *m, const float *obs, int obs_on_device, const int32_t *cat_ids, int ids_on_device,
+                             uint64_t dictionary_token, int n_samples, int n_num_features, int n_cat_features, int start_tree, int stop_tree,
+                             float *out, int out_on_device) {
+    return guarded([&] {
+        if (!m) throw gbrl::InvalidArgument("null model");
+        m->engine.predict_encoded(obs, obs_on_device != 0, cat_ids, ids_on_device != 0, dictionary_token, n_samples, n_num_features, n_cat_features,
+                                  start_tree, stop_tree, out, out_on_device != 0);
+    });
+}
+
 int gbrl_hip_set_collective(gbrl_hip_model *m, const gbrl_hip_collective *hooks) {
     return guarded([&] {
         if (!m) throw gbrl::InvalidArgument("null model");

@@ -87,6 +87,12 @@ class Engine {
               int n_num, int n_cat);
     void predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
                  int stop_tree, float *out, bool out_dev);
+    // Extension (not in the reference, which compares the 128-byte cells inside every predict call): the dictionary ids of a batch of
+    // categorical cells, and predict from such ids.  `token` identifies the model's category dictionary (a hash of its entries in order): ids are
+    // valid for any model whose dictionary is the same (this model until a later tree mentions a new category, its clones, its saved file).
+    void encode_categorical(const char *cat, bool cat_dev, int n, int n_cat, int32_t *ids_out, bool out_dev, uint64_t *token);
+    void predict_encoded(const float *obs, bool obs_dev, const int32_t *cat_ids, bool ids_dev, uint64_t token, int n, int n_num, int n_cat,
+                         int start_tree, int stop_tree, float *out, bool out_dev);
     // GBRL::fit (gbrl.cpp:983-1104) + Fitter::fit_cpu (fitter.cpp:117-261): bias = mean(targets), split candidates from the
     // WHOLE data set once, then `iterations` boosting rounds over consecutive batches of metadata.batch_size rows
     // (predict -> MultiRMSE gradients -> one tree per batch); returns the final MultiRMSE loss on the whole data set.
@@ -114,6 +120,9 @@ class Engine {
     void ensure_device();
     void sync_model_to_device();
     int32_t *encode_categorical_batch(const char *cat, bool cat_dev, int n, int n_cat);
+    void predict_core(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const int32_t *cat_ids, bool ids_dev, const uint64_t *token,
+                      int n, int n_num, int n_cat, int start_tree, int stop_tree, float *out, bool out_dev);
+    uint64_t cat_dict_token();
     void grow_tree(const detail::GrowCtx &c, std::vector<detail::HNode> &nodes, std::vector<int> &frontier, std::vector<int64_t> &acc,
                    double &leaf_scale);
     bool device_categorical_candidates(const char *dcells, const char *hcells, int N, int Fc, int B,
@@ -235,6 +244,8 @@ class Engine {
     int grd_max_nodes_ = 0, grd_max_leaves_ = 1;
     size_t grd_up_nodes_ = 0;
     std::vector<std::pair<int, std::string>> cat_dict_;
+    uint64_t dict_token_ = 0; size_t dict_token_size_ = static_cast<size_t>(-1);   // cat_dict_token(): cached per dictionary size (entries are only appended)
+    DevBuf d_pcat_in_;   // pre-encoded ids handed over in host memory
     size_t dict_version_ = static_cast<size_t>(-1);   // cat_dict_.size() the device dictionary was built from
     int dict_fc_ = -1;
     DevBuf d_dict_off_, d_dict_hash_, d_dict_id_, d_dict_words_, d_pcells_;

@@ -382,8 +382,51 @@ int32_t *Engine::encode_categorical_batch(const char *cat, bool cat_dev, int n, 
     return dcat;
 }
 
+uint64_t Engine::cat_dict_token() {
+    if (dict_token_size_ != cat_dict_.size()) {
+        uint64_t h = 0xcbf29ce484222325ull;      // FNV-1a over (feature, 128-byte category) in dictionary order
+        auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = static_cast<const unsigned char *>(p); for (size_t i = 0; i < nbytes; ++i) { h ^= b[i]; h *= 0x100000001b3ull; } };
+        for (const auto &e : cat_dict_) {
+            const int32_t f = e.first;
+            char cell[kCat] = {0};
+            std::memcpy(cell, e.second.data(), std::min<size_t>(kCat, e.second.size()));
+            mix(&f, sizeof(f));
+            mix(cell, kCat);
+        }
+        const uint64_t n_entries = cat_dict_.size();
+        mix(&n_entries, sizeof(n_entries));
+        dict_token_ = h;
+        dict_token_size_ = cat_dict_.size();
+    }
+    return dict_token_;
+}
+
+void Engine::encode_categorical(const char *cat, bool cat_dev, int n, int n_cat, int32_t *ids_out, bool out_dev, uint64_t *token) {
+    gbrl_hip_metadata &md = model.meta;
+    if (n <= 0 || n_cat <= 0 || cat == nullptr || ids_out == nullptr) throw InvalidArgument("encode_categorical: no cells");
+    if (md.iteration != 0 && n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
+    ensure_device();
+    sync_model_to_device();
+    hipStream_t s = stream_;
+    const int32_t *dcat = encode_categorical_batch(cat, cat_dev, n, n_cat);
+    hip_check(hipMemcpyAsync(ids_out, dcat, sizeof(int32_t) * static_cast<size_t>(n) * n_cat, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s), "ids out");
+    hip_check(hipStreamSynchronize(s), "sync");
+    if (token) *token = cat_dict_token();
+}
+
 void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_dev, int n, int n_num, int n_cat, int start_tree,
                      int stop_tree, float *out, bool out_dev) {
+    predict_core(obs, obs_dev, cat, cat_dev, nullptr, false, nullptr, n, n_num, n_cat, start_tree, stop_tree, out, out_dev);
+}
+
+void Engine::predict_encoded(const float *obs, bool obs_dev, const int32_t *cat_ids, bool ids_dev, uint64_t token, int n, int n_num, int n_cat,
+                             int start_tree, int stop_tree, float *out, bool out_dev) {
+    if (n_cat > 0 && cat_ids == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    predict_core(obs, obs_dev, nullptr, false, cat_ids, ids_dev, &token, n, n_num, n_cat, start_tree, stop_tree, out, out_dev);
+}
+
+void Engine::predict_core(const float *obs, bool obs_dev, const char *cat, bool cat_dev, const int32_t *cat_ids, bool ids_dev, const uint64_t *token,
+                          int n, int n_num, int n_cat, int start_tree, int stop_tree, float *out, bool out_dev) {
     gbrl_hip_metadata &md = model.meta;
     // GBRL::predict, gbrl.cpp:378-390
     if (md.iteration == 0) { md.n_num_features = n_num; md.n_cat_features = n_cat; }
@@ -391,7 +434,7 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
     if (n_num != md.n_num_features || n_cat != md.n_cat_features) throw InvalidArgument("Incompatible dataset");
     if (n <= 0 || out == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (n_num > 0 && obs == nullptr) throw InvalidArgument("Cannot call predict without observations!");
-    if (n_cat > 0 && cat == nullptr) throw InvalidArgument("Cannot call predict without observations!");
+    if (n_cat > 0 && cat == nullptr && cat_ids == nullptr) throw InvalidArgument("Cannot call predict without observations!");
     if (md.output_dim > 128) throw Unsupported("predict: output_dim > 128");
     if (start_tree < 0 || stop_tree < 0) throw InvalidArgument("invalid tree range");   // the reference would index out of bounds
     ensure_device();
@@ -412,7 +455,20 @@ void Engine::predict(const float *obs, bool obs_dev, const char *cat, bool cat_d
         dobs = static_cast<float *>(d_pobs_.ensure(sizeof(float) * static_cast<size_t>(n) * n_num));
         hip_check(hipMemcpyAsync(const_cast<float *>(dobs), obs, sizeof(float) * static_cast<size_t>(n) * n_num, hipMemcpyHostToDevice, s), "H2D obs");
     }
-    int32_t *dcat = n_cat > 0 ? encode_categorical_batch(cat, cat_dev, n, n_cat) : nullptr;
+    int32_t *dcat = nullptr;
+    if (n_cat > 0 && cat_ids != nullptr) {
+        // pre-encoded ids (encode_categorical): valid only for the dictionary they were made from
+        if (token == nullptr || *token != cat_dict_token())
+            throw InvalidArgument("predict: the categorical ids were encoded for another category dictionary (the model has grown or is a different one): encode the batch again");
+        if (ids_dev) {
+            dcat = const_cast<int32_t *>(cat_ids);
+        } else {
+            dcat = static_cast<int32_t *>(d_pcat_in_.ensure(sizeof(int32_t) * static_cast<size_t>(n) * n_cat));
+            hip_check(hipMemcpyAsync(dcat, cat_ids, sizeof(int32_t) * static_cast<size_t>(n) * n_cat, hipMemcpyHostToDevice, s), "H2D cat ids");
+        }
+    } else if (n_cat > 0) {
+        dcat = encode_categorical_batch(cat, cat_dev, n, n_cat);
+    }
     float *dout = out;
     if (!out_dev) dout = static_cast<float *>(d_pout_.ensure(sizeof(float) * static_cast<size_t>(n) * D));
     phase_end("inputs");

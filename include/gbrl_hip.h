@@ -150,6 +150,18 @@ int gbrl_hip_predict(gbrl_hip_model *m, const float *obs, int obs_on_device, con
                      int cat_on_device, int n_samples, int n_num_features, int n_cat_features,
                      int start_tree, int stop_tree, float *out, int out_on_device);
 
+/* Extension (no counterpart in the reference, which re-compares the 128-byte cells of every row inside every predict call,
+ * predictor.cpp:231-265 / 188-229): a serving loop that predicts the SAME categorical batch repeatedly, or produces its categorical columns
+ * from a small vocabulary, encodes them once.  gbrl_hip_encode_categorical writes int32 ids[n_samples, n_cat_features] (0 = a category no
+ * condition of the model mentions) and a token identifying the model's category dictionary; gbrl_hip_predict_encoded is gbrl_hip_predict
+ * with those ids in place of the cells and fails with GBRL_HIP_E_INVALID when the token is not the model's current one (a later tree
+ * mentioned a new category, or the ids belong to another model): encode again.  Same results as gbrl_hip_predict, bit for bit. */
+int gbrl_hip_encode_categorical(gbrl_hip_model *m, const char *cat_obs, int cat_on_device, int n_samples, int n_cat_features,
+                                int32_t *ids_out, int ids_on_device, uint64_t *dictionary_token);
+int gbrl_hip_predict_encoded(gbrl_hip_model *m, const float *obs, int obs_on_device, const int32_t *cat_ids, int ids_on_device,
+                             uint64_t dictionary_token, int n_samples, int n_num_features, int n_cat_features,
+                             int start_tree, int stop_tree, float *out, int out_on_device);
+
 /* ---- row-sharded multi-GPU (new; the reference is single-GPU) ------------------------------------------ */
 /* One process per GPU, each holding a contiguous block of rows.  When hooks are installed, step() calls them at
  * its exchange points so that every rank grows the identical tree; predict() needs no exchange.  Buffers are
