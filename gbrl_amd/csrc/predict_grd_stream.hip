@@ -24,8 +24,8 @@ namespace kern {
 
 namespace {
 
-// Waves per block (= per CU): four -- one per SIMD -- when the ensemble leaves room for four tiles, three for larger ensembles (11-20 trees at 128
-// features: 127-180 us against 151-195 for the cooperative kernel); with two the walk no longer overlaps enough (GBRL_HIP_PREDICT_GRD_STREAM_WAVES=2).
+// Waves per block (= per CU): four -- one per SIMD -- when the ensemble leaves room for four tiles, three for larger ensembles (11-21 trees at 128
+// features: 133-193 us against 149-209 for the cooperative kernel); with two the walk no longer overlaps enough (GBRL_HIP_PREDICT_GRD_STREAM_WAVES=2).
 constexpr size_t kGsLds = 160 * 1024;   // bytes of LDS a block may ask for
 
 template <int DMAX>

@@ -63,8 +63,8 @@ def test_streaming_greedy_predict_is_bitwise_the_other_kernels(F, D, depth, tree
 def test_the_streaming_kernel_is_the_one_that_runs_and_larger_ensembles_fall_back(monkeypatch):
     """configs[2]'s predict shape (128 features, 8 outputs, depth 6, 10 trees) is taken by k_predict_grd_stream -- checked through the kernel
     time the engine reports with and without the hook (the cooperative kernel is 14 % slower at 2^19 rows, 36 % at 2^20).  Up to 10 trees fit
-    beside four row tiles, up to 20 beside three (the three-wave shape); a 21st no longer fits: the call falls back and still gives the same bits."""
-    m = _model(6, 8, 128, 21, seed=8555)
+    beside four row tiles, up to 21 beside three (the three-wave shape); a 22nd no longer fits: the call falls back and still gives the same bits."""
+    m = _model(6, 8, 128, 22, seed=8555)
     rng = np.random.default_rng(5)
     X = rng.standard_normal((1 << 19, 128)).astype(np.float32)
     m.set_profiling(1)
@@ -82,6 +82,6 @@ def test_the_streaming_kernel_is_the_one_that_runs_and_larger_ensembles_fall_bac
     monkeypatch.delenv("GBRL_HIP_PREDICT_NO_GRD_STREAM", raising=False)
     print("10 greedy trees, 2^19 x 128 rows: streaming %.1f us, cooperative %.1f us" % (t["default"] * 1e3, t["cooperative"] * 1e3))
     assert t["default"] < 0.97 * t["cooperative"], t
-    for start, stop in ((0, 11), (0, 20), (1, 21), (0, 21), (11, 21)):      # three waves (11, 20 trees), not covered (21), four waves from a later record
+    for start, stop in ((0, 11), (0, 21), (1, 22), (0, 22), (12, 22)):      # three waves (11, 21 trees), not covered (22), four waves from a later record
         outs = _predict_all(m, X[:40000], monkeypatch, start, stop)
         assert _same(outs["default"], outs["cooperative"]) and _same(outs["default"], outs["generic"]), (start, stop)
