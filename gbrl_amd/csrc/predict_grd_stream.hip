@@ -202,6 +202,9 @@ bool launch_gs_f(const PredictModel &pm, const float *obs, int F, int n, int sta
 bool predict_grd_stream(const PredictModel &pm, const float *obs, int F, int Fc, int n, int start_tree, int stop_tree, float *out, hipStream_t s) {
     if (pm.oblivious || !pm.grd_ok || pm.values_sw == nullptr || Fc > 0 || pm.tree_chunk != 0 || n < 32768 || stop_tree <= start_tree) return false;
     if (hooks::on(hooks::PREDICT_NO_GRD_STREAM)) return false;      // test / measurement hook: the block-cooperative kernel (same bits)
+    // a hook that selects the cooperative kernel's launch plan (or the first-generation kernel) is set: that kernel is what the caller wants to run
+    if (hooks::on(hooks::PREDICT_OBL1) || hooks::on(hooks::PREDICT_NO_PERSIST) || hooks::raw(hooks::PREDICT_RG) || hooks::raw(hooks::PREDICT_TT) || hooks::raw(hooks::PREDICT_NB))
+        return false;
     if ((reinterpret_cast<uintptr_t>(obs) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return false;
     const int DMAX = obl2_padded_outputs(pm.D);
     if (pm.obl2_maxd == 6 && DMAX == 8) return launch_gs_f<6, 8>(pm, obs, F, n, start_tree, stop_tree, out, s);
