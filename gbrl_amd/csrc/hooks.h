@@ -34,6 +34,7 @@ namespace hooks {
     X(NO_SMALL_STATS) \
     X(PREDICT_CHAIN) \
     X(PREDICT_GENERIC) \
+    X(PREDICT_GRD_STREAM_MIN_ROWS) \
     X(PREDICT_GRD_STREAM_WAVES) \
     X(PREDICT_NB) \
     X(PREDICT_NOSPLIT) \

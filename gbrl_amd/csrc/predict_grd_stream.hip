@@ -197,10 +197,13 @@ bool launch_gs_f(const PredictModel &pm, const float *obs, int F, int n, int sta
 
 }  // namespace
 
-// Greedy ensembles whose records fit in LDS beside four 64-row tiles, numeric rows of 32 / 64 / 96 / 128 features, at most 8 outputs, at
-// least 32 768 rows (below that the launch-bound kernels are as fast): false = not covered, nothing was launched.
+// Greedy ensembles whose records fit in LDS beside four (or three) 64-row tiles, numeric rows of 32 / 64 / 96 / 128 features, at most 8 outputs,
+// at least 2^18 rows: false = not covered, nothing was launched.
 bool predict_grd_stream(const PredictModel &pm, const float *obs, int F, int Fc, int n, int start_tree, int stop_tree, float *out, hipStream_t s) {
-    if (pm.oblivious || !pm.grd_ok || pm.values_sw == nullptr || Fc > 0 || pm.tree_chunk != 0 || n < 32768 || stop_tree <= start_tree) return false;
+    // from 2^18 rows on (four tiles per wave): below that the pipeline has too few tiles per wave to pay for its start -- 32 768 rows 11.4 against
+    // 8.6 us for the cooperative kernel, 2^17 23.0 / 21.8, 2^18 34.5 / 34.6, 2^19 70 / 81, 2^20 111 / 145 (GBRL_HIP_PREDICT_GRD_STREAM_MIN_ROWS: tests)
+    const int min_rows = hooks::num(hooks::PREDICT_GRD_STREAM_MIN_ROWS, 1 << 18);
+    if (pm.oblivious || !pm.grd_ok || pm.values_sw == nullptr || Fc > 0 || pm.tree_chunk != 0 || n < min_rows || stop_tree <= start_tree) return false;
     if (hooks::on(hooks::PREDICT_NO_GRD_STREAM)) return false;      // test / measurement hook: the block-cooperative kernel (same bits)
     // a hook that selects the cooperative kernel's launch plan (or the first-generation kernel) is set: that kernel is what the caller wants to run
     if (hooks::on(hooks::PREDICT_OBL1) || hooks::on(hooks::PREDICT_NO_PERSIST) || hooks::raw(hooks::PREDICT_RG) || hooks::raw(hooks::PREDICT_TT) || hooks::raw(hooks::PREDICT_NB))

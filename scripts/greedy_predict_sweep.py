@@ -8,7 +8,7 @@ import numpy as np, torch, gbrl_amd, bench
 dev = torch.device("cuda:0")
 tup = lambda t: (t.data_ptr(), tuple(t.shape), str(t.dtype), "cuda")
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-N, F, D = 1 << 20, 128, 8
+N, F, D = int(os.environ.get("SWEEP_ROWS", 1 << 20)), 128, 8
 g = torch.Generator(device=dev); g.manual_seed(1)
 X = torch.randn((N, F), device=dev, generator=g); G = torch.randn((N, D), device=dev, generator=g)
 m = bench.make_model(gbrl_amd, np, "cfg3", F, 0, D, 6, 256, "sweep")
@@ -31,4 +31,4 @@ for env in ENVS:
     for _ in range(100):      # back to back, like bench.py's time_predict (spaced calls run ~7 % slower: clocks)
         q = m.predict(tup(X), None, 0, 0); del q
     best = m.last_phase_times().get("predict", 1e9)
-    print("%3d trees  %-60s kernel %.1f us, bits %s" % (T, env or "default (k_predict_grd_stream where it fits)", best * 1e3, "same" if same else "DIFFERENT"), flush=True)
+    print("%7d rows %3d trees  %-60s kernel %.1f us, bits %s" % (N, T, env or "default (k_predict_grd_stream where it fits)", best * 1e3, "same" if same else "DIFFERENT"), flush=True)

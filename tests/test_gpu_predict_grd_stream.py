@@ -3,7 +3,9 @@ half of the headline metric -- take a barrier-free kernel with the whole ensembl
 those of the block-cooperative kernel (`GBRL_HIP_PREDICT_NO_GRD_STREAM=1`: k_predict_obl2<GREEDY>) and of the general kernel
 (`GBRL_HIP_PREDICT_GENERIC=1`: the reference's leaf-by-leaf walk, predictor.cpp:188-229, with optimizer.cpp:110-118's update per tree):
 the same fma chain per output in tree order.  Shapes: 32 / 64 / 96 / 128 features, 1..8 outputs, depth 3..6, as many trees as fit in LDS
-beside the row tiles and one more (which must fall back), full tiles and a ragged last one, tree ranges, NaN / inf cells.
+beside the row tiles and one more (which must fall back), full tiles and a ragged last one, tree ranges, NaN / inf cells.  The kernel takes
+batches of 2^18 rows or more by default (below that it has too few tiles per wave to win); `GBRL_HIP_PREDICT_GRD_STREAM_MIN_ROWS=1` lets these
+tests run it on 33 000 .. 45 000 rows.
 """
 import numpy as np
 import pytest
@@ -26,6 +28,7 @@ def _model(depth, D, F, trees, seed, score="Cosine"):
 
 
 def _predict_all(m, X, monkeypatch, start=0, stop=0):
+    monkeypatch.setenv("GBRL_HIP_PREDICT_GRD_STREAM_MIN_ROWS", "1")      # (by default the kernel takes batches of 2^18+ rows)
     outs = {}
     for mode, env in (("default", {}), ("cooperative", {"GBRL_HIP_PREDICT_NO_GRD_STREAM": "1"}), ("generic", {"GBRL_HIP_PREDICT_GENERIC": "1"})):
         for h in HOOKS:
