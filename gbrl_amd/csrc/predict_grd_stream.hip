@@ -10,7 +10,7 @@
 //     while it walks tile t, holds tile t + 1 IN REGISTERS (F / 4 float4 per lane, 128 VGPRs at 128 features: one wave per SIMD has 512) --
 //     so every CU keeps 4 x 32 KB of row reads in flight the whole time, which is what 1/256 of 5.5 TB/s needs at ~2 us of loaded latency;
 //   * lane = row: all outputs of a row accumulate in the lane's registers, p = fma(-lr, v, p) tree by tree -- the operation sequence of
-//     k_predict_obl2 / the general kernel, so the bits are theirs (tests/test_gpu_predict_paths.py compares the paths);
+//     k_predict_obl2 / the general kernel, so the bits are theirs (tests/test_gpu_predict_grd_stream.py, scripts/grd_stream_sweep.py compare the paths);
 //   * four trees descend together (independent chains hide the LDS latency that one wave per SIMD cannot hide otherwise).
 #include "kernels.h"
 #include "hooks.h"
