@@ -78,9 +78,13 @@ def _worker(rank, world, port, result_dir):
     lo, hi = (0, 1234) if rank == 0 else (1234, N)   # deliberately uneven shards
     Xs, Gs = X[lo:hi], G[lo:hi]
     # 1. gradient statistics: global sum -> mean; centred squares -> std (fp64 sums exchanged)
-    s1 = Gs.astype(np.float64).sum(axis=0)
-    coll.allreduce_sum_f64(s1)
-    mean = (s1 / N).astype(np.float32)
+    #    (round 6: the first message also carries the rank's row count -- integers below 2^53 add exactly in float64 -- so the global count needs no
+    #    exchange of its own: engine_step.hip::exchange_stats)
+    msg = np.concatenate([Gs.astype(np.float64).sum(axis=0), [float(hi - lo)]])
+    coll.allreduce_sum_f64(msg)
+    s1, n_from_message = msg[:D], int(msg[D])
+    assert n_from_message == N
+    mean = (s1 / n_from_message).astype(np.float32)
     s2 = ((Gs - mean).astype(np.float64) ** 2).sum(axis=0)
     coll.allreduce_sum_f64(s2)
     den = (np.sqrt((s2.astype(np.float32)) * np.float32(1.0 / (N - 1.0))) + np.float32(1e-8)).astype(np.float32)
