@@ -328,7 +328,8 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *scratc
 // One block per feature; thread k < B owns target k.  `pass` = the counting pass being consumed.
 __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const uint32_t *__restrict__ partial, int n_chunks,
                                                                const int64_t *__restrict__ cum, int B, RadixState st,
-                                                               uint32_t *__restrict__ thr_keys, int p1_u16, uint32_t *__restrict__ le_out) {
+                                                               uint32_t *__restrict__ thr_keys, int p1_u16, uint32_t *__restrict__ le_out,
+                                                               const int64_t *__restrict__ gbuf /* row-sharded: the exchanged counts, read in place */, int F) {
     extern __shared__ uint32_t sums[];        // inclusive digit counts: pass 1 [4096]; later [n_slots][NB]
     __shared__ int tslot[kMaxTargets], tdig[kMaxTargets];
     __shared__ uint32_t scratch[16], total_slots;
@@ -340,7 +341,9 @@ __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const u
     if (pass == 1) {
         // 4 consecutive buckets per thread (one 16-byte load per chunk), block scan of the thread totals
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (p1_u16) {   // partials of k_transpose_count: uint16 [feature][chunk][4096], eight chunks in flight
+        if (gbuf) {     // exchange format [F][2048] x (two uint32 counters per word): digits 4k .. 4k+3 are one 16-byte piece
+            v = *reinterpret_cast<const uint4 *>(gbuf + static_cast<size_t>(f) * (kBins1 / 2) + 2 * k);
+        } else if (p1_u16) {   // partials of k_transpose_count: uint16 [feature][chunk][4096], eight chunks in flight
             const uint16_t *q0 = reinterpret_cast<const uint16_t *>(partial) + static_cast<size_t>(f) * n_chunks * kBins1 + k * 4;
             int c = 0;
             for (; c + 8 <= n_chunks; c += 8) {
@@ -366,7 +369,12 @@ __global__ __launch_bounds__(kTgtThreads) void k_radix_targets(int pass, const u
         // one wave per slot row: two digits per lane, wave scan
         for (int row = wave; row < n_slots; row += kTgtThreads / 64) {
             uint32_t a = 0, b = 0;
-            if (2 * lane < NB)
+            if (gbuf) {  // exchange format [slot][F][NB / 2] x (digit 2 lane | digit 2 lane + 1 << 32)
+                if (2 * lane < NB) {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(gbuf + (static_cast<size_t>(row) * F + f) * (NB / 2) + lane);
+                    a = t.x; b = t.y;
+                }
+            } else if (2 * lane < NB)
                 for (int c = 0; c < n_chunks; ++c) {
                     const uint2 t = *reinterpret_cast<const uint2 *>(p0 + c * pstride + row * kSlotStride + 2 * lane);
                     a += t.x; b += t.y;
@@ -462,22 +470,6 @@ __global__ __launch_bounds__(256) void k_radix_globalize(int pass, const uint32_
         gbuf[i] = static_cast<int64_t>(static_cast<uint64_t>(a) | (static_cast<uint64_t>(b) << 32));
     }
 }
-__global__ __launch_bounds__(256) void k_radix_unpack(int pass, const int64_t *__restrict__ gbuf, int F, int rows,
-                                                      uint32_t *__restrict__ partial_global) {
-    const int NB = radix_bins(pass), NBh = NB / 2;
-    const size_t pstride = pass == 1 ? kBins1 : kMaxTargets * kSlotStride;
-    const size_t total = static_cast<size_t>(rows) * F * NBh;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        const int pair = static_cast<int>(i % NBh);
-        const int f = static_cast<int>((i / NBh) % F);
-        const int slot = static_cast<int>(i / (static_cast<size_t>(NBh) * F));
-        const uint64_t v = static_cast<uint64_t>(gbuf[i]);
-        uint32_t *p = partial_global + static_cast<size_t>(f) * pstride + (pass == 1 ? 0 : slot * kSlotStride) + 2 * pair;
-        p[0] = static_cast<uint32_t>(v);
-        p[1] = static_cast<uint32_t>(v >> 32);
-    }
-}
-
 constexpr size_t align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
 }  // namespace
@@ -541,7 +533,7 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
             p1_u16 = 0;   // the summed counts come back as uint32
             if (comm->stream_ordered) {
                 // (round 5) no read-back, no synchronisation: a feature has at most one slot per target, so B slot rows bound every message
-                // (rows nobody filled are summed and ignored: k_radix_unpack / k_radix_targets stop at the feature's own slot count)
+                // (rows nobody filled are summed and ignored: k_radix_targets stops at the feature's own slot count)
                 if (pass >= 2) rows = std::min(B, kMaxTargets);
             } else {
                 if (pass >= 2) {
@@ -556,12 +548,11 @@ int radix_select(const uint32_t *kt, int n, int F, const int64_t *cum, int B, vo
             }
             const size_t words = static_cast<size_t>(rows) * F * (radix_bins(pass) / 2);
             if (comm->allreduce_sum_i64(comm->ctx, comm->gbuf, words) != 0) return 2;
-            hipLaunchKernelGGL(k_radix_unpack, dim3(1024), dim3(256), 0, s, pass, comm->gbuf, F, rows, comm->partial_global);
-            src = comm->partial_global;
-            chunks = 1;
+            chunks = 1;     // (round 6: the target pass reads the exchanged words in place -- no unpacking launch)
         }
         const size_t lds = pass == 1 ? kBins1 * 4 : static_cast<size_t>(kMaxTargets) * radix_bins(pass) * 4;
-        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys, p1_u16, le_out);
+        hipLaunchKernelGGL(k_radix_targets, dim3(F), dim3(kTgtThreads), lds, s, pass, src, chunks, cum, B, st, thr_keys, p1_u16, le_out,
+                           comm ? comm->gbuf : nullptr, F);
         return 0;
     };
     int rc = 0;
